@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- forward DifferentiableAstar throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is ONE pass of the hot path (one ``nastar_forward`` launch through the C ABI) over one batch of
+B = 4096 synthetic 32x32 Moore-8 maps that already sit in HBM.  With N > 1 (launched by
+``python -m torch.distributed.run --nproc-per-node N``) every rank owns its own 4096 maps (weak scaling) and each
+step also collates the bit-packed ``AstarOutput`` of all ranks with ONE RCCL all-gather, overlapped with the next
+step's search.  Rank 0 prints ONE JSON line.
+
+Workload (``config.workload``): ``maze32`` = seeded maze-like stand-in for the absent ``mazes_032_moore_c8.npz``
+(SURVEY.md section 8d-ii), VanillaAstar convention cost = map, g_ratio 0.5, eval mode (search runs to the goal).
+The easier ``rand32`` (random 25 % obstacles; what BASELINE.md's CPU probes used) is reported as a secondary figure.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "neural-astar_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H = W = 32
+B_PER_GPU = 4096
+G_RATIO = 0.5
+BYTES_PER_MAP = 28 * H * W  # reads cost+start+goal+passable (4x4 B/cell), writes fp32 hist + int64 paths
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_problem(kind: str, B: int, seed: int):
+    from neural_astar.utils import synthetic as syn
+    cache = os.path.join("/tmp", f"nastar_bench_{kind}_{B}_{seed}.npz")
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return syn.Problems(z["m"], z["s"], z["g"])
+    pr = syn.maze_maps(B, 32, seed=seed) if kind == "maze32" else syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
+    try:
+        np.savez(cache, m=pr.map_designs, s=pr.start_maps, g=pr.goal_maps)
+    except OSError:
+        pass
+    return pr
+
+
+class Runner:
+    """Device-resident inputs + preallocated outputs; step() = one nastar_forward launch on torch's current stream."""
+
+    def __init__(self, pr, dev):
+        from neural_astar import _native
+        self.lib = _native.load()
+        self._check = _native.check
+        self.dev = dev
+        self.m = torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous()
+        self.s = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
+        self.g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
+        self.B = self.m.shape[0]
+        self.hist = torch.empty((self.B, H, W), dtype=torch.float32, device=dev)
+        self.paths = torch.empty((self.B, H, W), dtype=torch.int64, device=dev)
+        self.iters = torch.empty((self.B,), dtype=torch.int32, device=dev)
+        self.status = torch.empty((self.B,), dtype=torch.int32, device=dev)
+
+    def step(self):
+        rc = self.lib.nastar_forward(self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
+                                     self.B, H, W, G_RATIO, W * W, self.hist.data_ptr(), self.paths.data_ptr(), None,
+                                     self.iters.data_ptr(), self.status.data_ptr(), None, 0, 0,
+                                     torch.cuda.current_stream(self.dev).cuda_stream)
+        self._check(rc, "nastar_forward")
+
+
+def timed_loop(run, steps, warmup, world, dev, collate=None):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds max over ranks, device ms)."""
+    pending = None
+    for _ in range(warmup):
+        run.step()
+        if collate is not None:
+            pending = collate(pending)
+    if pending is not None:
+        pending()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    pending = None
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        run.step()
+        if collate is not None:
+            pending = collate(pending)
+    e1.record()
+    if pending is not None:
+        pending()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, dev_ms
+
+
+def kernel_launch_ms(run, steps, dev):
+    """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
+    (torch's current stream), one event pair per launch."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize(dev)
+    evs[0].record()
+    for i in range(steps):
+        run.step()
+        evs[i + 1].record()
+    torch.cuda.synchronize(dev)
+    d = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    return sum(d) / len(d), d[len(d) // 2], d[0]
+
+
+def cpu_baseline(pr, gpu_hist, gpu_paths):
+    """Time the CPU oracle (literal C port of the reference's tensor program, OpenMP over maps) on a bounded sample
+    of the SAME workload, and use its outputs to parity-check the GPU results of those maps."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    O.build()
+    n0 = min(64, pr.map_designs.shape[0])
+    t0 = time.perf_counter()
+    O.forward(pr.map_designs[:n0], pr.start_maps[:n0], pr.goal_maps[:n0], pr.map_designs[:n0], G_RATIO, W * W)
+    rate0 = n0 / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 12.0)))  # aim at ~12 s of CPU work
+    t0 = time.perf_counter()
+    o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], G_RATIO, W * W)
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(o.histories, gpu_hist[:n]) and np.array_equal(o.paths, gpu_paths[:n]))
+    return {"value": n / dt, "unit": "maps/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} maps of the bench batch, oracle/nastar_oracle.c dense restatement, OpenMP over maps, {dt:.1f} s",
+            "gpu_matches_oracle_on_sample": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="maze32", choices=["maze32", "rand32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pr = make_problem(args.workload, B_PER_GPU, seed=1234 + rank)
+    run = Runner(pr, dev)
+
+    collate = None
+    collate_note = "n/a (single GPU)"
+    if world > 1 and not args.no_collate:
+        from neural_astar import parallel
+        from neural_astar.planner.differentiable_astar import AstarOutput
+
+        def collate(pending):
+            # all-gather of step i overlaps the search of step i+1: wait for the previous one only now
+            _, fin = parallel.all_gather_output(AstarOutput(run.hist.unsqueeze(1), run.paths.unsqueeze(1)), async_op=True)
+            if pending is not None:
+                pending()
+            return fin
+        try:
+            run.step()
+            collate(None)()
+            torch.cuda.synchronize(dev)
+            collate_note = "1 RCCL all-gather of bit-packed histories+paths per step, overlapped"
+        except Exception as e:  # reported, not hidden: the line then says the collective was not part of the step
+            collate = None
+            collate_note = f"FAILED ({type(e).__name__}: {e}); steps timed without the all-gather"
+
+    dt, dev_ms = timed_loop(run, args.steps, args.warmup, world, dev, collate)
+    total_maps = n_gpus * B_PER_GPU * args.steps
+    value = total_maps / dt
+
+    if rank == 0:
+        hist = run.hist.cpu().numpy()
+        paths = run.paths.cpu().numpy()
+        iters = run.iters.cpu().numpy()
+        assert int(run.status.abs().sum().item()) == 0, "unsolvable map in the synthetic batch"
+        avg_ms, med_ms, min_ms = kernel_launch_ms(run, min(args.steps, 100), dev)
+        achieved = BYTES_PER_MAP * B_PER_GPU / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic = tj.get(args.workload, {}).get("bytes_per_launch")
+        out = {
+            "metric": "map-instances/s (forward A*) 32x32 Moore-8 @batch 4096",
+            "value": value, "unit": "maps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {B_PER_GPU} maps/GPU of 32x32 Moore-8, cost=map (VanillaAstar), "
+                                   f"g_ratio={G_RATIO}, eval mode (search to goal), seed 1234+rank",
+                       "batch_per_gpu": B_PER_GPU, "global_batch": n_gpus * B_PER_GPU, "H": H, "W": W,
+                       "parallelism": f"shard{n_gpus}" if n_gpus > 1 else "single", "collate": collate_note},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "nastar_forward_kernel<vec4,single-chunk>",
+                         "algorithmic_bytes_per_launch": BYTES_PER_MAP * B_PER_GPU,
+                         "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms},
+            "expansions_per_s": float(iters.sum()) * n_gpus * args.steps / dt,
+            "mean_iters_per_map": float(iters.mean()), "max_iters_per_map": int(iters.max()),
+            "device_ms_per_step": dev_ms / args.steps,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pr, hist, paths)
+            # secondary workload on the same GPU (not the headline): random obstacles, short searches
+            other = "rand32" if args.workload == "maze32" else "maze32"
+            run2 = Runner(make_problem(other, B_PER_GPU, seed=1234), dev)
+            dt2, _ = timed_loop(run2, args.steps, args.warmup, 1, dev)
+            a2, _, _ = kernel_launch_ms(run2, min(args.steps, 100), dev)
+            out["secondary"] = {"workload": other, "value": B_PER_GPU * args.steps / dt2, "unit": "maps/s",
+                                "launch_ms_avg": a2, "hbm_frac": BYTES_PER_MAP * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "mean_iters_per_map": float(run2.iters.float().mean().item())}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+/*
+ * nastar.h -- C ABI of the MI355X-native differentiable A* hot path (libnastar_hip.so).
+ *
+ * The reference (omron-sinicx/neural-astar) is pure Python/PyTorch and has no FFI; these entry points are
+ * what a binding for its ONE hot path would bind.  Each function names the reference code it replaces
+ * (paths relative to /root/reference/src/neural_astar/planner/):
+ *
+ *   nastar_forward          <- DifferentiableAstar.forward   differentiable_astar.py:150-267
+ *                              (get_heuristic :26-52, _st_softmax_noexp :55-74, expand :77-93,
+ *                               backtrack :96-125 all fused into one launch)
+ *   nastar_backward         <- the autograd graph PyTorch records for that forward
+ *                              (what loss.backward() runs in utils/training.py:55-61)
+ *   nastar_heuristic        <- get_heuristic                 differentiable_astar.py:26-52 (debug/parity)
+ *   nastar_workspace_bytes  <- (new) workspace sizing; PyTorch owns every allocation
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer (inputs, outputs, workspace); no allocation and no
+ *     exception crosses the ABI; every function returns an int status (0 = ok).
+ *   - all pointers are DEVICE pointers (HBM) unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous with
+ *     respect to the host and re-entrant per stream.
+ *   - maps are dense row-major [B,H,W] fp32 (the reference's [B,1,H,W] tensors with the unit channel dropped):
+ *     cost >= 0 (the reference's encoders emit sigmoid outputs), start/goal one-hot, passable 1 = free cell.
+ *   - max_iters = int(Tmax_eff * W * W) exactly as differentiable_astar.py:200-202 computes it
+ *     (Tmax_eff = Tmax in training mode, 1.0 in eval mode).
+ */
+#ifndef NASTAR_H_
+#define NASTAR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NASTAR_VERSION 100 /* 0.1.0 */
+
+/* status codes (function return values) */
+#define NASTAR_OK 0
+#define NASTAR_ERR_BAD_SHAPE 1   /* B,H,W,max_iters out of range                                     */
+#define NASTAR_ERR_UNSUPPORTED 2 /* map too large for the implemented kernels                        */
+#define NASTAR_ERR_UNSOLVABLE 3  /* per-map status only: open list ran empty (reference: NaN+IndexError) */
+#define NASTAR_ERR_HIP 4         /* a HIP runtime call failed; see nastar_last_error()               */
+#define NASTAR_ERR_NULL 5        /* a required pointer is NULL                                       */
+#define NASTAR_ERR_WORKSPACE 6   /* workspace_bytes smaller than nastar_workspace_bytes()            */
+
+/* flags for nastar_workspace_bytes / nastar_forward / nastar_backward */
+#define NASTAR_FLAG_NONE 0
+
+int nastar_version(void);
+
+/* Human-readable description of the last NASTAR_ERR_HIP on this thread ("" if none). */
+const char* nastar_last_error(void);
+
+/* Bytes of device workspace the forward/backward need for this problem size (may be 0). */
+size_t nastar_workspace_bytes(int B, int H, int W, int flags);
+
+/*
+ * Forward search for B independent maps; one launch, no host synchronisation.
+ *   histories_out [B,H,W] fp32   exact 0.0/1.0: cells moved to the closed list   (AstarOutput.histories)
+ *   paths_out     [B,H,W] int64  0/1: back-tracked path incl. goal               (AstarOutput.paths)
+ *   sel_log_out   [B,max_iters] int32 or NULL: flat index selected at each executed step of map b; entries at
+ *                 positions >= iters_out[b] are left untouched (store_intermediate_results side channel,
+ *                 differentiable_astar.py:210-216)
+ *   iters_out     [B] int32      number of selection steps map b executed = (index of the step that selected
+ *                 the goal)+1, or max_iters if the budget ran out first.  The reference's batch-wide loop
+ *                 index is t_batch = max_b(iters_out[b]) - 1.
+ *   status_out    [B] int32      NASTAR_OK or NASTAR_ERR_UNSOLVABLE per map
+ */
+int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B,
+                   int H, int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                   int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
+                   size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * Backward of `histories` w.r.t. `cost` (paths carry no gradient).  Replays the search on-chip and accumulates
+ *   dL/dcost = sum_t (1-g_ratio) * (-1/sqrt(W)) * y_t * (G_t - <G_t, y_t>)       
+ * including the reference's batch-coupled terms: a map that reaches its goal at step tau < t_batch keeps being
+ * stepped at its fixed point until the slowest map of the batch finishes (differentiable_astar.py:251), which
+ * (i) adds (t_batch - tau) copies of the fixed-point term and (ii) zeroes the upstream gradient of its goal cell
+ * (torch.clamp backward at :223).
+ *   iters          [B] int32     iters_out of the matching forward
+ *   t_batch_dev    device int32* holding t_batch = max(iters)-1 over the WHOLE logical batch (across shards if
+ *                  the caller wants single-device semantics), or NULL to treat every map as its own batch
+ *                  (t_batch = iters[b]-1: no fixed-point terms).
+ *   grad_cost_out  [B,H,W] fp32
+ */
+int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
+                    const float* passable, int B, int H, int W, double g_ratio, int max_iters,
+                    const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
+                    size_t workspace_bytes, int flags, void* stream);
+
+/* h0 = get_heuristic(goal) for B maps: out [B,H,W] fp32 (parity/debug; the forward computes it on the fly). */
+int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NASTAR_H_ */

@@ -1,0 +1,314 @@
+// nastar_capi.hip -- HIP kernels + the C ABI declared in include/nastar.h (libnastar_hip.so).
+// gfx950 only.  Build: see neural-astar_amd/csrc/Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nastar.h"
+#include "nastar_search.hip.h"
+
+namespace nastar {
+
+constexpr size_t kMaxLdsBytes = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own all of it
+
+struct FwdArgs {
+    const float* cost;
+    const float* start;
+    const float* goal;
+    const float* passable;
+    float* hist;
+    long long* paths;
+    int* sel_log;
+    int* iters;
+    int* status;
+    int max_iters;
+    MapDims d;
+};
+
+// ---- forward: DifferentiableAstar.forward (differentiable_astar.py:150-267), one wavefront per map ------
+template <bool kVec4, bool kMultiChunk>
+__global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const MapDims d = a.d;
+    const MapLds l = carve_map_lds(smem, d);
+    const size_t off = (size_t)b * (size_t)d.HW;
+
+    int start_idx, goal_idx;
+    load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    if (start_idx < 0 || goal_idx < 0) {
+        status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
+    } else {
+        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
+            int C, cl;
+            uint32_t kv, M;
+            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv, M);
+            if (s < 0) {  // open list empty: the reference divides by zero here (:68)
+                status = NASTAR_ERR_UNSOLVABLE;
+                break;
+            }
+            if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            ++iters;
+            if (s == goal_idx) {  // :219-220,251: reached; every later step of the reference is a fixed point
+                if (lane == 0) l.meta[s] = (uint8_t)(l.meta[s] | M_CLOSED);
+                solved = true;
+                wave_sync();
+                break;
+            }
+            close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/false);
+        }
+    }
+    if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off);
+    if (lane == 0) {
+        a.iters[b] = iters;
+        a.status[b] = status;
+    }
+}
+
+struct BwdArgs {
+    const float* grad_hist;
+    const float* cost;
+    const float* start;
+    const float* goal;
+    const float* passable;
+    const int* iters;    // [B] iters_out of the forward (needed with t_batch)
+    const int* t_batch;  // device scalar or nullptr
+    float* grad_cost;
+    int max_iters;
+    float kfac;   // (1-g_ratio) * (-1/sqrt(W))
+    MapDims d;
+};
+
+// y_t = softmax over the open list of -f/sqrt(W) (:207-209,:67-68); acc += scale * kfac * y * (G - <G,y>)
+__device__ __forceinline__ void softmax_accumulate(const MapDims& d, const MapLds& l, const float* gh, float* acc,
+                                                   float* vbuf, int lane, float kfac, float scale)
+{
+    float ls = 0.f, ld = 0.f;
+    for (int i = lane; i < d.HWp; i += 64) {
+        const uint32_t k = l.key[i];
+        float v = 0.f;
+        if (k != KEY_INF) {
+            v = expf(-ord_to_f32(k));  // key holds q = f/sqrt(W)
+        }
+        vbuf[i] = v;
+        ls += v;
+        ld += v * gh[i];
+    }
+    const float S = wave_sum_f32(ls);
+    const float D = wave_sum_f32(ld);
+    const float dot = D / S;
+    const float w = scale * kfac;
+    for (int i = lane; i < d.HWp; i += 64) {
+        const float v = vbuf[i];
+        if (v != 0.f) acc[i] += w * (v / S) * (gh[i] - dot);
+    }
+    wave_sync();
+}
+
+// ---- backward: replays the search, accumulating dL/dcost --------------------------------
+template <bool kVec4, bool kMultiChunk>
+__global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const MapDims d = a.d;
+    const MapLds l = carve_map_lds(smem, d);
+    float* gh = reinterpret_cast<float*>(smem + ((map_lds_bytes(d.HWp, d.NCp) + 15) & ~(size_t)15));
+    float* acc = gh + d.HWp;
+    float* vbuf = acc + d.HWp;
+    const size_t off = (size_t)b * (size_t)d.HW;
+
+    int start_idx, goal_idx;
+    load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    for (int i = lane; i < d.HWp; i += 64) {
+        gh[i] = (i < d.HW) ? a.grad_hist[off + i] : 0.f;
+        acc[i] = 0.f;
+    }
+    wave_sync();
+
+    if (start_idx >= 0 && goal_idx >= 0) {
+        // The reference keeps stepping a finished map at its fixed point until the slowest map of the batch is done
+        // (:251).  extra = number of such steps = t_batch - tau with tau = iters[b]-1.  When extra > 0 the goal cell
+        // is re-selected while already closed, and torch.clamp's backward (:223) zeroes its upstream gradient.
+        int extra = 0;
+        if (a.t_batch != nullptr && a.iters != nullptr) extra = *a.t_batch - (a.iters[b] - 1);
+        if (extra > 0 && lane == 0) gh[goal_idx] = 0.f;
+        wave_sync();
+        int iters = 0;
+        while (iters < a.max_iters) {
+            softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, 1.0f);
+            int C, cl;
+            uint32_t kv, M;
+            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv, M);
+            if (s < 0) break;
+            ++iters;
+            if (s == goal_idx) {
+                if (extra > 0) {
+                    // goal's own expansion (it stays open, :224), then `extra` identical fixed-point steps
+                    close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/true);
+                    softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, (float)extra);
+                }
+                break;
+            }
+            close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/false);
+        }
+    }
+    for (int i = lane; i < d.HW; i += 64) a.grad_cost[off + i] = acc[i];
+}
+
+// ---- get_heuristic standalone (parity/debug) ------------------------------------------------------------
+__global__ __launch_bounds__(64) void nastar_heuristic_kernel(const float* goal, float* out, int H, int W, uint32_t magicW)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, HW = H * W;
+    const float* gm = goal + (size_t)b * HW;
+    int gidx = -1;
+    for (int i = lane; i < HW; i += 64)
+        if (gm[i] != 0.f) gidx = i;
+    gidx = wave_max_i32(gidx);
+    if (gidx < 0) gidx = 0;
+    const int gr = (int)div_magic((uint32_t)gidx, magicW), gc = gidx - gr * W;
+    for (int i = lane; i < HW; i += 64) {
+        int r = (int)div_magic((uint32_t)i, magicW), c = i - r * W;
+        out[(size_t)b * HW + i] = heuristic0(r, c, gr, gc);
+    }
+}
+
+static thread_local char g_last_error[256] = "";
+
+static int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return NASTAR_ERR_HIP;
+}
+
+static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H > 65535 || W > 65535 || (long long)H * W > 65535) return NASTAR_ERR_UNSUPPORTED;
+    d.H = H;
+    d.W = W;
+    d.HW = H * W;
+    d.nchunks = (d.HW + CHUNK - 1) / CHUNK;
+    d.HWp = d.nchunks * CHUNK;
+    d.NCp = ((d.nchunks + 63) / 64) * 64;
+    d.magicW = (uint32_t)((1ull << 32) / (unsigned)W) + 1u;
+    d.gr = (float)g_ratio;
+    d.omg = (float)(1.0 - g_ratio);  // python evaluates (1 - g_ratio) in double, ATen casts the scalar to fp32
+    d.sqrtW = (float)sqrt((double)W);  // math.sqrt(W) in double, then the fp32 scalar of the division (:207)
+    return NASTAR_OK;
+}
+
+template <typename K>
+static int ensure_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return NASTAR_OK;
+}
+
+template <typename K, typename A>
+static int launch(K kernel, const A& args, int B, size_t lds, hipStream_t stream)
+{
+    int rc = ensure_lds(kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), lds, stream, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace nastar
+
+using namespace nastar;
+
+extern "C" {
+
+int nastar_version(void) { return NASTAR_VERSION; }
+
+const char* nastar_last_error(void) { return g_last_error; }
+
+size_t nastar_workspace_bytes(int B, int H, int W, int flags)
+{
+    (void)B; (void)H; (void)W; (void)flags;
+    return 0;  // the whole search state lives in LDS
+}
+
+int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                   int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                   int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
+                   size_t workspace_bytes, int flags, void* stream)
+{
+    (void)workspace; (void)workspace_bytes; (void)flags;
+    if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
+        return NASTAR_ERR_NULL;
+    FwdArgs a;
+    int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
+    if (rc) return rc;
+    const size_t lds = map_lds_bytes(a.d.HWp, a.d.NCp);
+    if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
+    a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
+    a.hist = histories_out; a.paths = reinterpret_cast<long long*>(paths_out);
+    a.sel_log = sel_log_out; a.iters = iters_out; a.status = status_out; a.max_iters = max_iters;
+    const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
+                      aligned16(histories_out) && aligned16(paths_out);
+    const bool multi = a.d.nchunks > 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (vec4 && !multi) return launch(nastar_forward_kernel<true, false>, a, B, lds, s);
+    if (vec4 && multi) return launch(nastar_forward_kernel<true, true>, a, B, lds, s);
+    if (!vec4 && !multi) return launch(nastar_forward_kernel<false, false>, a, B, lds, s);
+    return launch(nastar_forward_kernel<false, true>, a, B, lds, s);
+}
+
+int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
+                    const float* passable, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
+                    const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes,
+                    int flags, void* stream)
+{
+    (void)workspace; (void)workspace_bytes; (void)flags;
+    if (t_batch_dev && !iters) return NASTAR_ERR_NULL;
+    if (!grad_histories || !cost || !start || !goal || !passable || !grad_cost_out) return NASTAR_ERR_NULL;
+    BwdArgs a;
+    int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
+    if (rc) return rc;
+    const size_t lds = ((map_lds_bytes(a.d.HWp, a.d.NCp) + 15) & ~(size_t)15) + (size_t)a.d.HWp * 12;
+    if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
+    a.grad_hist = grad_histories; a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
+    a.iters = iters; a.t_batch = t_batch_dev; a.grad_cost = grad_cost_out; a.max_iters = max_iters;
+    a.kfac = a.d.omg * (-1.0f / a.d.sqrtW);
+    const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable);
+    const bool multi = a.d.nchunks > 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (vec4 && !multi) return launch(nastar_backward_kernel<true, false>, a, B, lds, s);
+    if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, a, B, lds, s);
+    if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, a, B, lds, s);
+    return launch(nastar_backward_kernel<false, true>, a, B, lds, s);
+}
+
+int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream)
+{
+    if (!goal || !h0_out) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((long long)H * W > 65535) return NASTAR_ERR_UNSUPPORTED;
+    const uint32_t magicW = (uint32_t)((1ull << 32) / (unsigned)W) + 1u;
+    hipLaunchKernelGGL(nastar_heuristic_kernel, dim3((unsigned)B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                       goal, h0_out, H, W, magicW);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// nastar_device.hip.h -- device-side building blocks shared by the forward and backward kernels.
+// gfx950 (CDNA4) only: 64-lane wavefronts, DPP cross-lane ops, LDS-resident search state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nastar {
+
+constexpr uint32_t KEY_INF = 0xFFFFFFFFu;  // "not on the open list"
+// per-cell meta byte (LDS): low nibble = flags, high nibble = parent direction code
+constexpr uint32_t M_PASS = 1u, M_CLOSED = 2u, M_OPEN = 4u, M_PATH = 8u;
+constexpr uint32_t PARENT_UNSET = 8u;  // parents[] still holds its initial value goal_idx (differentiable_astar.py:195-198)
+constexpr int CHUNK = 64;              // cells per chunk == wavefront width
+
+// ---- cross-lane reductions: 4 DPP steps inside each 16-lane row, then 4 readlanes + scalar ops ----------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, (int)dpp_mov<DPP_QUAD_XOR1>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_QUAD_XOR2>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_ROW_HALF_MIRROR>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_ROW_MIRROR>((uint32_t)v));
+    int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += __uint_as_float(dpp_mov<DPP_QUAD_XOR1>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<DPP_QUAD_XOR2>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<DPP_ROW_HALF_MIRROR>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<DPP_ROW_MIRROR>(__float_as_uint(v)));
+    float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    float c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    float d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
+    return (a + b) + (c + d);
+}
+
+// ---- fp32 -> order-preserving uint32 (so LDS ds_min_u32 and integer DPP mins order f correctly) ----------
+__device__ __forceinline__ uint32_t f32_to_ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    uint32_t mask = (uint32_t)((int32_t)u >> 31) | 0x80000000u;
+    return u ^ mask;
+}
+__device__ __forceinline__ float ord_to_f32(uint32_t k)
+{
+    uint32_t mask = (k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(k ^ mask);
+}
+
+// exact n / d for n, d < 2^16 with magic = floor(2^32 / d) + 1
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+
+// ---- get_heuristic (differentiable_astar.py:26-52), one cell ------------------------------------------
+// h0 = fl( fl(|dr|+|dc| - min(|dr|,|dc|)) + fl( fl32(0.001) * fl(sqrt(dr^2+dc^2)) ) ); every op one fp32
+// rounding (the TU is compiled with -ffp-contract=off), sqrt correctly rounded.
+__device__ __forceinline__ float heuristic0(int r, int c, int goal_r, int goal_c)
+{
+    float a = (float)r - (float)goal_r;
+    float b = (float)c - (float)goal_c;
+    float dr = fabsf(a), dc = fabsf(b);
+    float cheb = (dr + dc) - fminf(dr, dc);
+    float euc = __fsqrt_rn(a * a + b * b);
+    return cheb + 0.001f * euc;
+}
+
+// neighbour code j in [0,8) -> (dr, dc), raster order of the 3x3 stencil without its centre
+__device__ __forceinline__ void neighbour_delta(int j, int& dr, int& dc)
+{
+    int k = j + (j >= 4);
+    int q = (k >= 6) ? 2 : ((k >= 3) ? 1 : 0);
+    dr = q - 1;
+    dc = (k - 3 * q) - 1;
+}
+
+}  // namespace nastar

@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI in ``include/nastar.h`` (``lib/libnastar_hip.so``).
+
+This is the ONLY compute path of the package: there is no CPU or PyTorch fallback.  If the shared library is
+missing the import of the planner still succeeds (so that CPU-only tooling can inspect the modules) but the
+first call fails loudly with instructions to build it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # neural-astar_amd/
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libnastar_hip.so")
+CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
+
+NASTAR_OK = 0
+NASTAR_ERR_BAD_SHAPE = 1
+NASTAR_ERR_UNSUPPORTED = 2
+NASTAR_ERR_UNSOLVABLE = 3
+NASTAR_ERR_HIP = 4
+NASTAR_ERR_NULL = 5
+NASTAR_ERR_WORKSPACE = 6
+
+_ERR_NAMES = {
+    NASTAR_ERR_BAD_SHAPE: "bad shape (B, H, W and max_iters must be positive)",
+    NASTAR_ERR_UNSUPPORTED: "map size not supported by the implemented kernels",
+    NASTAR_ERR_UNSOLVABLE: "unsolvable map",
+    NASTAR_ERR_HIP: "HIP runtime error",
+    NASTAR_ERR_NULL: "NULL pointer argument",
+    NASTAR_ERR_WORKSPACE: "workspace too small",
+}
+
+# every symbol include/nastar.h declares -- tests check the library exports all of them
+EXPORTED_SYMBOLS = (
+    "nastar_version",
+    "nastar_last_error",
+    "nastar_workspace_bytes",
+    "nastar_forward",
+    "nastar_backward",
+    "nastar_heuristic",
+)
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC_DIR], stdout=out)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: the MI355X HIP extension is the only compute path of this package "
+            f"(no CPU fallback). Build it with `make -C {CSRC_DIR}` or `python __graft_entry__.py build`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cd, cz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    lib.nastar_version.restype = ci
+    lib.nastar_version.argtypes = []
+    lib.nastar_last_error.restype = ctypes.c_char_p
+    lib.nastar_last_error.argtypes = []
+    lib.nastar_workspace_bytes.restype = cz
+    lib.nastar_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_forward.restype = ci
+    lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_backward.restype = ci
+    lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_heuristic.restype = ci
+    lib.nastar_heuristic.argtypes = [vp, ci, ci, ci, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == NASTAR_OK:
+        return
+    msg = _ERR_NAMES.get(rc, f"error {rc}")
+    if rc == NASTAR_ERR_HIP and _lib is not None:
+        msg += ": " + _lib.nastar_last_error().decode("utf-8", "replace")
+    raise RuntimeError(f"{what} failed: {msg}")

@@ -1,0 +1,155 @@
+"""PyTorch-ROCm custom ops over the C ABI (``include/nastar.h``).
+
+``torch.ops.nastar.astar_forward`` / ``astar_backward`` hand raw device pointers and torch's current HIP stream to
+``libnastar_hip.so``.  PyTorch is plumbing here (allocation, streams, autograd bookkeeping); the search itself is
+the hand-written HIP kernel.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native
+
+__all__ = ["astar_forward", "astar_backward", "heuristic", "max_iters_for"]
+
+
+def max_iters_for(W: int, Tmax: float, training: bool) -> int:
+    """Search budget exactly as the reference computes it (differentiable_astar.py:200-202)."""
+    t = Tmax if training else 1.0
+    return int(t * W * W)
+
+
+def _require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "neural_astar (MI355X-native): tensors must live on a HIP device; this package has no CPU "
+                "fallback for the A* search (the reference's CPU path is the oracle under oracle/, test-only).")
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32 maps, got {t.dtype}")
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _maps3(t: torch.Tensor) -> torch.Tensor:
+    """[B,1,H,W] or [B,C,H,W] (channel 0 is used, differentiable_astar.py:177-180) -> contiguous [B,H,W]."""
+    if t.ndim == 4:
+        t = t[:, 0]
+    return t.contiguous()
+
+
+@torch.library.custom_op("nastar::astar_forward", mutates_args=())
+def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
+                  g_ratio: float, max_iters: int, want_log: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Returns (histories [B,H,W] f32, paths [B,H,W] i64, iters [B] i32, status [B] i32, sel_log [B,T] i32 or [0])."""
+    _require_device(cost, start, goal, passable)
+    lib = _native.load()
+    cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
+    B, H, W = cost.shape
+    dev = cost.device
+    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    sel_log = (torch.full((B, max_iters), -1, dtype=torch.int32, device=dev) if want_log
+               else torch.empty((0,), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        rc = lib.nastar_forward(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
+                                float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
+                                sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
+                                None, 0, 0, _stream_ptr(dev))
+    _native.check(rc, "nastar_forward")
+    return hist, paths, iters, status, sel_log
+
+
+@astar_forward.register_fake
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log):
+    B, H, W = cost.shape
+    return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
+            cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
+            cost.new_empty((B, max_iters) if want_log else (0,), dtype=torch.int32))
+
+
+@torch.library.custom_op("nastar::astar_backward", mutates_args=())
+def astar_backward(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
+                   passable: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
+                   t_batch: Optional[torch.Tensor]) -> torch.Tensor:
+    _require_device(grad_hist, cost, start, goal, passable)
+    lib = _native.load()
+    grad_hist, cost, start, goal, passable = (x.contiguous() for x in (grad_hist, cost, start, goal, passable))
+    B, H, W = cost.shape
+    dev = cost.device
+    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_backward(grad_hist.data_ptr(), cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
+                                 passable.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
+                                 t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(),
+                                 None, 0, 0, _stream_ptr(dev))
+    _native.check(rc, "nastar_backward")
+    return grad_cost
+
+
+@astar_backward.register_fake
+def _(grad_hist, cost, start, goal, passable, g_ratio, max_iters, iters, t_batch):
+    return torch.empty_like(cost)
+
+
+def _setup_context(ctx, inputs, output):
+    cost, start, goal, passable, g_ratio, max_iters, _ = inputs
+    _, _, iters, _, _ = output
+    ctx.save_for_backward(cost, start, goal, passable, iters)
+    ctx.g_ratio = g_ratio
+    ctx.max_iters = max_iters
+
+
+def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
+    cost, start, goal, passable, iters = ctx.saved_tensors
+    if g_hist is None:
+        return None, None, None, None, None, None, None
+    # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
+    # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
+    t_batch = BatchCoupling.t_batch(iters)
+    grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
+                                                ctx.max_iters, iters, t_batch)
+    return grad_cost, None, None, None, None, None, None
+
+
+astar_forward.register_autograd(_backward, setup_context=_setup_context)
+
+
+class BatchCoupling:
+    """How a map's gradient is coupled to the rest of its batch.
+
+    ``mode``:
+      * ``"batch"`` (default, reference semantics): t_batch = max(iters) - 1 over the local batch;
+      * ``"none"``: every map is its own batch (no fixed-point terms, shard-size independent);
+      * a callable ``iters -> int32 device scalar`` (used by the sharded planner to all-reduce the maximum).
+    """
+
+    mode = "batch"
+
+    @classmethod
+    def t_batch(cls, iters: torch.Tensor) -> Optional[torch.Tensor]:
+        if cls.mode == "none":
+            return None
+        if callable(cls.mode):
+            return cls.mode(iters)
+        return (iters.amax() - 1).to(torch.int32).reshape(1)
+
+
+def heuristic(goal_maps: torch.Tensor) -> torch.Tensor:
+    """h0 = get_heuristic(goal_maps) on the device (differentiable_astar.py:26-52); parity/debug helper."""
+    _require_device(goal_maps)
+    lib = _native.load()
+    shape = goal_maps.shape
+    g = _maps3(goal_maps)
+    B, H, W = g.shape
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        rc = lib.nastar_heuristic(g.data_ptr(), B, H, W, out.data_ptr(), _stream_ptr(g.device))
+    _native.check(rc, "nastar_heuristic")
+    return out.reshape(shape)

@@ -1,0 +1,114 @@
+"""Multi-GPU sharding of the planner: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+
+Maps are independent, so the batch is partitioned into contiguous row blocks, one per rank,
+with NO exchange during the search.  The only collective is ONE all-gather that collates ``AstarOutput`` -- and it
+moves the information content, not the reference's fat tensors: ``histories`` and ``paths`` are exact 0/1 masks, so
+each rank contributes 2 bits per cell (bit-packed uint8) instead of 12 bytes per cell (fp32 + int64): 4096 maps of
+32x32 are 1 MiB per rank instead of 48 MiB, which over 7 point-to-point xGMI links is latency-, not bandwidth-bound.
+The fp32/int64 views are rebuilt locally on the ranks that want them.
+
+A second, scalar collective (all-reduce MAX of the step count) is optional and only used in training so that the
+batch-coupled gradient terms match a single-device run of the full batch.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .planner.differentiable_astar import AstarOutput
+
+_BIT_WEIGHTS = None
+
+
+def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block [lo, hi) of rank ``rank``; the first ``n % world_size`` ranks get one extra row."""
+    q, r = divmod(n, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def pack_masks(histories: torch.Tensor, paths: torch.Tensor) -> torch.Tensor:
+    """[B,1,H,W] fp32 0/1 + [B,1,H,W] int64 0/1 -> [B, 2*ceil(HW/8)] uint8 (histories bits, then path bits)."""
+    B = histories.shape[0]
+    hw = histories[0].numel()
+    nb = (hw + 7) // 8
+    w = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=histories.device)
+
+    def pk(x: torch.Tensor) -> torch.Tensor:
+        bits = (x.reshape(B, hw) != 0).to(torch.uint8)
+        if nb * 8 != hw:
+            bits = torch.nn.functional.pad(bits, (0, nb * 8 - hw))
+        return (bits.reshape(B, nb, 8) * w).sum(-1, dtype=torch.uint8)
+
+    return torch.cat((pk(histories), pk(paths)), dim=1).contiguous()
+
+
+def unpack_masks(packed: torch.Tensor, H: int, W: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inverse of :func:`pack_masks`: -> histories [B,1,H,W] fp32, paths [B,1,H,W] int64."""
+    B = packed.shape[0]
+    hw = H * W
+    nb = (hw + 7) // 8
+    shifts = torch.tensor([7, 6, 5, 4, 3, 2, 1, 0], dtype=torch.uint8, device=packed.device)
+
+    def un(x: torch.Tensor) -> torch.Tensor:
+        bits = (x.unsqueeze(-1) >> shifts) & 1
+        return bits.reshape(B, nb * 8)[:, :hw].reshape(B, 1, H, W)
+
+    return un(packed[:, :nb]).to(torch.float32), un(packed[:, nb:]).to(torch.int64)
+
+
+def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = None,
+                      async_op: bool = False):
+    """Collate the per-rank ``AstarOutput`` of equally sized shards with ONE all-gather (RCCL on GPUs).
+
+    Returns ``AstarOutput`` of the full batch (rank-major row order), or, with ``async_op=True``, a tuple
+    ``(work, finish)`` where ``finish()`` waits and returns the collated output -- lets the caller overlap the
+    collective with the next batch's search on the compute stream."""
+    H, W = out.histories.shape[-2:]
+    packed = pack_masks(out.histories.detach(), out.paths)
+    world = dist.get_world_size(group)
+    gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.uint8, device=packed.device)
+    work = dist.all_gather_into_tensor(gathered, packed, group=group, async_op=async_op)
+
+    def finish() -> AstarOutput:
+        if work is not None:
+            work.wait()
+        h, p = unpack_masks(gathered, H, W)
+        return AstarOutput(h, p, None)
+
+    if async_op:
+        return work, finish
+    return finish()
+
+
+def global_t_batch(group: Optional[dist.ProcessGroup] = None):
+    """``BatchCoupling.mode`` callable: t_batch = max over ALL ranks of (iters) - 1 (one int32 all-reduce MAX)."""
+
+    def fn(iters: torch.Tensor) -> torch.Tensor:
+        t = (iters.amax() - 1).to(torch.int32).reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return t
+
+    return fn
+
+
+class ShardedPlanner(torch.nn.Module):
+    """Wraps a planner (``VanillaAstar`` / ``NeuralAstar``): each rank plans ITS rows of the batch; ``gather=True``
+    collates the full-batch output on every rank with one all-gather.
+
+    ``forward`` takes the rank-local shard (the usual data-parallel convention: every rank's DataLoader yields its
+    own rows)."""
+
+    def __init__(self, planner: torch.nn.Module, group: Optional[dist.ProcessGroup] = None, gather: bool = True):
+        super().__init__()
+        self.planner = planner
+        self.group = group
+        self.gather = gather
+
+    def forward(self, map_designs, start_maps, goal_maps, store_intermediate_results: bool = False) -> AstarOutput:
+        out = self.planner(map_designs, start_maps, goal_maps, store_intermediate_results)
+        if not self.gather or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return out
+        return all_gather_output(out, self.group)

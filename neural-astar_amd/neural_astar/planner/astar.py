@@ -1,0 +1,79 @@
+"""``VanillaAstar`` / ``NeuralAstar`` -- the drop-in boundary (reference ``planner/astar.py``).
+
+Same constructors, attributes (``astar``, ``encoder``, ``g_ratio``, ``encode``, ``perform_astar``) and state-dict
+keys (``astar.neighbor_filter``, ``encoder.model.<n>.*``) as the reference (astar.py:17-46,105-152), so
+``scripts/train.py``, ``scripts/create_gif.py`` and ``utils/training.py`` run unchanged against this package.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import encoder
+from .differentiable_astar import AstarOutput, DifferentiableAstar
+
+
+class VanillaAstar(nn.Module):
+    def __init__(self, g_ratio: float = 0.5, use_differentiable_astar: bool = True):
+        """Vanilla A*: cost map = obstacle map = ``map_designs`` (reference astar.py:17-46,93-94).
+
+        Examples:
+            >>> planner = VanillaAstar().cuda()
+            >>> outputs = planner(map_designs, start_maps, goal_maps)
+            >>> outputs.histories, outputs.paths
+        """
+        super().__init__()
+        self.astar = DifferentiableAstar(g_ratio=g_ratio, Tmax=1.0)
+        self.g_ratio = g_ratio
+        self.use_differentiable_astar = use_differentiable_astar
+
+    def perform_astar(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
+                      obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
+        if not self.use_differentiable_astar:
+            # reference astar.py:57-61 dispatches to pq_astar (CPU numpy + pqdict): a different, non-differentiable
+            # algorithm (it charges the NEIGHBOUR's cost, pq_astar.py:138-144) that is outside the hot path.
+            raise NotImplementedError(
+                "use_differentiable_astar=False selects the reference's CPU-only pq_astar, which is out of scope for "
+                "the MI355X-native hot path; the HIP DifferentiableAstar kernel has no large-map penalty, use it.")
+        return self.astar(map_designs, start_maps, goal_maps, obstacles_maps, store_intermediate_results)
+
+    def forward(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
+                store_intermediate_results: bool = False) -> AstarOutput:
+        return self.perform_astar(map_designs, start_maps, goal_maps, map_designs, store_intermediate_results)
+
+
+class NeuralAstar(VanillaAstar):
+    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, encoder_input: str = "m+",
+                 encoder_arch: str = "CNN", encoder_depth: int = 4, learn_obstacles: bool = False,
+                 const: float = None, use_differentiable_astar: bool = True):
+        """Neural A*: an encoder predicts the cost map, then the same search runs (reference astar.py:105-152).
+
+        Args mirror the reference: ``encoder_input`` "m+" = map + (start+goal) channel, "m" = map only;
+        ``encoder_arch`` in {"CNN", "CNNDownSize", "Unet"}; ``learn_obstacles`` hides the obstacle map from the search;
+        ``const`` = learnable scale on the predicted cost.
+        """
+        super().__init__()
+        self.astar = DifferentiableAstar(g_ratio=g_ratio, Tmax=Tmax)
+        self.encoder_input = encoder_input
+        self.encoder = getattr(encoder, encoder_arch)(len(self.encoder_input), encoder_depth, const)
+        self.learn_obstacles = learn_obstacles
+        if self.learn_obstacles:
+            print("WARNING: learn_obstacles has been set to True")
+        self.g_ratio = g_ratio
+        self.use_differentiable_astar = use_differentiable_astar
+
+    def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
+        """Predict cost maps (reference astar.py:154-180)."""
+        inputs = map_designs
+        if "+" in self.encoder_input:
+            sg = start_maps + goal_maps
+            if map_designs.shape[-1] != start_maps.shape[-1]:  # WarCraft: 96x96 image vs 12x12 grid
+                sg = nn.functional.interpolate(sg, size=map_designs.shape[-2:], mode="nearest")
+            inputs = torch.cat((inputs, sg), dim=1)
+        return self.encoder(inputs)
+
+    def forward(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
+                store_intermediate_results: bool = False) -> AstarOutput:
+        cost_maps = self.encode(map_designs, start_maps, goal_maps)
+        obstacles_maps = map_designs if not self.learn_obstacles else torch.ones_like(start_maps)
+        return self.perform_astar(cost_maps, start_maps, goal_maps, obstacles_maps, store_intermediate_results)

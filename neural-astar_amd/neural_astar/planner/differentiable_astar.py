@@ -1,0 +1,104 @@
+"""``DifferentiableAstar`` -- host shim over the HIP search kernel.
+
+Mirrors the public surface of the reference module (``planner/differentiable_astar.py``): ``AstarOutput``
+(:16-23), ``DifferentiableAstar(g_ratio, Tmax)`` (:128-148) with the ``neighbor_filter`` parameter kept for
+state-dict compatibility (:140-143), and ``forward(cost_maps, start_maps, goal_maps, obstacles_maps,
+store_intermediate_results)`` (:150-267).  The body of the reference's loop is NOT here: it is
+``csrc/nastar_search.hip.h`` reached through ``torch.ops.nastar.astar_forward``.
+"""
+from __future__ import annotations
+
+from typing import List, NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class AstarOutput(NamedTuple):
+    """Output structure of A* search planners (same fields/order as the reference, :16-23)."""
+
+    histories: torch.Tensor
+    paths: torch.Tensor
+    intermediate_results: Optional[List[dict]] = None
+
+
+class UnsolvableMapError(RuntimeError):
+    """Raised (when ``check_solvable``) for maps whose goal is unreachable.
+
+    The reference produces NaNs and then an ``IndexError`` inside ``backtrack`` for the whole batch
+    (SURVEY.md section 0.4); here the kernel reports a per-map status instead."""
+
+
+class DifferentiableAstar(nn.Module):
+    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, check_solvable: bool = True):
+        """
+        Args:
+            g_ratio: weight of g(v) in f = g_ratio*g + (1-g_ratio)*h; 0 = best-first search (reference :129-135).
+            Tmax: fraction of W*W search steps allowed in training mode (reference :135,:200-202).
+            check_solvable: synchronise once per call and raise ``UnsolvableMapError`` if any map's open list ran
+                empty (extension over the reference, which crashes).  Set False to stay fully asynchronous; the
+                per-map status is then available as ``self.last_status``.
+        """
+        super().__init__()
+        nf = torch.ones(1, 1, 3, 3)
+        nf[0, 0, 1, 1] = 0
+        # never read by the kernel (the Moore-8 stencil is hard-wired) but part of every reference checkpoint
+        self.neighbor_filter = nn.Parameter(nf, requires_grad=False)
+        self.g_ratio = g_ratio
+        assert (Tmax > 0) & (Tmax <= 1), "Tmax must be within (0, 1]"
+        self.Tmax = Tmax
+        self.check_solvable = check_solvable
+        self.last_status: Optional[torch.Tensor] = None
+        self.last_iters: Optional[torch.Tensor] = None
+
+    def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
+                obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
+        assert cost_maps.ndim == 4
+        assert start_maps.ndim == 4
+        assert goal_maps.ndim == 4
+        assert obstacles_maps.ndim == 4
+
+        cost = cost_maps[:, 0]
+        start = start_maps[:, 0]
+        goal = goal_maps[:, 0]
+        passable = obstacles_maps[:, 0]
+        W = cost.shape[-1]
+        max_iters = ops.max_iters_for(W, self.Tmax, self.training)
+
+        hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
+            cost, start, goal, passable, float(self.g_ratio), max_iters, bool(store_intermediate_results))
+        self.last_status, self.last_iters = status, iters
+        if self.check_solvable and bool((status != 0).any()):
+            bad = torch.nonzero(status != 0).flatten().tolist()
+            raise UnsolvableMapError(
+                f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map "
+                f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''})")
+
+        intermediate_results: List[dict] = []
+        if store_intermediate_results:
+            intermediate_results = _intermediate_results(hist, paths, goal, iters, sel_log)
+        return AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), intermediate_results)
+
+
+def _intermediate_results(hist, paths, goal, iters, sel_log) -> List[dict]:
+    """Rebuild the reference's per-step side channel (:210-216,:257-263) from the kernel's selection log.
+
+    Entry t holds the histories BEFORE step t and the node selected AT step t; a map that already reached its goal
+    keeps re-selecting it (fixed point) until the slowest map of the batch is done; one final entry carries the
+    final histories and the int64 path maps."""
+    B, H, W = hist.shape
+    t_batch = int(iters.max().item()) - 1
+    goal_idx = goal.reshape(B, -1).argmax(-1)
+    rows = torch.arange(B, device=hist.device)
+    cur = torch.zeros((B, H * W), dtype=hist.dtype, device=hist.device)
+    out: List[dict] = []
+    for t in range(t_batch + 1):
+        sel = torch.where(t < iters, sel_log[:, t].long(), goal_idx)
+        onehot = torch.zeros_like(cur)
+        onehot[rows, sel] = 1
+        out.append({"histories": cur.reshape(B, 1, H, W).clone(), "paths": onehot.reshape(B, 1, H, W)})
+        cur[rows, sel] = 1
+    out.append({"histories": hist.unsqueeze(1).detach(), "paths": paths.unsqueeze(1).detach()})
+    return out

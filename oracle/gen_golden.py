@@ -183,6 +183,21 @@ def main():
     out, _ = run_ref(ref, c2, r2.start_maps, r2.goal_maps, r2.map_designs, 0.5)
     save("rand20x45_ucost_g050", r2, c2, out, 0.5)
 
+    # 6c. unit-cost maps with LONG distances: h0's 0.001*euclid term makes f values 1-2 ulp apart, which the fp32
+    #     division by sqrt(W) (:207) merges into exact ties -> pins the "order by q = f/sqrt(W)" reading
+    r3 = syn.random_obstacle_maps(8, 64, 128, 0.2, seed=1000 + 64 * 128 + 4)
+    out, _ = run_ref(ref, r3.map_designs, r3.start_maps, r3.goal_maps, r3.map_designs, 0.5)
+    save("rand64x128_vanilla_g050", r3, None, out, 0.5)
+    r4 = syn.random_obstacle_maps(16, 64, 64, 0.2, seed=321)
+    out, _ = run_ref(ref, r4.map_designs, r4.start_maps, r4.goal_maps, r4.map_designs, 0.5)
+    save("rand64_vanilla_g050", r4, None, out, 0.5)
+    f96 = syn.fixture_block(1, 96, 96)
+    out, _ = run_ref(ref, f96.map_designs, f96.start_maps, f96.goal_maps, f96.map_designs, 0.5)
+    save("fixture96_g050", f96, None, out, 0.5)
+    r5 = syn.random_obstacle_maps(4, 100, 100, 0.1, seed=55)
+    out, _ = run_ref(ref, r5.map_designs, r5.start_maps, r5.goal_maps, r5.map_designs, 0.5)
+    save("rand100_vanilla_g050", r5, None, out, 0.5)
+
     # 7. gradients (autograd through the reference), batch with uneven finishing times
     rng = np.random.Generator(np.random.PCG64(5))
     rg = syn.Problems(*(x[:8] for x in ro))

@@ -23,8 +23,9 @@
  *
  *  (2) nastar_oracle_forward_sm
  *      The integer "state machine" reading of the same algorithm: first-index
- *      arg-min of f over open cells, <=8 neighbour updates, per-map early exit, walk-to-start
- *      backtrack.  This is the algorithm the HIP kernel implements; the CPU tests prove (1)==(2)
+ *      arg-min over open cells of q = fl(f / fl32(sqrt(W))) (the IEEE division of :207 merges f values
+ *      one ulp apart into exact ties, so ordering by f itself is NOT equivalent), <=8 neighbour
+ *      updates, per-map early exit, walk-to-start backtrack.  This is the algorithm the HIP kernel implements; the CPU tests prove (1)==(2)
  *      on the golden vectors so that kernel-vs-(1) failures can be told apart from algorithmic ones.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
@@ -336,6 +337,7 @@ int nastar_oracle_forward_sm(const float* cost, const float* start, const float*
     const int HW = H * W;
     const float gr = (float)g_ratio;
     const float omg = (float)(1.0 - g_ratio);
+    const float sqrtW = (float)sqrt((double)W);
     int any_unsolvable = 0;
 #pragma omp parallel for schedule(dynamic, 8) reduction(|| : any_unsolvable)
     for (int b = 0; b < B; ++b) {
@@ -355,7 +357,7 @@ int nastar_oracle_forward_sm(const float* cost, const float* start, const float*
             par[i] = g_idx;
         }
         st[s_idx] = 1;
-        key[s_idx] = gr * 0.0f + hh[s_idx];
+        key[s_idx] = (gr * 0.0f + hh[s_idx]) / sqrtW;
         int iters = 0, solved = 0, empty = 0;
         if (sel_log) for (int t = 0; t < max_iters; ++t) sel_log[(size_t)b * max_iters + t] = -1;
         while (iters < max_iters) {
@@ -380,7 +382,7 @@ int nastar_oracle_forward_sm(const float* cost, const float* start, const float*
                     if (pb[n] == 0.0f || (st[n] & 2)) continue;
                     if ((st[n] & 1) && !(g[n] > g2)) continue;
                     g[n] = g2;
-                    key[n] = gr * g2 + hh[n];
+                    key[n] = (gr * g2 + hh[n]) / sqrtW;
                     st[n] |= 1;
                     par[n] = s;
                 }

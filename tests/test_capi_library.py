@@ -1,0 +1,58 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol include/nastar.h declares.
+No compute call is made (there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nastar.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nastar_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    from neural_astar import _native
+    assert _declared_symbols() == sorted(_native.EXPORTED_SYMBOLS)
+
+
+def test_library_builds_loads_and_exports_everything():
+    from neural_astar import _native
+    if not os.path.exists(_native.LIB_PATH):
+        _native.build()
+    lib = _native.load()
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), sym
+    assert lib.nastar_version() == 100
+    assert lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
+    assert lib.nastar_last_error() == b""
+
+
+def test_argument_validation_needs_no_gpu():
+    """Status codes for bad arguments are produced before any HIP call."""
+    from neural_astar import _native
+    lib = _native.load()
+    one = 16  # any non-NULL pointer value; never dereferenced on these paths
+    assert lib.nastar_forward(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
+    assert lib.nastar_forward(one, one, one, one, 1, 8, 8, 0.5, 0, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
+    assert lib.nastar_forward(one, one, one, one, 1, 512, 512, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_backward(one, one, one, one, one, 1, 8, 8, 0.5, 64, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
+
+
+def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
+    import torch
+    from neural_astar.planner import VanillaAstar
+    x = torch.ones(1, 1, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        VanillaAstar()(x, x, x)
+    pkg = os.path.join(ROOT, "neural-astar_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "nastar_oracle" not in src, f

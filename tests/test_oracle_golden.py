@@ -1,0 +1,86 @@
+"""CPU: the oracle (oracle/nastar_oracle.c) against the vectors the reference itself produced (tests/golden/)
+and the known-answer table of SURVEY.md section 8(c).  This is what "parity pinned" rests on."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from oracle import oracle as O
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a.astype(np.uint8)).tobytes()).hexdigest()[:16]
+
+
+# (iterations == sum(histories), sum(paths), sha(hist), sha(paths)) of the reference's test fixture
+KNOWN = {
+    "fixture64_g050": (1169, 88, "e67de477757755bc", "05408cdd67dd1928"),
+    "fixture64_g000": (88, 88, "05408cdd67dd1928", "05408cdd67dd1928"),
+    "fixture64_g100": (3520, 88, "1faaa23cc6146510", "55f4ea8803a6ebfb"),
+    "fixture64_g020": (265, 88, "cd3e414c0287049f", "05408cdd67dd1928"),
+    "rect64x128_g050": (128, 128, "c9dc5b662a7a660e", "c9dc5b662a7a660e"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN))
+def test_golden_files_hold_the_surveyed_known_answers(name):
+    g = G.load(name)
+    hs, ps, sh, sp = KNOWN[name]
+    assert int(g.histories[0].sum()) == hs and int(g.paths[0].sum()) == ps
+    assert sha16(g.histories[:1]) == sh and sha16(g.paths[:1]) == sp
+
+
+@pytest.mark.parametrize("mode", ["dense", "sm"])
+@pytest.mark.parametrize("name", G.names())
+def test_oracle_forward_matches_reference(name, mode):
+    g = G.load(name)
+    o = O.forward(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode=mode,
+                  want_log=g.sel_log is not None)
+    assert o.status == 0
+    assert np.array_equal(o.histories, g.histories[:, 0])
+    # paths of a truncated batch depend on the batch-wide t only through the cap, which both modes reproduce
+    assert np.array_equal(o.paths, g.paths[:, 0])
+    if g.sel_log is not None and mode == "dense":
+        T = g.sel_log.shape[1]
+        assert o.t_batch == T - 1 and np.array_equal(o.sel_log[:, :T], g.sel_log)
+
+
+@pytest.mark.parametrize("name", [n for n in G.names() if n.startswith("grad_")])
+def test_oracle_backward_matches_reference_autograd(name):
+    g = G.load(name)
+    got = O.backward(g.grad_up, g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters)
+    scale = max(1.0, float(np.abs(g.grad_cost).max()))
+    assert float(np.abs(got - g.grad_cost[:, 0]).max()) <= 1e-6 * scale
+
+
+def test_heuristic_known_values():
+    h = O.heuristic(64, 64, 63, 63)
+    assert h[0, 0] == np.float32(63.08909606933594)
+    assert h[0, 63] == np.float32(63.0629997253418)
+    assert h[63, 62] == h[62, 63] == np.float32(1.0010000467300415)
+    assert h[63, 63] == 0.0
+
+
+def test_state_machine_equals_dense_on_fresh_inputs():
+    """(2)==(1): arg-min over q=f/sqrt(W) + early exit + walk-to-start == the literal tensor program."""
+    from neural_astar.utils import synthetic as syn
+    for (H, W, B, p, gr, seed) in [(32, 32, 96, 0.25, 0.5, 1), (24, 40, 32, 0.2, 0.9, 2), (64, 64, 12, 0.2, 0.5, 3),
+                                   (64, 128, 4, 0.2, 0.5, 1000 + 64 * 128 + 4)]:
+        pr = syn.random_obstacle_maps(B, H, W, p, seed=seed)
+        for cost in (pr.map_designs, syn.random_costs(B, H, W, seed=seed + 10)):
+            a = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, W * W, mode="dense")
+            b = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, W * W, mode="sm")
+            assert np.array_equal(a.histories, b.histories) and np.array_equal(a.paths, b.paths)
+            assert np.array_equal(a.iters, b.iters)
+
+
+def test_unsolvable_is_reported():
+    m = np.ones((1, 1, 8, 8), np.float32)
+    m[0, 0, 4, :] = 0
+    s = np.zeros_like(m)
+    g = np.zeros_like(m)
+    s[0, 0, 0, 0] = 1
+    g[0, 0, 7, 7] = 1
+    assert O.forward(m, s, g, m, mode="dense").status == O.ERR_UNSOLVABLE
+    assert O.forward(m, s, g, m, mode="sm").status == O.ERR_UNSOLVABLE
