@@ -47,6 +47,8 @@ extern "C" {
 
 /* flags for nastar_workspace_bytes / nastar_forward / nastar_backward */
 #define NASTAR_FLAG_NONE 0
+#define NASTAR_FLAG_FORCE_LDS 1 /* forward: always use the LDS-resident kernel */
+#define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
 
 int nastar_version(void);
 

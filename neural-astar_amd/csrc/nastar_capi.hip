@@ -7,6 +7,7 @@
 
 #include "../../include/nastar.h"
 #include "nastar_search.hip.h"
+#include "nastar_search_reg.hip.h"
 
 namespace nastar {
 
@@ -27,8 +28,8 @@ struct FwdArgs {
 };
 
 // ---- forward: DifferentiableAstar.forward (differentiable_astar.py:150-267), one wavefront per map ------
-template <bool kVec4, bool kMultiChunk>
-__global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a)
+template <bool kVec4, bool kMultiChunk, int LOGW, bool kFastDiv, bool kLog>
+__global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -40,33 +41,92 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a)
     int start_idx, goal_idx;
     load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
 
+    const LaneConst lc = make_lane_const(d, lane);
     int status = NASTAR_OK;
     int iters = 0;
     bool solved = false;
     if (start_idx < 0 || goal_idx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
     } else {
+        int s = 0;
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             int C, cl;
-            uint32_t kv, M;
-            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv, M);
+            uint32_t kv;
+            s = select_min<kMultiChunk>(d, l, lane, C, cl, kv);
+            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
+            if constexpr (kLog) {
+                if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            }
+            ++iters;
+            close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
+        }
+        if (iters < a.max_iters) {
+            if (s < 0) {
+                status = NASTAR_ERR_UNSOLVABLE;
+            } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
+                if constexpr (kLog) {
+                    if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+                }
+                ++iters;
+                solved = true;
+                if (lane == 0) l.g[s] = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
+            }
+        }
+    }
+    wave_sync();
+    if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off);
+    if (lane == 0) {
+        a.iters[b] = iters;
+        a.status[b] = status;
+    }
+}
+
+// ---- forward, register-resident variant for maps of <= 1024 cells (nastar_search_reg.hip.h) ----------------
+template <int NSTEP, bool kLog, bool kFastDiv, int LOGW>
+__global__ __launch_bounds__(64) void nastar_forward_reg_kernel(const FwdArgs a, const float rcp_sqrtW)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t pdir[REG_MAX_CELLS + 64];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const MapDims d = a.d;
+    const size_t off = (size_t)b * (size_t)d.HW;
+    RegState st;
+    int start_idx, goal_idx;
+    reg_load_map(d, st, pdir, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    int gC = 0, gcl = 0;
+    if (start_idx < 0 || goal_idx < 0) {
+        status = NASTAR_ERR_UNSOLVABLE;
+    } else {
+        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
+            int C, cl;
+            const int s = reg_select(st, C, cl);
             if (s < 0) {  // open list empty: the reference divides by zero here (:68)
                 status = NASTAR_ERR_UNSOLVABLE;
                 break;
             }
-            if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            if constexpr (kLog) {
+                if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            }
             ++iters;
-            if (s == goal_idx) {  // :219-220,251: reached; every later step of the reference is a fixed point
-                if (lane == 0) l.meta[s] = (uint8_t)(l.meta[s] | M_CLOSED);
+            if (s == goal_idx) {  // :219-220,:251 reached; every later step of the reference is a fixed point
                 solved = true;
-                wave_sync();
+                gC = C;
+                gcl = cl;
                 break;
             }
-            close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/false);
+            reg_expand<NSTEP, kFastDiv, LOGW>(d, st, pdir, lane, s, C, cl, /*keep_open=*/false, rcp_sqrtW);
         }
     }
-    if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off);
+    if (solved) reg_close_only(st, lane, gC, gcl);
+    wave_sync();
+    uint32_t pathbits = 0;
+    if (goal_idx >= 0) pathbits = reg_backtrack(d, pdir, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    reg_store_outputs(d, st, pathbits, lane, a.hist + off, a.paths + off);
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
@@ -139,6 +199,7 @@ __global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
         // The reference keeps stepping a finished map at its fixed point until the slowest map of the batch is done
         // (:251).  extra = number of such steps = t_batch - tau with tau = iters[b]-1.  When extra > 0 the goal cell
         // is re-selected while already closed, and torch.clamp's backward (:223) zeroes its upstream gradient.
+        const LaneConst lc = make_lane_const(d, lane);
         int extra = 0;
         if (a.t_batch != nullptr && a.iters != nullptr) extra = *a.t_batch - (a.iters[b] - 1);
         if (extra > 0 && lane == 0) gh[goal_idx] = 0.f;
@@ -147,19 +208,21 @@ __global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
         while (iters < a.max_iters) {
             softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, 1.0f);
             int C, cl;
-            uint32_t kv, M;
-            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv, M);
+            uint32_t kv;
+            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv);
             if (s < 0) break;
             ++iters;
             if (s == goal_idx) {
                 if (extra > 0) {
                     // goal's own expansion (it stays open, :224), then `extra` identical fixed-point steps
-                    close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/true);
+                    close_and_expand<0, false>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/true, 0.f);
+                    wave_sync();
                     softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, (float)extra);
                 }
                 break;
             }
-            close_and_expand(d, l, lane, s, C, cl, kv, /*keep_open=*/false);
+            close_and_expand<0, false>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, 0.f);
+            wave_sync();
         }
     }
     for (int i = lane; i < d.HW; i += 64) a.grad_cost[off + i] = acc[i];
@@ -218,15 +281,40 @@ static int ensure_lds(K kernel, size_t bytes)
     return NASTAR_OK;
 }
 
-template <typename K, typename A>
-static int launch(K kernel, const A& args, int B, size_t lds, hipStream_t stream)
+template <typename K, typename... A>
+static int launch(K kernel, int B, size_t lds, hipStream_t stream, const A&... args)
 {
     int rc = ensure_lds(kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), lds, stream, args);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), lds, stream, args...);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
+}
+
+// largest number of 64-cell slots the (clipped) 3x3 neighbourhood of any cell spans, for the register-resident kernel
+static int reg_max_slot_steps(int H, int W)
+{
+    int best = 1;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+            const int r_lo = r > 0 ? r - 1 : 0, r_hi = r < H - 1 ? r + 1 : r;
+            const int c_lo = c > 0 ? c - 1 : 0, c_hi = c < W - 1 ? c + 1 : c;
+            const int n = (((r_hi * W + c_hi) >> 6) - ((r_lo * W + c_lo) >> 6)) + 1;
+            if (n > best) best = n;
+        }
+    return best;
+}
+
+// map widths for which the FMA-based division by fl32(sqrt(W)) was verified bit-exact against IEEE division for
+// every fp32 f in [2^-100, FLT_MAX] (tools/fastdiv_check.c); widths whose sqrt is a power of two divide exactly.
+static bool fastdiv_verified(int W)
+{
+    static const int ok[] = {2, 8, 32, 128, 512, 10, 12, 20, 24, 28, 40, 45, 48, 50, 60, 96, 100,  // exhaustively checked
+                             1, 4, 16, 64, 256, 1024};                                             // sqrt(W) is a power of two
+    for (int w : ok)
+        if (w == W) return true;
+    return false;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -252,7 +340,7 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
                    int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                    size_t workspace_bytes, int flags, void* stream)
 {
-    (void)workspace; (void)workspace_bytes; (void)flags;
+    (void)workspace; (void)workspace_bytes;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
     FwdArgs a;
@@ -267,10 +355,44 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
                       aligned16(histories_out) && aligned16(paths_out);
     const bool multi = a.d.nchunks > 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (vec4 && !multi) return launch(nastar_forward_kernel<true, false>, a, B, lds, s);
-    if (vec4 && multi) return launch(nastar_forward_kernel<true, true>, a, B, lds, s);
-    if (!vec4 && !multi) return launch(nastar_forward_kernel<false, false>, a, B, lds, s);
-    return launch(nastar_forward_kernel<false, true>, a, B, lds, s);
+    const int nstep = reg_max_slot_steps(H, W);
+    if (a.d.HW <= REG_MAX_CELLS && nstep <= 3 && (flags & NASTAR_FLAG_FORCE_REG)) {
+        const float rcp = 1.0f / a.d.sqrtW;
+        const bool fast = fastdiv_verified(W);
+        const bool lg = sel_log_out != nullptr;
+        void (*kern)(const FwdArgs, const float);
+#define NASTAR_PICK(NS, LW)                                                                                   \
+    kern = fast ? (lg ? &nastar_forward_reg_kernel<NS, true, true, LW> : &nastar_forward_reg_kernel<NS, false, true, LW>) \
+                : (lg ? &nastar_forward_reg_kernel<NS, true, false, LW> : &nastar_forward_reg_kernel<NS, false, false, LW>)
+        if (W == 32) { NASTAR_PICK(2, 5); }
+        else if (W == 16) { NASTAR_PICK(2, 4); }
+        else if (W == 64) { NASTAR_PICK(3, 6); }
+        else if (nstep <= 2) { NASTAR_PICK(2, 0); }
+        else { NASTAR_PICK(3, 0); }
+#undef NASTAR_PICK
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), 0, s, a, rcp);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        return NASTAR_OK;
+    }
+    {
+        const float rcp = 1.0f / a.d.sqrtW;
+        const bool fast = fastdiv_verified(W);
+        const bool lg = sel_log_out != nullptr;
+        void (*kern)(const FwdArgs, const float) = nullptr;
+        // hot configurations: aligned, <= 64 chunks, power-of-two width, verified fast division
+#define NASTAR_PICK_LW(LW)                                                                                      \
+    kern = lg ? &nastar_forward_kernel<true, false, LW, true, true> : &nastar_forward_kernel<true, false, LW, true, false>
+        if (vec4 && !multi && fast && W == 32) { NASTAR_PICK_LW(5); }
+        else if (vec4 && !multi && fast && W == 64) { NASTAR_PICK_LW(6); }
+        else if (vec4 && !multi && fast && W == 16) { NASTAR_PICK_LW(4); }
+#undef NASTAR_PICK_LW
+        else if (vec4 && !multi) kern = lg ? &nastar_forward_kernel<true, false, 0, false, true> : &nastar_forward_kernel<true, false, 0, false, false>;
+        else if (vec4 && multi) kern = lg ? &nastar_forward_kernel<true, true, 0, false, true> : &nastar_forward_kernel<true, true, 0, false, false>;
+        else if (!vec4 && !multi) kern = lg ? &nastar_forward_kernel<false, false, 0, false, true> : &nastar_forward_kernel<false, false, 0, false, false>;
+        else kern = lg ? &nastar_forward_kernel<false, true, 0, false, true> : &nastar_forward_kernel<false, true, 0, false, false>;
+        return launch(kern, B, lds, s, a, rcp);
+    }
 }
 
 int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
@@ -292,10 +414,10 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
     const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable);
     const bool multi = a.d.nchunks > 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (vec4 && !multi) return launch(nastar_backward_kernel<true, false>, a, B, lds, s);
-    if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, a, B, lds, s);
-    if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, a, B, lds, s);
-    return launch(nastar_backward_kernel<false, true>, a, B, lds, s);
+    if (vec4 && !multi) return launch(nastar_backward_kernel<true, false>, B, lds, s, a);
+    if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, B, lds, s, a);
+    if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
+    return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
 }
 
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream)

@@ -18,6 +18,12 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
+// `old` = identity of the consuming op lets LLVM's DPP combiner fold the move into the VALU op (v_min_u32_dpp ...)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov_id(uint32_t v, uint32_t identity)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, 0xF, 0xF, false);
+}
 constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
@@ -25,15 +31,30 @@ constexpr int DPP_ROW_MIRROR = 0x140;
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v));
-    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v));
-    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR1>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR2>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_HALF_MIRROR>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_MIRROR>(v, 0xFFFFFFFFu));
     uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
     uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
     uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
     uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
     return min(min(a, b), min(c, d));
+}
+
+// min over all 64 lanes, result in EVERY lane (stays in a VGPR: no VALU->SALU->VALU round trip, which costs a lone
+// wavefront ~25 cycles per hop on gfx950).  4 DPP steps reduce each 16-lane row, v_permlane16_swap / v_permlane32_swap
+// (gfx950) then exchange rows / halves.
+__device__ __forceinline__ uint32_t wave_min_all_u32(uint32_t v)
+{
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR1>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR2>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_HALF_MIRROR>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_MIRROR>(v, 0xFFFFFFFFu));
+    auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(a[0], a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(b[0], b[1]);
 }
 
 __device__ __forceinline__ int wave_max_i32(int v)

@@ -2,16 +2,22 @@
 //
 // Replaces the reference's per-iteration tensor program (differentiable_astar.py:203-252; ~45 ATen ops over
 // [B,H,W] fp32 maps to move ONE node per map) by:
-//   * LDS-resident state per map:  key[] (q = f/sqrt(W) of open cells as order-preserving u32, KEY_INF otherwise),
-//     g[], cost[], hh[] = fl((1-g_ratio)*fl(h0+cost)), meta[] (flags + parent direction), chunkmin[] (min key of
-//     every 64-cell chunk, maintained with ds_min_u32);
-//   * selection  = first-index arg-min over the open list of q = fl(f / fl32(sqrt(W))) -- the reference's first
-//     arg-max of the masked softmax exp(-f/sqrt(W))/sum (differentiable_astar.py:55-74,206-209) orders cells by
-//     exactly this quotient: the IEEE division merges f values one ulp apart into exact ties that then resolve by
-//     flat index, so the key must be q, not f.  Wave-min over chunkmin[] -> first chunk -> wave ballot inside the
-//     chunk: two DPP reductions + two ballots per step instead of a full-map softmax;
-//   * expansion  = lanes 0..7 each own one Moore neighbour (expand() of a one-hot == "touch <=8 cells",
-//     differentiable_astar.py:77-93,228-249).
+//   * LDS-resident state per map:
+//       key[]   q = fl(f / fl32(sqrt(W))) of every OPEN cell as an order-preserving u32, KEY_INF otherwise
+//       g[]     fp32 g-value; the sign of infinity doubles as the node state so that ONE comparison decides a
+//               relaxation:  +inf = passable & never opened,  -inf = closed or obstacle,  finite = open.
+//               "update neighbour n" (differentiable_astar.py:235: (1-open)(1-hist) + open*(g > g2), times the
+//               obstacle mask :229) is exactly  g[n] > g2.
+//       cost[], hh[] = fl((1-g_ratio) * fl(h0 + cost))     (:191-192,:206)
+//       pdir[]  bits 0-3 parent direction code (8 = unset), bit 6 passable, bit 7 on-path
+//       chunkmin[] min key of every 64-cell chunk, maintained with ds_min_u32
+//   * selection  = first-index arg-min over the open list of q -- the reference's first arg-max of the masked
+//     softmax exp(-f/sqrt(W))/sum (:55-74,:206-209) orders cells by exactly this quotient: the IEEE division merges
+//     f values one ulp apart into exact ties that then resolve by flat index, so the key must be q, not f.
+//     wave-min over chunkmin[] -> first chunk -> wave ballot inside the chunk: two DPP reductions + two ballots
+//     per step instead of a full-map softmax;
+//   * expansion  = lanes 0..7 each own one Moore neighbour (expand() of a one-hot == "touch <=8 cells", :77-93,
+//     :228-249); all LDS reads of a step are issued as one batch, no read-modify-write, no data-dependent branches.
 // Everything is fp32 with one rounding per reference op (TU compiled with -ffp-contract=off).
 #pragma once
 #include "nastar_device.hip.h"
@@ -34,10 +40,15 @@ struct MapLds {
     float* cost;
     float* hh;
     uint32_t* chunkmin;
-    uint8_t* meta;
+    uint8_t* pdir;
+    uint32_t* dump;  // 64 scratch words: lanes with nothing to write store here instead of branching around the store
 };
 
-__host__ __device__ inline size_t map_lds_bytes(int HWp, int NCp) { return (size_t)HWp * 17 + (size_t)NCp * 4; }
+constexpr uint32_t P_DIRMASK = 0x0Fu, P_PASS = 0x40u, P_PATH = 0x80u;
+#define NASTAR_POS_INF (__uint_as_float(0x7f800000u))
+#define NASTAR_NEG_INF (__uint_as_float(0xff800000u))
+
+__host__ __device__ inline size_t map_lds_bytes(int HWp, int NCp) { return (size_t)HWp * 17 + (size_t)NCp * 4 + 256; }
 
 __device__ __forceinline__ MapLds carve_map_lds(unsigned char* smem, const MapDims& d)
 {
@@ -47,12 +58,19 @@ __device__ __forceinline__ MapLds carve_map_lds(unsigned char* smem, const MapDi
     l.cost = l.g + d.HWp;
     l.hh = l.cost + d.HWp;
     l.chunkmin = reinterpret_cast<uint32_t*>(l.hh + d.HWp);
-    l.meta = reinterpret_cast<uint8_t*>(l.chunkmin + d.NCp);
+    l.dump = l.chunkmin + d.NCp;
+    l.pdir = reinterpret_cast<uint8_t*>(l.dump + 64);
     return l;
 }
 
 // single-wave workgroup: this is a scheduling + LDS-visibility point, not an s_barrier
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+__device__ __forceinline__ uint32_t make_key(const MapDims& d, float g2, float hh)
+{
+    const float f = d.gr * g2 + hh;       // :206  f = g_ratio*g + (1-g_ratio)*h   (two roundings, no FMA)
+    return f32_to_ord(f / d.sqrtW);       // :207  -1*f / sqrt(W): IEEE fp32 division (negation is exact)
+}
 
 // ---- load one map from HBM into LDS; returns start / goal flat indices (wave-uniform) -------------------------
 template <bool kVec4>
@@ -103,18 +121,23 @@ __device__ __forceinline__ void load_map(const MapDims& d, const MapLds& l, cons
             int i = q << 2;
             int r = (int)div_magic((uint32_t)i, d.magicW);
             int c = i - r * d.W;  // W % 4 == 0: the four cells share a row
-            float4 hv;
+            float4 hv, gv;
             hv.x = d.omg * (heuristic0(r, c, goal_r, goal_c) + cv.x);  // :191-192 h = h0 + cost ; :206 (1-g_ratio)*h
             hv.y = d.omg * (heuristic0(r, c + 1, goal_r, goal_c) + cv.y);
             hv.z = d.omg * (heuristic0(r, c + 2, goal_r, goal_c) + cv.z);
             hv.w = d.omg * (heuristic0(r, c + 3, goal_r, goal_c) + cv.w);
+            gv.x = pv.x != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
+            gv.y = pv.y != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
+            gv.z = pv.z != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
+            gv.w = pv.w != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
             *reinterpret_cast<float4*>(l.cost + i) = cv;
             *reinterpret_cast<float4*>(l.hh + i) = hv;
+            *reinterpret_cast<float4*>(l.g + i) = gv;
             *reinterpret_cast<uint4*>(l.key + i) = make_uint4(KEY_INF, KEY_INF, KEY_INF, KEY_INF);
-            const uint32_t un = PARENT_UNSET << 4;
-            uint32_t m = (un | (pv.x != 0.f ? M_PASS : 0u)) | ((un | (pv.y != 0.f ? M_PASS : 0u)) << 8) |
-                         ((un | (pv.z != 0.f ? M_PASS : 0u)) << 16) | ((un | (pv.w != 0.f ? M_PASS : 0u)) << 24);
-            *reinterpret_cast<uint32_t*>(l.meta + i) = m;
+            uint32_t m = (PARENT_UNSET | (pv.x != 0.f ? P_PASS : 0u)) | ((PARENT_UNSET | (pv.y != 0.f ? P_PASS : 0u)) << 8) |
+                         ((PARENT_UNSET | (pv.z != 0.f ? P_PASS : 0u)) << 16) |
+                         ((PARENT_UNSET | (pv.w != 0.f ? P_PASS : 0u)) << 24);
+            *reinterpret_cast<uint32_t*>(l.pdir + i) = m;
         }
     } else {
         for (int i = lane; i < d.HW; i += 64) {
@@ -124,8 +147,9 @@ __device__ __forceinline__ void load_map(const MapDims& d, const MapLds& l, cons
             int c = i - r * d.W;
             l.cost[i] = cv;
             l.hh[i] = d.omg * (heuristic0(r, c, goal_r, goal_c) + cv);
+            l.g[i] = pv != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
             l.key[i] = KEY_INF;
-            l.meta[i] = (uint8_t)((PARENT_UNSET << 4) | (pv != 0.f ? M_PASS : 0u));
+            l.pdir[i] = (uint8_t)(PARENT_UNSET | (pv != 0.f ? P_PASS : 0u));
         }
     }
     for (int i = d.HW + lane; i < d.HWp; i += 64) l.key[i] = KEY_INF;  // tail padding of the last chunk
@@ -133,28 +157,47 @@ __device__ __forceinline__ void load_map(const MapDims& d, const MapLds& l, cons
     wave_sync();
     // open list = {start} (:187), g[start] = 0 (:193)
     if (lane == 0 && sidx >= 0) {
-        float f0 = d.gr * 0.0f + l.hh[sidx];
-        uint32_t k0 = f32_to_ord(f0 / d.sqrtW);
+        const uint32_t k0 = make_key(d, 0.0f, l.hh[sidx]);
         l.g[sidx] = 0.0f;
         l.key[sidx] = k0;
-        l.meta[sidx] = (uint8_t)(l.meta[sidx] | M_OPEN);
         l.chunkmin[sidx >> 6] = k0;
+        l.pdir[sidx] = (uint8_t)(PARENT_UNSET | P_PASS);  // the start is expanded even if it sits on an obstacle (:187)
     }
     wave_sync();
 }
 
+// per-lane constants of the expansion: lane j < 8 owns Moore neighbour j
+struct LaneConst {
+    int dr, dc;   // neighbour offset of this lane (lanes >= 8: 0,0)
+    int off;      // dr * W + dc
+    bool is_nb;   // lane < 8
+    uint32_t pcode;  // pdir byte this lane writes when it relaxes its neighbour
+};
+
+__device__ __forceinline__ LaneConst make_lane_const(const MapDims& d, int lane)
+{
+    LaneConst lc;
+    neighbour_delta(lane & 7, lc.dr, lc.dc);
+    lc.is_nb = lane < 8;
+    lc.off = lc.dr * d.W + lc.dc;
+    lc.pcode = P_PASS | (uint32_t)(lane & 7);
+    return lc;
+}
+
+// LDS accesses of one wavefront execute in program order, so the hand-off between the lanes of a step needs no
+// s_waitcnt -- only a compiler-level ordering point.
+__device__ __forceinline__ void wave_order() { __builtin_amdgcn_wave_barrier(); }
+
 // ---- selection: first flat index of the minimal key; returns -1 when the open list is empty ------------------
 // On return kv is the key this lane read from the selected chunk C (lane cl holds the selected cell).
 template <bool kMultiChunk>
-__device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int lane, int& C, int& cl, uint32_t& kv,
-                                          uint32_t& M)
+__device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int lane, int& C, int& cl, uint32_t& kv)
 {
+    uint32_t Mv;  // the minimum, replicated in every lane
     if constexpr (!kMultiChunk) {
-        uint32_t cm = l.chunkmin[lane];
-        M = wave_min_u32(cm);
-        if (M == KEY_INF) return -1;
-        unsigned long long bal = __ballot(cm == M);
-        C = __builtin_ctzll(bal);
+        const uint32_t cm = l.chunkmin[lane];
+        Mv = wave_min_all_u32(cm);
+        C = __builtin_ctzll(__ballot(cm == Mv) | (1ull << 63));
     } else {
         uint32_t best = KEY_INF;
         int bestc = 0x7fffffff;
@@ -162,55 +205,73 @@ __device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int
             uint32_t v = l.chunkmin[c];
             if (v < best) { best = v; bestc = c; }
         }
-        M = wave_min_u32(best);
-        if (M == KEY_INF) return -1;
-        C = (int)wave_min_u32(best == M ? (uint32_t)bestc : 0x7fffffffu);
+        Mv = wave_min_all_u32(best);
+        C = (int)__builtin_amdgcn_readfirstlane((int)wave_min_all_u32(best == Mv ? (uint32_t)bestc : 0x7fffffffu));
+        if (C >= d.nchunks) C = 0;
     }
     kv = l.key[C * CHUNK + lane];
-    unsigned long long bal2 = __ballot(kv == M);
-    cl = __builtin_ctzll(bal2);
+    const unsigned long long hit = __ballot(kv == Mv && Mv != KEY_INF);
+    if (hit == 0) return -1;  // open list empty (every chunk minimum is KEY_INF)
+    cl = __builtin_ctzll(hit);
     return C * CHUNK + cl;
 }
 
 // ---- close s (:222-225) and relax its <=8 Moore neighbours (:228-249) --------------------------------------
-__device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds& l, int lane, int s, int C, int cl,
-                                                 uint32_t kv, bool keep_open)
+// keep_open: the selected node is the goal being stepped at its fixed point (backward only, :224).
+// LOGW > 0: W == 1 << LOGW at compile time.
+template <int LOGW, bool kFastDiv>
+__device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds& l, const LaneConst& lc, int lane, int s,
+                                                 int C, int cl, uint32_t kv, bool keep_open, float rcp_sqrtW)
 {
+    int r, c;
+    if constexpr (LOGW) {
+        r = s >> LOGW;
+        c = s & ((1 << LOGW) - 1);
+    } else {
+        r = (int)div_magic((uint32_t)s, d.magicW);
+        c = s - r * d.W;
+    }
+    // one batch of LDS reads: g[s*], cost[s*] (broadcast) and each neighbour lane's g[n], hh[n]
+    const int nr = r + lc.dr, nc = c + lc.dc;
+    const bool inb = lc.is_nb && ((unsigned)nr < (unsigned)d.H) && ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+    const int n = inb ? s + lc.off : s;
+    const float gs = l.g[s];
+    const float cs = l.cost[s];
+    const float gn = l.g[n];
+    const float hn = l.hh[n];
+    // chunk minimum without s (independent of the reads above, overlaps their latency)
+    const uint32_t nm = wave_min_all_u32(lane == cl ? KEY_INF : kv);
     // g2 = g[s*] + cost[s*]  (:234: expand((g + cost_maps) * selected)) -- step cost of the node being LEFT
-    const float g2 = l.g[s] + l.cost[s];
-    if (!keep_open) {
-        const uint32_t nm = wave_min_u32(lane == cl ? KEY_INF : kv);  // chunk minimum without s
-        if (lane == 0) {
-            l.key[s] = KEY_INF;
-            l.chunkmin[C] = nm;
-            l.meta[s] = (uint8_t)((l.meta[s] & ~M_OPEN) | M_CLOSED);
-        }
-    } else if (lane == 0) {
-        l.meta[s] = (uint8_t)(l.meta[s] | M_CLOSED);  // a reached goal stays on the open list (:224)
+    const float g2 = gs + cs;
+    // :229,:235  neighbour is passable, not closed, and (not open, or open with g > g2)   <=>   g[n] > g2
+    const bool upd = inb && (gn > g2);
+    const float f = d.gr * g2 + hn;   // :206  f = g_ratio*g + (1-g_ratio)*h   (two roundings, no FMA)
+    float q;
+    if constexpr (kFastDiv) {
+        // correctly rounded f / sqrt(W) for f >= 2^-100 (exhaustively verified per W, tools/fastdiv_check.c):
+        // q0 = RN(f*y), rem = f - q0*b exactly (FMA), q = RN(q0 + rem*y)
+        const float q0 = f * rcp_sqrtW;
+        const float rem = __builtin_fmaf(-q0, d.sqrtW, f);
+        q = __builtin_fmaf(rem, rcp_sqrtW, q0);
+    } else {
+        q = f / d.sqrtW;               // :207  -1*f / sqrt(W): IEEE fp32 division (negation is exact)
     }
-    const int r = (int)div_magic((uint32_t)s, d.magicW);
-    const int c = s - r * d.W;
-    if (lane < 8) {
-        int dr, dc;
-        neighbour_delta(lane, dr, dc);
-        const int nr = r + dr, nc = c + dc;
-        if ((unsigned)nr < (unsigned)d.H && (unsigned)nc < (unsigned)d.W) {  // zero padding of conv2d, no wrap
-            const int n = s + dr * d.W + dc;
-            const uint32_t m = l.meta[n];
-            if ((m & M_PASS) && !(m & M_CLOSED)) {                            // :229 * obstacles ; (1 - histories)
-                const bool is_open = (m & M_OPEN) != 0;
-                if (!is_open || l.g[n] > g2) {                                 // :235 idx
-                    const float f = d.gr * g2 + l.hh[n];                       // :206 for the next selection
-                    const uint32_t k = f32_to_ord(f / d.sqrtW);                // :207 IEEE fp32 division
-                    l.g[n] = g2;                                               // :238
-                    l.key[n] = k;
-                    l.meta[n] = (uint8_t)(M_PASS | M_OPEN | ((uint32_t)lane << 4));  // :242 open ; :246-249 parent = s*
-                    atomicMin(&l.chunkmin[n >> 6], k);
-                }
-            }
-        }
-    }
-    wave_sync();
+    const uint32_t k = f32_to_ord(q);
+    // All stores are unconditional: a lane with nothing to write targets its private dump word, so the step has no
+    // exec-mask regions / skip branches.  Lane 8 closes s*, lane 9 publishes the chunk minimum without s*.
+    const bool closer = (lane == 8) && !keep_open;
+    uint32_t* const dmp = l.dump + lane;
+    float* const g_dst = upd ? &l.g[n] : (closer ? &l.g[s] : reinterpret_cast<float*>(dmp));
+    uint32_t* const k_dst = upd ? &l.key[n] : (closer ? &l.key[s] : dmp);
+    uint8_t* const p_dst = upd ? &l.pdir[n] : reinterpret_cast<uint8_t*>(dmp);
+    uint32_t* const c_dst = ((lane == 9) && !keep_open) ? &l.chunkmin[C] : dmp;
+    uint32_t* const a_dst = upd ? &l.chunkmin[n >> 6] : dmp;
+    *g_dst = upd ? g2 : NASTAR_NEG_INF;      // :238 g update          | :222-223 s* joins the closed list
+    *k_dst = upd ? k : KEY_INF;              // :242 (re)opened        | :224 s* leaves the open list
+    *p_dst = (uint8_t)lc.pcode;              // :246-249 parent = s*
+    *c_dst = nm;                             // chunk minimum of C without s* (before the atomics below)
+    atomicMin(a_dst, k);
+    wave_order();
 }
 
 // parent of cell n from its direction code (code j means "n is neighbour j of its parent")
@@ -221,7 +282,7 @@ __device__ __forceinline__ int parent_of(const MapDims& d, int n, uint32_t code)
     return n - (dr * d.W + dc);
 }
 
-// ---- backtrack (differentiable_astar.py:96-125): mark M_PATH from the goal towards the start ------------------
+// ---- backtrack (differentiable_astar.py:96-125): mark P_PATH from the goal towards the start ------------------
 // The reference walks exactly t_batch steps; once the start is reached the walk re-enters the same cycle
 // (parents[start] keeps its initial value goal_idx), so stopping at the start is equivalent as long as at most
 // `cap` steps are taken (cap = own step count - 1 matters only when the Tmax budget ran out).
@@ -229,16 +290,16 @@ __device__ __forceinline__ void backtrack(const MapDims& d, const MapLds& l, int
                                           int cap)
 {
     if (lane == 0) {
-        uint32_t m = l.meta[goal_idx];
-        l.meta[goal_idx] = (uint8_t)(m | M_PATH);
-        uint32_t code = m >> 4;
+        uint32_t m = l.pdir[goal_idx];
+        l.pdir[goal_idx] = (uint8_t)(m | P_PATH);
+        uint32_t code = m & P_DIRMASK;
         if (code != PARENT_UNSET) {
             int loc = parent_of(d, goal_idx, code);
             for (int k = 0; k < cap; ++k) {
-                uint32_t ml = l.meta[loc];
-                l.meta[loc] = (uint8_t)(ml | M_PATH);
+                uint32_t ml = l.pdir[loc];
+                l.pdir[loc] = (uint8_t)(ml | P_PATH);
                 if (loc == start_idx) break;
-                uint32_t cd = ml >> 4;
+                uint32_t cd = ml & P_DIRMASK;
                 if (cd == PARENT_UNSET) break;  // cannot happen for an opened non-start node
                 loc = parent_of(d, loc, cd);
             }
@@ -248,6 +309,7 @@ __device__ __forceinline__ void backtrack(const MapDims& d, const MapLds& l, int
 }
 
 // ---- write AstarOutput.histories (fp32 0/1) and .paths (int64 0/1) with 16-byte coalesced stores --------------
+// closed <=> g == -inf on a passable cell.
 template <bool kVec4>
 __device__ __forceinline__ void store_outputs(const MapDims& d, const MapLds& l, int lane, float* __restrict__ hist,
                                               long long* __restrict__ paths)
@@ -256,28 +318,29 @@ __device__ __forceinline__ void store_outputs(const MapDims& d, const MapLds& l,
         const int n4 = d.HW >> 2;
         float4* h4 = reinterpret_cast<float4*>(hist);
         for (int q = lane; q < n4; q += 64) {
-            uint32_t m = *reinterpret_cast<const uint32_t*>(l.meta + (q << 2));
+            const uint32_t m = *reinterpret_cast<const uint32_t*>(l.pdir + (q << 2));
+            const float4 gv = *reinterpret_cast<const float4*>(l.g + (q << 2));
             float4 v;
-            v.x = (m & M_CLOSED) ? 1.0f : 0.0f;
-            v.y = (m & (M_CLOSED << 8)) ? 1.0f : 0.0f;
-            v.z = (m & (M_CLOSED << 16)) ? 1.0f : 0.0f;
-            v.w = (m & (M_CLOSED << 24)) ? 1.0f : 0.0f;
+            v.x = ((m & P_PASS) && gv.x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.y = ((m & (P_PASS << 8)) && gv.y == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.z = ((m & (P_PASS << 16)) && gv.z == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.w = ((m & (P_PASS << 24)) && gv.w == NASTAR_NEG_INF) ? 1.0f : 0.0f;
             h4[q] = v;
         }
         const int n2 = d.HW >> 1;
         longlong2* p2 = reinterpret_cast<longlong2*>(paths);
         for (int q = lane; q < n2; q += 64) {
-            uint32_t m = *reinterpret_cast<const uint16_t*>(l.meta + (q << 1));
+            const uint32_t m = *reinterpret_cast<const uint16_t*>(l.pdir + (q << 1));
             longlong2 v;
-            v.x = (m & M_PATH) ? 1 : 0;
-            v.y = (m & (M_PATH << 8)) ? 1 : 0;
+            v.x = (m & P_PATH) ? 1 : 0;
+            v.y = (m & (P_PATH << 8)) ? 1 : 0;
             p2[q] = v;
         }
     } else {
         for (int i = lane; i < d.HW; i += 64) {
-            uint32_t m = l.meta[i];
-            hist[i] = (m & M_CLOSED) ? 1.0f : 0.0f;
-            paths[i] = (m & M_PATH) ? 1 : 0;
+            const uint32_t m = l.pdir[i];
+            hist[i] = ((m & P_PASS) && l.g[i] == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            paths[i] = (m & P_PATH) ? 1 : 0;
         }
     }
 }

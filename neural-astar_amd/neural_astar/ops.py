@@ -6,6 +6,7 @@ the hand-written HIP kernel.  There is no CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -29,6 +30,10 @@ def _require_device(*tensors: torch.Tensor) -> None:
                 "fallback for the A* search (the reference's CPU path is the oracle under oracle/, test-only).")
         if t.dtype != torch.float32:
             raise TypeError(f"expected float32 maps, got {t.dtype}")
+
+
+# development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
+FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -61,7 +66,7 @@ def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, p
         rc = lib.nastar_forward(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
                                 float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
                                 sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
-                                None, 0, 0, _stream_ptr(dev))
+                                None, 0, FORWARD_FLAGS, _stream_ptr(dev))
     _native.check(rc, "nastar_forward")
     return hist, paths, iters, status, sel_log
 
