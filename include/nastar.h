@@ -96,6 +96,10 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
 /* h0 = get_heuristic(goal) for B maps: out [B,H,W] fp32 (parity/debug; the forward computes it on the fly). */
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream);
 
+/* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
+ * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */
+int nastar_debug_occupancy(int H, int W, int* lds_bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -420,6 +420,20 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
     return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
 }
 
+int nastar_debug_occupancy(int H, int W, int* lds_bytes_out)
+{
+    MapDims d;
+    if (make_dims(1, H, W, 1, 0.5, d)) return -1;
+    const size_t lds = map_lds_bytes(d.HWp, d.NCp);
+    if (lds_bytes_out) *lds_bytes_out = (int)lds;
+    if (lds > kMaxLdsBytes) return 0;
+    void (*kern)(const FwdArgs, const float) = &nastar_forward_kernel<true, false, 0, false, false>;
+    if (ensure_lds(kern, lds)) return -1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, lds) != hipSuccess) return -1;
+    return nb;
+}
+
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream)
 {
     if (!goal || !h0_out) return NASTAR_ERR_NULL;

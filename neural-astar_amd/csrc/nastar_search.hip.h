@@ -194,8 +194,10 @@ template <bool kMultiChunk>
 __device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int lane, int& C, int& cl, uint32_t& kv)
 {
     uint32_t Mv;  // the minimum, replicated in every lane
+    unsigned long long any_open;
     if constexpr (!kMultiChunk) {
         const uint32_t cm = l.chunkmin[lane];
+        any_open = __ballot(cm != KEY_INF);
         Mv = wave_min_all_u32(cm);
         C = __builtin_ctzll(__ballot(cm == Mv) | (1ull << 63));
     } else {
@@ -205,14 +207,14 @@ __device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int
             uint32_t v = l.chunkmin[c];
             if (v < best) { best = v; bestc = c; }
         }
+        any_open = __ballot(best != KEY_INF);
         Mv = wave_min_all_u32(best);
         C = (int)__builtin_amdgcn_readfirstlane((int)wave_min_all_u32(best == Mv ? (uint32_t)bestc : 0x7fffffffu));
         if (C >= d.nchunks) C = 0;
     }
     kv = l.key[C * CHUNK + lane];
-    const unsigned long long hit = __ballot(kv == Mv && Mv != KEY_INF);
-    if (hit == 0) return -1;  // open list empty (every chunk minimum is KEY_INF)
-    cl = __builtin_ctzll(hit);
+    if (any_open == 0) return -1;  // open list empty (every chunk minimum is KEY_INF)
+    cl = __builtin_ctzll(__ballot(kv == Mv) | (1ull << 63));
     return C * CHUNK + cl;
 }
 
@@ -233,7 +235,7 @@ __device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds&
     }
     // one batch of LDS reads: g[s*], cost[s*] (broadcast) and each neighbour lane's g[n], hh[n]
     const int nr = r + lc.dr, nc = c + lc.dc;
-    const bool inb = lc.is_nb && ((unsigned)nr < (unsigned)d.H) && ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+    const bool inb = lc.is_nb & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
     const int n = inb ? s + lc.off : s;
     const float gs = l.g[s];
     const float cs = l.cost[s];
@@ -244,7 +246,7 @@ __device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds&
     // g2 = g[s*] + cost[s*]  (:234: expand((g + cost_maps) * selected)) -- step cost of the node being LEFT
     const float g2 = gs + cs;
     // :229,:235  neighbour is passable, not closed, and (not open, or open with g > g2)   <=>   g[n] > g2
-    const bool upd = inb && (gn > g2);
+    const bool upd = inb & (gn > g2);
     const float f = d.gr * g2 + hn;   // :206  f = g_ratio*g + (1-g_ratio)*h   (two roundings, no FMA)
     float q;
     if constexpr (kFastDiv) {

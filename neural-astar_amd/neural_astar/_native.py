@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "nastar_forward",
     "nastar_backward",
     "nastar_heuristic",
+    "nastar_debug_occupancy",
 )
 
 
@@ -79,6 +80,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_heuristic.restype = ci
     lib.nastar_heuristic.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.nastar_debug_occupancy.restype = ci
+    lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib
     return lib
 
