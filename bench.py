@@ -157,16 +157,19 @@ def main():
     ap.add_argument("--workload", default="maze32", choices=["maze32", "rand32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
+    ap.add_argument("--force-collate", action="store_true",
+                    help="dev: run the N>1 collation path (pack kernel + all-gather) in a 1-rank RCCL group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_collate:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
     dev = torch.device("cuda", local_rank)
@@ -177,13 +180,14 @@ def main():
 
     collate = None
     collate_note = "n/a (single GPU)"
-    if world > 1 and not args.no_collate:
+    if (world > 1 or args.force_collate) and not args.no_collate:
         from neural_astar import parallel
         from neural_astar.planner.differentiable_astar import AstarOutput
 
         def collate(pending):
             # all-gather of step i overlaps the search of step i+1: wait for the previous one only now
-            _, fin = parallel.all_gather_output(AstarOutput(run.hist.unsqueeze(1), run.paths.unsqueeze(1)), async_op=True)
+            _, fin = parallel.all_gather_output(AstarOutput(run.hist.unsqueeze(1), run.paths.unsqueeze(1)), async_op=True,
+                                                    unpack=False)
             if pending is not None:
                 pending()
             return fin
@@ -191,7 +195,8 @@ def main():
             run.step()
             collate(None)()
             torch.cuda.synchronize(dev)
-            collate_note = "1 RCCL all-gather of bit-packed histories+paths per step, overlapped"
+            collate_note = ("1 HIP pack kernel + 1 RCCL all-gather of bit-packed histories+paths per step (kept packed), "
+                            "overlapped with the next step's search")
         except Exception as e:  # reported, not hidden: the line then says the collective was not part of the step
             collate = None
             collate_note = f"FAILED ({type(e).__name__}: {e}); steps timed without the all-gather"
@@ -242,7 +247,7 @@ def main():
                                 "launch_ms_avg": a2, "hbm_frac": BYTES_PER_MAP * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "mean_iters_per_map": float(run2.iters.float().mean().item())}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_collate:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,6 +12,7 @@
  *                              (what loss.backward() runs in utils/training.py:55-61)
  *   nastar_heuristic        <- get_heuristic                 differentiable_astar.py:26-52 (debug/parity)
  *   nastar_workspace_bytes  <- (new) workspace sizing; PyTorch owns every allocation
+ *   nastar_pack_outputs / nastar_unpack_outputs <- (new) multi-GPU collation payload, see below
  *
  * Conventions
  *   - plain C types only; the caller owns every buffer (inputs, outputs, workspace); no allocation and no
@@ -95,6 +96,16 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
 
 /* h0 = get_heuristic(goal) for B maps: out [B,H,W] fp32 (parity/debug; the forward computes it on the fly). */
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream);
+
+/*
+ * AstarOutput <-> bit-packed masks: the payload of the multi-GPU collation (one RCCL all-gather of 2 bits per cell
+ * instead of the reference's fp32 + int64 = 12 bytes per cell).
+ *   packed [B, 2*ceil(H*W/8)] uint8: row b = histories bits then path bits of map b, most significant bit first.
+ */
+int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out,
+                        void* stream);
+int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* histories_out, int64_t* paths_out,
+                          void* stream);
 
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */

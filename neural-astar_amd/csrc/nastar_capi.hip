@@ -245,6 +245,46 @@ __global__ __launch_bounds__(64) void nastar_heuristic_kernel(const float* goal,
     }
 }
 
+// ---- AstarOutput <-> bit-packed masks (what the multi-GPU all-gather moves: 2 bits per cell instead of 12 bytes) ----
+// packed row layout: [ceil(HW/8) bytes of histories bits | ceil(HW/8) bytes of path bits], MSB = first cell (numpy.packbits)
+__global__ __launch_bounds__(256) void nastar_pack_kernel(const float* __restrict__ hist, const long long* __restrict__ paths,
+                                                          uint8_t* __restrict__ packed, int B, int HW, int nb)
+{
+    const long long total = (long long)B * nb;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / nb), j = (int)(t - (long long)b * nb);
+        const size_t base = (size_t)b * HW + (size_t)j * 8;
+        uint32_t hb = 0, pb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (j * 8 + k < HW) {
+                hb |= (hist[base + k] != 0.f ? 1u : 0u) << (7 - k);
+                pb |= (paths[base + k] != 0 ? 1u : 0u) << (7 - k);
+            }
+        }
+        packed[(size_t)b * 2 * nb + j] = (uint8_t)hb;
+        packed[(size_t)b * 2 * nb + nb + j] = (uint8_t)pb;
+    }
+}
+
+__global__ __launch_bounds__(256) void nastar_unpack_kernel(const uint8_t* __restrict__ packed, float* __restrict__ hist,
+                                                            long long* __restrict__ paths, int B, int HW, int nb)
+{
+    const long long total = (long long)B * nb;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / nb), j = (int)(t - (long long)b * nb);
+        const uint32_t hb = packed[(size_t)b * 2 * nb + j], pb = packed[(size_t)b * 2 * nb + nb + j];
+        const size_t base = (size_t)b * HW + (size_t)j * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (j * 8 + k < HW) {
+                hist[base + k] = ((hb >> (7 - k)) & 1u) ? 1.0f : 0.0f;
+                paths[base + k] = (pb >> (7 - k)) & 1u;
+            }
+        }
+    }
+}
+
 static thread_local char g_last_error[256] = "";
 
 static int hip_fail(hipError_t e, const char* what)
@@ -418,6 +458,34 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
     if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, B, lds, s, a);
     if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
     return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
+}
+
+int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out, void* stream)
+{
+    if (!histories || !paths || !packed_out) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    const int HW = H * W, nb = (HW + 7) / 8;
+    const long long total = (long long)B * nb;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nastar_pack_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), histories,
+                       reinterpret_cast<const long long*>(paths), packed_out, B, HW, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* histories_out, int64_t* paths_out, void* stream)
+{
+    if (!histories_out || !paths_out || !packed) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    const int HW = H * W, nb = (HW + 7) / 8;
+    const long long total = (long long)B * nb;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nastar_unpack_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), packed,
+                       histories_out, reinterpret_cast<long long*>(paths_out), B, HW, nb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
 }
 
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out)

@@ -41,6 +41,8 @@ EXPORTED_SYMBOLS = (
     "nastar_backward",
     "nastar_heuristic",
     "nastar_debug_occupancy",
+    "nastar_pack_outputs",
+    "nastar_unpack_outputs",
 )
 
 
@@ -80,6 +82,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_heuristic.restype = ci
     lib.nastar_heuristic.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.nastar_pack_outputs.restype = ci
+    lib.nastar_pack_outputs.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    lib.nastar_unpack_outputs.restype = ci
+    lib.nastar_unpack_outputs.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     lib.nastar_debug_occupancy.restype = ci
     lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib

@@ -30,10 +30,25 @@ def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def pack_masks(histories: torch.Tensor, paths: torch.Tensor) -> torch.Tensor:
-    """[B,1,H,W] fp32 0/1 + [B,1,H,W] int64 0/1 -> [B, 2*ceil(HW/8)] uint8 (histories bits, then path bits)."""
+    """[B,1,H,W] fp32 0/1 + [B,1,H,W] int64 0/1 -> [B, 2*ceil(HW/8)] uint8 (histories bits, then path bits).
+
+    Device tensors go through ``nastar_pack_outputs`` (one HIP kernel on the current stream); host tensors (the gloo
+    tests) use the equivalent torch expression below."""
     B = histories.shape[0]
     hw = histories[0].numel()
     nb = (hw + 7) // 8
+    if histories.is_cuda:
+        from . import _native
+        lib = _native.load()
+        H, W = histories.shape[-2:]
+        h = histories.contiguous()
+        p = paths.contiguous()
+        out = torch.empty((B, 2 * nb), dtype=torch.uint8, device=h.device)
+        with torch.cuda.device(h.device):
+            rc = lib.nastar_pack_outputs(h.data_ptr(), p.data_ptr(), B, H, W, out.data_ptr(),
+                                         torch.cuda.current_stream(h.device).cuda_stream)
+        _native.check(rc, "nastar_pack_outputs")
+        return out
     w = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=histories.device)
 
     def pk(x: torch.Tensor) -> torch.Tensor:
@@ -50,6 +65,17 @@ def unpack_masks(packed: torch.Tensor, H: int, W: int) -> Tuple[torch.Tensor, to
     B = packed.shape[0]
     hw = H * W
     nb = (hw + 7) // 8
+    if packed.is_cuda:
+        from . import _native
+        lib = _native.load()
+        pk = packed.contiguous()
+        hist = torch.empty((B, 1, H, W), dtype=torch.float32, device=pk.device)
+        paths = torch.empty((B, 1, H, W), dtype=torch.int64, device=pk.device)
+        with torch.cuda.device(pk.device):
+            rc = lib.nastar_unpack_outputs(pk.data_ptr(), B, H, W, hist.data_ptr(), paths.data_ptr(),
+                                           torch.cuda.current_stream(pk.device).cuda_stream)
+        _native.check(rc, "nastar_unpack_outputs")
+        return hist, paths
     shifts = torch.tensor([7, 6, 5, 4, 3, 2, 1, 0], dtype=torch.uint8, device=packed.device)
 
     def un(x: torch.Tensor) -> torch.Tensor:
@@ -60,21 +86,26 @@ def unpack_masks(packed: torch.Tensor, H: int, W: int) -> Tuple[torch.Tensor, to
 
 
 def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = None,
-                      async_op: bool = False):
+                      async_op: bool = False, unpack: bool = True):
     """Collate the per-rank ``AstarOutput`` of equally sized shards with ONE all-gather (RCCL on GPUs).
 
     Returns ``AstarOutput`` of the full batch (rank-major row order), or, with ``async_op=True``, a tuple
     ``(work, finish)`` where ``finish()`` waits and returns the collated output -- lets the caller overlap the
-    collective with the next batch's search on the compute stream."""
+    collective with the next batch's search on the compute stream.  ``unpack=False`` keeps the collated batch in its
+    bit-packed form (``[world*B, 2*ceil(HW/8)] uint8``; :func:`unpack_masks` materialises the reference's fp32 / int64
+    tensors on demand): expanding 2 bits per cell to 12 bytes per cell for the whole global batch on every rank is the
+    expensive part of the collation and few consumers need it."""
     H, W = out.histories.shape[-2:]
     packed = pack_masks(out.histories.detach(), out.paths)
     world = dist.get_world_size(group)
     gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.uint8, device=packed.device)
     work = dist.all_gather_into_tensor(gathered, packed, group=group, async_op=async_op)
 
-    def finish() -> AstarOutput:
+    def finish():
         if work is not None:
             work.wait()
+        if not unpack:
+            return gathered
         h, p = unpack_masks(gathered, H, W)
         return AstarOutput(h, p, None)
 

@@ -50,9 +50,17 @@ def test_native_library_loaded_and_heuristic_bit_exact():
     assert h[63, 62] == h[62, 63] == np.float32(1.0010000467300415) and h[63, 63] == 0
 
 
+LDS_CELL_LIMIT = (160 * 1024 - 512) // 17 - 64  # forward state is LDS-resident: 17 B/cell ("limits")
+
+
 @pytest.mark.parametrize("name", G.names())
 def test_forward_matches_reference_golden(name):
     g = G.load(name)
+    if g.H * g.W > LDS_CELL_LIMIT:
+        from neural_astar import _native
+        with pytest.raises(RuntimeError, match="not supported"):
+            _run_capi(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters)
+        pytest.skip(f"{g.H}x{g.W} exceeds the LDS-resident limit; the C ABI reports NASTAR_ERR_UNSUPPORTED (checked)")
     hist, paths, iters, status, log = _run_capi(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio,
                                                 g.max_iters, want_log=g.sel_log is not None)
     assert (status == 0).all()
@@ -185,3 +193,18 @@ def test_full_size_properties_b4096():
     # and a 256-row slice against the dense oracle
     o = O.forward(pr.map_designs[:256], pr.start_maps[:256], pr.goal_maps[:256], pr.map_designs[:256], 0.5, 1024)
     assert np.array_equal(hist[:256], o.histories) and np.array_equal(paths[:256], o.paths)
+
+
+def test_pack_unpack_kernels_match_host_expression():
+    """nastar_pack_outputs / nastar_unpack_outputs (multi-GPU collation payload) vs the torch expression used on CPU."""
+    from neural_astar import parallel
+    rng = np.random.Generator(np.random.PCG64(0))
+    for (H, W, B) in [(32, 32, 64), (20, 45, 7), (7, 5, 3), (64, 64, 16)]:
+        h = (rng.random((B, 1, H, W)) > 0.5).astype(np.float32)
+        p = (rng.random((B, 1, H, W)) > 0.5).astype(np.int64)
+        host = parallel.pack_masks(torch.from_numpy(h), torch.from_numpy(p))
+        dev = parallel.pack_masks(_t(h), _t(p))
+        assert torch.equal(dev.cpu(), host)
+        h2, p2 = parallel.unpack_masks(dev, H, W)
+        assert np.array_equal(h2.cpu().numpy(), h) and np.array_equal(p2.cpu().numpy(), p)
+        assert h2.dtype == torch.float32 and p2.dtype == torch.int64
