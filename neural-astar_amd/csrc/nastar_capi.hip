@@ -8,6 +8,7 @@
 #include "../../include/nastar.h"
 #include "nastar_search.hip.h"
 #include "nastar_search_reg.hip.h"
+#include "nastar_search_global.hip.h"
 
 namespace nastar {
 
@@ -317,6 +318,15 @@ static int hip_fail(hipError_t e, const char* what)
     return NASTAR_ERR_HIP;
 }
 
+constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
+
+static bool needs_global_state(int H, int W)
+{
+    const long long HW = (long long)H * W;
+    const long long nchunks = (HW + 63) / 64;
+    return map_lds_bytes((int)(nchunks * 64), (int)(((nchunks + 63) / 64) * 64)) > kMaxLdsBytes;
+}
+
 static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
 {
     if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
@@ -395,8 +405,10 @@ const char* nastar_last_error(void) { return g_last_error; }
 
 size_t nastar_workspace_bytes(int B, int H, int W, int flags)
 {
-    (void)B; (void)H; (void)W; (void)flags;
-    return 0;  // the whole search state lives in LDS
+    (void)flags;
+    if (B <= 0 || H <= 0 || W <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
+    if (!needs_global_state(H, W)) return 0;  // the whole search state lives in LDS
+    return (size_t)B * global_slab_bytes(H * W);
 }
 
 int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
@@ -404,9 +416,28 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
                    int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                    size_t workspace_bytes, int flags, void* stream)
 {
-    (void)workspace; (void)workspace_bytes;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
+    if (B > 0 && H > 0 && W > 0 && max_iters > 0 && (long long)H * W <= kMaxGlobalCells && needs_global_state(H, W)) {
+        // large map: state in the caller's HBM workspace (nastar_search_global.hip.h)
+        const size_t slab = global_slab_bytes(H * W);
+        if (!workspace) return NASTAR_ERR_NULL;
+        if (workspace_bytes < (size_t)B * slab) return NASTAR_ERR_WORKSPACE;
+        FwdGlobalArgs ga;
+        ga.cost = cost; ga.start = start; ga.goal = goal; ga.passable = passable;
+        ga.hist = histories_out; ga.paths = reinterpret_cast<long long*>(paths_out);
+        ga.sel_log = sel_log_out; ga.iters = iters_out; ga.status = status_out;
+        ga.workspace = static_cast<unsigned char*>(workspace); ga.slab_bytes = slab; ga.max_iters = max_iters;
+        GlobalDims& gd = ga.d;
+        gd.H = H; gd.W = W; gd.HW = H * W;
+        gd.nchunks = (gd.HW + 63) / 64; gd.HWp = gd.nchunks * 64; gd.NC64 = ((gd.nchunks + 63) / 64) * 64;
+        gd.nsuper = gd.NC64 / 64;
+        gd.gr = (float)g_ratio; gd.omg = (float)(1.0 - g_ratio); gd.sqrtW = (float)sqrt((double)W);
+        hipLaunchKernelGGL(nastar_forward_global_kernel, dim3((unsigned)B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ga);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        return NASTAR_OK;
+    }
     FwdArgs a;
     int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
     if (rc) return rc;

@@ -62,11 +62,14 @@ def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, p
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     sel_log = (torch.full((B, max_iters), -1, dtype=torch.int32, device=dev) if want_log
                else torch.empty((0,), dtype=torch.int32, device=dev))
+    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, FORWARD_FLAGS))  # > 0 only for maps too large for LDS
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     with torch.cuda.device(dev):
         rc = lib.nastar_forward(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
                                 float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
                                 sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
-                                None, 0, FORWARD_FLAGS, _stream_ptr(dev))
+                                workspace.data_ptr() if workspace is not None else None, ws_bytes, FORWARD_FLAGS,
+                                _stream_ptr(dev))
     _native.check(rc, "nastar_forward")
     return hist, paths, iters, status, sel_log
 

@@ -28,6 +28,7 @@ def test_library_builds_loads_and_exports_everything():
         assert hasattr(lib, sym), sym
     assert lib.nastar_version() == 100
     assert lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
+    assert lib.nastar_workspace_bytes(2, 128, 128, 0) >= 2 * 128 * 128 * 17
     assert lib.nastar_last_error() == b""
 
 
@@ -39,7 +40,9 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_forward(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_forward(one, one, one, one, 1, 8, 8, 0.5, 0, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
-    assert lib.nastar_forward(one, one, one, one, 1, 512, 512, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward(one, one, one, one, 1, 128, 128, 0.5, 64, one, one, None, one, one, one, 16, 0, None) == _native.NASTAR_ERR_WORKSPACE
+    assert lib.nastar_forward(one, one, one, one, 1, 128, 128, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_backward(one, one, one, one, one, 1, 8, 8, 0.5, 64, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
 
