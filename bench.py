@@ -43,7 +43,14 @@ def make_problem(kind: str, B: int, seed: int):
     if os.path.exists(cache):
         z = np.load(cache)
         return syn.Problems(z["m"], z["s"], z["g"])
-    pr = syn.maze_maps(B, 32, seed=seed) if kind == "maze32" else syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
+    if kind == "maze32":
+        pr = syn.maze_maps(B, 32, seed=seed)
+    elif kind == "rand32":
+        pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
+    elif kind == "rand64":  # 64x64, p = 0.20 (the per-GPU shard of BASELINE config 4)
+        pr = syn.random_obstacle_maps(B, 64, 64, 0.20, seed=seed)
+    else:
+        raise ValueError(kind)
     try:
         np.savez(cache, m=pr.map_designs, s=pr.start_maps, g=pr.goal_maps)
     except OSError:
@@ -62,15 +69,16 @@ class Runner:
         self.m = torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous()
         self.s = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
         self.g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
-        self.B = self.m.shape[0]
-        self.hist = torch.empty((self.B, H, W), dtype=torch.float32, device=dev)
-        self.paths = torch.empty((self.B, H, W), dtype=torch.int64, device=dev)
+        self.B, self.H, self.W = self.m.shape
+        self.hist = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=dev)
+        self.paths = torch.empty((self.B, self.H, self.W), dtype=torch.int64, device=dev)
         self.iters = torch.empty((self.B,), dtype=torch.int32, device=dev)
         self.status = torch.empty((self.B,), dtype=torch.int32, device=dev)
 
     def step(self):
         rc = self.lib.nastar_forward(self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
-                                     self.B, H, W, G_RATIO, W * W, self.hist.data_ptr(), self.paths.data_ptr(), None,
+                                     self.B, self.H, self.W, G_RATIO, self.W * self.W, self.hist.data_ptr(),
+                                     self.paths.data_ptr(), None,
                                      self.iters.data_ptr(), self.status.data_ptr(), None, 0, 0,
                                      torch.cuda.current_stream(self.dev).cuda_stream)
         self._check(rc, "nastar_forward")
@@ -135,11 +143,12 @@ def cpu_baseline(pr, gpu_hist, gpu_paths):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     O.build()
-    n0 = min(64, pr.map_designs.shape[0])
+    n0 = min(128, pr.map_designs.shape[0])
+    O.forward(pr.map_designs[:8], pr.start_maps[:8], pr.goal_maps[:8], pr.map_designs[:8], G_RATIO, W * W)  # spin up the OpenMP team
     t0 = time.perf_counter()
     O.forward(pr.map_designs[:n0], pr.start_maps[:n0], pr.goal_maps[:n0], pr.map_designs[:n0], G_RATIO, W * W)
     rate0 = n0 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 12.0)))  # aim at ~12 s of CPU work
+    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 12.0)))  # aim at ~12 s of CPU work (bounded by the batch)
     t0 = time.perf_counter()
     o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], G_RATIO, W * W)
     dt = time.perf_counter() - t0
@@ -238,14 +247,22 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pr, hist, paths)
-            # secondary workload on the same GPU (not the headline): random obstacles, short searches
-            other = "rand32" if args.workload == "maze32" else "maze32"
-            run2 = Runner(make_problem(other, B_PER_GPU, seed=1234), dev)
-            dt2, _ = timed_loop(run2, args.steps, args.warmup, 1, dev)
-            a2, _, _ = kernel_launch_ms(run2, min(args.steps, 100), dev)
-            out["secondary"] = {"workload": other, "value": B_PER_GPU * args.steps / dt2, "unit": "maps/s",
-                                "launch_ms_avg": a2, "hbm_frac": BYTES_PER_MAP * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "mean_iters_per_map": float(run2.iters.float().mean().item())}
+        if n_gpus == 1:
+            # secondary workloads on the same GPU (not the headline): short searches and the 64x64 shard of config 4
+            sec = []
+            for other in ("maze32", "rand32", "rand64"):
+                if other == args.workload:
+                    continue
+                run2 = Runner(make_problem(other, B_PER_GPU, seed=1234), dev)
+                dt2, _ = timed_loop(run2, max(10, args.steps // 4), max(2, args.warmup // 4), 1, dev)
+                a2, _, _ = kernel_launch_ms(run2, max(10, min(args.steps // 4, 50)), dev)
+                nbytes = 28 * run2.H * run2.W * B_PER_GPU
+                sec.append({"workload": f"{other}: {B_PER_GPU} maps of {run2.H}x{run2.W}", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
+                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "mean_iters_per_map": float(run2.iters.float().mean().item()),
+                            "max_iters_per_map": int(run2.iters.max().item())})
+                del run2
+            out["secondary"] = sec
         print(json.dumps(out))
     if world > 1 or args.force_collate:
         dist.barrier()

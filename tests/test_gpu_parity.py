@@ -202,3 +202,63 @@ def test_pack_unpack_kernels_match_host_expression():
         h2, p2 = parallel.unpack_masks(dev, H, W)
         assert np.array_equal(h2.cpu().numpy(), h) and np.array_equal(p2.cpu().numpy(), p)
         assert h2.dtype == torch.float32 and p2.dtype == torch.int64
+
+
+def test_boundary_edge_cases_match_reference_semantics():
+    """B=1, multi-channel inputs (channel 0 is used, reference :177-180), non-contiguous views, start on an obstacle,
+    start adjacent to goal, g_ratio extremes -- all against the dense oracle."""
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    dev = _dev()
+    pr = syn.random_obstacle_maps(6, 24, 24, 0.2, seed=77)
+    cost = syn.random_costs(6, 24, 24, seed=78)
+    for gr in (0.0, 0.3, 1.0):
+        da = DifferentiableAstar(g_ratio=gr).to(dev).eval()
+        o = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, 24 * 24)
+        # (a) plain call
+        out = da(_t(cost), _t(pr.start_maps), _t(pr.goal_maps), _t(pr.map_designs))
+        assert np.array_equal(out.histories[:, 0].cpu().numpy(), o.histories) and np.array_equal(out.paths[:, 0].cpu().numpy(), o.paths)
+        # (b) extra channels + non-contiguous batch views: only channel 0 counts
+        c2 = torch.cat((_t(cost), torch.rand(6, 2, 24, 24, device=dev)), 1)
+        big = torch.zeros(12, 1, 24, 24, device=dev)
+        big[::2] = _t(pr.start_maps)
+        out2 = da(c2, big[::2], _t(pr.goal_maps), _t(pr.map_designs))
+        assert torch.equal(out2.histories, out.histories) and torch.equal(out2.paths, out.paths)
+        # (c) B = 1 (the reference's squeeze() quirk at :91-92 must not matter)
+        out1 = da(_t(cost[:1]), _t(pr.start_maps[:1]), _t(pr.goal_maps[:1]), _t(pr.map_designs[:1]))
+        assert torch.equal(out1.histories, out.histories[:1]) and torch.equal(out1.paths, out.paths[:1])
+    # start on an obstacle cell: the reference still expands it (open_maps = start_maps, :187)
+    m = np.ones((2, 1, 12, 12), np.float32)
+    m[:, 0, 5, 5] = 0
+    s = np.zeros_like(m)
+    g = np.zeros_like(m)
+    s[:, 0, 5, 5] = 1
+    g[0, 0, 5, 6] = 1  # goal adjacent to the start
+    g[1, 0, 11, 0] = 1
+    o = O.forward(m, s, g, m, 0.5, 144)
+    hist, paths, iters, status, _ = _run_capi(m, s, g, m, 0.5, 144)
+    assert (status == 0).all() and np.array_equal(hist, o.histories) and np.array_equal(paths, o.paths)
+    assert hist[0, 5, 5] == 1 and iters[0] == 2
+
+
+def test_module_train_eval_budget_and_state_dict_roundtrip():
+    """Tmax applies in training mode only (:200-202); the module's state dict survives a save/load cycle."""
+    import io
+    from neural_astar.planner import NeuralAstar
+    g = G.load("maze32_train_T025")
+    dev = _dev()
+    na = NeuralAstar(Tmax=0.25).to(dev)
+    buf = io.BytesIO()
+    torch.save(na.state_dict(), buf)
+    buf.seek(0)
+    nb = NeuralAstar(Tmax=0.25).to(dev)
+    nb.load_state_dict(torch.load(buf, weights_only=True), strict=True)
+    nb.astar.check_solvable = False
+    nb.train()
+    out_t = nb.astar(_t(g.map_designs), _t(g.start_maps), _t(g.goal_maps), _t(g.map_designs))
+    assert np.array_equal(out_t.histories.cpu().numpy(), g.histories) and np.array_equal(out_t.paths.cpu().numpy(), g.paths)
+    assert int(nb.astar.last_iters.max()) <= 256
+    nb.eval()
+    out_e = nb.astar(_t(g.map_designs), _t(g.start_maps), _t(g.goal_maps), _t(g.map_designs))
+    assert int(nb.astar.last_iters.max()) > 256  # eval mode ignores Tmax
