@@ -8,10 +8,10 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the exact bench command (N=1)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.log 2>&1
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot limit), kernel-trace only
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/pmc_$C.log 2>&1
 done
 python - <<PY
 import csv, glob, json, collections
