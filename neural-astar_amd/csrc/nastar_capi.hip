@@ -34,6 +34,8 @@ struct FwdArgs {
 template <bool kVec4, bool kMultiChunk, int LOGW, bool kFastDiv, bool kLog, int LOGH = 0>
 __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, const float rcp_sqrtW)
 {
+    // 1024-cell maps use 16-cell chunks (64 chunks, one per lane); everything else 64-cell chunks
+    constexpr int CL = (LOGH > 0 && LOGW > 0 && LOGH + LOGW == 10) ? 4 : 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
         d.H = 1 << LOGH;
         d.W = 1 << LOGW;
         d.HW = 1 << (LOGH + LOGW);
-        d.nchunks = d.HW / CHUNK;
+        d.nchunks = d.HW >> CL;
         d.HWp = d.HW;
         d.NCp = 64;
         d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
     const size_t off = (size_t)b * (size_t)d.HW;
 
     int start_idx, goal_idx;
-    load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    load_map<kVec4, CL>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
 
     const LaneConst lc = make_lane_const(d, lane);
     int status = NASTAR_OK;
@@ -64,13 +66,13 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             int C, cl;
             uint32_t kv;
-            s = select_min<kMultiChunk>(d, l, lane, C, cl, kv);
+            s = select_min<kMultiChunk, CL>(d, l, lane, C, cl, kv);
             if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
             if constexpr (kLog) {
                 if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
             }
             ++iters;
-            close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
+            close_and_expand<LOGW, kFastDiv, CL>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
         }
         if (iters < a.max_iters) {
             if (s < 0) {

@@ -57,6 +57,35 @@ __device__ __forceinline__ uint32_t wave_min_all_u32(uint32_t v)
     return min(b[0], b[1]);
 }
 
+// min over all 64 lanes as a wave-uniform SCALAR: 4 DPP steps per 16-lane row, then row_bcast:15 (rows 1,3 absorb the
+// row before them) and row_bcast:31 (rows 2,3 absorb lane 31) leave the total in lane 63; one v_readlane moves it to an
+// SGPR that later VALU compares take directly as an operand.  Three instructions shorter than the permlane-swap form.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov_rows(uint32_t v, uint32_t identity)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_min_scalar_u32(uint32_t v)
+{
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR1>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR2>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_HALF_MIRROR>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_MIRROR>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_rows<0x142, 0xA>(v, 0xFFFFFFFFu));  // row_bcast:15
+    v = min(v, dpp_mov_rows<0x143, 0xC>(v, 0xFFFFFFFFu));  // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// min over each 16-lane DPP row, result in every lane of the row
+__device__ __forceinline__ uint32_t row_min16_u32(uint32_t v)
+{
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR1>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_QUAD_XOR2>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_HALF_MIRROR>(v, 0xFFFFFFFFu));
+    v = min(v, dpp_mov_id<DPP_ROW_MIRROR>(v, 0xFFFFFFFFu));
+    return v;
+}
+
 __device__ __forceinline__ int wave_max_i32(int v)
 {
     v = max(v, (int)dpp_mov<DPP_QUAD_XOR1>((uint32_t)v));

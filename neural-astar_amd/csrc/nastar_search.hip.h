@@ -73,7 +73,9 @@ __device__ __forceinline__ uint32_t make_key(const MapDims& d, float g2, float h
 }
 
 // ---- load one map from HBM into LDS; returns start / goal flat indices (wave-uniform) -------------------------
-template <bool kVec4>
+// CL = log2(cells per chunk): 6 (one chunk = one wavefront-wide row read) or 4 (one chunk = one 16-lane DPP row, used
+// for 32x32 where it still gives <= 64 chunks: the "chunk minimum without s*" is then a 4-step row reduction).
+template <bool kVec4, int CL = 6>
 __device__ __forceinline__ void load_map(const MapDims& d, const MapLds& l, const float* __restrict__ cost,
                                          const float* __restrict__ start, const float* __restrict__ goal,
                                          const float* __restrict__ passable, int lane, int& start_idx,
@@ -160,7 +162,7 @@ __device__ __forceinline__ void load_map(const MapDims& d, const MapLds& l, cons
         const uint32_t k0 = make_key(d, 0.0f, l.hh[sidx]);
         l.g[sidx] = 0.0f;
         l.key[sidx] = k0;
-        l.chunkmin[sidx >> 6] = k0;
+        l.chunkmin[sidx >> CL] = k0;
         l.pdir[sidx] = (uint8_t)(PARENT_UNSET | P_PASS);  // the start is expanded even if it sits on an obstacle (:187)
     }
     wave_sync();
@@ -190,15 +192,16 @@ __device__ __forceinline__ void wave_order() { __builtin_amdgcn_wave_barrier(); 
 
 // ---- selection: first flat index of the minimal key; returns -1 when the open list is empty ------------------
 // On return kv is the key this lane read from the selected chunk C (lane cl holds the selected cell).
-template <bool kMultiChunk>
+template <bool kMultiChunk, int CL = 6>
 __device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int lane, int& C, int& cl, uint32_t& kv)
 {
+    constexpr int CSZ = 1 << CL;
     uint32_t Mv;  // the minimum, replicated in every lane
     unsigned long long any_open;
     if constexpr (!kMultiChunk) {
         const uint32_t cm = l.chunkmin[lane];
         any_open = __ballot(cm != KEY_INF);
-        Mv = wave_min_all_u32(cm);
+        Mv = wave_min_scalar_u32(cm);
         C = __builtin_ctzll(__ballot(cm == Mv) | (1ull << 63));
     } else {
         uint32_t best = KEY_INF;
@@ -212,16 +215,16 @@ __device__ __forceinline__ int select_min(const MapDims& d, const MapLds& l, int
         C = (int)__builtin_amdgcn_readfirstlane((int)wave_min_all_u32(best == Mv ? (uint32_t)bestc : 0x7fffffffu));
         if (C >= d.nchunks) C = 0;
     }
-    kv = l.key[C * CHUNK + lane];
+    kv = l.key[C * CSZ + (lane & (CSZ - 1))];  // CL == 4: the four 16-lane rows read the same 16 keys
     if (any_open == 0) return -1;  // open list empty (every chunk minimum is KEY_INF)
     cl = __builtin_ctzll(__ballot(kv == Mv) | (1ull << 63));
-    return C * CHUNK + cl;
+    return C * CSZ + cl;
 }
 
 // ---- close s (:222-225) and relax its <=8 Moore neighbours (:228-249) --------------------------------------
 // keep_open: the selected node is the goal being stepped at its fixed point (backward only, :224).
 // LOGW > 0: W == 1 << LOGW at compile time.
-template <int LOGW, bool kFastDiv>
+template <int LOGW, bool kFastDiv, int CL = 6>
 __device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds& l, const LaneConst& lc, int lane, int s,
                                                  int C, int cl, uint32_t kv, bool keep_open, float rcp_sqrtW)
 {
@@ -242,7 +245,9 @@ __device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds&
     const float gn = l.g[n];
     const float hn = l.hh[n];
     // chunk minimum without s (independent of the reads above, overlaps their latency)
-    const uint32_t nm = wave_min_all_u32(lane == cl ? KEY_INF : kv);
+    uint32_t nm;
+    if constexpr (CL == 4) nm = row_min16_u32((lane & 15) == cl ? KEY_INF : kv);
+    else nm = wave_min_all_u32(lane == cl ? KEY_INF : kv);
     // g2 = g[s*] + cost[s*]  (:234: expand((g + cost_maps) * selected)) -- step cost of the node being LEFT
     const float g2 = gs + cs;
     // :229,:235  neighbour is passable, not closed, and (not open, or open with g > g2)   <=>   g[n] > g2
@@ -267,7 +272,7 @@ __device__ __forceinline__ void close_and_expand(const MapDims& d, const MapLds&
     uint32_t* const k_dst = upd ? &l.key[n] : (closer ? &l.key[s] : dmp);
     uint8_t* const p_dst = upd ? &l.pdir[n] : reinterpret_cast<uint8_t*>(dmp);
     uint32_t* const c_dst = ((lane == 9) && !keep_open) ? &l.chunkmin[C] : dmp;
-    uint32_t* const a_dst = upd ? &l.chunkmin[n >> 6] : dmp;
+    uint32_t* const a_dst = upd ? &l.chunkmin[n >> CL] : dmp;
     *g_dst = upd ? g2 : NASTAR_NEG_INF;      // :238 g update          | :222-223 s* joins the closed list
     *k_dst = upd ? k : KEY_INF;              // :242 (re)opened        | :224 s* leaves the open list
     *p_dst = (uint8_t)lc.pcode;              // :246-249 parent = s*

@@ -28,15 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int REG_SLOTS = 16;
 constexpr int REG_MAX_CELLS = REG_SLOTS * 64;
 
-// min over the 16 lanes of each DPP row; every lane of a row gets its row's result
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t v)
-{
-    v = min(v, dpp_mov_id<DPP_QUAD_XOR1>(v, 0xFFFFFFFFu));
-    v = min(v, dpp_mov_id<DPP_QUAD_XOR2>(v, 0xFFFFFFFFu));
-    v = min(v, dpp_mov_id<DPP_ROW_HALF_MIRROR>(v, 0xFFFFFFFFu));
-    v = min(v, dpp_mov_id<DPP_ROW_MIRROR>(v, 0xFFFFFFFFu));
-    return v;
-}
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) { return row_min16_u32(v); }
 
 struct RegState {
     u32x16 key;
