@@ -77,6 +77,16 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
                    size_t workspace_bytes, int flags, void* stream);
 
 /*
+ * nastar_forward that ALSO emits the bit-packed masks (layout: see nastar_pack_outputs) in the same launch where the
+ * shape allows it (W % 4 == 0, H*W % 8 == 0, LDS-resident), otherwise by one extra pack launch on the same stream.
+ * This is what one rank of the multi-GPU path calls right before the all-gather.
+ */
+int nastar_forward_packed(const float* cost, const float* start, const float* goal, const float* passable, int B,
+                          int H, int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                          int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out,
+                          void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
  * Backward of `histories` w.r.t. `cost` (paths carry no gradient).  Replays the search on-chip and accumulates
  *   dL/dcost = sum_t (1-g_ratio) * (-1/sqrt(W)) * y_t * (G_t - <G_t, y_t>)       
  * including the reference's batch-coupled terms: a map that reaches its goal at step tau < t_batch keeps being

@@ -24,6 +24,7 @@ struct FwdArgs {
     int* sel_log;
     int* iters;
     int* status;
+    uint8_t* packed;  // optional [B, 2*HW/8] bit-packed masks (fused in the vec4 LDS kernel), else nullptr
     int max_iters;
     MapDims d;
 };
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
     }
     wave_sync();
     if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off);
+    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off,
+                         a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
@@ -413,11 +415,12 @@ size_t nastar_workspace_bytes(int B, int H, int W, int flags)
     return (size_t)B * global_slab_bytes(H * W);
 }
 
-int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
-                   int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
-                   int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
-                   size_t workspace_bytes, int flags, void* stream)
+static int forward_impl(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                        int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                        int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
+                        size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done)
 {
+    *packed_done = false;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
     if (B > 0 && H > 0 && W > 0 && max_iters > 0 && (long long)H * W <= kMaxGlobalCells && needs_global_state(H, W)) {
@@ -448,6 +451,7 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
     a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
     a.hist = histories_out; a.paths = reinterpret_cast<long long*>(paths_out);
     a.sel_log = sel_log_out; a.iters = iters_out; a.status = status_out; a.max_iters = max_iters;
+    a.packed = nullptr;
     const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                       aligned16(histories_out) && aligned16(paths_out);
     const bool multi = a.d.nchunks > 64;
@@ -476,6 +480,10 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
         const float rcp = 1.0f / a.d.sqrtW;
         const bool fast = fastdiv_verified(W);
         const bool lg = sel_log_out != nullptr;
+        if (packed_out && vec4 && (a.d.HW % 8 == 0)) {  // fused emission of the bit-packed masks
+            a.packed = packed_out;
+            *packed_done = true;
+        }
         void (*kern)(const FwdArgs, const float) = nullptr;
         // hot configurations: aligned, <= 64 chunks, power-of-two width, verified fast division
 #define NASTAR_PICK_LW(LW)                                                                                      \
@@ -494,6 +502,29 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
         else kern = lg ? &nastar_forward_kernel<false, true, 0, false, true> : &nastar_forward_kernel<false, true, 0, false, false>;
         return launch(kern, B, lds, s, a, rcp);
     }
+}
+
+int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                   int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                   int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
+                   size_t workspace_bytes, int flags, void* stream)
+{
+    bool done;
+    return forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
+                        iters_out, status_out, workspace, workspace_bytes, flags, stream, nullptr, &done);
+}
+
+int nastar_forward_packed(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                          int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                          int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out,
+                          void* workspace, size_t workspace_bytes, int flags, void* stream)
+{
+    if (!packed_out) return NASTAR_ERR_NULL;
+    bool done = false;
+    int rc = forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
+                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done);
+    if (rc != NASTAR_OK || done) return rc;
+    return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);  // shapes the fused path skips
 }
 
 int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,

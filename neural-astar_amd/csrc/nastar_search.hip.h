@@ -317,9 +317,12 @@ __device__ __forceinline__ void backtrack(const MapDims& d, const MapLds& l, int
 
 // ---- write AstarOutput.histories (fp32 0/1) and .paths (int64 0/1) with 16-byte coalesced stores --------------
 // closed <=> g == -inf on a passable cell.
+// packed (optional, kVec4 and HW % 8 == 0 only): the same masks as 2 bits per cell -- [HW/8 bytes histories | HW/8 bytes
+// paths], MSB = first cell -- the payload of the multi-GPU all-gather, emitted here so that no second kernel has to
+// re-read 12 bytes per cell.
 template <bool kVec4>
 __device__ __forceinline__ void store_outputs(const MapDims& d, const MapLds& l, int lane, float* __restrict__ hist,
-                                              long long* __restrict__ paths)
+                                              long long* __restrict__ paths, uint8_t* __restrict__ packed = nullptr)
 {
     if constexpr (kVec4) {
         const int n4 = d.HW >> 2;
@@ -327,12 +330,28 @@ __device__ __forceinline__ void store_outputs(const MapDims& d, const MapLds& l,
         for (int q = lane; q < n4; q += 64) {
             const uint32_t m = *reinterpret_cast<const uint32_t*>(l.pdir + (q << 2));
             const float4 gv = *reinterpret_cast<const float4*>(l.g + (q << 2));
+            const bool c0 = (m & P_PASS) && gv.x == NASTAR_NEG_INF;
+            const bool c1 = (m & (P_PASS << 8)) && gv.y == NASTAR_NEG_INF;
+            const bool c2 = (m & (P_PASS << 16)) && gv.z == NASTAR_NEG_INF;
+            const bool c3 = (m & (P_PASS << 24)) && gv.w == NASTAR_NEG_INF;
             float4 v;
-            v.x = ((m & P_PASS) && gv.x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
-            v.y = ((m & (P_PASS << 8)) && gv.y == NASTAR_NEG_INF) ? 1.0f : 0.0f;
-            v.z = ((m & (P_PASS << 16)) && gv.z == NASTAR_NEG_INF) ? 1.0f : 0.0f;
-            v.w = ((m & (P_PASS << 24)) && gv.w == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.x = c0 ? 1.0f : 0.0f;
+            v.y = c1 ? 1.0f : 0.0f;
+            v.z = c2 ? 1.0f : 0.0f;
+            v.w = c3 ? 1.0f : 0.0f;
             h4[q] = v;
+            if (packed != nullptr) {  // wave-uniform
+                const uint32_t nh = (c0 ? 8u : 0u) | (c1 ? 4u : 0u) | (c2 ? 2u : 0u) | (c3 ? 1u : 0u);
+                const uint32_t np = ((m & P_PATH) ? 8u : 0u) | ((m & (P_PATH << 8)) ? 4u : 0u) |
+                                    ((m & (P_PATH << 16)) ? 2u : 0u) | ((m & (P_PATH << 24)) ? 1u : 0u);
+                const uint32_t both = nh | (np << 8);
+                const uint32_t other = dpp_mov<DPP_QUAD_XOR1>(both);  // the odd lane's quad = low nibble of the byte
+                if ((lane & 1) == 0) {
+                    const int nb = d.HW >> 3;
+                    packed[q >> 1] = (uint8_t)((nh << 4) | (other & 0xFu));
+                    packed[nb + (q >> 1)] = (uint8_t)((np << 4) | ((other >> 8) & 0xFu));
+                }
+            }
         }
         const int n2 = d.HW >> 1;
         longlong2* p2 = reinterpret_cast<longlong2*>(paths);

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "nastar_last_error",
     "nastar_workspace_bytes",
     "nastar_forward",
+    "nastar_forward_packed",
     "nastar_backward",
     "nastar_heuristic",
     "nastar_debug_occupancy",
@@ -78,6 +79,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.nastar_forward.restype = ci
     lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_forward_packed.restype = ci
+    lib.nastar_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_backward.restype = ci
     lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_heuristic.restype = ci

@@ -114,6 +114,23 @@ def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = Non
     return finish()
 
 
+def all_gather_packed(packed: torch.Tensor, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
+    """All-gather an already bit-packed shard (``nastar_forward_packed`` emits it in the search launch itself).
+    Returns the collated ``[world*B, 2*ceil(HW/8)] uint8`` tensor, or ``(work, finish)`` with ``async_op=True``."""
+    world = dist.get_world_size(group)
+    gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.uint8, device=packed.device)
+    work = dist.all_gather_into_tensor(gathered, packed, group=group, async_op=async_op)
+
+    def finish() -> torch.Tensor:
+        if work is not None:
+            work.wait()
+        return gathered
+
+    if async_op:
+        return work, finish
+    return finish()
+
+
 def global_t_batch(group: Optional[dist.ProcessGroup] = None):
     """``BatchCoupling.mode`` callable: t_batch = max over ALL ranks of (iters) - 1 (one int32 all-reduce MAX)."""
 

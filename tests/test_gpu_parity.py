@@ -262,3 +262,48 @@ def test_module_train_eval_budget_and_state_dict_roundtrip():
     nb.eval()
     out_e = nb.astar(_t(g.map_designs), _t(g.start_maps), _t(g.goal_maps), _t(g.map_designs))
     assert int(nb.astar.last_iters.max()) > 256  # eval mode ignores Tmax
+
+
+def test_fused_packed_output_equals_pack_kernel():
+    """nastar_forward_packed: masks emitted by the search launch (32x32, 64x64: fused; 20x45, 7x5: extra pack launch)
+    are byte-identical to nastar_pack_outputs of the regular outputs."""
+    from neural_astar import _native, parallel
+    from neural_astar.utils import synthetic as syn
+    lib = _native.load()
+    dev = _dev()
+    for (H, W, B) in [(32, 32, 96), (64, 64, 8), (20, 45, 5), (7, 5, 4), (16, 16, 32)]:
+        pr = syn.random_obstacle_maps(B, H, W, 0.2, seed=H * W)
+        m, s, g = (_t(x[:, 0]) for x in pr)
+        hist = torch.empty((B, H, W), device=dev)
+        paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+        nb = (H * W + 7) // 8
+        packed = torch.zeros((B, 2 * nb), dtype=torch.uint8, device=dev)
+        rc = lib.nastar_forward_packed(m.data_ptr(), s.data_ptr(), g.data_ptr(), m.data_ptr(), B, H, W, 0.5, W * W,
+                                       hist.data_ptr(), paths.data_ptr(), None, iters.data_ptr(), status.data_ptr(),
+                                       packed.data_ptr(), None, 0, 0, torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0
+        ref = parallel.pack_masks(hist.unsqueeze(1), paths.unsqueeze(1))
+        assert torch.equal(packed, ref), (H, W)
+        h2, p2 = parallel.unpack_masks(packed, H, W)
+        assert torch.equal(h2[:, 0], hist) and torch.equal(p2[:, 0], paths)
+
+
+def test_register_resident_kernel_variant_still_matches_reference():
+    """The opt-in VGPR-resident kernel (NASTAR_FLAG_FORCE_REG) is kept correct even though it is not the default."""
+    from neural_astar import _native
+    lib = _native.load()
+    dev = _dev()
+    for name in ("rand32_ucost_g050", "maze32_vanilla_g050", "rand32_qcost_g050", "rand20x45_ucost_g050", "maze32_train_T025"):
+        g = G.load(name)
+        c, s, go, p = (_t(x[:, 0]) for x in (g.cost_maps, g.start_maps, g.goal_maps, g.passable))
+        hist = torch.empty((g.B, g.H, g.W), device=dev)
+        paths = torch.empty((g.B, g.H, g.W), dtype=torch.int64, device=dev)
+        iters = torch.empty((g.B,), dtype=torch.int32, device=dev)
+        status = torch.empty((g.B,), dtype=torch.int32, device=dev)
+        rc = lib.nastar_forward(c.data_ptr(), s.data_ptr(), go.data_ptr(), p.data_ptr(), g.B, g.H, g.W, g.g_ratio, g.max_iters,
+                                hist.data_ptr(), paths.data_ptr(), None, iters.data_ptr(), status.data_ptr(), None, 0, 2,
+                                torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0
+        assert np.array_equal(hist.cpu().numpy(), g.histories[:, 0]) and np.array_equal(paths.cpu().numpy(), g.paths[:, 0]), name
