@@ -155,6 +155,35 @@ def two_stream_throughput(pr, steps, dev):
     return runs[0].B * steps / (time.perf_counter() - t0)
 
 
+def training_step_ms(pr, dev, reps=10):
+    """Extra: forward + straight-through backward (nastar_backward) of one 4096-map batch with U(0,1) costs in
+    training mode, Tmax = 0.25 (the reference's scripts/config/train.yaml), through the torch custom ops."""
+    from neural_astar import ops  # noqa: F401
+    from neural_astar.utils import synthetic as syn
+    m = torch.from_numpy(pr.map_designs[:, 0]).to(dev)
+    s = torch.from_numpy(pr.start_maps[:, 0]).to(dev)
+    g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev)
+    cost = torch.from_numpy(syn.random_costs(m.shape[0], H, W, seed=3)[:, 0]).to(dev)
+    mi = int(0.25 * W * W)
+    hist, _, iters, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
+    gh = torch.randn_like(hist)
+    tb = (iters.amax() - 1).to(torch.int32).reshape(1)
+
+    def once():
+        h, _, it, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
+        torch.ops.nastar.astar_backward(gh, cost, s, g, m, G_RATIO, mi, it, tb)
+    for _ in range(2):
+        once()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
 def kernel_launch_ms(run, steps, dev):
     """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
     (torch's current stream), one event pair per launch."""
@@ -298,7 +327,8 @@ def main():
                             "max_iters_per_map": int(run2.iters.max().item())})
                 del run2
             out["secondary"] = sec
-            out["extra"] = {"two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
+            out["extra"] = {"train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
+                            "two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "
                                     "not the headline value, which times strictly serial launches on one stream"}
         print(json.dumps(out))

@@ -257,6 +257,96 @@ __global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
     for (int i = lane; i < d.HW; i += 64) a.grad_cost[off + i] = acc[i];
 }
 
+// ---- backward, compile-time sized maps of <= 1024 cells (the 32x32 training case) -----------------------------------
+// Same replay, but the three per-cell backward arrays (upstream gradient, gradient accumulator, softmax numerators) live
+// in REGISTERS: cell i <-> lane (i & 63), slot (i >> 6) with the slot loop fully unrolled, so every index is static.  The
+// LDS footprint drops from 29 to 17 B/cell (9 maps per CU instead of 5) and the softmax of a step touches only the chunks
+// that hold an open cell, with exp2-based exponentials (|rel err| ~1e-6, the contract tolerance is 1e-5).
+template <int LOGW, int LOGH, bool kFastDiv>
+__global__ __launch_bounds__(64) void nastar_backward_small_kernel(const BwdArgs a, const float rcp_sqrtW)
+{
+    constexpr int HW = 1 << (LOGW + LOGH);
+    constexpr int NCH = HW / CHUNK;
+    static_assert(NCH >= 1 && NCH <= 16, "register-resident backward state: at most 16 slots");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    MapDims d = a.d;
+    d.H = 1 << LOGH;
+    d.W = 1 << LOGW;
+    d.HW = HW;
+    d.nchunks = NCH;
+    d.HWp = HW;
+    d.NCp = 64;
+    d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
+    const MapLds l = carve_map_lds(smem, d);
+    const size_t off = (size_t)b * (size_t)HW;
+
+    int start_idx, goal_idx;
+    load_map<true>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    float gh[NCH], acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        gh[c] = a.grad_hist[off + c * CHUNK + lane];
+        acc[c] = 0.f;
+    }
+
+    if (start_idx >= 0 && goal_idx >= 0) {
+        const LaneConst lc = make_lane_const(d, lane);
+        int extra = 0;  // fixed-point steps the reference adds after this map's goal step (:251), see the generic kernel
+        if (a.t_batch != nullptr && a.iters != nullptr) extra = *a.t_batch - (a.iters[b] - 1);
+        if (extra > 0) {  // torch.clamp backward (:223) zeroes the goal cell's upstream gradient
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (c == (goal_idx >> 6) && lane == (goal_idx & 63)) gh[c] = 0.f;
+        }
+        // y_t = softmax over the open list; acc += scale * kfac * y * (G - <G,y>)   (:207-209, :67-68)
+        auto softmax_step = [&](float scale) {
+            const uint32_t cmv = l.chunkmin[lane];                  // lanes >= NCH read KEY_INF padding
+            const uint32_t act = (uint32_t)__ballot(cmv != KEY_INF);  // bit c: chunk c holds an open cell
+            float v[NCH];
+            float ls = 0.f, ld = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                v[c] = 0.f;
+                if ((act >> c) & 1u) {  // wave-uniform
+                    const uint32_t k = l.key[c * CHUNK + lane];
+                    const float e = __builtin_amdgcn_exp2f(ord_to_f32(k) * -1.4426950408889634f);  // exp(-q), key holds q
+                    v[c] = (k != KEY_INF) ? e : 0.f;
+                    ls += v[c];
+                    ld += v[c] * gh[c];
+                }
+            }
+            const float S = wave_sum_f32(ls);
+            const float D = wave_sum_f32(ld);
+            const float dot = D / S;
+            const float w = scale * a.kfac / S;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if ((act >> c) & 1u) acc[c] += w * v[c] * (gh[c] - dot);
+        };
+        int iters = 0;
+        while (iters < a.max_iters) {
+            softmax_step(1.0f);
+            int C, cl;
+            uint32_t kv;
+            const int s = select_min<false>(d, l, lane, C, cl, kv);
+            if (s < 0) break;
+            ++iters;
+            if (s == goal_idx) {
+                if (extra > 0) {  // the goal's own expansion (it stays open, :224), then `extra` identical steps
+                    close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/true, rcp_sqrtW);
+                    softmax_step((float)extra);
+                }
+                break;
+            }
+            close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a.grad_cost[off + c * CHUNK + lane] = acc[c];
+}
+
 // ---- get_heuristic standalone (parity/debug) ------------------------------------------------------------
 __global__ __launch_bounds__(64) void nastar_heuristic_kernel(const float* goal, float* out, int H, int W, uint32_t magicW)
 {
@@ -546,6 +636,14 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
     const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable);
     const bool multi = a.d.nchunks > 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (vec4 && H == 32 && W == 32 && fastdiv_verified(W)) {  // training configuration of the reference (mazes_032)
+        const size_t lds17 = map_lds_bytes(a.d.HWp, a.d.NCp);
+        return launch(nastar_backward_small_kernel<5, 5, true>, B, lds17, s, a, 1.0f / a.d.sqrtW);
+    }
+    if (vec4 && H == 16 && W == 16) {
+        const size_t lds17 = map_lds_bytes(a.d.HWp, a.d.NCp);
+        return launch(nastar_backward_small_kernel<4, 4, true>, B, lds17, s, a, 1.0f / a.d.sqrtW);
+    }
     if (vec4 && !multi) return launch(nastar_backward_kernel<true, false>, B, lds, s, a);
     if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, B, lds, s, a);
     if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
