@@ -137,6 +137,21 @@ def timed_loop(run, steps, warmup, world, dev, collate=None):
     return dt, dev_ms
 
 
+def multi_stream_throughput(pr, steps, dev, nstreams):
+    runs = [Runner(pr, dev) for _ in range(nstreams)]
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    for i in range(2 * nstreams):
+        with torch.cuda.stream(streams[i % nstreams]):
+            runs[i % nstreams].step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % nstreams]):
+            runs[i % nstreams].step()
+    torch.cuda.synchronize(dev)
+    return runs[0].B * steps / (time.perf_counter() - t0)
+
+
 def two_stream_throughput(pr, steps, dev):
     """Extra (not the headline): the same steps issued round-robin on TWO HIP streams with their own output buffers,
     so the serial tail of one batch (its longest search) overlaps the bulk of the next -- the throughput a planning
@@ -329,6 +344,7 @@ def main():
             out["secondary"] = sec
             out["extra"] = {"train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
                             "two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
+                            "streams_sweep_maps_per_s": {str(k): multi_stream_throughput(pr, args.steps, dev, k) for k in (1, 2, 3, 4, 6)},
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "
                                     "not the headline value, which times strictly serial launches on one stream"}
         print(json.dumps(out))

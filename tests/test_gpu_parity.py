@@ -307,3 +307,23 @@ def test_register_resident_kernel_variant_still_matches_reference():
                                 torch.cuda.current_stream(dev).cuda_stream)
         assert rc == 0
         assert np.array_equal(hist.cpu().numpy(), g.histories[:, 0]) and np.array_equal(paths.cpu().numpy(), g.paths[:, 0]), name
+
+
+def test_validation_pair_launch_equals_two_separate_searches():
+    """plan_with_vanilla (SURVEY 8f next #2): planner + VanillaAstar in one launch == two separate forward() calls."""
+    from neural_astar.planner import NeuralAstar, VanillaAstar
+    from neural_astar.utils.metrics import plan_with_vanilla, validation_metrics
+    g = G.load("maze32_vanilla_g050")
+    dev = _dev()
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="CNN").to(dev).eval()
+    va = VanillaAstar().to(dev).eval()
+    m, s, go = _t(g.map_designs), _t(g.start_maps), _t(g.goal_maps)
+    o_p, o_v = plan_with_vanilla(na, m, s, go)
+    with torch.no_grad():
+        r_p, r_v = na(m, s, go), va(m, s, go)
+    assert torch.equal(o_p.histories, r_p.histories) and torch.equal(o_p.paths, r_p.paths)
+    assert torch.equal(o_v.histories, r_v.histories) and torch.equal(o_v.paths, r_v.paths)
+    assert np.array_equal(o_v.histories.cpu().numpy(), g.histories)  # and the vanilla half is the reference's answer
+    met = validation_metrics(o_p, o_v)
+    assert 0.0 <= float(met.p_opt) <= 1.0 and 0.0 <= float(met.p_exp) <= 1.0

@@ -120,3 +120,23 @@ def test_sharded_collation_world_size_2_gloo(tmp_path):
     s.close()
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
+
+
+def test_validation_metrics_match_the_reference_numpy_formulas():
+    """utils/metrics.py vs a literal numpy restatement of training.py:73-81."""
+    from neural_astar.planner.differentiable_astar import AstarOutput
+    from neural_astar.utils.metrics import validation_metrics
+    rng = np.random.Generator(np.random.PCG64(1))
+    B = 32
+    hp = (rng.random((B, 1, 16, 16)) > 0.7).astype(np.float32)
+    hv = (rng.random((B, 1, 16, 16)) > 0.6).astype(np.float32)
+    pp = (rng.random((B, 1, 16, 16)) > 0.9).astype(np.int64)
+    pv = pp.copy()
+    pv[: B // 2] = (rng.random((B // 2, 1, 16, 16)) > 0.9).astype(np.int64)
+    m = validation_metrics(AstarOutput(torch.from_numpy(hp), torch.from_numpy(pp)), AstarOutput(torch.from_numpy(hv), torch.from_numpy(pv)))
+    pathlen_astar = pv.sum((1, 2, 3)); pathlen_model = pp.sum((1, 2, 3))
+    p_opt = (pathlen_astar == pathlen_model).mean()
+    exp_astar = hv.sum((1, 2, 3)); exp_na = hp.sum((1, 2, 3))
+    p_exp = np.maximum((exp_astar - exp_na) / exp_astar, 0.0).mean()
+    h_mean = 2.0 / (1.0 / (p_opt + 1e-10) + 1.0 / (p_exp + 1e-10))
+    assert abs(float(m.p_opt) - p_opt) < 1e-12 and abs(float(m.p_exp) - p_exp) < 1e-6 and abs(float(m.h_mean) - h_mean) < 1e-6
