@@ -220,12 +220,12 @@ def cpu_baseline(pr, gpu_hist, gpu_paths):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     O.build()
-    n0 = min(128, pr.map_designs.shape[0])
+    n0 = min(512, pr.map_designs.shape[0])
     O.forward(pr.map_designs[:8], pr.start_maps[:8], pr.goal_maps[:8], pr.map_designs[:8], G_RATIO, W * W)  # spin up the OpenMP team
     t0 = time.perf_counter()
     O.forward(pr.map_designs[:n0], pr.start_maps[:n0], pr.goal_maps[:n0], pr.map_designs[:n0], G_RATIO, W * W)
     rate0 = n0 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 12.0)))  # aim at ~12 s of CPU work (bounded by the batch)
+    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 15.0)))  # aim at ~15 s of CPU work (bounded by the batch)
     t0 = time.perf_counter()
     o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], G_RATIO, W * W)
     dt = time.perf_counter() - t0

@@ -7,9 +7,7 @@
 namespace nastar {
 
 constexpr uint32_t KEY_INF = 0xFFFFFFFFu;  // "not on the open list"
-// per-cell meta byte (LDS): low nibble = flags, high nibble = parent direction code
-constexpr uint32_t M_PASS = 1u, M_CLOSED = 2u, M_OPEN = 4u, M_PATH = 8u;
-constexpr uint32_t PARENT_UNSET = 8u;  // parents[] still holds its initial value goal_idx (differentiable_astar.py:195-198)
+constexpr uint32_t PARENT_UNSET = 8u;      // parents[] still holds its initial value goal_idx (differentiable_astar.py:195-198)
 constexpr int CHUNK = 64;              // cells per chunk == wavefront width
 
 // ---- cross-lane reductions: 4 DPP steps inside each 16-lane row, then 4 readlanes + scalar ops ----------
