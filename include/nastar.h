@@ -117,6 +117,25 @@ int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int
 int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* histories_out, int64_t* paths_out,
                           void* stream);
 
+/*
+ * CNN cost-map encoder of NeuralAstar, inference only (SURVEY.md section 8f "next #1"; reference planner/encoder.py:60-78,
+ * :32-34 and the input assembly of astar.py:171-177), bf16 MFMA with fp32 accumulation:
+ *     cost = sigmoid(conv5(relu(bn4(conv4(...relu(bn1(conv1(cat(map, start+goal)))))))))) * final_mul
+ *   map/start/goal [B,H,W] fp32 (start/goal may be NULL when plus == 0), cost_out [B,H,W] fp32;
+ *   H % 16 == 0 and W % 32 == 0; channels fixed to the reference's depth-4 CNN (2 -> 32 -> 64 -> 128 -> 256 -> 1).
+ *   wpack[l]  device bf16 [9][CINp/8][COUTp][8]  (tap = ky*3+kx; CINp = 16,32,64,128,256; COUTp = 32,64,128,256,32; zero padded)
+ *   scale[l], shift[l]  device fp32 [COUTp]: eval-mode BatchNorm and conv bias folded: y = acc*scale + shift
+ *   wpack/scale/shift themselves are HOST arrays of 5 device pointers.
+ *   workspace: nastar_encoder_workspace_bytes(B,H,W) bytes (fewer = more, smaller passes).
+ */
+size_t nastar_encoder_workspace_bytes(int B, int H, int W);
+int nastar_encoder_cnn_forward(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                               const uint16_t* const* wpack, const float* const* scale, const float* const* shift,
+                               float final_mul, float* cost_out, void* workspace, size_t workspace_bytes, void* stream);
+/* one layer of the above on its own (unit tests): (cin, cout) in {(16,32), (32,64), (64,128), (128,256)} */
+int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
+                        int B, int H, int W, int cin, int cout, int relu, void* stream);
+
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out);

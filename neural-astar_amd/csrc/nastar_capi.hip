@@ -9,6 +9,7 @@
 #include "nastar_search.hip.h"
 #include "nastar_search_reg.hip.h"
 #include "nastar_search_global.hip.h"
+#include "nastar_encoder.hip.h"
 
 namespace nastar {
 
@@ -487,6 +488,21 @@ static bool fastdiv_verified(int W)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
+static int launch_conv(const ConvArgs& ca, hipStream_t stream)
+{
+    constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)9 * (KS / 16) * 2 * NT * 16;
+    auto kern = &nastar_conv3x3_kernel<CIN, COUT, NT, kRelu, kFinal>;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW) * (COUT / NT));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 }  // namespace nastar
 
 using namespace nastar;
@@ -676,6 +692,75 @@ int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* his
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
+}
+
+// ---- CNN encoder (eval mode, bf16 MFMA) -------------------------------------------------------------------------------
+// padded channels per layer: in 16, 32, 64, 128, 256 (layer 1: 2 real + 14 zero); out 32, 64, 128, 256, 32 (layer 5: 1 real)
+constexpr size_t kEncBytesPerPixel = (16 + 128 + 256) * 2;  // x0 + ping (<=128 ch) + pong (<=256 ch), bf16
+
+size_t nastar_encoder_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int chunk = B < 1024 ? B : 1024;  // images processed per pass (keeps the activations L2/MALL friendly)
+    return (size_t)chunk * H * W * kEncBytesPerPixel;
+}
+
+int nastar_encoder_cnn_forward(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                               const uint16_t* const* wpack, const float* const* scale, const float* const* shift,
+                               float final_mul, float* cost_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!map || !cost_out || !wpack || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_UNSUPPORTED;
+    const size_t per_img = (size_t)H * W * kEncBytesPerPixel;
+    int chunk = (int)(workspace_bytes / per_img);
+    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
+    if (chunk > B) chunk = B;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    uint16_t* x0 = static_cast<uint16_t*>(workspace);
+    uint16_t* ping = x0 + (size_t)chunk * H * W * 16;
+    uint16_t* pong = ping + (size_t)chunk * H * W * 128;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const size_t off = (size_t)b0 * H * W;
+        const long long npix = (long long)nb * H * W;
+        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+        hipLaunchKernelGGL(nastar_encoder_prep_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
+                           plus ? goal + off : map, x0, npix, plus);
+        ConvArgs ca;
+        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+        int rc;
+        ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
+        if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
+        ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
+        if ((rc = launch_conv<32, 64, 64, true, false>(ca, s))) return rc;
+        ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
+        if ((rc = launch_conv<64, 128, 64, true, false>(ca, s))) return rc;
+        ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
+        if ((rc = launch_conv<128, 256, 64, true, false>(ca, s))) return rc;
+        ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
+        if ((rc = launch_conv<256, 32, 32, false, true>(ca, s))) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// One 3x3 convolution layer on its own (unit tests): in [B,H,W,CIN] bf16 -> out [B,H,W,COUT] bf16, y = relu?(acc*scale+shift).
+int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
+                        int B, int H, int W, int cin, int cout, int relu, void* stream)
+{
+    if (!in || !wpack || !scale || !shift || !out) return NASTAR_ERR_NULL;
+    if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
+    ConvArgs ca;
+    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
+    ca.B = B; ca.H = H; ca.W = W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);
+    if (cin == 32 && cout == 64) return relu ? launch_conv<32, 64, 64, true, false>(ca, s) : launch_conv<32, 64, 64, false, false>(ca, s);
+    if (cin == 64 && cout == 128) return relu ? launch_conv<64, 128, 64, true, false>(ca, s) : launch_conv<64, 128, 64, false, false>(ca, s);
+    if (cin == 128 && cout == 256) return relu ? launch_conv<128, 256, 64, true, false>(ca, s) : launch_conv<128, 256, 64, false, false>(ca, s);
+    return NASTAR_ERR_UNSUPPORTED;
 }
 
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out)

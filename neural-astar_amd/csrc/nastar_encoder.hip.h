@@ -1,0 +1,193 @@
+// nastar_encoder.hip.h -- the CNN cost-map encoder of NeuralAstar on MFMA (SURVEY.md section 8f "next #1").
+//
+// Reference: planner/encoder.py:60-78 (CNN: 3x3 convs input -> 32 -> 64 -> 128 -> 256 -> 1 with BatchNorm + ReLU between
+// them) and :32-34 (sigmoid(model(x)) * const); input assembly astar.py:171-177 (cat(map, start + goal)).
+// Inference (eval-mode BatchNorm folded into a per-channel scale/shift) in bf16 with fp32 accumulation:
+//
+//   * activations are NHWC bf16, channels padded to a multiple of 16, so the reduction index k = (tap, channel) of the
+//     implicit GEMM is contiguous per pixel;
+//   * one 256-thread workgroup computes 16 image rows x 32 columns x NT output channels; per 32-channel input slice it
+//     stages the (16+2) x (32+2) pixel halo tile and the slice's 9 x 32 x NT weights in LDS, then every wavefront runs
+//     v_mfma_f32_32x32x16_bf16 with   A = weights [32 out-channels x 16 k],  B = pixels [16 k x 32 columns of one row],
+//     so that C/D = [channel][pixel]: a lane ends up with 4 consecutive channels of its pixel per register quad, i.e.
+//     8-byte NHWC stores;
+//   * the pixel tile uses a 64-byte pixel stride with the 16-byte chunk index rotated by (column >> 2), which makes every
+//     16-lane group of a ds_read_b128 hit 16 distinct 4-bank slots (no padding, no conflicts);
+//   * epilogue: y = relu(acc * scale[c] + shift[c]) -> bf16, or for the last layer sigmoid(acc + bias) * const -> fp32
+//     [B,1,H,W] (only output channel 0 of the zero-padded 32-channel block is real).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nastar {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 accumulator fragment
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rn(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+constexpr int ENC_TW = 32;        // tile width  = image width handled per workgroup column block
+constexpr int ENC_TH = 16;        // tile height (4 rows per wavefront)
+constexpr int ENC_KS = 32;        // input channels per LDS slice
+constexpr int ENC_PIX_B = 64;     // bytes per pixel in the LDS tile (32 bf16)
+
+struct ConvArgs {
+    const uint16_t* in;     // [B,H,W,CIN] bf16
+    const uint16_t* wpack;  // [9][CIN/8][COUT][8] bf16   (tap = (dy+1)*3 + (dx+1))
+    const float* scale;     // [COUT]
+    const float* shift;     // [COUT]
+    uint16_t* out;          // [B,H,W,COUT] bf16        (kFinal == false)
+    float* out_f32;         // [B,H,W] fp32             (kFinal == true: sigmoid(acc*scale+shift) * mul)
+    float final_mul;
+    int B, H, W;
+};
+
+// LDS pixel tile address (bytes): pixel (ty, tx) of the (TH+2) x (TW+2) halo tile, 16-byte chunk c (0..3), rotated.
+__device__ __forceinline__ int enc_tile_off(int ty, int tx, int c)
+{
+    return (ty * (ENC_TW + 2) + tx) * ENC_PIX_B + (((c + (tx >> 2)) & 3) << 4);
+}
+
+// CIN, COUT: padded channel counts (CIN % 16 == 0, COUT % 32 == 0); NT: output channels per workgroup (32 or 64).
+template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
+__global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
+{
+    constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;      // channels per slice (16 or 32)
+    constexpr int KSTEPS = KS / 16;                          // MFMA k-steps per tap and slice
+    constexpr int NSLICE = CIN / KS;
+    constexpr int NB = NT / 32;                              // 32-channel output blocks per workgroup
+    constexpr int TILE_BYTES = (ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B;
+    // weights in LDS: [tap][kk][khalf][n][8 bf16] = 9 * KSTEPS * 2 * NT * 16 bytes after the pixel tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    unsigned char* wl = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tiles_x = a.W / ENC_TW, tiles_y = a.H / ENC_TH;
+    int t = blockIdx.x;
+    const int nblk = t % (COUT / NT); t /= (COUT / NT);
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y; t /= tiles_y;
+    const int b = t;
+    const int y0 = tyb * ENC_TH, x0 = txb * ENC_TW;
+    const int n0 = nblk * NT;
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int px = lane & 31;      // pixel column inside the tile (MFMA B column / C column)
+    const int kh = lane >> 5;      // which 8-element half of a 16-wide k-step this lane feeds
+
+    for (int s = 0; s < NSLICE; ++s) {
+        __syncthreads();  // previous slice fully consumed
+        // ---- stage the pixel halo tile: (TH+2) x (TW+2) pixels x KS channels, zero outside the image ----------------
+        constexpr int CH16 = KS / 8;  // 16-byte chunks per pixel (2 or 4)
+        for (int q = tid; q < (ENC_TH + 2) * (ENC_TW + 2) * CH16; q += 256) {
+            const int c = q % CH16;
+            const int p = q / CH16;
+            const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
+            const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+                const uint16_t* src = a.in + (((size_t)b * a.H + gy) * a.W + gx) * CIN + s * KS + c * 8;
+                v = *reinterpret_cast<const uint4*>(src);
+            }
+            *reinterpret_cast<uint4*>(tile + enc_tile_off(ty, tx, c)) = v;
+        }
+        // ---- stage the weights of this slice: LDS [tap][kk][khalf][n][8] <- global [tap][cin/8][cout][8] ---------------
+        for (int q = tid; q < 9 * KSTEPS * 2 * NT; q += 256) {
+            const int n = q % NT;
+            int r = q / NT;
+            const int h = r % 2; r /= 2;
+            const int kk = r % KSTEPS; r /= KSTEPS;
+            const int tap = r;
+            const int kc = (s * KS) / 8 + kk * 2 + h;  // global 8-channel group
+            const uint16_t* src = a.wpack + (((size_t)tap * (CIN / 8) + kc) * COUT + n0 + n) * 8;
+            *reinterpret_cast<uint4*>(wl + (size_t)q * 16) = *reinterpret_cast<const uint4*>(src);
+        }
+        __syncthreads();
+        // ---- 9 taps x KSTEPS k-steps of MFMA ----------------------------------------------------------------------------
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;  // halo-tile offsets (0..2) == (dy-1, dx-1) in image space
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                bf16x8 wa[NB];
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    wa[n] = *reinterpret_cast<const bf16x8*>(wl + ((((tap * KSTEPS + kk) * 2 + kh) * NT) + n * 32 + px) * 16);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ty = wave * 4 + m + dy;
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(ty, px + dx, kk * 2 + kh));
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[n], xb, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31 = pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel in block ------
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int gy = y0 + wave * 4 + m, gx = x0 + px;
+        const size_t pix = ((size_t)b * a.H + gy) * a.W + gx;
+        if constexpr (kFinal) {
+            if (kh == 0 && nblk == 0) {  // channel 0 = reg 0 of the lanes with lane>>5 == 0
+                const float z = acc[m][0][0] * a.scale[0] + a.shift[0];
+                a.out_f32[pix] = a.final_mul / (1.0f + __expf(-z));
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = n0 + n * 32 + 8 * g + 4 * kh;
+                    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
+                    const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+                    float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
+                    float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
+                    float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
+                    float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
+                    if constexpr (kRelu) {
+                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    }
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
+                    o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                    *reinterpret_cast<uint2*>(a.out + pix * COUT + c) = o;
+                }
+            }
+        }
+    }
+}
+
+// input assembly (astar.py:171-177): x0[b][y][x][0] = map, [1] = start + goal, channels 2..15 = 0   (bf16 NHWC, 16 ch)
+__global__ __launch_bounds__(256) void nastar_encoder_prep_kernel(const float* __restrict__ map, const float* __restrict__ start,
+                                                                  const float* __restrict__ goal, uint16_t* __restrict__ x0,
+                                                                  long long npix, int plus)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t c0 = f32_to_bf16_rn(map[i]);
+        const uint32_t c1 = plus ? f32_to_bf16_rn(start[i] + goal[i]) : 0u;
+        uint4* dst = reinterpret_cast<uint4*>(x0 + i * 16);
+        dst[0] = make_uint4(c0 | (c1 << 16), 0u, 0u, 0u);
+        dst[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+}  // namespace nastar

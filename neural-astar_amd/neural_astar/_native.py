@@ -44,6 +44,9 @@ EXPORTED_SYMBOLS = (
     "nastar_debug_occupancy",
     "nastar_pack_outputs",
     "nastar_unpack_outputs",
+    "nastar_encoder_workspace_bytes",
+    "nastar_encoder_cnn_forward",
+    "nastar_conv3x3_bf16",
 )
 
 
@@ -89,6 +92,13 @@ def load() -> ctypes.CDLL:
     lib.nastar_pack_outputs.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     lib.nastar_unpack_outputs.restype = ci
     lib.nastar_unpack_outputs.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+    lib.nastar_encoder_workspace_bytes.restype = cz
+    lib.nastar_encoder_workspace_bytes.argtypes = [ci, ci, ci]
+    lib.nastar_encoder_cnn_forward.restype = ci
+    lib.nastar_encoder_cnn_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                               ctypes.POINTER(vp), ctypes.c_float, vp, vp, cz, vp]
+    lib.nastar_conv3x3_bf16.restype = ci
+    lib.nastar_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.nastar_debug_occupancy.restype = ci
     lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib

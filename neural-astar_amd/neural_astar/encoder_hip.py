@@ -1,0 +1,103 @@
+"""bf16-MFMA inference path of the reference's ``CNN`` encoder (``csrc/nastar_encoder.hip.h``).
+
+``HipCnnEncoder`` wraps a ``planner.encoder.CNN`` module (depth 4: 2 -> 32 -> 64 -> 128 -> 256 -> 1): it folds the eval-mode
+BatchNorm and the conv bias into per-channel scale/shift, packs the weights in the kernel's ``[tap][cin/8][cout][8]`` bf16
+layout (zero padded), and runs ``nastar_encoder_cnn_forward``.  Inference only: gradients do not flow (training keeps the
+torch path).  Numerics: bf16 operands, fp32 accumulation -> the cost map differs from the fp32 torch encoder by ~1e-3
+(tests bound it); the search downstream is still exact for whatever cost map it is given.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+_CIN_P = (16, 32, 64, 128, 256)
+_COUT_P = (32, 64, 128, 256, 32)
+
+
+def pack_conv_weight(w: torch.Tensor, cin_p: int, cout_p: int) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 -> [9, cin_p/8, cout_p, 8] bf16 (as int16 bits), zero padded, tap = ky*3 + kx."""
+    cout, cin = w.shape[:2]
+    wp = torch.zeros((cout_p, cin_p, 3, 3), dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w
+    wp = wp.permute(2, 3, 1, 0).reshape(9, cin_p // 8, 8, cout_p).permute(0, 1, 3, 2).contiguous()
+    return wp.to(torch.bfloat16).view(torch.int16)
+
+
+def fold_bn(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], cout_p: int):
+    """y = BN_eval(conv(x) + bias) = acc * scale + shift  (per output channel; padded channels get scale 0, shift 0)."""
+    cout = conv.out_channels
+    dev = conv.weight.device
+    bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout, device=dev)
+    if bn is not None:
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        sh = bn.bias.detach().float() + (bias - bn.running_mean.detach().float()) * s
+    else:
+        s, sh = torch.ones(cout, device=dev), bias
+    scale = torch.zeros(cout_p, device=dev)
+    shift = torch.zeros(cout_p, device=dev)
+    scale[:cout], shift[:cout] = s, sh
+    return scale.contiguous(), shift.contiguous()
+
+
+class HipCnnEncoder:
+    def __init__(self, cnn: nn.Module):
+        layers = list(cnn.model)
+        convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+        if [c.out_channels for c in convs] != [32, 64, 128, 256, 1] or convs[0].in_channels > 16:
+            raise NotImplementedError("the HIP encoder implements the reference's depth-4 CNN (.. -> 32 -> 64 -> 128 -> 256 -> 1)")
+        self.cnn = cnn
+        self.in_channels = convs[0].in_channels
+        self._key = None
+        self._refresh()
+
+    def _refresh(self) -> None:
+        layers = list(self.cnn.model)
+        key = tuple(int(p._version) for p in self.cnn.parameters()) + tuple(int(b._version) for b in self.cnn.buffers())
+        if key == self._key:
+            return
+        self.wpack: List[torch.Tensor] = []
+        self.scale: List[torch.Tensor] = []
+        self.shift: List[torch.Tensor] = []
+        idx = 0
+        for li in range(5):
+            conv = layers[idx]
+            bn = layers[idx + 1] if idx + 1 < len(layers) and isinstance(layers[idx + 1], nn.BatchNorm2d) else None
+            self.wpack.append(pack_conv_weight(conv.weight.detach().float(), _CIN_P[li], _COUT_P[li]))
+            sc, sh = fold_bn(conv, bn, _COUT_P[li])
+            self.scale.append(sc)
+            self.shift.append(sh)
+            idx += 3 if li < 4 else 2  # conv, bn, relu  |  conv, bn
+        self._key = key
+
+    def __call__(self, map_designs: torch.Tensor, start_maps: Optional[torch.Tensor], goal_maps: Optional[torch.Tensor],
+                 plus: bool) -> torch.Tensor:
+        """map/start/goal [B,1,H,W] fp32 on the device -> cost [B,1,H,W] fp32 = sigmoid(model(x)) * const."""
+        if self.cnn.training:
+            raise RuntimeError("HipCnnEncoder is inference only (eval-mode BatchNorm is folded into the kernel)")
+        self._refresh()
+        lib = _native.load()
+        m = map_designs[:, 0].contiguous()
+        B, H, W = m.shape
+        dev = m.device
+        s = start_maps[:, 0].contiguous() if plus else None
+        g = goal_maps[:, 0].contiguous() if plus else None
+        cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        ws_bytes = int(lib.nastar_encoder_workspace_bytes(B, H, W))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        arr = ctypes.c_void_p * 5
+        const = self.cnn.const
+        mul = float(const.detach().item()) if isinstance(const, torch.Tensor) else float(const)
+        with torch.cuda.device(dev):
+            rc = lib.nastar_encoder_cnn_forward(
+                m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, H, W,
+                arr(*[t.data_ptr() for t in self.wpack]), arr(*[t.data_ptr() for t in self.scale]),
+                arr(*[t.data_ptr() for t in self.shift]), mul, cost.data_ptr(), ws.data_ptr(), ws_bytes,
+                torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "nastar_encoder_cnn_forward")
+        return cost.unsqueeze(1)

@@ -61,9 +61,21 @@ class NeuralAstar(VanillaAstar):
             print("WARNING: learn_obstacles has been set to True")
         self.g_ratio = g_ratio
         self.use_differentiable_astar = use_differentiable_astar
+        # "torch" (default, fp32, differentiable) or "hip_bf16": bf16-MFMA inference kernels for the depth-4 CNN encoder
+        # (eval mode, no gradients; csrc/nastar_encoder.hip.h).  Not part of the reference's constructor signature.
+        self.encoder_backend = "torch"
+        self._hip_encoder = None
 
     def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
         """Predict cost maps (reference astar.py:154-180)."""
+        if (self.encoder_backend == "hip_bf16" and not self.training and not torch.is_grad_enabled()
+                and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
+                and map_designs.shape[-2] % 16 == 0 and map_designs.shape[-1] % 32 == 0
+                and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)):
+            if self._hip_encoder is None:
+                from ..encoder_hip import HipCnnEncoder
+                self._hip_encoder = HipCnnEncoder(self.encoder)
+            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         inputs = map_designs
         if "+" in self.encoder_input:
             sg = start_maps + goal_maps

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "nastar.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(nastar_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(nastar_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_and_binding_agree():

@@ -327,3 +327,63 @@ def test_validation_pair_launch_equals_two_separate_searches():
     assert np.array_equal(o_v.histories.cpu().numpy(), g.histories)  # and the vanilla half is the reference's answer
     met = validation_metrics(o_p, o_v)
     assert 0.0 <= float(met.p_opt) <= 1.0 and 0.0 <= float(met.p_exp) <= 1.0
+
+
+def test_conv3x3_mfma_layer_matches_torch():
+    """One encoder layer (implicit-GEMM 3x3 conv on v_mfma_f32_32x32x16_bf16) vs torch conv2d on the SAME bf16-rounded
+    operands: differences are accumulation order + the final bf16 rounding only."""
+    from neural_astar import _native
+    from neural_astar.encoder_hip import pack_conv_weight
+    lib = _native.load()
+    dev = _dev()
+    torch.manual_seed(0)
+    for (cin, cout, cin_p) in [(2, 32, 16), (32, 64, 32), (64, 128, 64), (128, 256, 128)]:
+        B, H, W = 3, 32, 32
+        x = torch.randn(B, cin, H, W, device=dev).to(torch.bfloat16).float()
+        w = (torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5).to(torch.bfloat16).float()
+        scale = torch.rand(cout, device=dev) + 0.5
+        shift = torch.randn(cout, device=dev) * 0.1
+        ref = torch.relu(torch.nn.functional.conv2d(x, w, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+        xin = torch.zeros(B, H, W, cin_p, device=dev)
+        xin[..., :cin] = x.permute(0, 2, 3, 1)
+        xin = xin.to(torch.bfloat16).contiguous()
+        wp = pack_conv_weight(w, cin_p, cout)
+        out = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=dev)
+        rc = lib.nastar_conv3x3_bf16(xin.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                                     B, H, W, cin_p, cout, 1, torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0
+        got = out.float().permute(0, 3, 1, 2)
+        err = (got - ref).abs()
+        tol = 1e-2 * ref.abs().clamp(min=1.0)  # bf16 output rounding (2^-8 relative) dominates
+        assert bool((err <= tol).all()), (cin, cout, float(err.max()))
+        # asymmetric sanity: a transposed / mis-tapped kernel would be off by O(1)
+        assert float(err.mean()) < 2e-3
+
+
+def test_hip_encoder_matches_torch_encoder_and_feeds_the_search():
+    """NeuralAstar(encoder_backend="hip_bf16"): cost map within bf16 tolerance of the fp32 torch encoder (shipped-checkpoint-like
+    random weights with non-trivial BatchNorm statistics), and the planner runs end to end on it."""
+    from neural_astar.planner import NeuralAstar
+    g = G.load("maze32_vanilla_g050")
+    dev = _dev()
+    torch.manual_seed(1)
+    na = NeuralAstar(encoder_arch="CNN").to(dev)
+    with torch.no_grad():  # make BN statistics / affine parameters non-trivial
+        for mod in na.encoder.model:
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    na.eval()
+    m, s, go = _t(g.map_designs), _t(g.start_maps), _t(g.goal_maps)
+    with torch.no_grad():
+        ref = na.encode(m, s, go)
+        na.encoder_backend = "hip_bf16"
+        got = na.encode(m, s, go)
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        err = (got - ref).abs()
+        assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+        out = na(m, s, go)
+        assert out.histories.shape == (g.B, 1, 32, 32) and int((na.astar.last_status != 0).sum()) == 0
+    na.encoder_backend = "torch"
