@@ -492,7 +492,7 @@ template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
 static int launch_conv(const ConvArgs& ca, hipStream_t stream)
 {
     constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;
-    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)9 * (KS / 16) * 2 * NT * 16;
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)9 * (KS / 16) * 2 * NT * 16 + (size_t)NT * 8;
     auto kern = &nastar_conv3x3_kernel<CIN, COUT, NT, kRelu, kFinal>;
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;

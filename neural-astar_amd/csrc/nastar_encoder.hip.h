@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
     unsigned char* wl = smem + TILE_BYTES;
+    float* ss = reinterpret_cast<float*>(wl + 9 * KSTEPS * 2 * NT * 16);  // scale[NT] | shift[NT] of this channel block
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,53 +92,101 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     const int px = lane & 31;      // pixel column inside the tile (MFMA B column / C column)
     const int kh = lane >> 5;      // which 8-element half of a 16-wide k-step this lane feeds
 
+    // ---- staging: a slice = the (TH+2) x (TW+2) pixel halo tile x KS channels + the 9 x KS x NT weights.  The global loads
+    // of slice s+1 are issued into registers BEFORE the MFMAs of slice s and written to LDS after them, so HBM/L2 latency
+    // hides behind the matrix pipe.  All per-chunk offsets are computed once (the index arithmetic would otherwise cost
+    // ~1000 VALU instructions per slice and wave).
+    constexpr int CH16 = KS / 8;                                               // 16-byte chunks per pixel (2 or 4)
+    constexpr int NTC = (ENC_TH + 2) * (ENC_TW + 2) * CH16;                    // tile chunks per slice
+    constexpr int NWC = 9 * KSTEPS * 2 * NT;                                   // weight chunks per slice
+    constexpr int NTQ = (NTC + 255) / 256, NWQ = (NWC + 255) / 256;            // ... per thread
+    int t_src[NTQ], t_dst[NTQ], w_src[NWQ];  // element offsets into a.in / a.wpack (slice 0), byte offset into the tile
+#pragma unroll
+    for (int i = 0; i < NTQ; ++i) {
+        const int q = tid + i * 256;
+        const int c = q % CH16;
+        const int p = q / CH16;
+        const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
+        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+        const bool ok = q < NTC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        t_src[i] = ok ? (int)(((gy * a.W + gx) * CIN) + c * 8) : -1;
+        t_dst[i] = q < NTC ? enc_tile_off(ty, tx, c) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NWQ; ++i) {
+        const int q = tid + i * 256;
+        const int n = q % NT;
+        int r = q / NT;
+        const int h = r % 2; r /= 2;
+        const int kk = r % KSTEPS; r /= KSTEPS;  // r = tap
+        w_src[i] = q < NWC ? (int)((((r * (CIN / 8)) + kk * 2 + h) * COUT + n0 + n) * 8) : -1;
+    }
+    const uint16_t* in_img = a.in + (size_t)b * a.H * a.W * CIN;
+    uint4 tq[NTQ], wq[NWQ];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NTQ; ++i) {
+            tq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (t_src[i] >= 0) tq[i] = *reinterpret_cast<const uint4*>(in_img + t_src[i] + s * KS);
+        }
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) {
+            wq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (w_src[i] >= 0) wq[i] = *reinterpret_cast<const uint4*>(a.wpack + w_src[i] + (size_t)s * (KS / 8) * COUT * 8);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < NTQ; ++i)
+            if (t_dst[i] >= 0) *reinterpret_cast<uint4*>(tile + t_dst[i]) = tq[i];
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i)
+            if (w_src[i] >= 0) *reinterpret_cast<uint4*>(wl + (size_t)(tid + i * 256) * 16) = wq[i];  // [tap][kk][khalf][n][8]
+    };
+    // ---- compute: a stage = (k-step kk, column offset dx).  It needs the 6 tile rows wave*4 .. wave*4+5 (shared by the three
+    // row offsets dy) and the weights of the 3 taps (dy, dx): 12 ds_read_b128 feed 4 x 3 x NB MFMAs.  The fragments of stage
+    // i+1 are read while the MFMAs of stage i run (two register sets), because with one wavefront per SIMD nothing else
+    // hides the LDS latency.
+    constexpr int NST = 3 * KSTEPS;
+    bf16x8 xb[2][6], wa[2][3][NB];
+    auto load_stage = [&](int st, int buf) {
+        const int kk = st / 3, dx = st % 3;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            xb[buf][r] = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(wave * 4 + r, px + dx, kk * 2 + kh));
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                wa[buf][dy][n] = *reinterpret_cast<const bf16x8*>(
+                    wl + (((((dy * 3 + dx) * KSTEPS + kk) * 2 + kh) * NT) + n * 32 + px) * 16);
+    };
+
+    load_slice(0);
+    if (tid < NT) {  // epilogue constants: fetched now, read from LDS after the last slice (no exposed global latency there)
+        ss[tid] = a.scale[n0 + tid];
+        ss[NT + tid] = a.shift[n0 + tid];
+    }
+    store_slice();
+    __syncthreads();
     for (int s = 0; s < NSLICE; ++s) {
-        __syncthreads();  // previous slice fully consumed
-        // ---- stage the pixel halo tile: (TH+2) x (TW+2) pixels x KS channels, zero outside the image ----------------
-        constexpr int CH16 = KS / 8;  // 16-byte chunks per pixel (2 or 4)
-        for (int q = tid; q < (ENC_TH + 2) * (ENC_TW + 2) * CH16; q += 256) {
-            const int c = q % CH16;
-            const int p = q / CH16;
-            const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
-            const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-                const uint16_t* src = a.in + (((size_t)b * a.H + gy) * a.W + gx) * CIN + s * KS + c * 8;
-                v = *reinterpret_cast<const uint4*>(src);
-            }
-            *reinterpret_cast<uint4*>(tile + enc_tile_off(ty, tx, c)) = v;
-        }
-        // ---- stage the weights of this slice: LDS [tap][kk][khalf][n][8] <- global [tap][cin/8][cout][8] ---------------
-        for (int q = tid; q < 9 * KSTEPS * 2 * NT; q += 256) {
-            const int n = q % NT;
-            int r = q / NT;
-            const int h = r % 2; r /= 2;
-            const int kk = r % KSTEPS; r /= KSTEPS;
-            const int tap = r;
-            const int kc = (s * KS) / 8 + kk * 2 + h;  // global 8-channel group
-            const uint16_t* src = a.wpack + (((size_t)tap * (CIN / 8) + kc) * COUT + n0 + n) * 8;
-            *reinterpret_cast<uint4*>(wl + (size_t)q * 16) = *reinterpret_cast<const uint4*>(src);
-        }
-        __syncthreads();
-        // ---- 9 taps x KSTEPS k-steps of MFMA ----------------------------------------------------------------------------
+        if (s + 1 < NSLICE) load_slice(s + 1);  // in flight during the MFMAs below
+        load_stage(0, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;  // halo-tile offsets (0..2) == (dy-1, dx-1) in image space
+        for (int st = 0; st < NST; ++st) {
+            if (st + 1 < NST) load_stage(st + 1, (st + 1) & 1);
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                bf16x8 wa[NB];
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int n = 0; n < NB; ++n)
-                    wa[n] = *reinterpret_cast<const bf16x8*>(wl + ((((tap * KSTEPS + kk) * 2 + kh) * NT) + n * 32 + px) * 16);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int ty = wave * 4 + m + dy;
-                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(ty, px + dx, kk * 2 + kh));
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int n = 0; n < NB; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[n], xb, acc[m][n], 0, 0, 0);
-                }
-            }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[st & 1][dy][n], xb[st & 1][m + dy], acc[m][n], 0, 0, 0);
+        }
+        if (s + 1 < NSLICE) {
+            __syncthreads();  // every wave is done reading this slice
+            store_slice();
+            __syncthreads();
         }
     }
 
@@ -148,7 +197,7 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
         const size_t pix = ((size_t)b * a.H + gy) * a.W + gx;
         if constexpr (kFinal) {
             if (kh == 0 && nblk == 0) {  // channel 0 = reg 0 of the lanes with lane>>5 == 0
-                const float z = acc[m][0][0] * a.scale[0] + a.shift[0];
+                const float z = acc[m][0][0] * ss[0] + ss[NT];
                 a.out_f32[pix] = a.final_mul / (1.0f + __expf(-z));
             }
         } else {
@@ -156,9 +205,10 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
             for (int n = 0; n < NB; ++n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int c = n0 + n * 32 + 8 * g + 4 * kh;
-                    const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-                    const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+                    const int cl = n * 32 + 8 * g + 4 * kh;  // channel inside this workgroup's block
+                    const int c = n0 + cl;
+                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(ss + NT + cl);
                     float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
                     float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
                     float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
