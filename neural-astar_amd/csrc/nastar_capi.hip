@@ -497,7 +497,7 @@ static int launch_conv(const ConvArgs& ca, hipStream_t stream)
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
     const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW) * (COUT / NT));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, ca);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;

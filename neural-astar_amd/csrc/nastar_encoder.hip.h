@@ -36,6 +36,14 @@ constexpr int ENC_TW = 32;        // tile width  = image width handled per workg
 constexpr int ENC_TH = 16;        // tile height (4 rows per wavefront)
 constexpr int ENC_KS = 32;        // input channels per LDS slice
 constexpr int ENC_PIX_B = 64;     // bytes per pixel in the LDS tile (32 bf16)
+#ifndef ENC_FRAG_BUFS
+#define ENC_FRAG_BUFS 1           // register sets for the MFMA operand fragments (2 = explicit double buffering)
+#endif
+#ifndef ENC_WAVES
+#define ENC_WAVES 8               // wavefronts per workgroup: 8 -> two per SIMD, each owning 2 of the tile's 16 rows
+#endif
+constexpr int ENC_THREADS = ENC_WAVES * 64;
+constexpr int ENC_RPW = ENC_TH / ENC_WAVES;  // image rows per wavefront
 
 struct ConvArgs {
     const uint16_t* in;     // [B,H,W,CIN] bf16
@@ -56,7 +64,7 @@ __device__ __forceinline__ int enc_tile_off(int ty, int tx, int c)
 
 // CIN, COUT: padded channel counts (CIN % 16 == 0, COUT % 32 == 0); NT: output channels per workgroup (32 or 64).
 template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
-__global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
+__global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_kernel(const ConvArgs a)
 {
     constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;      // channels per slice (16 or 32)
     constexpr int KSTEPS = KS / 16;                          // MFMA k-steps per tap and slice
@@ -81,9 +89,9 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     const int y0 = tyb * ENC_TH, x0 = txb * ENC_TW;
     const int n0 = nblk * NT;
 
-    f32x16 acc[4][NB];
+    f32x16 acc[ENC_RPW][NB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < ENC_RPW; ++m)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -99,11 +107,11 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     constexpr int CH16 = KS / 8;                                               // 16-byte chunks per pixel (2 or 4)
     constexpr int NTC = (ENC_TH + 2) * (ENC_TW + 2) * CH16;                    // tile chunks per slice
     constexpr int NWC = 9 * KSTEPS * 2 * NT;                                   // weight chunks per slice
-    constexpr int NTQ = (NTC + 255) / 256, NWQ = (NWC + 255) / 256;            // ... per thread
+    constexpr int NTQ = (NTC + ENC_THREADS - 1) / ENC_THREADS, NWQ = (NWC + ENC_THREADS - 1) / ENC_THREADS;  // ... per thread
     int t_src[NTQ], t_dst[NTQ], w_src[NWQ];  // element offsets into a.in / a.wpack (slice 0), byte offset into the tile
 #pragma unroll
     for (int i = 0; i < NTQ; ++i) {
-        const int q = tid + i * 256;
+        const int q = tid + i * ENC_THREADS;
         const int c = q % CH16;
         const int p = q / CH16;
         const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     }
 #pragma unroll
     for (int i = 0; i < NWQ; ++i) {
-        const int q = tid + i * 256;
+        const int q = tid + i * ENC_THREADS;
         const int n = q % NT;
         int r = q / NT;
         const int h = r % 2; r /= 2;
@@ -141,19 +149,20 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
             if (t_dst[i] >= 0) *reinterpret_cast<uint4*>(tile + t_dst[i]) = tq[i];
 #pragma unroll
         for (int i = 0; i < NWQ; ++i)
-            if (w_src[i] >= 0) *reinterpret_cast<uint4*>(wl + (size_t)(tid + i * 256) * 16) = wq[i];  // [tap][kk][khalf][n][8]
+            if (w_src[i] >= 0) *reinterpret_cast<uint4*>(wl + (size_t)(tid + i * ENC_THREADS) * 16) = wq[i];  // [tap][kk][khalf][n][8]
     };
-    // ---- compute: a stage = (k-step kk, column offset dx).  It needs the 6 tile rows wave*4 .. wave*4+5 (shared by the three
-    // row offsets dy) and the weights of the 3 taps (dy, dx): 12 ds_read_b128 feed 4 x 3 x NB MFMAs.  The fragments of stage
+    // ---- compute: a stage = (k-step kk, column offset dx).  It needs the RPW+2 tile rows of this wave (shared by the three
+    // row offsets dy) and the weights of the 3 taps (dy, dx): RPW+2 + 3*NB ds_read_b128 feed RPW x 3 x NB MFMAs.  The fragments of stage
     // i+1 are read while the MFMAs of stage i run (two register sets), because with one wavefront per SIMD nothing else
     // hides the LDS latency.
     constexpr int NST = 3 * KSTEPS;
-    bf16x8 xb[2][6], wa[2][3][NB];
+    constexpr int NBUF = ENC_FRAG_BUFS;
+    bf16x8 xb[NBUF][ENC_RPW + 2], wa[NBUF][3][NB];
     auto load_stage = [&](int st, int buf) {
         const int kk = st / 3, dx = st % 3;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-            xb[buf][r] = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(wave * 4 + r, px + dx, kk * 2 + kh));
+        for (int r = 0; r < ENC_RPW + 2; ++r)
+            xb[buf][r] = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(wave * ENC_RPW + r, px + dx, kk * 2 + kh));
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -171,17 +180,22 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
     __syncthreads();
     for (int s = 0; s < NSLICE; ++s) {
         if (s + 1 < NSLICE) load_slice(s + 1);  // in flight during the MFMAs below
-        load_stage(0, 0);
+        if constexpr (NBUF == 2) load_stage(0, 0);
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            if (st + 1 < NST) load_stage(st + 1, (st + 1) & 1);
+            if constexpr (NBUF == 2) {
+                if (st + 1 < NST) load_stage(st + 1, (st + 1) & 1);
+            } else {
+                load_stage(st, 0);
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < ENC_RPW; ++m)
 #pragma unroll
                     for (int n = 0; n < NB; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[st & 1][dy][n], xb[st & 1][m + dy], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[st & (NBUF - 1)][dy][n], xb[st & (NBUF - 1)][m + dy],
+                                                                            acc[m][n], 0, 0, 0);
         }
         if (s + 1 < NSLICE) {
             __syncthreads();  // every wave is done reading this slice
@@ -192,8 +206,8 @@ __global__ __launch_bounds__(256) void nastar_conv3x3_kernel(const ConvArgs a)
 
     // ---- epilogue: C/D layout col = lane&31 = pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel in block ------
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int gy = y0 + wave * 4 + m, gx = x0 + px;
+    for (int m = 0; m < ENC_RPW; ++m) {
+        const int gy = y0 + wave * ENC_RPW + m, gx = x0 + px;
         const size_t pix = ((size_t)b * a.H + gy) * a.W + gx;
         if constexpr (kFinal) {
             if (kh == 0 && nblk == 0) {  // channel 0 = reg 0 of the lanes with lane>>5 == 0
