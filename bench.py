@@ -199,6 +199,38 @@ def training_step_ms(pr, dev, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def neural_astar_forward_ms(pr, dev, reps=5):
+    """Extra (BASELINE config 3 stand-in): NeuralAstar(CNN encoder, depth 4) forward on the bench batch with the bf16-MFMA
+    HIP encoder + the HIP search, eval mode.  (The torch/MIOpen encoder is not timed here: its first call autotunes for
+    minutes; DESIGN.md quotes it from tools/probe_encoder.py.)"""
+    from neural_astar.planner import NeuralAstar
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="CNN").to(dev).eval()
+    na.encoder_backend = "hip_bf16"
+    na.astar.check_solvable = False
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        for _ in range(2):
+            na(m, s, g)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            na.encode(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        enc_ms = e0.elapsed_time(e1) / reps
+        e0.record()
+        for _ in range(reps):
+            na(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        full_ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * m.shape[0] * H * W * 9 * (2 * 32 + 32 * 64 + 64 * 128 + 128 * 256 + 256)
+    return {"encoder_ms": enc_ms, "encoder_useful_tflops": flop / enc_ms / 1e9, "forward_ms": full_ms,
+            "maps_per_s": m.shape[0] / full_ms * 1e3, "dtype": "bf16 operands / fp32 accumulate (encoder), f32 (search)"}
+
+
 def kernel_launch_ms(run, steps, dev):
     """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
     (torch's current stream), one event pair per launch."""
@@ -342,7 +374,8 @@ def main():
                             "max_iters_per_map": int(run2.iters.max().item())})
                 del run2
             out["secondary"] = sec
-            out["extra"] = {"train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
+            out["extra"] = {"neural_astar_cnn_hip_bf16": neural_astar_forward_ms(pr, dev),
+                            "train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
                             "two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
                             "streams_sweep_maps_per_s": {str(k): multi_stream_throughput(pr, args.steps, dev, k) for k in (1, 2, 3, 4, 6)},
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "

@@ -503,6 +503,18 @@ static int launch_conv(const ConvArgs& ca, hipStream_t stream)
     return NASTAR_OK;
 }
 
+static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
+    auto kern = &nastar_conv3x3_final_kernel<256>;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
 }  // namespace nastar
 
 using namespace nastar;
@@ -739,7 +751,7 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
         if ((rc = launch_conv<128, 256, 64, true, false>(ca, s))) return rc;
         ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
-        if ((rc = launch_conv<256, 32, 32, false, true>(ca, s))) return rc;
+        if ((rc = launch_conv_final(ca, s))) return rc;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");

@@ -240,6 +240,129 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_kernel(const ConvA
     }
 }
 
+// ---- last layer (256 -> 1 channel) + sigmoid * const -------------------------------------------------------------------
+// With ONE output channel an implicit GEMM wastes 31 of the 32 MFMA rows.  Instead the 9 taps become the "output channels"
+// of a 1x1 convolution:  P[p][t] = sum_c x[p][c] * w[t][c]  for every pixel p of the halo tile (MFMA rows = taps), and the
+// 3x3 convolution is the shifted sum  out[y][x] = sum_t P[(y+dy, x+dx)][t].  9x fewer MFMAs than the padded GEMM; the layer
+// becomes a pure stream over its 512-byte-per-pixel input.
+template <int CIN>
+__global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const ConvArgs a)
+{
+    constexpr int KS = ENC_KS, KSTEPS = KS / 16, NSLICE = CIN / KS, CH16 = KS / 8;
+    constexpr int HP = (ENC_TH + 2) * (ENC_TW + 2);       // halo pixels (612)
+    constexpr int NBLK = (HP + 31) / 32;                  // 32-pixel MFMA column blocks (20)
+    constexpr int BPW = (NBLK + ENC_WAVES - 1) / ENC_WAVES;
+    constexpr int TILE_BYTES = HP * ENC_PIX_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    float* part = reinterpret_cast<float*>(smem + TILE_BYTES);  // [NBLK*32][9] partial sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = a.W / ENC_TW, tiles_y = a.H / ENC_TH;
+    int t = blockIdx.x;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y; t /= tiles_y;
+    const int b = t;
+    const int y0 = tyb * ENC_TH, x0 = txb * ENC_TW;
+    const int px = lane & 31, kh = lane >> 5;
+
+    // A operand: row = tap (lanes with px < 9), all CIN channels of output channel 0, kept in registers
+    bf16x8 wa[NSLICE * KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < NSLICE * KSTEPS; ++ks) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (px < 9) v = *reinterpret_cast<const uint4*>(a.wpack + (((size_t)px * (CIN / 8) + ks * 2 + kh) * 32 + 0) * 8);
+        wa[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    // staging offsets (see nastar_conv3x3_kernel)
+    constexpr int NTC = HP * CH16, NTQ = (NTC + ENC_THREADS - 1) / ENC_THREADS;
+    int t_src[NTQ], t_dst[NTQ];
+#pragma unroll
+    for (int i = 0; i < NTQ; ++i) {
+        const int q = tid + i * ENC_THREADS;
+        const int c = q % CH16, p = q / CH16;
+        const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
+        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+        const bool ok = q < NTC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        t_src[i] = ok ? (int)(((gy * a.W + gx) * CIN) + c * 8) : -1;
+        t_dst[i] = q < NTC ? enc_tile_off(ty, tx, c) : -1;
+    }
+    const uint16_t* in_img = a.in + (size_t)b * a.H * a.W * CIN;
+    uint4 tq[NTQ];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NTQ; ++i) {
+            tq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (t_src[i] >= 0) tq[i] = *reinterpret_cast<const uint4*>(in_img + t_src[i] + s * KS);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < NTQ; ++i)
+            if (t_dst[i] >= 0) *reinterpret_cast<uint4*>(tile + t_dst[i]) = tq[i];
+    };
+    // this lane's pixel in each of the wave's column blocks
+    int boff[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        int hp = (wave + j * ENC_WAVES) * 32 + px;
+        hp = hp < HP ? hp : HP - 1;  // padding columns of the last block recompute the last pixel (never read back)
+        boff[j] = hp;
+    }
+    f32x16 acc[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    load_slice(0);
+    store_slice();
+    __syncthreads();
+    for (int s = 0; s < NSLICE; ++s) {
+        if (s + 1 < NSLICE) load_slice(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                if ((wave + j * ENC_WAVES) < NBLK) {  // wave-uniform
+                    const int ty = boff[j] / (ENC_TW + 2), tx = boff[j] % (ENC_TW + 2);
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(ty, tx, kk * 2 + kh));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s * KSTEPS + kk], xb, acc[j], 0, 0, 0);
+                }
+            }
+        if (s + 1 < NSLICE) {
+            __syncthreads();
+            store_slice();
+            __syncthreads();
+        }
+    }
+    // partial sums to LDS: D row = tap = (reg&3) + 8*(reg>>2) + 4*kh, column = pixel
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        if ((wave + j * ENC_WAVES) < NBLK) {
+            float* dst = part + ((wave + j * ENC_WAVES) * 32 + px) * 9;
+            if (kh == 0) {
+                dst[0] = acc[j][0]; dst[1] = acc[j][1]; dst[2] = acc[j][2]; dst[3] = acc[j][3];
+                dst[8] = acc[j][4];
+            } else {
+                dst[4] = acc[j][0]; dst[5] = acc[j][1]; dst[6] = acc[j][2]; dst[7] = acc[j][3];
+            }
+        }
+    }
+    __syncthreads();
+    // shifted sum + BatchNorm(1 channel) + sigmoid * const  (encoder.py:32-34)
+    for (int o = tid; o < ENC_TH * ENC_TW; o += ENC_THREADS) {
+        const int oy = o / ENC_TW, ox = o % ENC_TW;
+        float z = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) z += part[((oy + dy) * (ENC_TW + 2) + ox + dx) * 9 + dy * 3 + dx];
+        z = z * a.scale[0] + a.shift[0];
+        a.out_f32[((size_t)b * a.H + y0 + oy) * a.W + x0 + ox] = a.final_mul / (1.0f + __expf(-z));
+    }
+}
+
 // input assembly (astar.py:171-177): x0[b][y][x][0] = map, [1] = start + goal, channels 2..15 = 0   (bf16 NHWC, 16 ch)
 __global__ __launch_bounds__(256) void nastar_encoder_prep_kernel(const float* __restrict__ map, const float* __restrict__ start,
                                                                   const float* __restrict__ goal, uint16_t* __restrict__ x0,
