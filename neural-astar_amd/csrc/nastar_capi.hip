@@ -1,6 +1,7 @@
 // nastar_capi.hip -- HIP kernels + the C ABI declared in include/nastar.h (libnastar_hip.so).
 // gfx950 only.  Build: see neural-astar_amd/csrc/Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -488,6 +489,13 @@ static bool fastdiv_verified(int W)
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// bit 0: force the tiled conv kernel even for 32x32 images (parity tests of both kernels); read per call
+static int enc_flags()
+{
+    const char* e = getenv("NASTAR_ENCODER_FLAGS");
+    return e ? atoi(e) : 0;
+}
+
 template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
 static int launch_conv(const ConvArgs& ca, hipStream_t stream)
 {
@@ -498,6 +506,33 @@ static int launch_conv(const ConvArgs& ca, hipStream_t stream)
     if (rc) return rc;
     const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW) * (COUT / NT));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// 32x32 images, CIN >= 32 and COUT >= 64: whole-image workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
+template <int CIN, int COUT, bool kRelu>
+static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
+{
+    if (ca.H != 32 || ca.W != 32 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
+    const int ex = (enc_flags() >> 1) & 3;
+    if (ex == 1) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 1>;
+    if (ex == 2) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 2>;
+    if (ex == 3) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 3>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device query");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long items = (long long)ca.B * (COUT / I32_NT);
+    const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);  // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
@@ -745,11 +780,11 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
         if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
         ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
-        if ((rc = launch_conv<32, 64, 64, true, false>(ca, s))) return rc;
+        if ((rc = launch_conv_auto<32, 64, true>(ca, s))) return rc;
         ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
-        if ((rc = launch_conv<64, 128, 64, true, false>(ca, s))) return rc;
+        if ((rc = launch_conv_auto<64, 128, true>(ca, s))) return rc;
         ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
-        if ((rc = launch_conv<128, 256, 64, true, false>(ca, s))) return rc;
+        if ((rc = launch_conv_auto<128, 256, true>(ca, s))) return rc;
         ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
         if ((rc = launch_conv_final(ca, s))) return rc;
     }
@@ -769,9 +804,9 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
     ca.B = B; ca.H = H; ca.W = W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);
-    if (cin == 32 && cout == 64) return relu ? launch_conv<32, 64, 64, true, false>(ca, s) : launch_conv<32, 64, 64, false, false>(ca, s);
-    if (cin == 64 && cout == 128) return relu ? launch_conv<64, 128, 64, true, false>(ca, s) : launch_conv<64, 128, 64, false, false>(ca, s);
-    if (cin == 128 && cout == 256) return relu ? launch_conv<128, 256, 64, true, false>(ca, s) : launch_conv<128, 256, 64, false, false>(ca, s);
+    if (cin == 32 && cout == 64) return relu ? launch_conv_auto<32, 64, true>(ca, s) : launch_conv_auto<32, 64, false>(ca, s);
+    if (cin == 64 && cout == 128) return relu ? launch_conv_auto<64, 128, true>(ca, s) : launch_conv_auto<64, 128, false>(ca, s);
+    if (cin == 128 && cout == 256) return relu ? launch_conv_auto<128, 256, true>(ca, s) : launch_conv_auto<128, 256, false>(ca, s);
     return NASTAR_ERR_UNSUPPORTED;
 }
 

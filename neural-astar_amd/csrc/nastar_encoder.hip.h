@@ -240,6 +240,180 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_kernel(const ConvA
     }
 }
 
+// ---- 32x32 images: one workgroup = the whole image x 64 output channels -------------------------------------------------
+// The generic kernel above reads 0.83 LDS operand fragments per MFMA and drains the matrix pipe at two barriers per slice.
+// For 32x32 images (the reference's maze / MPD / TMPD datasets) the tile is the image itself, which buys:
+//   * a 4 row x 64 channel register tile per wavefront (8 accumulators): 6 pixel-row + 6 weight fragments feed 24 MFMAs,
+//     0.5 ds_read_b128 per MFMA;
+//   * 16-channel slices (32 bytes per pixel in LDS, chunk index XORed with bit 3 of the column: any 16 consecutive columns hit
+//     16 distinct 16-byte bank slots), small enough for TWO LDS buffers: slice s+1 is written while slice s is being
+//     multiplied, one barrier per slice;
+//   * the halo is the zero padding, written once; staging copies exactly 4 (pixels) + 2.25 (weights) 16-byte chunks per
+//     thread and slice at constant strides (no offset tables).
+constexpr int I32_KS = 16, I32_NT = 64, I32_RPW = 4, I32_NB = 2, I32_PIX_B = 32;
+constexpr int I32_TILE_BYTES = 34 * 34 * I32_PIX_B;               // 36992
+constexpr int I32_W_BYTES = 9 * 2 * I32_NT * 16;                  // 18432: [tap][khalf][n][8 bf16]
+constexpr int I32_BUF_BYTES = I32_TILE_BYTES + I32_W_BYTES;       // 55424
+constexpr int I32_OB_BYTES = 8 * 4096;                           // epilogue transpose patches
+constexpr size_t I32_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + I32_OB_BYTES + 2 * 256 * 4;
+
+__device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
+{
+    return (ty * 34 + tx) * I32_PIX_B + ((c ^ ((tx >> 3) & 1)) << 4);
+}
+
+template <int CIN, int COUT, bool kRelu, int EXP = 0>
+__global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
+{
+    constexpr int NSLICE = CIN / I32_KS;
+    constexpr int NGRP = COUT / I32_NT;
+    static_assert(NSLICE % 2 == 0, "buffer parity must repeat per work item");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* obase = smem + 2 * I32_BUF_BYTES;                               // epilogue transpose: 8 waves x 4 KB
+    float* ss = reinterpret_cast<float*>(smem + 2 * I32_BUF_BYTES + I32_OB_BYTES);  // scale[COUT] | shift[COUT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 31, kh = lane >> 5;
+    // PERSISTENT workgroups (one per CU: the kernel needs 146 KB of LDS): a workgroup walks work items (image, 64-channel
+    // group), so its fixed costs -- launch, zero fill, the exposed first load, the store drain -- are paid once, the loads
+    // of the next item's first slice fly during this item's epilogue and its stores drain under the next item's MFMAs.
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): number them so that the channel groups of one
+    // image -- which read the same input -- are worked on at the same time on the SAME XCD.
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int nitems = a.B * NGRP;
+
+    // zero both pixel tiles (the halo stays zero = the convolution's padding)
+    for (int q = tid; q < I32_TILE_BYTES / 16; q += 512) {
+        *reinterpret_cast<uint4*>(smem + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(smem + I32_BUF_BYTES + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid < COUT) {
+        ss[tid] = a.scale[tid];
+        ss[COUT + tid] = a.shift[tid];
+    }
+    // staging: chunk q = tid + 512 i.  pixels: p = q >> 1 = (tid >> 1) + 256 i -> row (tid >> 6) + 8 i, column (tid >> 1) & 31
+    const int t_dst = i32_tile_off((tid >> 6) + 1, ((tid >> 1) & 31) + 1, tid & 1);
+    const size_t t_lane = (size_t)(tid >> 1) * CIN + (tid & 1) * 8;
+    // weights: q -> n = q & 63, khalf = (q >> 6) & 1, tap = (q >> 7) = (tid >> 7) + 4 i
+    const size_t w_lane = ((size_t)((tid >> 7) * (CIN / 8) + ((tid >> 6) & 1)) * COUT + (tid & 63)) * 8;
+    // (named scalars, not arrays: the arrays were left in scratch memory by the compiler)
+    uint4 t0, t1, t2, t3, w0, w1, w2 = make_uint4(0u, 0u, 0u, 0u);
+    const bool w2on = tid < 128;
+    constexpr size_t TSTR = (size_t)256 * CIN, WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
+#define I32_LOAD_SLICE(item_, s_)                                                                        \
+    do {                                                                                                 \
+        const int ib_ = (item_) / NGRP, ig_ = (item_) % NGRP;                                            \
+        const uint16_t* tp_ = a.in + (size_t)ib_ * 1024 * CIN + t_lane + (s_) * I32_KS;                  \
+        const uint16_t* wp_ = a.wpack + w_lane + ig_ * I32_NT * 8 + (size_t)(s_) * WSL;                  \
+        t0 = *reinterpret_cast<const uint4*>(tp_);                                                       \
+        t1 = *reinterpret_cast<const uint4*>(tp_ + TSTR);                                                \
+        t2 = *reinterpret_cast<const uint4*>(tp_ + 2 * TSTR);                                            \
+        t3 = *reinterpret_cast<const uint4*>(tp_ + 3 * TSTR);                                            \
+        w0 = *reinterpret_cast<const uint4*>(wp_);                                                       \
+        w1 = *reinterpret_cast<const uint4*>(wp_ + WSTR);                                                \
+        if (w2on) w2 = *reinterpret_cast<const uint4*>(wp_ + 2 * WSTR);                                  \
+    } while (0)
+#define I32_STORE_SLICE(buf_)                                                                       \
+    do {                                                                                            \
+        unsigned char* b_ = (buf_);                                                                 \
+        *reinterpret_cast<uint4*>(b_ + t_dst) = t0;                                                 \
+        *reinterpret_cast<uint4*>(b_ + t_dst + 8 * 34 * I32_PIX_B) = t1;                            \
+        *reinterpret_cast<uint4*>(b_ + t_dst + 16 * 34 * I32_PIX_B) = t2;                           \
+        *reinterpret_cast<uint4*>(b_ + t_dst + 24 * 34 * I32_PIX_B) = t3;                           \
+        *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + tid * 16) = w0;                             \
+        *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + (tid + 512) * 16) = w1;                     \
+        if (w2on) *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + (tid + 1024) * 16) = w2;          \
+    } while (0)
+
+    int item = wg;
+    if (item < nitems) I32_LOAD_SLICE(item, 0);
+    __syncthreads();  // zero fill and ss visible
+    for (; item < nitems; item += gridDim.x) {
+        const int b = item / NGRP, n0 = (item % NGRP) * I32_NT;
+        const int next = item + gridDim.x;
+        f32x16 acc[I32_RPW][I32_NB];
+#pragma unroll
+        for (int m = 0; m < I32_RPW; ++m)
+#pragma unroll
+            for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        // buffer 0 was last read for slice NSLICE-2 of the previous item, i.e. before that slice's barrier
+        I32_STORE_SLICE(smem);
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < NSLICE; ++s) {
+            unsigned char* cur = smem + (s & 1) * I32_BUF_BYTES;
+            if (!(EXP & 2)) {
+                if (s + 1 < NSLICE) I32_LOAD_SLICE(item, s + 1);
+                else if (next < nitems) I32_LOAD_SLICE(next, 0);
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 xb[I32_RPW + 2], wa[3][I32_NB];
+#pragma unroll
+                for (int r = 0; r < I32_RPW + 2; ++r)
+                    xb[r] = *reinterpret_cast<const bf16x8*>(cur + i32_tile_off(wave * I32_RPW + r, px + dx, kh));
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int n = 0; n < I32_NB; ++n)
+                        wa[dy][n] = *reinterpret_cast<const bf16x8*>(cur + I32_TILE_BYTES + ((((dy * 3 + dx) * 2 + kh) * I32_NT) + n * 32 + px) * 16);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int m = 0; m < I32_RPW; ++m)
+#pragma unroll
+                        for (int n = 0; n < I32_NB; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[dy][n], xb[m + dy], acc[m][n], 0, 0, 0);
+            }
+            if (s + 1 < NSLICE) {
+                I32_STORE_SLICE(smem + ((s + 1) & 1) * I32_BUF_BYTES);  // last read in iteration s-1, before the previous barrier
+                __syncthreads();
+            }
+        }
+        // ---- epilogue: scale/shift/ReLU -> bf16, transposed through a wave-private LDS patch so that 8 lanes write one pixel's
+        // 128 contiguous bytes.  D layout: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel.
+        unsigned char* ob = obase + wave * 4096;  // one image row: 32 pixels x 64 channels
+#pragma unroll
+        for (int m = 0; m < I32_RPW; ++m) {
+#pragma unroll
+            for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = n0 + n * 32 + 8 * g + 4 * kh;
+                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
+                    float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
+                    float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
+                    float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
+                    float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
+                    if constexpr (kRelu) {
+                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                    }
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
+                    o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                    const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
+                    *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j * 8 + (lane >> 3), chunk = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                const size_t pix = (size_t)b * 1024 + (wave * I32_RPW + m) * 32 + p;
+                if (!(EXP & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4*>(a.out + pix * COUT + n0 + chunk * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+#undef I32_LOAD_SLICE
+#undef I32_STORE_SLICE
+
 // ---- last layer (256 -> 1 channel) + sigmoid * const -------------------------------------------------------------------
 // With ONE output channel an implicit GEMM wastes 31 of the 32 MFMA rows.  Instead the 9 taps become the "output channels"
 // of a 1x1 convolution:  P[p][t] = sum_c x[p][c] * w[t][c]  for every pixel p of the halo tile (MFMA rows = taps), and the

@@ -12,8 +12,8 @@ for f in sorted(glob.glob("$OUT/*counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv3x3_kernel<128" in k or "conv3x3_kernel<64" in k:
-            acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "_kernel<128" in k:
+            acc[k[:75]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(k)
         for c, v in d.items(): print("   ", c, sum(v) / len(v))
