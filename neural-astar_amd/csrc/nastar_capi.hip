@@ -512,17 +512,8 @@ static int launch_conv(const ConvArgs& ca, hipStream_t stream)
 }
 
 // 32x32 images, CIN >= 32 and COUT >= 64: whole-image workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
-template <int CIN, int COUT, bool kRelu>
-static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
+static int conv_cu_count(int* out)
 {
-    if (ca.H != 32 || ca.W != 32 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
-    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
-    const int ex = (enc_flags() >> 1) & 3;
-    if (ex == 1) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 1>;
-    if (ex == 2) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 2>;
-    if (ex == 3) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, 3>;
-    int rc = ensure_lds(kern, I32_LDS_BYTES);
-    if (rc) return rc;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -530,8 +521,37 @@ static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device query");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    *out = n_cu;
+    return NASTAR_OK;
+}
+
+// 32x32 images, CIN >= 32 and COUT >= 64: whole-image persistent workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
+template <int CIN, int COUT, bool kRelu>
+static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
+{
+    if (ca.H != 32 || ca.W != 32 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
     const long long items = (long long)ca.B * (COUT / I32_NT);
     const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);  // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
+static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
+{
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const unsigned grid = (unsigned)(ca.B < n_cu ? ca.B : n_cu);  // a workgroup owns whole images
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -776,6 +796,7 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
                            plus ? goal + off : map, x0, npix, plus);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
         int rc;
         ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
         if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
@@ -784,6 +805,11 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
         if ((rc = launch_conv_auto<64, 128, true>(ca, s))) return rc;
         ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
+        if (H == 32 && W == 32 && !(enc_flags() & 9)) {  // bit 3: keep the last layer a separate launch
+            ca.wfin = wpack[4]; ca.fscale = scale[4]; ca.fshift = shift[4]; ca.out_f32 = cost_out + off;
+            if ((rc = launch_conv_fused_final(ca, s))) return rc;
+            continue;
+        }
         if ((rc = launch_conv_auto<128, 256, true>(ca, s))) return rc;
         ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
         if ((rc = launch_conv_final(ca, s))) return rc;
@@ -801,6 +827,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
     if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
     ConvArgs ca;
     ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
+    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
     ca.B = B; ca.H = H; ca.W = W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);

@@ -52,6 +52,9 @@ struct ConvArgs {
     const float* shift;     // [COUT]
     uint16_t* out;          // [B,H,W,COUT] bf16        (kFinal == false)
     float* out_f32;         // [B,H,W] fp32             (kFinal == true: sigmoid(acc*scale+shift) * mul)
+    const uint16_t* wfin;   // fused last layer (img32 kernel, kFuse): its packed weights [9][COUT/8][32][8] ...
+    const float* fscale;    // ... and its folded BatchNorm scale / shift (1 channel)
+    const float* fshift;
     float final_mul;
     int B, H, W;
 };
@@ -254,7 +257,8 @@ constexpr int I32_KS = 16, I32_NT = 64, I32_RPW = 4, I32_NB = 2, I32_PIX_B = 32;
 constexpr int I32_TILE_BYTES = 34 * 34 * I32_PIX_B;               // 36992
 constexpr int I32_W_BYTES = 9 * 2 * I32_NT * 16;                  // 18432: [tap][khalf][n][8 bf16]
 constexpr int I32_BUF_BYTES = I32_TILE_BYTES + I32_W_BYTES;       // 55424
-constexpr int I32_OB_BYTES = 8 * 4096;                           // epilogue transpose patches
+constexpr int I32_P_BYTES = 1024 * 9 * 4;                         // fused last layer: per-pixel tap sums P[pixel][9] fp32
+constexpr int I32_OB_BYTES = I32_P_BYTES + 4096;                 // epilogue scratch: 8 transpose patches of 4 KB | P + last-layer fragments
 constexpr size_t I32_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + I32_OB_BYTES + 2 * 256 * 4;
 
 __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
@@ -262,7 +266,7 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
     return (ty * 34 + tx) * I32_PIX_B + ((c ^ ((tx >> 3) & 1)) << 4);
 }
 
-template <int CIN, int COUT, bool kRelu, int EXP = 0>
+template <int CIN, int COUT, bool kRelu, bool kFuse = false, int EXP = 0>
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
     constexpr int NSLICE = CIN / I32_KS;
@@ -270,6 +274,8 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     static_assert(NSLICE % 2 == 0, "buffer parity must repeat per work item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* obase = smem + 2 * I32_BUF_BYTES;                               // epilogue transpose: 8 waves x 4 KB
+    float* P = reinterpret_cast<float*>(obase);                                    // (kFuse) tap sums of the last layer
+    unsigned char* wf = obase + I32_P_BYTES;                                       // (kFuse) its A fragments for this channel group
     float* ss = reinterpret_cast<float*>(smem + 2 * I32_BUF_BYTES + I32_OB_BYTES);  // scale[COUT] | shift[COUT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -326,12 +332,30 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         if (w2on) *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + (tid + 1024) * 16) = w2;          \
     } while (0)
 
-    int item = wg;
+    // LDS byte offsets of this lane's operand fragments (buffer 0): pixel rows at the three column offsets, weights
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t rowb0 = i32_tile_off(wave * I32_RPW, px + 0, kh), rowb1 = i32_tile_off(wave * I32_RPW, px + 1, kh),
+                   rowb2 = i32_tile_off(wave * I32_RPW, px + 2, kh), wgtb = I32_TILE_BYTES + (kh * I32_NT + px) * 16;
+    // work item = image * NGRP + group.  Plain: items dealt cyclically.  Fused: a workgroup owns whole images (all groups in turn)
+    int item = kFuse ? blockIdx.x * NGRP : wg;
     if (item < nitems) I32_LOAD_SLICE(item, 0);
     __syncthreads();  // zero fill and ss visible
-    for (; item < nitems; item += gridDim.x) {
-        const int b = item / NGRP, n0 = (item % NGRP) * I32_NT;
-        const int next = item + gridDim.x;
+    while (item < nitems) {
+        const int b = item / NGRP, grp = item % NGRP, n0 = grp * I32_NT;
+        const int next = !kFuse ? item + (int)gridDim.x : (grp == NGRP - 1 ? item + ((int)gridDim.x - 1) * NGRP + 1 : item + 1);
+        uint4 wfq = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (kFuse) {
+            // last layer's weights for this channel group as MFMA A fragments: row = tap (lanes 0..8 of each half), k = the 8
+            // channels this lane's accumulator registers 8j..8j+7 hold: n0 + 32 n + 16 j + 4 kh + {0..3} and the same + 8
+            if (tid < 256) {
+                const int f = tid >> 6, l = tid & 63, tap = l & 31, base = n0 + (f >> 1) * 32 + (f & 1) * 16 + 4 * (l >> 5);
+                if (tap < 9) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(a.wfin + ((size_t)(tap * (COUT / 8) + (base >> 3)) * 32) * 8 + (base & 7));
+                    const uint2 hi = *reinterpret_cast<const uint2*>(a.wfin + ((size_t)(tap * (COUT / 8) + ((base + 8) >> 3)) * 32) * 8 + (base & 7));
+                    wfq = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+        }
         f32x16 acc[I32_RPW][I32_NB];
 #pragma unroll
         for (int m = 0; m < I32_RPW; ++m)
@@ -344,70 +368,200 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         __syncthreads();
 #pragma unroll 1
         for (int s = 0; s < NSLICE; ++s) {
-            unsigned char* cur = smem + (s & 1) * I32_BUF_BYTES;
             if (!(EXP & 2)) {
                 if (s + 1 < NSLICE) I32_LOAD_SLICE(item, s + 1);
                 else if (next < nitems) I32_LOAD_SLICE(next, 0);
             }
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                bf16x8 xb[I32_RPW + 2], wa[3][I32_NB];
-#pragma unroll
-                for (int r = 0; r < I32_RPW + 2; ++r)
-                    xb[r] = *reinterpret_cast<const bf16x8*>(cur + i32_tile_off(wave * I32_RPW + r, px + dx, kh));
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int n = 0; n < I32_NB; ++n)
-                        wa[dy][n] = *reinterpret_cast<const bf16x8*>(cur + I32_TILE_BYTES + ((((dy * 3 + dx) * 2 + kh) * I32_NT) + n * 32 + px) * 16);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int m = 0; m < I32_RPW; ++m)
-#pragma unroll
-                        for (int n = 0; n < I32_NB; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[dy][n], xb[m + dy], acc[m][n], 0, 0, 0);
+            // 9 steps (dx, dy) of 8 MFMAs.  A step needs pixel rows dy..dy+3 at column offset dx and the 2 weight fragments of
+            // tap (dy, dx); the fragments of step t+1 are requested BEFORE the MFMAs of step t (one new row + 2 weights inside
+            // a column offset, 4 rows + 2 weights when dx advances), so LDS latency hides behind 256 matrix-pipe cycles.
+            // The reads are inline asm: left to itself the register-starved compiler sinks every ds_read next to its use and
+            // the wave eats the LDS latency ~20 times per slice (measured: matrix pipe 50 % busy inside the loop).
+            const uint32_t cb = lds0 + (s & 1) * I32_BUF_BYTES;
+            const uint32_t ra0 = cb + rowb0, ra1 = cb + rowb1, ra2 = cb + rowb2, wa_ = cb + wgtb;
+            bf16x8 A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, WA0, WA1, WB0, WB1;
+#define DSR(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
+#define WOFF(dx_, dy_, n_) (((((dy_) * 3 + (dx_)) * 2) * I32_NT + (n_) * 32) * 16)
+#define ROFF(r_) ((r_) * 34 * I32_PIX_B)
+#define MM8(W0_, W1_, R0_, R1_, R2_, R3_)                                                         \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, R0_, acc[0][0], 0, 0, 0);            \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, R0_, acc[0][1], 0, 0, 0);            \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, R1_, acc[1][0], 0, 0, 0);            \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, R1_, acc[1][1], 0, 0, 0);            \
+    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, R2_, acc[2][0], 0, 0, 0);            \
+    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, R2_, acc[2][1], 0, 0, 0);            \
+    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, R3_, acc[3][0], 0, 0, 0);            \
+    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, R3_, acc[3][1], 0, 0, 0)
+#define LGKM3(a_, b_, c_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_))
+#define LGKM6(a_, b_, c_, d_, e_, f_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_))
+            DSR(A0, ra0, ROFF(0)); DSR(A1, ra0, ROFF(1)); DSR(A2, ra0, ROFF(2)); DSR(A3, ra0, ROFF(3));
+            DSR(WA0, wa_, WOFF(0, 0, 0)); DSR(WA1, wa_, WOFF(0, 0, 1));
+            LGKM6(A0, A1, A2, A3, WA0, WA1);
+            // dx = 0
+            DSR(A4, ra0, ROFF(4)); DSR(WB0, wa_, WOFF(0, 1, 0)); DSR(WB1, wa_, WOFF(0, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WA0, WA1, A0, A1, A2, A3);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(A4, WB0, WB1);
+            DSR(A5, ra0, ROFF(5)); DSR(WA0, wa_, WOFF(0, 2, 0)); DSR(WA1, wa_, WOFF(0, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WB0, WB1, A1, A2, A3, A4);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(A5, WA0, WA1);
+            DSR(B0, ra1, ROFF(0)); DSR(B1, ra1, ROFF(1)); DSR(B2, ra1, ROFF(2)); DSR(B3, ra1, ROFF(3));
+            DSR(WB0, wa_, WOFF(1, 0, 0)); DSR(WB1, wa_, WOFF(1, 0, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WA0, WA1, A2, A3, A4, A5);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM6(B0, B1, B2, B3, WB0, WB1);
+            // dx = 1
+            DSR(B4, ra1, ROFF(4)); DSR(WA0, wa_, WOFF(1, 1, 0)); DSR(WA1, wa_, WOFF(1, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WB0, WB1, B0, B1, B2, B3);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(B4, WA0, WA1);
+            DSR(B5, ra1, ROFF(5)); DSR(WB0, wa_, WOFF(1, 2, 0)); DSR(WB1, wa_, WOFF(1, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WA0, WA1, B1, B2, B3, B4);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(B5, WB0, WB1);
+            DSR(A0, ra2, ROFF(0)); DSR(A1, ra2, ROFF(1)); DSR(A2, ra2, ROFF(2)); DSR(A3, ra2, ROFF(3));
+            DSR(WA0, wa_, WOFF(2, 0, 0)); DSR(WA1, wa_, WOFF(2, 0, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WB0, WB1, B2, B3, B4, B5);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM6(A0, A1, A2, A3, WA0, WA1);
+            // dx = 2
+            DSR(A4, ra2, ROFF(4)); DSR(WB0, wa_, WOFF(2, 1, 0)); DSR(WB1, wa_, WOFF(2, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WA0, WA1, A0, A1, A2, A3);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(A4, WB0, WB1);
+            DSR(A5, ra2, ROFF(5)); DSR(WA0, wa_, WOFF(2, 2, 0)); DSR(WA1, wa_, WOFF(2, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WB0, WB1, A1, A2, A3, A4);
+            __builtin_amdgcn_sched_barrier(0);
+            LGKM3(A5, WA0, WA1);
+            __builtin_amdgcn_sched_barrier(0);
+            MM8(WA0, WA1, A2, A3, A4, A5);
+            __builtin_amdgcn_sched_barrier(0);
+#undef DSR
+#undef WOFF
+#undef ROFF
+#undef MM8
+#undef LGKM3
+#undef LGKM6
+            if constexpr (kFuse) {
+                if (s == 0 && tid < 256) *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;  // epilogue readers are >= 1 barrier away
             }
             if (s + 1 < NSLICE) {
                 I32_STORE_SLICE(smem + ((s + 1) & 1) * I32_BUF_BYTES);  // last read in iteration s-1, before the previous barrier
                 __syncthreads();
             }
         }
-        // ---- epilogue: scale/shift/ReLU -> bf16, transposed through a wave-private LDS patch so that 8 lanes write one pixel's
-        // 128 contiguous bytes.  D layout: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel.
-        unsigned char* ob = obase + wave * 4096;  // one image row: 32 pixels x 64 channels
-#pragma unroll
-        for (int m = 0; m < I32_RPW; ++m) {
+        if constexpr (kFuse) {
+            // ---- fused last layer (encoder.py:77 conv 256 -> 1, BatchNorm, :32-34 sigmoid * const).  Its 9 taps are the rows of a 1x1
+            // convolution P[pixel][tap] += sum_c w[tap][c] y[c][pixel] whose B operand is exactly this lane's freshly rounded bf16
+            // outputs (D rows 8j..8j+7 of a 32-channel block = one 16-wide k-step under a fixed channel permutation, which the A
+            // fragments in wf follow).  P accumulates over the 4 channel groups in LDS; the 3x3 shifted sum runs once per image.
+            bf16x8 fa[I32_NB][2];
 #pragma unroll
             for (int n = 0; n < I32_NB; ++n)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = n0 + n * 32 + 8 * g + 4 * kh;
-                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                    const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
-                    float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
-                    float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
-                    float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
-                    float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
-                    if constexpr (kRelu) {
-                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    }
-                    uint2 o;
-                    o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
-                    o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
-                    const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
-                    *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
-                }
-            __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < 2; ++j) fa[n][j] = *reinterpret_cast<const bf16x8*>(wf + ((n * 2 + j) * 64 + lane) * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = j * 8 + (lane >> 3), chunk = lane & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
-                const size_t pix = (size_t)b * 1024 + (wave * I32_RPW + m) * 32 + p;
-                if (!(EXP & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4*>(a.out + pix * COUT + n0 + chunk * 8) = v;
+            for (int m = 0; m < I32_RPW; ++m) {
+                f32x16 pa;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+                for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint32_t yw[4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int g = 2 * j + h, cl = n0 + n * 32 + 8 * g + 4 * kh;
+                            const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                            const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
+                            float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
+                            float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
+                            float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
+                            float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
+                            if constexpr (kRelu) {
+                                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                            }
+                            yw[2 * h + 0] = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
+                            yw[2 * h + 1] = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                        }
+                        const uint4 yq = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+                        pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa, 0, 0, 0);
+                    }
+                // D row = tap = (reg & 3) + 8 (reg >> 2) + 4 kh: taps 0-3 / 8 in the lower half-wave, 4-7 in the upper
+                float* pp = P + ((wave * I32_RPW + m) * 32 + px) * 9 + 4 * kh;
+                if (grp == 0) {
+                    pp[0] = pa[0]; pp[1] = pa[1]; pp[2] = pa[2]; pp[3] = pa[3];
+                    if (kh == 0) pp[8] = pa[4];
+                } else {
+                    pp[0] += pa[0]; pp[1] += pa[1]; pp[2] += pa[2]; pp[3] += pa[3];
+                    if (kh == 0) pp[8] += pa[4];
+                }
             }
-            __builtin_amdgcn_wave_barrier();
+            if (grp == NGRP - 1) {
+                __syncthreads();  // the shifted sum reads the rows of neighbouring waves
+                const float fs = a.fscale[0], fb = a.fshift[0];
+                for (int o = tid; o < 1024; o += 512) {
+                    const int oy = o >> 5, ox = o & 31;
+                    float z = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int yy = oy + dy - 1, xx = ox + dx - 1;
+                            if ((unsigned)yy < 32u && (unsigned)xx < 32u) z += P[(yy * 32 + xx) * 9 + dy * 3 + dx];
+                        }
+                    z = z * fs + fb;
+                    a.out_f32[(size_t)b * 1024 + o] = a.final_mul / (1.0f + __expf(-z));
+                }
+            }
+        } else {
+            // ---- epilogue: scale/shift/ReLU -> bf16, transposed through a wave-private LDS patch so that 8 lanes write one pixel's
+            // 128 contiguous bytes.  D layout: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel.
+            unsigned char* ob = obase + wave * 4096;  // one image row: 32 pixels x 64 channels
+    #pragma unroll
+            for (int m = 0; m < I32_RPW; ++m) {
+    #pragma unroll
+                for (int n = 0; n < I32_NB; ++n)
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = n0 + n * 32 + 8 * g + 4 * kh;
+                        const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                        const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
+                        float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
+                        float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
+                        float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
+                        float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
+                        if constexpr (kRelu) {
+                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                        }
+                        uint2 o;
+                        o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
+                        o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                        const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
+                        *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
+                    }
+                __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = j * 8 + (lane >> 3), chunk = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                    const size_t pix = (size_t)b * 1024 + (wave * I32_RPW + m) * 32 + p;
+                    if (!(EXP & 1) || v.x == 0x12345678u) *reinterpret_cast<uint4*>(a.out + pix * COUT + n0 + chunk * 8) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+        item = next;
     }
 }
 

@@ -386,4 +386,15 @@ def test_hip_encoder_matches_torch_encoder_and_feeds_the_search():
         assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
         out = na(m, s, go)
         assert out.histories.shape == (g.B, 1, 32, 32) and int((na.astar.last_status != 0).sum()) == 0
+        # the three kernel routes for 32x32 maps -- fused last layer (default), separate last-layer launch (8), tiled kernels (1) --
+        # use the same bf16 operands and differ only in fp32 summation order
+        import os
+        try:
+            for flags in ("8", "1"):
+                os.environ["NASTAR_ENCODER_FLAGS"] = flags
+                alt = na.encode(m, s, go)
+                d = (alt - got).abs()
+                assert float(d.max()) < 2e-3 and float(d.mean()) < 1e-4, (flags, float(d.max()), float(d.mean()))
+        finally:
+            os.environ.pop("NASTAR_ENCODER_FLAGS", None)
     na.encoder_backend = "torch"
