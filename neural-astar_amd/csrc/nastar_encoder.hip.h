@@ -30,6 +30,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f)
     u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
     return (uint16_t)(u >> 16);
 }
+// two floats -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the integer sequence above costs ~10)
+typedef __bf16 nastar_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nastar_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    const nastar_f32x2 v = {lo, hi};
+    const nastar_bf16x2 b = __builtin_convertvector(v, nastar_bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&b);
+}
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 constexpr int ENC_TW = 32;        // tile width  = image width handled per workgroup column block
@@ -234,8 +243,8 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_kernel(const ConvA
                         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                     }
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
-                    o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
                     *reinterpret_cast<uint2*>(a.out + pix * COUT + c) = o;
                 }
             }
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     constexpr size_t TSTR = (size_t)256 * CIN, WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
 #define I32_LOAD_SLICE(item_, s_)                                                                        \
     do {                                                                                                 \
-        const int ib_ = (item_) / NGRP, ig_ = (item_) % NGRP;                                            \
+        const int ib_ = (EXP & 32) ? 0 : (item_) / NGRP, ig_ = (item_) % NGRP;                           \
         const uint16_t* tp_ = a.in + (size_t)ib_ * 1024 * CIN + t_lane + (s_) * I32_KS;                  \
         const uint16_t* wp_ = a.wpack + w_lane + ig_ * I32_NT * 8 + (size_t)(s_) * WSL;                  \
         t0 = *reinterpret_cast<const uint4*>(tp_);                                                       \
@@ -340,6 +349,9 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     int item = kFuse ? blockIdx.x * NGRP : wg;
     if (item < nitems) I32_LOAD_SLICE(item, 0);
     __syncthreads();  // zero fill and ss visible
+    // (EXP & 16) dev instrumentation: per-wave cycle totals of the barrier waits, the slice loops and the epilogues
+    long long tk_bar = 0, tk_main = 0, tk_epi = 0, tk0 = 0, tk_start = 0;
+    if constexpr ((EXP & 16) != 0) tk_start = clock64();
     while (item < nitems) {
         const int b = item / NGRP, grp = item % NGRP, n0 = grp * I32_NT;
         const int next = !kFuse ? item + (int)gridDim.x : (grp == NGRP - 1 ? item + ((int)gridDim.x - 1) * NGRP + 1 : item + 1);
@@ -365,7 +377,9 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
         // buffer 0 was last read for slice NSLICE-2 of the previous item, i.e. before that slice's barrier
         I32_STORE_SLICE(smem);
+        if constexpr ((EXP & 16) != 0) tk0 = clock64();
         __syncthreads();
+        if constexpr ((EXP & 16) != 0) { const long long t = clock64(); tk_bar += t - tk0; tk0 = t; }
 #pragma unroll 1
         for (int s = 0; s < NSLICE; ++s) {
             if (!(EXP & 2)) {
@@ -380,7 +394,11 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             const uint32_t cb = lds0 + (s & 1) * I32_BUF_BYTES;
             const uint32_t ra0 = cb + rowb0, ra1 = cb + rowb1, ra2 = cb + rowb2, wa_ = cb + wgtb;
             bf16x8 A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, WA0, WA1, WB0, WB1;
-#define DSR(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
+#define DSR(dst_, addr_, off_)                                                                        \
+    do {                                                                                              \
+        if constexpr (!(EXP & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_)); \
+        else asm volatile("" : "=v"(dst_));                                                           \
+    } while (0)
 #define WOFF(dx_, dy_, n_) (((((dy_) * 3 + (dx_)) * 2) * I32_NT + (n_) * 32) * 16)
 #define ROFF(r_) ((r_) * 34 * I32_PIX_B)
 #define MM8(W0_, W1_, R0_, R1_, R2_, R3_)                                                         \
@@ -397,53 +415,235 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             DSR(A0, ra0, ROFF(0)); DSR(A1, ra0, ROFF(1)); DSR(A2, ra0, ROFF(2)); DSR(A3, ra0, ROFF(3));
             DSR(WA0, wa_, WOFF(0, 0, 0)); DSR(WA1, wa_, WOFF(0, 0, 1));
             LGKM6(A0, A1, A2, A3, WA0, WA1);
-            // dx = 0
-            DSR(A4, ra0, ROFF(4)); DSR(WB0, wa_, WOFF(0, 1, 0)); DSR(WB1, wa_, WOFF(0, 1, 1));
+            // step 0: dx = 0, dy = 0
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WA0, WA1, A0, A1, A2, A3);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A4, ra0, ROFF(4));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A0, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB0, wa_, WOFF(0, 1, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A1, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB1, wa_, WOFF(0, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A2, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A2, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A3, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A3, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(A4, WB0, WB1);
-            DSR(A5, ra0, ROFF(5)); DSR(WA0, wa_, WOFF(0, 2, 0)); DSR(WA1, wa_, WOFF(0, 2, 1));
+            // step 1: dx = 0, dy = 1
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WB0, WB1, A1, A2, A3, A4);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A1, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A5, ra0, ROFF(5));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A1, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA0, wa_, WOFF(0, 2, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A2, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA1, wa_, WOFF(0, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A2, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A3, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A3, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A4, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A4, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(A5, WA0, WA1);
-            DSR(B0, ra1, ROFF(0)); DSR(B1, ra1, ROFF(1)); DSR(B2, ra1, ROFF(2)); DSR(B3, ra1, ROFF(3));
-            DSR(WB0, wa_, WOFF(1, 0, 0)); DSR(WB1, wa_, WOFF(1, 0, 1));
+            // step 2: dx = 0, dy = 2
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WA0, WA1, A2, A3, A4, A5);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A2, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B0, ra1, ROFF(0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A2, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B1, ra1, ROFF(1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A3, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B2, ra1, ROFF(2));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A3, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B3, ra1, ROFF(3));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A4, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB0, wa_, WOFF(1, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A4, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB1, wa_, WOFF(1, 0, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A5, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A5, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM6(B0, B1, B2, B3, WB0, WB1);
-            // dx = 1
-            DSR(B4, ra1, ROFF(4)); DSR(WA0, wa_, WOFF(1, 1, 0)); DSR(WA1, wa_, WOFF(1, 1, 1));
+            // step 3: dx = 1, dy = 0
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WB0, WB1, B0, B1, B2, B3);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B4, ra1, ROFF(4));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B0, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA0, wa_, WOFF(1, 1, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B1, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA1, wa_, WOFF(1, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B2, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B2, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B3, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B3, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(B4, WA0, WA1);
-            DSR(B5, ra1, ROFF(5)); DSR(WB0, wa_, WOFF(1, 2, 0)); DSR(WB1, wa_, WOFF(1, 2, 1));
+            // step 4: dx = 1, dy = 1
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WA0, WA1, B1, B2, B3, B4);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, B1, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(B5, ra1, ROFF(5));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, B1, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB0, wa_, WOFF(1, 2, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, B2, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB1, wa_, WOFF(1, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, B2, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, B3, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, B3, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, B4, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, B4, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(B5, WB0, WB1);
-            DSR(A0, ra2, ROFF(0)); DSR(A1, ra2, ROFF(1)); DSR(A2, ra2, ROFF(2)); DSR(A3, ra2, ROFF(3));
-            DSR(WA0, wa_, WOFF(2, 0, 0)); DSR(WA1, wa_, WOFF(2, 0, 1));
+            // step 5: dx = 1, dy = 2
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WB0, WB1, B2, B3, B4, B5);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B2, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A0, ra2, ROFF(0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B2, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A1, ra2, ROFF(1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B3, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A2, ra2, ROFF(2));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B3, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A3, ra2, ROFF(3));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B4, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA0, wa_, WOFF(2, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B4, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA1, wa_, WOFF(2, 0, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, B5, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, B5, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM6(A0, A1, A2, A3, WA0, WA1);
-            // dx = 2
-            DSR(A4, ra2, ROFF(4)); DSR(WB0, wa_, WOFF(2, 1, 0)); DSR(WB1, wa_, WOFF(2, 1, 1));
+            // step 6: dx = 2, dy = 0
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WA0, WA1, A0, A1, A2, A3);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A4, ra2, ROFF(4));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A0, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB0, wa_, WOFF(2, 1, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A1, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WB1, wa_, WOFF(2, 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A2, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A2, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A3, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A3, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(A4, WB0, WB1);
-            DSR(A5, ra2, ROFF(5)); DSR(WA0, wa_, WOFF(2, 2, 0)); DSR(WA1, wa_, WOFF(2, 2, 1));
+            // step 7: dx = 2, dy = 1
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WB0, WB1, A1, A2, A3, A4);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A1, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(A5, ra2, ROFF(5));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A1, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA0, wa_, WOFF(2, 2, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A2, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            DSR(WA1, wa_, WOFF(2, 2, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A2, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A3, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A3, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB0, A4, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WB1, A4, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             LGKM3(A5, WA0, WA1);
+            // step 8: dx = 2, dy = 2
             __builtin_amdgcn_sched_barrier(0);
-            MM8(WA0, WA1, A2, A3, A4, A5);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A2, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A2, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A3, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A3, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A4, acc[2][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A4, acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA0, A5, acc[3][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA1, A5, acc[3][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #undef DSR
 #undef WOFF
@@ -456,9 +656,13 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             }
             if (s + 1 < NSLICE) {
                 I32_STORE_SLICE(smem + ((s + 1) & 1) * I32_BUF_BYTES);  // last read in iteration s-1, before the previous barrier
-                __syncthreads();
+                long long tb = 0;
+                if constexpr ((EXP & 16) != 0) tb = clock64();
+                if (!(EXP & 8)) __syncthreads();
+                if constexpr ((EXP & 16) != 0) tk_bar += clock64() - tb;
             }
         }
+        if constexpr ((EXP & 16) != 0) { const long long t = clock64(); tk_main += t - tk0; tk0 = t; }
         if constexpr (kFuse) {
             // ---- fused last layer (encoder.py:77 conv 256 -> 1, BatchNorm, :32-34 sigmoid * const).  Its 9 taps are the rows of a 1x1
             // convolution P[pixel][tap] += sum_c w[tap][c] y[c][pixel] whose B operand is exactly this lane's freshly rounded bf16
@@ -491,8 +695,8 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                             if constexpr (kRelu) {
                                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                             }
-                            yw[2 * h + 0] = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
-                            yw[2 * h + 1] = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                            yw[2 * h + 0] = pack_bf16x2(v0, v1);
+                            yw[2 * h + 1] = pack_bf16x2(v2, v3);
                         }
                         const uint4 yq = make_uint4(yw[0], yw[1], yw[2], yw[3]);
                         pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa, 0, 0, 0);
@@ -545,8 +749,8 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                         }
                         uint2 o;
-                        o.x = (uint32_t)f32_to_bf16_rn(v0) | ((uint32_t)f32_to_bf16_rn(v1) << 16);
-                        o.y = (uint32_t)f32_to_bf16_rn(v2) | ((uint32_t)f32_to_bf16_rn(v3) << 16);
+                        o.x = pack_bf16x2(v0, v1);
+                        o.y = pack_bf16x2(v2, v3);
                         const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
                         *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
                     }
@@ -561,7 +765,14 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if constexpr ((EXP & 16) != 0) tk_epi += clock64() - tk0;
         item = next;
+    }
+    if constexpr ((EXP & 16) != 0) {
+        if (lane == 0) {
+            long long* dbg = reinterpret_cast<long long*>(a.out) + ((size_t)blockIdx.x * 8 + wave) * 4;
+            dbg[0] = clock64() - tk_start; dbg[1] = tk_bar; dbg[2] = tk_main; dbg[3] = tk_epi;
+        }
     }
 }
 
