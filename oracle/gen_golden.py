@@ -97,25 +97,47 @@ def sel_from_intermediate(out) -> np.ndarray:
     return sel
 
 
-def cnn_cost_maps(prob):
-    """Cost maps from the reference's shipped checkpoint (CNN encoder, depth 4; encoder.py:60-78,
-    astar.py:154-180): the only source of realistic non-uniform costs in the tree."""
+REF_ENCODER = "/root/reference/src/neural_astar/planner/encoder.py"
+
+
+def load_reference_encoder():
+    """The reference's own encoder module (planner/encoder.py).  Its only unavailable import is
+    segmentation_models_pytorch (used by Unet alone), stubbed with an empty module."""
+    import sys
+    import types
+    sys.modules.setdefault("segmentation_models_pytorch", types.ModuleType("segmentation_models_pytorch"))
+    spec = importlib.util.spec_from_file_location("ref_encoder", REF_ENCODER)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def shipped_state_dict():
+    """state_dict of the shipped checkpoint model/mazes_032_moore_c8 (NeuralAstar, CNN depth 4), `planner.` prefix kept off."""
     import glob
-    import re
-    import torch.nn as nn
     ck = sorted(glob.glob("/root/reference/model/mazes_032_moore_c8/**/*.ckpt", recursive=True))[-1]
     sd = torch.load(ck, map_location="cpu", weights_only=True)["state_dict"]
-    sd = {re.split("planner.encoder.model.", k)[-1]: v for k, v in sd.items() if "planner.encoder.model." in k}
-    chans = [2, 32, 64, 128, 256, 1]
-    blocks = []
-    for i in range(5):
-        blocks += [nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1), nn.BatchNorm2d(chans[i + 1]), nn.ReLU()]
-    model = nn.Sequential(*blocks[:-1]).eval()
-    model.load_state_dict(sd, strict=True)
+    return {k[len("planner."):]: v for k, v in sd.items() if k.startswith("planner.")}
+
+
+def cnn_cost_maps(prob):
+    """Cost maps from the reference's shipped checkpoint through the reference's OWN encoder class (encoder.py:60-78 CNN,
+    :32-34 forward) and input assembly (astar.py:171-177): the only source of realistic non-uniform costs in the tree."""
+    enc = load_reference_encoder().CNN(input_dim=2, encoder_depth=4, const=None).eval()
+    sd = {k[len("encoder."):]: v for k, v in shipped_state_dict().items() if k.startswith("encoder.")}
+    enc.load_state_dict(sd, strict=True)
     m, s, g = (torch.from_numpy(x) for x in prob)
     with torch.no_grad():
-        y = torch.sigmoid(model(torch.cat((m, s + g), dim=1)))
+        y = enc(torch.cat((m, s + g), dim=1))
     return y.numpy().astype(np.float32)
+
+
+def export_checkpoint():
+    """tests/golden/ckpt_mazes032_cnn.npz: the shipped checkpoint's planner state_dict as plain arrays, so that GPU-box tests
+    (no /root/reference there) can load it strict=True and compare encoders against `maze32_cnncost_g050.cost`."""
+    sd = shipped_state_dict()
+    np.savez_compressed(os.path.join(OUT, "ckpt_mazes032_cnn.npz"), **{k: v.numpy() for k, v in sd.items()})
+    print("ckpt_mazes032_cnn.npz:", len(sd), "tensors")
 
 
 def main():
@@ -164,6 +186,7 @@ def main():
     cc = cnn_cost_maps(mz16)
     out, _ = run_ref(ref, cc, mz16.start_maps, mz16.goal_maps, mz16.map_designs, 0.5)
     save("maze32_cnncost_g050", mz16, cc, out, 0.5)
+    export_checkpoint()
     # 5c. train mode, Tmax = 0.25 (scripts/config/train.yaml:4): budget-truncated searches
     out, _ = run_ref(ref, mz.map_designs[:32], mz.start_maps[:32], mz.goal_maps[:32], mz.map_designs[:32], 0.5,
                      Tmax=0.25, training=True)

@@ -398,3 +398,42 @@ def test_hip_encoder_matches_torch_encoder_and_feeds_the_search():
         finally:
             os.environ.pop("NASTAR_ENCODER_FLAGS", None)
     na.encoder_backend = "torch"
+
+
+def test_shipped_checkpoint_encoders_match_the_reference_cost_maps():
+    """Reference CNN + shipped checkpoint -> golden cost maps (maze32_cnncost_g050).  On the GPU: the fp32 torch encoder within
+    1e-5, the bf16 MFMA encoder within the bf16 tolerance (max 3e-2, mean 3e-3); and the planner driven by the MFMA encoder
+    solves every map with paths that are valid 8-connected start->goal chains."""
+    from test_host_logic import _shipped_planner
+    g = G.load("maze32_cnncost_g050")
+    dev = _dev()
+    na = _shipped_planner().to(dev)
+    m, s, go = _t(g.map_designs), _t(g.start_maps), _t(g.goal_maps)
+    ref = _t(g.cost_maps)
+    with torch.no_grad():
+        c32 = na.encode(m, s, go)
+        assert float((c32 - ref).abs().max()) < 1e-5
+        na.encoder_backend = "hip_bf16"
+        c16 = na.encode(m, s, go)
+        err = (c16 - ref).abs()
+        assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+        out = na(m, s, go)
+    assert int((na.astar.last_status != 0).sum()) == 0
+    paths = out.paths[:, 0].cpu().numpy()
+    for b in range(g.B):
+        ys, xs = np.nonzero(paths[b])
+        cells = set(zip(ys.tolist(), xs.tolist()))
+        sy, sx = divmod(int(g.start_maps[b].reshape(-1).argmax()), 32)
+        gy, gx = divmod(int(g.goal_maps[b].reshape(-1).argmax()), 32)
+        assert (sy, sx) in cells and (gy, gx) in cells
+        assert all(g.map_designs[b, 0, y, x] == 1 for y, x in cells)
+        # connected under 8-neighbourhood: flood fill from the start reaches the goal through path cells only
+        seen, todo = {(sy, sx)}, [(sy, sx)]
+        while todo:
+            y, x = todo.pop()
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    q = (y + dy, x + dx)
+                    if q in cells and q not in seen:
+                        seen.add(q); todo.append(q)
+        assert (gy, gx) in seen

@@ -140,3 +140,31 @@ def test_validation_metrics_match_the_reference_numpy_formulas():
     p_exp = np.maximum((exp_astar - exp_na) / exp_astar, 0.0).mean()
     h_mean = 2.0 / (1.0 / (p_opt + 1e-10) + 1.0 / (p_exp + 1e-10))
     assert abs(float(m.p_opt) - p_opt) < 1e-12 and abs(float(m.p_exp) - p_exp) < 1e-6 and abs(float(m.h_mean) - h_mean) < 1e-6
+
+
+def _shipped_planner():
+    """NeuralAstar with the reference's shipped mazes_032_moore_c8 checkpoint (tests/golden/ckpt_mazes032_cnn.npz, exported by
+    oracle/gen_golden.py), loaded strict=True: every key and shape of the reference's state_dict must exist here."""
+    import os
+    import numpy as np
+    import torch
+    from neural_astar.planner import NeuralAstar
+    import golden_util as G
+    z = np.load(os.path.join(G.GOLDEN_DIR, "ckpt_mazes032_cnn.npz"))
+    na = NeuralAstar(encoder_arch="CNN", encoder_depth=4, encoder_input="m+", const=None)
+    na.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=True)
+    return na.eval()
+
+
+def test_shipped_checkpoint_loads_strict_and_torch_encoder_matches_reference_cost_maps():
+    """The cost maps in maze32_cnncost_g050 were produced by the reference's own CNN class from the shipped checkpoint
+    (encoder.py:60-78, :32-34; astar.py:171-177).  The fp32 torch encoder of this package must reproduce them (CPU, ~1e-7)."""
+    import torch
+    import golden_util as G
+    g = G.load("maze32_cnncost_g050")
+    na = _shipped_planner()
+    with torch.no_grad():
+        cost = na.encode(torch.from_numpy(g.map_designs), torch.from_numpy(g.start_maps), torch.from_numpy(g.goal_maps))
+    err = (cost.numpy() - g.cost_maps)
+    assert cost.shape == (g.B, 1, 32, 32)
+    assert float(abs(err).max()) < 1e-6, float(abs(err).max())
