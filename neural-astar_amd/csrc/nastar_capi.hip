@@ -531,13 +531,6 @@ static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
 {
     if (ca.H != 32 || ca.W != 32 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
     void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
-    if constexpr (CIN == 128) {  // dev ablations (timing only, results are garbage)
-        const int ex = enc_flags() >> 4;
-        if (ex == 1) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 3>;
-        if (ex == 2) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 7>;
-        if (ex == 3) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 15>;
-        if (ex == 4) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 5>;
-    }
     int rc = ensure_lds(kern, I32_LDS_BYTES);
     if (rc) return rc;
     int n_cu = 0;
@@ -554,8 +547,8 @@ static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
 static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
 {
     void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
-    if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 32>;  // dev: every workgroup reads image 0 (L2 hits)
-    if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 16>;  // dev: cycle totals into the (unused) output slab
+    if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 2>;  // dev: every workgroup reads image 0 (L2 hits)
+    if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 1>;  // dev: cycle totals into the (unused) output slab
     int rc = ensure_lds(kern, I32_LDS_BYTES);
     if (rc) return rc;
     int n_cu = 0;
