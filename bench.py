@@ -199,6 +199,42 @@ def training_step_ms(pr, dev, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def l1_training_step_ms(pr, dev, batch, reps=20):
+    """Extra: the reference's training step on `batch` maps (utils/training.py:55-61, Tmax = 0.25, cost = leaf tensor):
+    L1Loss through autograd vs the fused node (nastar_l1_loss + nastar_backward_l1)."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    m = torch.from_numpy(pr.map_designs[:batch, 0]).to(dev).contiguous()
+    s = torch.from_numpy(pr.start_maps[:batch, 0]).to(dev).contiguous()
+    g = torch.from_numpy(pr.goal_maps[:batch, 0]).to(dev).contiguous()
+    traj = ((torch.rand_like(m) < 0.2).float() * m).contiguous()
+    cost = torch.from_numpy(syn.random_costs(batch, H, W, seed=3)[:, 0]).to(dev).requires_grad_(True)
+    mi = int(0.25 * W * W)
+    l1 = torch.nn.L1Loss()
+
+    def unfused():
+        cost.grad = None
+        hist, _, _, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
+        l1(hist, traj).backward()
+
+    def fused():
+        cost.grad = None
+        ops.astar_l1_loss(cost, s, g, m, traj, G_RATIO, mi)[0].backward()
+    out = {}
+    for name, fn in (("autograd_l1loss_ms", unfused), ("fused_ms", fused)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = e0.elapsed_time(e1) / reps
+    return out
+
+
 def neural_astar_forward_ms(pr, dev, reps=5):
     """Extra (BASELINE config 3 stand-in): NeuralAstar(CNN encoder, depth 4) forward on the bench batch with the bf16-MFMA
     HIP encoder + the HIP search, eval mode.  (The torch/MIOpen encoder is not timed here: its first call autotunes for
@@ -376,6 +412,8 @@ def main():
             out["secondary"] = sec
             out["extra"] = {"neural_astar_cnn_hip_bf16": neural_astar_forward_ms(pr, dev),
                             "train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
+                            "train_l1_step_Tmax025": {"batch_100": l1_training_step_ms(pr, dev, 100),
+                                                      "batch_4096": l1_training_step_ms(pr, dev, 4096)},
                             "two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
                             "streams_sweep_maps_per_s": {str(k): multi_stream_throughput(pr, args.steps, dev, k) for k in (1, 2, 3, 4, 6)},
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "

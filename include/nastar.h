@@ -104,6 +104,20 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
                     const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
                     size_t workspace_bytes, int flags, void* stream);
 
+/*
+ * Training step with the loss fused in (SURVEY.md 8f "next #3"; reference utils/training.py:55-61):
+ *   loss = nn.L1Loss()(outputs.histories, opt_trajs); loss.backward()
+ * nastar_l1_loss: loss_out[0] = mean |histories - opt_trajs| over numel elements (fixed-order double reduction, bitwise
+ *   reproducible); workspace >= 2048 bytes.
+ * nastar_backward_l1: nastar_backward with dL/dhistories = (*grad_loss_dev or 1) * sign(histories - opt_trajs) / (B*H*W)
+ *   formed inside the kernel (no gradient tensor is materialised).  histories = the forward's own output.
+ */
+int nastar_l1_loss(const float* histories, const float* opt_trajs, long long numel, float* loss_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int nastar_backward_l1(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
+                       const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
+                       int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream);
+
 /* h0 = get_heuristic(goal) for B maps: out [B,H,W] fp32 (parity/debug; the forward computes it on the fly). */
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream);
 

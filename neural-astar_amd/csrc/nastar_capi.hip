@@ -152,7 +152,11 @@ __global__ __launch_bounds__(64) void nastar_forward_reg_kernel(const FwdArgs a,
 }
 
 struct BwdArgs {
-    const float* grad_hist;
+    const float* grad_hist;  // upstream dL/dhistories, or nullptr: L1 loss fused (below)
+    const float* l1_hist;    // fused L1 (training.py:58): dL/dhistories = l1_scale * *l1_up * sign(histories - opt_trajs)
+    const float* l1_traj;
+    const float* l1_up;      // device scalar dL/dloss (nullptr = 1)
+    float l1_scale;          // 1 / numel (nn.L1Loss reduction='mean')
     const float* cost;
     const float* start;
     const float* goal;
@@ -164,6 +168,15 @@ struct BwdArgs {
     float kfac;   // (1-g_ratio) * (-1/sqrt(W))
     MapDims d;
 };
+
+// upstream gradient of one cell: given, or the L1 loss's sign gradient computed in place (torch: grad * sign(x - y) / numel)
+__device__ __forceinline__ float upstream_grad(const BwdArgs& a, size_t i)
+{
+    if (a.grad_hist != nullptr) return a.grad_hist[i];
+    const float dlt = a.l1_hist[i] - a.l1_traj[i];
+    const float sg = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+    return sg * (a.l1_scale * (a.l1_up != nullptr ? *a.l1_up : 1.f));
+}
 
 // y_t = softmax over the open list of -f/sqrt(W) (:207-209,:67-68); acc += scale * kfac * y * (G - <G,y>).
 // Only chunks that hold an open cell are visited (chunkmin != KEY_INF): the open list is a thin frontier, typically
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
     int start_idx, goal_idx;
     load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
     for (int i = lane; i < d.HWp; i += 64) {
-        gh[i] = (i < d.HW) ? a.grad_hist[off + i] : 0.f;
+        gh[i] = (i < d.HW) ? upstream_grad(a, off + i) : 0.f;
         acc[i] = 0.f;
     }
     wave_sync();
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(64) void nastar_backward_small_kernel(const BwdArgs
     float gh[NCH], acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        gh[c] = a.grad_hist[off + c * CHUNK + lane];
+        gh[c] = upstream_grad(a, off + c * CHUNK + lane);
         acc[c] = 0.f;
     }
 
@@ -560,6 +573,33 @@ static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
     return NASTAR_OK;
 }
 
+// ---- mean |histories - opt_trajs| (nn.L1Loss, training.py:58): fixed-order two-stage reduction in double, deterministic --------
+constexpr int kL1Blocks = 256;
+__device__ __forceinline__ double block_sum_256(double v, double* sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    return sh[0];
+}
+__global__ __launch_bounds__(256) void nastar_l1_partial_kernel(const float* h, const float* t, long long n, double* part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kL1Blocks * 256) acc += (double)fabsf(h[i] - t[i]);
+    const double tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void nastar_l1_final_kernel(const double* part, long long n, float* loss)
+{
+    __shared__ double sh[256];
+    const double tot = block_sum_256(part[threadIdx.x], sh);
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)n);
+}
+
 static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
 {
     constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
@@ -702,20 +742,17 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);  // shapes the fused path skips
 }
 
-int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
-                    const float* passable, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
-                    const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes,
-                    int flags, void* stream)
+static int backward_impl(BwdArgs& a, const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                         int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
+                         float* grad_cost_out, void* stream)
 {
-    (void)workspace; (void)workspace_bytes; (void)flags;
     if (t_batch_dev && !iters) return NASTAR_ERR_NULL;
-    if (!grad_histories || !cost || !start || !goal || !passable || !grad_cost_out) return NASTAR_ERR_NULL;
-    BwdArgs a;
+    if (!cost || !start || !goal || !passable || !grad_cost_out) return NASTAR_ERR_NULL;
     int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
     if (rc) return rc;
     const size_t lds = ((map_lds_bytes(a.d.HWp, a.d.NCp) + 15) & ~(size_t)15) + (size_t)a.d.HWp * 12;
     if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
-    a.grad_hist = grad_histories; a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
+    a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
     a.iters = iters; a.t_batch = t_batch_dev; a.grad_cost = grad_cost_out; a.max_iters = max_iters;
     a.kfac = a.d.omg * (-1.0f / a.d.sqrtW);
     const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable);
@@ -733,6 +770,45 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
     if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, B, lds, s, a);
     if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
     return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
+}
+
+int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
+                    const float* passable, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
+                    const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes,
+                    int flags, void* stream)
+{
+    (void)workspace; (void)workspace_bytes; (void)flags;
+    if (!grad_histories) return NASTAR_ERR_NULL;
+    BwdArgs a;
+    a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
+    return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
+}
+
+int nastar_backward_l1(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
+                       const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
+                       int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream)
+{
+    if (!histories || !opt_trajs) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    BwdArgs a;
+    a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
+    a.l1_scale = (float)(1.0 / ((double)B * H * W));
+    return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
+}
+
+int nastar_l1_loss(const float* histories, const float* opt_trajs, long long numel, float* loss_out, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    if (!histories || !opt_trajs || !loss_out || !workspace) return NASTAR_ERR_NULL;
+    if (numel <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (workspace_bytes < (size_t)kL1Blocks * sizeof(double)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(nastar_l1_partial_kernel, dim3(kL1Blocks), dim3(256), 0, s, histories, opt_trajs, numel, part);
+    hipLaunchKernelGGL(nastar_l1_final_kernel, dim3(1), dim3(256), 0, s, part, numel, loss_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
 }
 
 int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out, void* stream)

@@ -40,6 +40,8 @@ EXPORTED_SYMBOLS = (
     "nastar_forward",
     "nastar_forward_packed",
     "nastar_backward",
+    "nastar_backward_l1",
+    "nastar_l1_loss",
     "nastar_heuristic",
     "nastar_debug_occupancy",
     "nastar_pack_outputs",
@@ -86,6 +88,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_backward.restype = ci
     lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_backward_l1.restype = ci
+    lib.nastar_backward_l1.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp]
+    lib.nastar_l1_loss.restype = ci
+    lib.nastar_l1_loss.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, cz, vp]
     lib.nastar_heuristic.restype = ci
     lib.nastar_heuristic.argtypes = [vp, ci, ci, ci, vp, vp]
     lib.nastar_pack_outputs.restype = ci

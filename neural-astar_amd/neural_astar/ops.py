@@ -13,7 +13,7 @@ import torch
 
 from . import _native
 
-__all__ = ["astar_forward", "astar_backward", "heuristic", "max_iters_for"]
+__all__ = ["astar_forward", "astar_backward", "astar_backward_l1", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
 
 
 def max_iters_for(W: int, Tmax: float, training: bool) -> int:
@@ -147,6 +147,82 @@ class BatchCoupling:
         if callable(cls.mode):
             return cls.mode(iters)
         return (iters.amax() - 1).to(torch.int32).reshape(1)
+
+
+# ---- training step with the L1 loss fused in (SURVEY.md 8f "next #3"; reference utils/training.py:55-61) ------------------
+@torch.library.custom_op("nastar::l1_loss", mutates_args=())
+def l1_loss(histories: torch.Tensor, opt_trajs: torch.Tensor) -> torch.Tensor:
+    """mean |histories - opt_trajs| as a 1-element device tensor (fixed-order reduction: bitwise reproducible)."""
+    _require_device(histories, opt_trajs)
+    if histories.shape != opt_trajs.shape:
+        raise ValueError(f"shape mismatch {tuple(histories.shape)} vs {tuple(opt_trajs.shape)}")
+    lib = _native.load()
+    h, t = histories.contiguous(), opt_trajs.contiguous()
+    dev = h.device
+    out = torch.empty((1,), dtype=torch.float32, device=dev)
+    ws = torch.empty((2048,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_l1_loss(h.data_ptr(), t.data_ptr(), h.numel(), out.data_ptr(), ws.data_ptr(), 2048, _stream_ptr(dev))
+    _native.check(rc, "nastar_l1_loss")
+    return out
+
+
+@l1_loss.register_fake
+def _(histories, opt_trajs):
+    return histories.new_empty((1,))
+
+
+@torch.library.custom_op("nastar::astar_backward_l1", mutates_args=())
+def astar_backward_l1(histories: torch.Tensor, opt_trajs: torch.Tensor, grad_loss: Optional[torch.Tensor], cost: torch.Tensor,
+                      start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor, g_ratio: float, max_iters: int,
+                      iters: torch.Tensor, t_batch: Optional[torch.Tensor]) -> torch.Tensor:
+    """dL/dcost for L = grad_loss * mean|histories - opt_trajs|: the sign gradient is formed inside the backward kernel."""
+    _require_device(histories, opt_trajs, cost, start, goal, passable)
+    lib = _native.load()
+    histories, opt_trajs, cost, start, goal, passable = (x.contiguous() for x in (histories, opt_trajs, cost, start, goal, passable))
+    B, H, W = cost.shape
+    dev = cost.device
+    gl = grad_loss.reshape(1).to(torch.float32).contiguous() if grad_loss is not None else None
+    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_backward_l1(histories.data_ptr(), opt_trajs.data_ptr(), gl.data_ptr() if gl is not None else None,
+                                    cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
+                                    float(g_ratio), int(max_iters), iters.data_ptr(),
+                                    t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(), _stream_ptr(dev))
+    _native.check(rc, "nastar_backward_l1")
+    return grad_cost
+
+
+@astar_backward_l1.register_fake
+def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, g_ratio, max_iters, iters, t_batch):
+    return torch.empty_like(cost)
+
+
+class _AstarL1Loss(torch.autograd.Function):
+    """search + L1 loss as ONE autograd node: forward = nastar_forward + nastar_l1_loss, backward = nastar_backward_l1."""
+
+    @staticmethod
+    def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters):
+        with torch.no_grad():
+            hist, paths, iters, status, _ = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, False)
+            loss = torch.ops.nastar.l1_loss(hist, opt_trajs)
+        ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters)
+        ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
+        ctx.mark_non_differentiable(hist, paths, iters, status)
+        return loss.reshape(()), hist, paths, iters, status
+
+    @staticmethod
+    def backward(ctx, g_loss, g_hist, g_paths, g_iters, g_status):
+        cost, start, goal, passable, opt_trajs, hist, iters = ctx.saved_tensors
+        grad_cost = torch.ops.nastar.astar_backward_l1(hist, opt_trajs, g_loss, cost, start, goal, passable, ctx.g_ratio,
+                                                       ctx.max_iters, iters, BatchCoupling.t_batch(iters))
+        return grad_cost, None, None, None, None, None, None
+
+
+def astar_l1_loss(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
+                  opt_trajs: torch.Tensor, g_ratio: float, max_iters: int):
+    """[B,H,W] maps -> (loss scalar, histories, paths, iters, status); only ``loss`` carries gradient (to ``cost``)."""
+    return _AstarL1Loss.apply(cost, start, goal, passable, opt_trajs, float(g_ratio), int(max_iters))
 
 
 def heuristic(goal_maps: torch.Tensor) -> torch.Tensor:

@@ -437,3 +437,57 @@ def test_shipped_checkpoint_encoders_match_the_reference_cost_maps():
                     if q in cells and q not in seen:
                         seen.add(q); todo.append(q)
         assert (gy, gx) in seen
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_l1_training_step_matches_autograd_through_l1loss(training):
+    """utils/training.py:55-61: loss = L1Loss(histories, opt_trajs); loss.backward().  The fused node (nastar_l1_loss +
+    nastar_backward_l1) must give the same loss and the same dL/dcost as torch's L1Loss feeding nastar_backward."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    pr = syn.maze_maps(64, 32, seed=77)
+    m, s, go = (_t(x)[:, 0].contiguous() for x in pr)
+    traj = (torch.rand_like(m) < 0.2).float() * m          # 0/1 "optimal trajectory" masks
+    mi = ops.max_iters_for(32, 0.25, training)
+    c1 = _t(syn.random_costs(64, 32, 32, seed=5))[:, 0].contiguous().requires_grad_(True)
+    c2 = c1.detach().clone().requires_grad_(True)
+    hist, _, _, _, _ = torch.ops.nastar.astar_forward(c1, s, go, m, 0.5, mi, False)
+    loss_ref = torch.nn.L1Loss()(hist, traj)
+    (3.0 * loss_ref).backward()
+    loss, h2, p2, it2, st2 = ops.astar_l1_loss(c2, s, go, m, traj, 0.5, mi)
+    (3.0 * loss).backward()
+    assert torch.equal(h2, hist.detach()) and int(st2.abs().sum()) == 0
+    assert abs(float(loss) - float(loss_ref)) <= 1e-7 * max(1.0, abs(float(loss_ref)))
+    assert float(c1.grad.abs().max()) > 0
+    assert torch.allclose(c2.grad, c1.grad, rtol=1e-5, atol=1e-10), float((c2.grad - c1.grad).abs().max())
+    # reproducible bit for bit
+    loss_b, *_ = ops.astar_l1_loss(c2.detach(), s, go, m, traj, 0.5, mi)
+    assert float(loss_b) == float(loss)
+
+
+def test_fused_l1_step_trains_the_encoder_like_the_reference_step():
+    """fused_l1_step(NeuralAstar) vs the reference's own training_step lines: identical loss, matching encoder gradients."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    from neural_astar.utils.training import fused_l1_step
+    dev = _dev()
+    pr = syn.maze_maps(16, 32, seed=78)
+    m, s, go = (_t(x) for x in pr)
+    traj = (torch.rand_like(m) < 0.2).float() * m
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="CNN", Tmax=0.25).to(dev).train()
+    out = na(m, s, go)
+    loss_ref = torch.nn.L1Loss()(out.histories, traj)
+    loss_ref.backward()
+    g_ref = [p.grad.clone() for p in na.encoder.parameters() if p.grad is not None]
+    na.zero_grad()
+    loss, out2 = fused_l1_step(na, m, s, go, traj)
+    loss.backward()
+    g_fused = [p.grad.clone() for p in na.encoder.parameters() if p.grad is not None]
+    assert len(g_ref) == len(g_fused) > 0
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6
+    # BatchNorm in train mode updates running stats between the two passes but uses batch statistics: same cost maps
+    assert torch.equal(out2.histories, out.histories.detach())
+    for a, b in zip(g_fused, g_ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-8), float((a - b).abs().max())
