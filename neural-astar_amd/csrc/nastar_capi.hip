@@ -538,17 +538,20 @@ static int conv_cu_count(int* out)
     return NASTAR_OK;
 }
 
-// 32x32 images, CIN >= 32 and COUT >= 64: whole-image persistent workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
+// CIN >= 32 and COUT >= 64, H and W multiples of 32: persistent 32x32-tile workgroups (nastar_conv3x3_img32_kernel; 32x32 images
+// take its whole-image form), otherwise the generic tiled kernel
 template <int CIN, int COUT, bool kRelu>
 static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
 {
-    if (ca.H != 32 || ca.W != 32 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
+    if (ca.H % 32 != 0 || ca.W % 32 != 0 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
+    const bool whole = ca.H == 32 && ca.W == 32;
     void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
+    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 0, true>;
     int rc = ensure_lds(kern, I32_LDS_BYTES);
     if (rc) return rc;
     int n_cu = 0;
     if ((rc = conv_cu_count(&n_cu))) return rc;
-    const long long items = (long long)ca.B * (COUT / I32_NT);
+    const long long items = (long long)ca.B * (ca.H / 32) * (ca.W / 32) * (COUT / I32_NT);
     const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);  // persistent: one workgroup per CU
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
     hipError_t e = hipGetLastError();

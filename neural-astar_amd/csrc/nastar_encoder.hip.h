@@ -276,9 +276,12 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
 }
 
 // kProbe (dev builds only): 1 = per-wave cycle totals written to the output slab, 2 = every workgroup reads image 0 (L2-hit ablation)
-template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0>
+// kTiled: the image is H x W with H, W multiples of 32 and a work item is one of its 32x32 tiles: the halo ring (132 pixels) is
+// then real data, loaded as a fifth chunk by threads 0..263 (zero outside the image); kTiled = false is the whole-image case above.
+template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, bool kTiled = false>
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
+    static_assert(!(kFuse && kTiled), "the fused last layer needs the whole image in one workgroup");
     constexpr int NSLICE = CIN / I32_KS;
     constexpr int NGRP = COUT / I32_NT;
     static_assert(NSLICE % 2 == 0, "buffer parity must repeat per work item");
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     // image -- which read the same input -- are worked on at the same time on the SAME XCD.
     int wg = blockIdx.x;
     if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int nitems = a.B * NGRP;
+    const int tiles_x = kTiled ? a.W / 32 : 1, ntile = kTiled ? tiles_x * (a.H / 32) : 1, img_w = kTiled ? a.W : 32;
+    const int nitems = a.B * ntile * NGRP;
 
     // zero both pixel tiles (the halo stays zero = the convolution's padding)
     for (int q = tid; q < I32_TILE_BYTES / 16; q += 512) {
@@ -310,18 +314,40 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     }
     // staging: chunk q = tid + 512 i.  pixels: p = q >> 1 = (tid >> 1) + 256 i -> row (tid >> 6) + 8 i, column (tid >> 1) & 31
     const int t_dst = i32_tile_off((tid >> 6) + 1, ((tid >> 1) & 31) + 1, tid & 1);
-    const size_t t_lane = (size_t)(tid >> 1) * CIN + (tid & 1) * 8;
+    const size_t t_lane = ((size_t)(tid >> 6) * img_w + ((tid >> 1) & 31)) * CIN + (tid & 1) * 8;
     // weights: q -> n = q & 63, khalf = (q >> 6) & 1, tap = (q >> 7) = (tid >> 7) + 4 i
     const size_t w_lane = ((size_t)((tid >> 7) * (CIN / 8) + ((tid >> 6) & 1)) * COUT + (tid & 63)) * 8;
     // (named scalars, not arrays: the arrays were left in scratch memory by the compiler)
     uint4 t0, t1, t2, t3, w0, w1, w2 = make_uint4(0u, 0u, 0u, 0u);
     const bool w2on = tid < 128;
-    constexpr size_t TSTR = (size_t)256 * CIN, WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
+    constexpr size_t WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
+    const size_t TSTR = (size_t)8 * img_w * CIN;  // 8 image rows
+    // halo ring (kTiled): chunk tid < 264 -> ring pixel tid >> 1: top row, bottom row, left column, right column of the 34x34 tile
+    uint4 hq = make_uint4(0u, 0u, 0u, 0u);
+    int h_dst = 0, h_y = 0, h_x = 0;
+    if constexpr (kTiled) {
+        const int r = tid >> 1;
+        h_y = r < 34 ? 0 : (r < 68 ? 33 : (r < 100 ? r - 67 : r - 99));
+        h_x = r < 34 ? r : (r < 68 ? r - 34 : (r < 100 ? 0 : 33));
+        h_dst = i32_tile_off(h_y, h_x, tid & 1);
+    }
+    const bool h_on = kTiled && tid < 264;
+    // item -> (image b, tile origin y0/x0, channel group)
+#define I32_DECODE(item_, b_, y0_, x0_, g_)                                                              \
+    const int g_ = (item_) % NGRP, tl_##b_ = ((item_) / NGRP) % ntile, b_ = (kProbe == 2) ? 0 : (item_) / (NGRP * ntile), \
+              y0_ = (tl_##b_ / tiles_x) * 32, x0_ = (tl_##b_ % tiles_x) * 32
 #define I32_LOAD_SLICE(item_, s_)                                                                        \
     do {                                                                                                 \
-        const int ib_ = (kProbe == 2) ? 0 : (item_) / NGRP, ig_ = (item_) % NGRP;                           \
-        const uint16_t* tp_ = a.in + (size_t)ib_ * 1024 * CIN + t_lane + (s_) * I32_KS;                  \
+        I32_DECODE(item_, ib_, iy_, ix_, ig_);                                                           \
+        const uint16_t* ip_ = a.in + (((size_t)ib_ * (kTiled ? a.H : 32) + iy_) * img_w + ix_) * CIN + (s_) * I32_KS; \
+        const uint16_t* tp_ = ip_ + t_lane;                                                              \
         const uint16_t* wp_ = a.wpack + w_lane + ig_ * I32_NT * 8 + (size_t)(s_) * WSL;                  \
+        if constexpr (kTiled) {                                                                          \
+            const int gy_ = iy_ + h_y - 1, gx_ = ix_ + h_x - 1;                                          \
+            hq = make_uint4(0u, 0u, 0u, 0u);                                                             \
+            if (h_on && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)                  \
+                hq = *reinterpret_cast<const uint4*>(ip_ + ((ptrdiff_t)(h_y - 1) * img_w + (h_x - 1)) * CIN + (tid & 1) * 8); \
+        }                                                                                                \
         t0 = *reinterpret_cast<const uint4*>(tp_);                                                       \
         t1 = *reinterpret_cast<const uint4*>(tp_ + TSTR);                                                \
         t2 = *reinterpret_cast<const uint4*>(tp_ + 2 * TSTR);                                            \
@@ -340,6 +366,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + tid * 16) = w0;                             \
         *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + (tid + 512) * 16) = w1;                     \
         if (w2on) *reinterpret_cast<uint4*>(b_ + I32_TILE_BYTES + (tid + 1024) * 16) = w2;          \
+        if (h_on) *reinterpret_cast<uint4*>(b_ + h_dst) = hq;                                       \
     } while (0)
 
     // LDS byte offsets of this lane's operand fragments (buffer 0): pixel rows at the three column offsets, weights
@@ -354,7 +381,8 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     long long tk_bar = 0, tk_main = 0, tk_epi = 0, tk0 = 0, tk_start = 0;
     if constexpr (kProbe == 1) tk_start = clock64();
     while (item < nitems) {
-        const int b = item / NGRP, grp = item % NGRP, n0 = grp * I32_NT;
+        I32_DECODE(item, b, ty0, tx0, grp);
+        const int n0 = grp * I32_NT;
         const int next = !kFuse ? item + (int)gridDim.x : (grp == NGRP - 1 ? item + ((int)gridDim.x - 1) * NGRP + 1 : item + 1);
         uint4 wfq = make_uint4(0u, 0u, 0u, 0u);
         if constexpr (kFuse) {
@@ -554,7 +582,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                 for (int j = 0; j < 4; ++j) {
                     const int p = j * 8 + (lane >> 3), chunk = lane & 7;
                     const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
-                    const size_t pix = (size_t)b * 1024 + (wave * I32_RPW + m) * 32 + p;
+                    const size_t pix = ((size_t)b * (kTiled ? a.H : 32) + ty0 + wave * I32_RPW + m) * img_w + tx0 + p;
                     *reinterpret_cast<uint4*>(a.out + pix * COUT + n0 + chunk * 8) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -571,6 +599,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     }
 }
 
+#undef I32_DECODE
 #undef I32_LOAD_SLICE
 #undef I32_STORE_SLICE
 

@@ -491,3 +491,32 @@ def test_fused_l1_step_trains_the_encoder_like_the_reference_step():
     assert torch.equal(out2.histories, out.histories.detach())
     for a, b in zip(g_fused, g_ref):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-8), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (64, 64), (16, 32)])
+def test_hip_encoder_on_maps_that_are_not_32x32(shape):
+    """Sizes other than 32x32 take the tiled conv kernels + the stand-alone tap-major last layer (H % 16 == 0, W % 32 == 0);
+    anything else falls back to the torch encoder transparently."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    H, W = shape
+    dev = _dev()
+    pr = syn.random_obstacle_maps(24, H, W, 0.2, seed=9)
+    m, s, go = (_t(x) for x in pr)
+    torch.manual_seed(3)
+    na = NeuralAstar(encoder_arch="CNN").to(dev)
+    with torch.no_grad():
+        for mod in na.encoder.model:
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+    na.eval()
+    with torch.no_grad():
+        ref = na.encode(m, s, go)
+        na.encoder_backend = "hip_bf16"
+        got = na.encode(m, s, go)
+        assert na._hip_encoder is not None, "the HIP encoder was not used"
+        err = (got - ref).abs()
+        assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (shape, float(err.max()), float(err.mean()))
+        out = na(m, s, go)
+        assert int((na.astar.last_status != 0).sum()) == 0 and out.paths.shape == (24, 1, H, W)
