@@ -329,16 +329,17 @@ def test_validation_pair_launch_equals_two_separate_searches():
     assert 0.0 <= float(met.p_opt) <= 1.0 and 0.0 <= float(met.p_exp) <= 1.0
 
 
-def test_conv3x3_mfma_layer_matches_torch():
+@pytest.mark.parametrize("B,H,W", [(3, 32, 32), (2, 64, 96), (3, 16, 64), (300, 32, 32)])
+def test_conv3x3_mfma_layer_matches_torch(B, H, W):
     """One encoder layer (implicit-GEMM 3x3 conv on v_mfma_f32_32x32x16_bf16) vs torch conv2d on the SAME bf16-rounded
-    operands: differences are accumulation order + the final bf16 rounding only."""
+    operands: differences are accumulation order + the final bf16 rounding only.  32x32 = whole-image persistent kernel,
+    64x96 = its 32x32-tile form (halo across tile borders), 16x64 = generic tiled kernel, B = 300 = more work items than CUs."""
     from neural_astar import _native
     from neural_astar.encoder_hip import pack_conv_weight
     lib = _native.load()
     dev = _dev()
     torch.manual_seed(0)
     for (cin, cout, cin_p) in [(2, 32, 16), (32, 64, 32), (64, 128, 64), (128, 256, 128)]:
-        B, H, W = 3, 32, 32
         x = torch.randn(B, cin, H, W, device=dev).to(torch.bfloat16).float()
         w = (torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5).to(torch.bfloat16).float()
         scale = torch.rand(cout, device=dev) + 0.5
