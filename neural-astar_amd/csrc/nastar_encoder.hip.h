@@ -377,6 +377,10 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     int item = kFuse ? blockIdx.x * NGRP : wg;
     if (item < nitems) I32_LOAD_SLICE(item, 0);
     __syncthreads();  // zero fill and ss visible
+    if (item < nitems) {
+        I32_STORE_SLICE(smem);
+        __syncthreads();
+    }
     // kProbe == 1: per-wave cycle totals of the barrier waits, the slice loops and the epilogues
     long long tk_bar = 0, tk_main = 0, tk_epi = 0, tk0 = 0, tk_start = 0;
     if constexpr (kProbe == 1) tk_start = clock64();
@@ -404,11 +408,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             for (int n = 0; n < I32_NB; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        // buffer 0 was last read for slice NSLICE-2 of the previous item, i.e. before that slice's barrier
-        I32_STORE_SLICE(smem);
         if constexpr (kProbe == 1) tk0 = clock64();
-        __syncthreads();
-        if constexpr (kProbe == 1) { const long long t = clock64(); tk_bar += t - tk0; tk0 = t; }
 #pragma unroll 1
         for (int s = 0; s < NSLICE; ++s) {
             if (s + 1 < NSLICE) I32_LOAD_SLICE(item, s + 1);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
 #undef LGKM3
 #undef LGKM6
             if constexpr (kFuse) {
-                if (s == 0 && tid < 256) *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;  // epilogue readers are >= 1 barrier away
+                if (s == 0 && tid < 256) *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;  // the previous item's epilogue copied its fragments before the hand-over barrier
             }
             if (s + 1 < NSLICE) {
                 I32_STORE_SLICE(smem + ((s + 1) & 1) * I32_BUF_BYTES);  // last read in iteration s-1, before the previous barrier
@@ -485,17 +485,30 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                 if constexpr (kProbe == 1) tk_bar += clock64() - tb;
             }
         }
+        // Hand both operand buffers to the NEXT item before this item's epilogue: its first slice goes to buffer 0 (last read for
+        // slice NSLICE-2, i.e. before that slice's barrier) and the barrier that publishes it is the last synchronisation of this
+        // item.  The epilogue then runs unsynchronised: the SIMD's older wavefront finishes it first and starts the next item's
+        // MFMAs while the younger one is still converting and storing -- half of the epilogue disappears behind the matrix pipe.
+        bf16x8 fa[I32_NB][2];
+        if constexpr (kFuse) {  // (read before the barrier: a fast wave rewrites wf at the end of the next item's first slice)
+#pragma unroll
+            for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fa[n][j] = *reinterpret_cast<const bf16x8*>(wf + ((n * 2 + j) * 64 + lane) * 16);
+        }
+        if (next < nitems) {
+            I32_STORE_SLICE(smem);
+            long long tb = 0;
+            if constexpr (kProbe == 1) tb = clock64();
+            __syncthreads();
+            if constexpr (kProbe == 1) tk_bar += clock64() - tb;
+        }
         if constexpr (kProbe == 1) { const long long t = clock64(); tk_main += t - tk0; tk0 = t; }
         if constexpr (kFuse) {
             // ---- fused last layer (encoder.py:77 conv 256 -> 1, BatchNorm, :32-34 sigmoid * const).  Its 9 taps are the rows of a 1x1
             // convolution P[pixel][tap] += sum_c w[tap][c] y[c][pixel] whose B operand is exactly this lane's freshly rounded bf16
             // outputs (D rows 8j..8j+7 of a 32-channel block = one 16-wide k-step under a fixed channel permutation, which the A
             // fragments in wf follow).  P accumulates over the 4 channel groups in LDS; the 3x3 shifted sum runs once per image.
-            bf16x8 fa[I32_NB][2];
-#pragma unroll
-            for (int n = 0; n < I32_NB; ++n)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fa[n][j] = *reinterpret_cast<const bf16x8*>(wf + ((n * 2 + j) * 64 + lane) * 16);
 #pragma unroll
             for (int m = 0; m < I32_RPW; ++m) {
                 f32x16 pa;
