@@ -521,3 +521,25 @@ def test_hip_encoder_on_maps_that_are_not_32x32(shape):
         assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (shape, float(err.max()), float(err.mean()))
         out = na(m, s, go)
         assert int((na.astar.last_status != 0).sum()) == 0 and out.paths.shape == (24, 1, H, W)
+
+
+def test_hip_encoder_map_only_input_and_learned_const():
+    """encoder_input="m" (astar.py:171: no start/goal channel) and a learnable `const` multiplier (encoder.py:24-27,:34)."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    pr = syn.random_obstacle_maps(40, 32, 32, 0.2, seed=11)
+    m, s, go = (_t(x) for x in pr)
+    torch.manual_seed(4)
+    na = NeuralAstar(encoder_input="m", encoder_arch="CNN", const=0.7).to(dev).eval()
+    with torch.no_grad():
+        ref = na.encode(m, s, go)
+        na.encoder_backend = "hip_bf16"
+        got = na.encode(m, s, go)
+        assert na._hip_encoder is not None
+        assert float(ref.max()) <= 0.7 + 1e-6 and float(got.max()) <= 0.7 + 1e-6
+        err = (got - ref).abs()
+        assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+        na.encoder.const.mul_(2.0)  # a changed parameter must be picked up (weights are re-packed per version)
+        got2 = na.encode(m, s, go)
+        assert torch.allclose(got2, 2.0 * got, rtol=1e-5, atol=1e-6)
