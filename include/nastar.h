@@ -118,6 +118,17 @@ int nastar_backward_l1(const float* histories, const float* opt_trajs, const flo
                        const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
                        int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream);
 
+/*
+ * Dataset path (SURVEY.md 8f "next #4"; reference utils/data.py:171-199 MazeDataset.get_opt_traj, :222-244 next_loc): roll the
+ * pre-computed optimal policy out from every start cell until the goal, for a whole batch in one launch.
+ *   opt_policies [n_maps, n_actions<=8, H, W] fp32 (one-hot over actions, planning-datasets "moore" action order),
+ *   start_idx [n_maps*starts_per_map] / goal_idx [n_maps] int32 flat cell indices,
+ *   opt_trajs_out [n_maps, starts_per_map, H, W] fp32 0/1 (start and intermediate cells, NOT the goal; fully written),
+ *   status_out [n_maps*starts_per_map]: 0 ok, 1 policy revisits a cell (the reference asserts), 2 leaves the map, 3 no goal in H*W steps.
+ */
+int nastar_policy_rollout(const float* opt_policies, const int32_t* start_idx, const int32_t* goal_idx, int n_maps,
+                          int starts_per_map, int n_actions, int H, int W, float* opt_trajs_out, int32_t* status_out, void* stream);
+
 /* h0 = get_heuristic(goal) for B maps: out [B,H,W] fp32 (parity/debug; the forward computes it on the fly). */
 int nastar_heuristic(const float* goal, int B, int H, int W, float* h0_out, void* stream);
 

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "nastar_backward",
     "nastar_backward_l1",
     "nastar_l1_loss",
+    "nastar_policy_rollout",
     "nastar_heuristic",
     "nastar_debug_occupancy",
     "nastar_pack_outputs",
@@ -92,6 +93,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_backward_l1.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp]
     lib.nastar_l1_loss.restype = ci
     lib.nastar_l1_loss.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, cz, vp]
+    lib.nastar_policy_rollout.restype = ci
+    lib.nastar_policy_rollout.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]
     lib.nastar_heuristic.restype = ci
     lib.nastar_heuristic.argtypes = [vp, ci, ci, ci, vp, vp]
     lib.nastar_pack_outputs.restype = ci

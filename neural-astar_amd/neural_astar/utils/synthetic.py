@@ -170,3 +170,43 @@ def random_costs(B: int, H: int, W: int, seed: int = 4321, lo: float = 0.0, hi: 
     """Encoder-like cost maps: U(lo,hi) fp32 (the reference's encoders emit sigmoid outputs in (0,1))."""
     rng = _rng(seed)
     return (lo + (hi - lo) * rng.random((B, 1, H, W))).astype(np.float32)
+
+
+# ---- datasets in the reference's on-disk format (utils/data.py:130-150) --------------------------------------------------
+# action index -> (dy, dx), the planning-datasets "moore" order that MazeDataset.next_loc decodes (utils/data.py:232-241)
+ACTION_MOVES = ((-1, 0), (0, 1), (0, -1), (1, 0), (-1, 1), (-1, -1), (1, 1), (1, -1))
+
+
+def optimal_policies(passable: np.ndarray, dist: np.ndarray) -> np.ndarray:
+    """One-hot optimal action per cell, [N, 8, 1, H, W] float32: the move to the reachable neighbour with the smallest
+    distance-to-goal (first action in ``ACTION_MOVES`` order on ties); all-zero on obstacles, unreachable cells and the goal."""
+    N, H, W = passable.shape
+    big = np.iinfo(np.int32).max
+    d = np.where((dist >= 0) & passable, dist, big).astype(np.int64)
+    pad = np.full((N, H + 2, W + 2), big, np.int64)
+    pad[:, 1:-1, 1:-1] = d
+    nb = np.stack([pad[:, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W] for dy, dx in ACTION_MOVES], 1)  # [N,8,H,W]
+    best = nb.argmin(1)
+    ok = (d < big) & (d > 0) & (nb.min(1) < d)
+    pol = np.zeros((N, 8, H, W), np.float32)
+    n, y, x = np.nonzero(ok)
+    pol[n, best[n, y, x], y, x] = 1.0
+    return pol[:, :, None]
+
+
+def write_maze_npz(path: str, n_train: int = 32, n_valid: int = 8, n_test: int = 8, size: int = 32, seed: int = 7) -> None:
+    """A small dataset file in the layout ``MazeDataset._process`` reads: arr_{0,4,8} map_designs [N,W,W], arr_{1,5,9}
+    goal_maps [N,1,W,W], arr_{2,6,10} opt_policies [N,8,1,W,W], arr_{3,7,11} opt_dists [N,1,W,W] (NEGATIVE distances to the
+    goal, the map's minimum on obstacles / unreachable cells, as in the planning-datasets files)."""
+    rng = _rng(seed)
+    arrs = []
+    for n in (n_train, n_valid, n_test):
+        maps = np.stack([_carve_maze(rng, size, 0.1) for _ in range(n)])
+        flat = maps.reshape(n, -1)
+        g_idx = (rng.random((n, size * size)) * flat).argmax(1)
+        dist = geodesic_distance(maps, g_idx)
+        od = np.where(dist >= 0, -dist.astype(np.float32), -(dist.max((1, 2), keepdims=True) + 1.0)).astype(np.float32)
+        goal = np.zeros((n, size * size), np.float32)
+        goal[np.arange(n), g_idx] = 1
+        arrs += [maps.astype(np.float32), goal.reshape(n, 1, size, size), optimal_policies(maps, dist), od[:, None]]
+    np.savez_compressed(path, *arrs)

@@ -12,13 +12,96 @@ tensor, three fewer elementwise launches per step (they are a visible fraction o
 """
 from __future__ import annotations
 
+import random
+import re
+from glob import glob
 from typing import Tuple
 
+import numpy as np
 import torch
+import torch.nn as nn
 
 from .. import ops
 from ..planner.astar import VanillaAstar
 from ..planner.differentiable_astar import AstarOutput
+from .metrics import plan_with_vanilla, validation_metrics
+
+try:  # the reference's trainer; optional here (not in the MI355X image)
+    import pytorch_lightning as pl
+    _ModuleBase = pl.LightningModule
+except ImportError:  # pragma: no cover - depends on the environment
+    pl = None
+    _ModuleBase = nn.Module
+
+__all__ = ["load_from_ptl_checkpoint", "PlannerModule", "set_global_seeds", "fused_l1_step"]
+
+
+def load_from_ptl_checkpoint(checkpoint_path: str) -> dict:
+    """state_dict of the planner stored in the newest ``.ckpt`` under ``checkpoint_path`` (keys with the ``planner.`` prefix
+    removed; same contract as reference utils/training.py:18-39).  Tensors are mapped to the CPU; ``load_state_dict`` moves them."""
+    ckpt_file = sorted(glob(f"{checkpoint_path}/**/*.ckpt", recursive=True))[-1]
+    print(f"load {ckpt_file}")
+    state_dict = torch.load(ckpt_file, map_location="cpu", weights_only=False)["state_dict"]
+    return {re.split("planner.", k)[-1]: v for k, v in state_dict.items() if "planner" in k}
+
+
+def set_global_seeds(seed: int) -> None:
+    """torch / numpy / random seeds (reference utils/training.py:90-106); numpy's drives ``MazeDataset``'s start sampling."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+class PlannerModule(_ModuleBase):
+    """Training / validation steps of the reference's Lightning module (utils/training.py:42-87), with the same attribute names
+    (``planner``, ``vanilla_astar``, ``config``) and logged metric names.  A ``pytorch_lightning.LightningModule`` when that
+    package is installed, otherwise a plain ``nn.Module`` whose ``log`` collects into ``self.logged`` (drive it with any loop).
+
+    MI355X specifics: the training step is one fused autograd node (``fused_l1_step``); the validation step runs the planner's
+    and the VanillaAstar search in ONE launch and reduces the three metrics on the device (``utils/metrics.py``)."""
+
+    def __init__(self, planner, config):
+        super().__init__()
+        self.planner = planner
+        self.vanilla_astar = VanillaAstar()
+        self.config = config
+        self.logged = {}
+
+    if pl is None:
+        def log(self, name, value, *args, **kwargs):  # noqa: D401 - Lightning's signature
+            self.logged[name] = value
+
+    def forward(self, map_designs, start_maps, goal_maps):
+        return self.planner(map_designs, start_maps, goal_maps)
+
+    def configure_optimizers(self) -> torch.optim.Optimizer:
+        return torch.optim.RMSprop(self.planner.parameters(), self.config.params.lr)
+
+    def training_step(self, train_batch, batch_idx):
+        map_designs, start_maps, goal_maps, opt_trajs = train_batch
+        loss, _ = fused_l1_step(self.planner, map_designs, start_maps, goal_maps, opt_trajs)
+        self.log("metrics/train_loss", loss)
+        return loss
+
+    def validation_step(self, val_batch, batch_idx):
+        map_designs, start_maps, goal_maps, opt_trajs = val_batch
+        if map_designs.shape[1] == 1 and hasattr(self.planner, "encode"):  # shortest-path problems (:72-85)
+            outputs, va_outputs = plan_with_vanilla(self.planner, map_designs, start_maps, goal_maps)
+            loss = nn.L1Loss()(outputs.histories, opt_trajs)
+            self.log("metrics/val_loss", loss)
+            m = validation_metrics(outputs, va_outputs)
+            self.log("metrics/p_opt", m.p_opt)
+            self.log("metrics/p_exp", m.p_exp)
+            self.log("metrics/h_mean", m.h_mean)
+            return loss
+        outputs = self.forward(map_designs, start_maps, goal_maps)
+        loss = nn.L1Loss()(outputs.histories, opt_trajs)
+        self.log("metrics/val_loss", loss)
+        return loss
 
 
 def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,

@@ -140,6 +140,62 @@ def export_checkpoint():
     print("ckpt_mazes032_cnn.npz:", len(sd), "tensors")
 
 
+REF_DATA = "/root/reference/src/neural_astar/utils/data.py"
+
+
+def load_reference_data():
+    """The reference's utils/data.py.  Unavailable imports are stubbed: torchvision.utils.make_grid (visualisation only) and the
+    ``neural_astar.planner.differentiable_astar`` it takes AstarOutput from (resolved to the reference file loaded above)."""
+    import sys
+    import types
+    tv, tvu = types.ModuleType("torchvision"), types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("stub"))
+    tv.utils = tvu
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.utils", tvu)
+    ref_da = load_reference()
+    pkg = types.ModuleType("neural_astar")
+    pl_ = types.ModuleType("neural_astar.planner")
+    saved = {k: sys.modules.get(k) for k in ("neural_astar", "neural_astar.planner", "neural_astar.planner.differentiable_astar")}
+    sys.modules["neural_astar"], sys.modules["neural_astar.planner"] = pkg, pl_
+    sys.modules["neural_astar.planner.differentiable_astar"] = ref_da
+    try:
+        spec = importlib.util.spec_from_file_location("ref_data", REF_DATA)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def data_golden():
+    """tests/golden/data_maze32.npz: a small dataset in the reference's file layout + what the reference's OWN MazeDataset makes of
+    it (seeded): sampled start cells and the optimal trajectories rolled out from them (utils/data.py:152-220)."""
+    import tempfile
+    ref = load_reference_data()
+    src = os.path.join(tempfile.mkdtemp(), "mazes.npz")
+    syn.write_maze_npz(src, n_train=8, n_valid=2, n_test=2, size=32, seed=7)
+    ds = ref.MazeDataset(src, "train", num_starts=4)
+    np.random.seed(0)
+    starts, trajs = [], []
+    for i in range(len(ds)):
+        m, s, g, t = ds[i]
+        assert m.shape == (1, 32, 32) and s.shape == (4, 32, 32) and g.shape == (1, 32, 32) and t.shape == (4, 32, 32)
+        starts.append(s.reshape(4, -1).argmax(1))
+        trajs.append(np.packbits(t.reshape(4, -1).astype(np.uint8), axis=1))
+    samples = np.stack([[int(ds.get_random_start_map(ds.opt_dists[i]).reshape(-1).argmax()) for _ in range(64)]
+                        for i in range(len(ds))])
+    with np.load(src) as f:
+        arrs = {k: f[k] for k in f.files}
+    np.savez_compressed(os.path.join(OUT, "data_maze32.npz"), ref_start_idx=np.stack(starts).astype(np.int32),
+                        ref_traj_bits=np.stack(trajs), ref_samples=samples.astype(np.int32), **arrs)
+    print("data_maze32.npz: starts", np.stack(starts)[:2].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -187,6 +243,7 @@ def main():
     out, _ = run_ref(ref, cc, mz16.start_maps, mz16.goal_maps, mz16.map_designs, 0.5)
     save("maze32_cnncost_g050", mz16, cc, out, 0.5)
     export_checkpoint()
+    data_golden()
     # 5c. train mode, Tmax = 0.25 (scripts/config/train.yaml:4): budget-truncated searches
     out, _ = run_ref(ref, mz.map_designs[:32], mz.start_maps[:32], mz.goal_maps[:32], mz.map_designs[:32], 0.5,
                      Tmax=0.25, training=True)

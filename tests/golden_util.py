@@ -46,8 +46,8 @@ def _onehot(idx, B, H, W):
 
 
 def names():
-    """search fixtures (ckpt_*.npz are weight fixtures, not search cases)"""
-    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith("ckpt_"))
+    """search fixtures (ckpt_*.npz are weight fixtures, data_*.npz dataset fixtures: not search cases)"""
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("ckpt_", "data_")))
 
 
 def load(name: str) -> Golden:
