@@ -235,6 +235,38 @@ def l1_training_step_ms(pr, dev, batch, reps=20):
     return out
 
 
+def data_path_ms(dev, n_maps=400, batch=100):
+    """Extra: time to produce one collated training batch of `batch` maze problems (start sampling + optimal-trajectory roll-out):
+    the reference-style per-sample host loop (DataLoader over MazeDataset.__getitem__) vs the device-resident loader."""
+    import tempfile
+    from neural_astar.utils import synthetic as syn
+    from neural_astar.utils.data import create_dataloader, create_device_loader
+    path = os.path.join(tempfile.mkdtemp(), "mazes.npz")
+    syn.write_maze_npz(path, n_train=n_maps, n_valid=1, n_test=1, size=32, seed=11)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        host = create_dataloader(path, "train", batch, shuffle=True)
+        devl = create_device_loader(path, "train", batch, dev, shuffle=True)
+    t0 = time.perf_counter()
+    n = 0
+    for b in host:
+        b = [x.to(dev, non_blocking=True) for x in b]
+        n += 1
+    torch.cuda.synchronize(dev)
+    host_ms = (time.perf_counter() - t0) * 1e3 / n
+    for _ in devl:
+        pass
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(5):
+        for b in devl:
+            n += 1
+    torch.cuda.synchronize(dev)
+    dev_ms = (time.perf_counter() - t0) * 1e3 / n
+    return {"host_dataloader_ms_per_batch": host_ms, "device_loader_ms_per_batch": dev_ms, "batch": batch, "maps": n_maps}
+
+
 def neural_astar_forward_ms(pr, dev, reps=5):
     """Extra (BASELINE config 3 stand-in): NeuralAstar(CNN encoder, depth 4) forward on the bench batch with the bf16-MFMA
     HIP encoder + the HIP search, eval mode.  (The torch/MIOpen encoder is not timed here: its first call autotunes for
@@ -412,6 +444,7 @@ def main():
             out["secondary"] = sec
             out["extra"] = {"neural_astar_cnn_hip_bf16": neural_astar_forward_ms(pr, dev),
                             "train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
+                            "data_path_32x32": data_path_ms(dev),
                             "train_l1_step_Tmax025": {"batch_100": l1_training_step_ms(pr, dev, 100),
                                                       "batch_4096": l1_training_step_ms(pr, dev, 4096)},
                             "two_stream_pipelined_maps_per_s": two_stream_throughput(pr, args.steps, dev),
