@@ -168,3 +168,21 @@ def test_shipped_checkpoint_loads_strict_and_torch_encoder_matches_reference_cos
     err = (cost.numpy() - g.cost_maps)
     assert cost.shape == (g.B, 1, 32, 32)
     assert float(abs(err).max()) < 1e-6, float(abs(err).max())
+
+
+def test_every_import_the_reference_callers_use_resolves_here():
+    """All `neural_astar.*` imports found in the reference's scripts, notebooks, tests and its own package modules
+    (grep over /root/reference: scripts/train.py, train_warcraft.py, create_gif.py, notebooks/example.ipynb, tests/, utils/*.py)."""
+    import importlib
+    wanted = {
+        "neural_astar.planner": ["NeuralAstar", "VanillaAstar"],
+        "neural_astar.planner.astar": ["VanillaAstar", "NeuralAstar"],
+        "neural_astar.planner.differentiable_astar": ["AstarOutput", "DifferentiableAstar"],
+        "neural_astar.planner.encoder": ["CNN", "CNNDownSize", "Unet"],
+        "neural_astar.utils.data": ["create_dataloader", "visualize_results", "create_warcraft_dataloader", "MazeDataset", "WarCraftDataset"],
+        "neural_astar.utils.training": ["PlannerModule", "set_global_seeds", "load_from_ptl_checkpoint"],
+    }
+    for mod, names in wanted.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
