@@ -903,12 +903,24 @@ int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* his
 
 // ---- CNN encoder (eval mode, bf16 MFMA) -------------------------------------------------------------------------------
 // padded channels per layer: in 16, 32, 64, 128, 256 (layer 1: 2 real + 14 zero); out 32, 64, 128, 256, 32 (layer 5: 1 real)
+// Images per pass: the activation slabs of a pass (800 B per pixel) are far larger than the 256 MB MALL either way, so the pass is
+// sized for few launches and even work per persistent workgroup: 4 Mi pixels (4096 maps of 32x32, 3.3 GB of the 288 GB HBM).
+// NASTAR_ENCODER_CHUNK overrides it (dev).
+static int enc_chunk_images(int H, int W)
+{
+    const char* e = getenv("NASTAR_ENCODER_CHUNK");
+    if (e && atoi(e) > 0) return atoi(e);
+    const long long px = (long long)H * W;
+    const long long n = (4ll << 20) / px;
+    return n < 1 ? 1 : (int)n;
+}
 constexpr size_t kEncBytesPerPixel = (16 + 128 + 256) * 2;  // x0 + ping (<=128 ch) + pong (<=256 ch), bf16
 
 size_t nastar_encoder_workspace_bytes(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const int chunk = B < 1024 ? B : 1024;  // images processed per pass (keeps the activations L2/MALL friendly)
+    const int cap = enc_chunk_images(H, W);
+    const int chunk = B < cap ? B : cap;  // images processed per pass
     return (size_t)chunk * H * W * kEncBytesPerPixel;
 }
 
