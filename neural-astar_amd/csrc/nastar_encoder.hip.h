@@ -275,6 +275,56 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
     return (ty * 34 + tx) * I32_PIX_B + ((c ^ ((tx >> 3) & 1)) << 4);
 }
 
+// ---- the MFMA inner loop of the 32x32-tile kernels: one 16-channel slice = 9 steps (dx, dy) of 8 MFMAs ------------------------------
+// A step needs pixel rows dy..dy+3 at column offset dx and the 2 weight fragments of tap (dy, dx); the fragments of step t+1 are
+// requested BEFORE the MFMAs of step t (one new row + 2 weights inside a column offset, 4 rows + 2 weights when dx advances), so
+// LDS latency hides behind 256 matrix-pipe cycles.  The reads are inline asm slotted one per MFMA gap and pinned with
+// sched_barriers: left to itself the register-starved compiler sinks every ds_read next to its use.
+#define DSR(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
+#define WOFF(dx_, dy_, n_) (((((dy_) * 3 + (dx_)) * 2) * I32_NT + (n_) * 32) * 16)
+#define ROFF(r_) ((r_) * 34 * I32_PIX_B)
+#define SB __builtin_amdgcn_sched_barrier(0)
+#define LGKM3(a_, b_, c_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_))
+#define LGKM6(a_, b_, c_, d_, e_, f_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_))
+// one MFMA of the 4 x 2 register tile (row m of the step's window, channel block n), order pinned
+#define MF(m_, n_, W_, R_) acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W_##n_, R_, acc[m_][n_], 0, 0, 0); SB
+// a step: 8 MFMAs on weights W_{0,1} x rows R0_..R3_, with the next step's fragment reads slotted one per MFMA gap
+#define STEP0(W_, R0_, R1_, R2_, R3_) \
+    SB; MF(0, 0, W_, R0_); MF(0, 1, W_, R0_); MF(1, 0, W_, R1_); MF(1, 1, W_, R1_);  \
+    MF(2, 0, W_, R2_); MF(2, 1, W_, R2_); MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
+#define STEP3(W_, R0_, R1_, R2_, R3_, RD0_, RD1_, RD2_)       \
+    SB; MF(0, 0, W_, R0_); RD0_; SB; MF(0, 1, W_, R0_); RD1_; SB; MF(1, 0, W_, R1_); RD2_; SB; MF(1, 1, W_, R1_);        \
+    MF(2, 0, W_, R2_); MF(2, 1, W_, R2_); MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
+#define STEP6(W_, R0_, R1_, R2_, R3_, RD0_, RD1_, RD2_, RD3_, RD4_, RD5_) \
+    SB; MF(0, 0, W_, R0_); RD0_; SB; MF(0, 1, W_, R0_); RD1_; SB; MF(1, 0, W_, R1_); RD2_; SB; MF(1, 1, W_, R1_); RD3_; SB; \
+    MF(2, 0, W_, R2_); RD4_; SB; MF(2, 1, W_, R2_); RD5_; SB; MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
+// the whole slice; cb_ = LDS byte address of the operand buffer, rowb*/wgtb = this lane's fragment offsets, acc = the 4x2 tile
+#define I32_SLICE_MFMAS(cb_)                                                                                              \
+    do {                                                                                                                  \
+        const uint32_t ra0 = (cb_) + rowb0, ra1 = (cb_) + rowb1, ra2 = (cb_) + rowb2, wa_ = (cb_) + wgtb;                 \
+        bf16x8 A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, WA0, WA1, WB0, WB1;                                        \
+        DSR(A0, ra0, ROFF(0)); DSR(A1, ra0, ROFF(1)); DSR(A2, ra0, ROFF(2)); DSR(A3, ra0, ROFF(3)); \
+        DSR(WA0, wa_, WOFF(0, 0, 0)); DSR(WA1, wa_, WOFF(0, 0, 1)); \
+        LGKM6(A0, A1, A2, A3, WA0, WA1); \
+        STEP3(WA, A0, A1, A2, A3, DSR(A4, ra0, ROFF(4)), DSR(WB0, wa_, WOFF(0, 1, 0)), DSR(WB1, wa_, WOFF(0, 1, 1))); \
+        LGKM3(A4, WB0, WB1); \
+        STEP3(WB, A1, A2, A3, A4, DSR(A5, ra0, ROFF(5)), DSR(WA0, wa_, WOFF(0, 2, 0)), DSR(WA1, wa_, WOFF(0, 2, 1))); \
+        LGKM3(A5, WA0, WA1); \
+        STEP6(WA, A2, A3, A4, A5, DSR(B0, ra1, ROFF(0)), DSR(B1, ra1, ROFF(1)), DSR(B2, ra1, ROFF(2)), DSR(B3, ra1, ROFF(3)), DSR(WB0, wa_, WOFF(1, 0, 0)), DSR(WB1, wa_, WOFF(1, 0, 1))); \
+        LGKM6(B0, B1, B2, B3, WB0, WB1); \
+        STEP3(WB, B0, B1, B2, B3, DSR(B4, ra1, ROFF(4)), DSR(WA0, wa_, WOFF(1, 1, 0)), DSR(WA1, wa_, WOFF(1, 1, 1))); \
+        LGKM3(B4, WA0, WA1); \
+        STEP3(WA, B1, B2, B3, B4, DSR(B5, ra1, ROFF(5)), DSR(WB0, wa_, WOFF(1, 2, 0)), DSR(WB1, wa_, WOFF(1, 2, 1))); \
+        LGKM3(B5, WB0, WB1); \
+        STEP6(WB, B2, B3, B4, B5, DSR(A0, ra2, ROFF(0)), DSR(A1, ra2, ROFF(1)), DSR(A2, ra2, ROFF(2)), DSR(A3, ra2, ROFF(3)), DSR(WA0, wa_, WOFF(2, 0, 0)), DSR(WA1, wa_, WOFF(2, 0, 1))); \
+        LGKM6(A0, A1, A2, A3, WA0, WA1); \
+        STEP3(WA, A0, A1, A2, A3, DSR(A4, ra2, ROFF(4)), DSR(WB0, wa_, WOFF(2, 1, 0)), DSR(WB1, wa_, WOFF(2, 1, 1))); \
+        LGKM3(A4, WB0, WB1); \
+        STEP3(WB, A1, A2, A3, A4, DSR(A5, ra2, ROFF(5)), DSR(WA0, wa_, WOFF(2, 2, 0)), DSR(WA1, wa_, WOFF(2, 2, 1))); \
+        LGKM3(A5, WA0, WA1); \
+        STEP0(WA, A2, A3, A4, A5); \
+    } while (0)
+
 // kProbe (dev builds only): 1 = per-wave cycle totals written to the output slab, 2 = every workgroup reads image 0 (L2-hit ablation)
 // kTiled: the image is H x W with H, W multiples of 32 and a work item is one of its 32x32 tiles: the halo ring (132 pixels) is
 // then real data, loaded as a fifth chunk by threads 0..263 (zero outside the image); kTiled = false is the whole-image case above.
@@ -413,67 +463,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         for (int s = 0; s < NSLICE; ++s) {
             if (s + 1 < NSLICE) I32_LOAD_SLICE(item, s + 1);
             else if (next < nitems) I32_LOAD_SLICE(next, 0);
-            // 9 steps (dx, dy) of 8 MFMAs.  A step needs pixel rows dy..dy+3 at column offset dx and the 2 weight fragments of
-            // tap (dy, dx); the fragments of step t+1 are requested BEFORE the MFMAs of step t (one new row + 2 weights inside
-            // a column offset, 4 rows + 2 weights when dx advances), so LDS latency hides behind 256 matrix-pipe cycles.
-            // The reads are inline asm: left to itself the register-starved compiler sinks every ds_read next to its use and
-            // the wave eats the LDS latency ~20 times per slice (measured: matrix pipe 50 % busy inside the loop).
-            const uint32_t cb = lds0 + (s & 1) * I32_BUF_BYTES;
-            const uint32_t ra0 = cb + rowb0, ra1 = cb + rowb1, ra2 = cb + rowb2, wa_ = cb + wgtb;
-            bf16x8 A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, WA0, WA1, WB0, WB1;
-#define DSR(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
-#define WOFF(dx_, dy_, n_) (((((dy_) * 3 + (dx_)) * 2) * I32_NT + (n_) * 32) * 16)
-#define ROFF(r_) ((r_) * 34 * I32_PIX_B)
-#define SB __builtin_amdgcn_sched_barrier(0)
-#define LGKM3(a_, b_, c_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_))
-#define LGKM6(a_, b_, c_, d_, e_, f_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_))
-// one MFMA of the 4 x 2 register tile (row m of the step's window, channel block n), order pinned
-#define MF(m_, n_, W_, R_) acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W_##n_, R_, acc[m_][n_], 0, 0, 0); SB
-// a step: 8 MFMAs on weights W_{0,1} x rows R0_..R3_, with the next step's fragment reads slotted one per MFMA gap
-#define STEP0(W_, R0_, R1_, R2_, R3_)                                                                                     \
-    SB; MF(0, 0, W_, R0_); MF(0, 1, W_, R0_); MF(1, 0, W_, R1_); MF(1, 1, W_, R1_);                                      \
-    MF(2, 0, W_, R2_); MF(2, 1, W_, R2_); MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
-#define STEP3(W_, R0_, R1_, R2_, R3_, RD0_, RD1_, RD2_)                                                                   \
-    SB; MF(0, 0, W_, R0_); RD0_; SB; MF(0, 1, W_, R0_); RD1_; SB; MF(1, 0, W_, R1_); RD2_; SB; MF(1, 1, W_, R1_);        \
-    MF(2, 0, W_, R2_); MF(2, 1, W_, R2_); MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
-#define STEP6(W_, R0_, R1_, R2_, R3_, RD0_, RD1_, RD2_, RD3_, RD4_, RD5_)                                                 \
-    SB; MF(0, 0, W_, R0_); RD0_; SB; MF(0, 1, W_, R0_); RD1_; SB; MF(1, 0, W_, R1_); RD2_; SB; MF(1, 1, W_, R1_); RD3_; SB; \
-    MF(2, 0, W_, R2_); RD4_; SB; MF(2, 1, W_, R2_); RD5_; SB; MF(3, 0, W_, R3_); MF(3, 1, W_, R3_)
-            DSR(A0, ra0, ROFF(0)); DSR(A1, ra0, ROFF(1)); DSR(A2, ra0, ROFF(2)); DSR(A3, ra0, ROFF(3));
-            DSR(WA0, wa_, WOFF(0, 0, 0)); DSR(WA1, wa_, WOFF(0, 0, 1));
-            LGKM6(A0, A1, A2, A3, WA0, WA1);
-            // column offset 0 (rows in A*), taps (dy, 0)
-            STEP3(WA, A0, A1, A2, A3, DSR(A4, ra0, ROFF(4)), DSR(WB0, wa_, WOFF(0, 1, 0)), DSR(WB1, wa_, WOFF(0, 1, 1)));
-            LGKM3(A4, WB0, WB1);
-            STEP3(WB, A1, A2, A3, A4, DSR(A5, ra0, ROFF(5)), DSR(WA0, wa_, WOFF(0, 2, 0)), DSR(WA1, wa_, WOFF(0, 2, 1)));
-            LGKM3(A5, WA0, WA1);
-            STEP6(WA, A2, A3, A4, A5, DSR(B0, ra1, ROFF(0)), DSR(B1, ra1, ROFF(1)), DSR(B2, ra1, ROFF(2)), DSR(B3, ra1, ROFF(3)),
-                  DSR(WB0, wa_, WOFF(1, 0, 0)), DSR(WB1, wa_, WOFF(1, 0, 1)));
-            LGKM6(B0, B1, B2, B3, WB0, WB1);
-            // column offset 1 (rows in B*)
-            STEP3(WB, B0, B1, B2, B3, DSR(B4, ra1, ROFF(4)), DSR(WA0, wa_, WOFF(1, 1, 0)), DSR(WA1, wa_, WOFF(1, 1, 1)));
-            LGKM3(B4, WA0, WA1);
-            STEP3(WA, B1, B2, B3, B4, DSR(B5, ra1, ROFF(5)), DSR(WB0, wa_, WOFF(1, 2, 0)), DSR(WB1, wa_, WOFF(1, 2, 1)));
-            LGKM3(B5, WB0, WB1);
-            STEP6(WB, B2, B3, B4, B5, DSR(A0, ra2, ROFF(0)), DSR(A1, ra2, ROFF(1)), DSR(A2, ra2, ROFF(2)), DSR(A3, ra2, ROFF(3)),
-                  DSR(WA0, wa_, WOFF(2, 0, 0)), DSR(WA1, wa_, WOFF(2, 0, 1)));
-            LGKM6(A0, A1, A2, A3, WA0, WA1);
-            // column offset 2 (rows in A* again)
-            STEP3(WA, A0, A1, A2, A3, DSR(A4, ra2, ROFF(4)), DSR(WB0, wa_, WOFF(2, 1, 0)), DSR(WB1, wa_, WOFF(2, 1, 1)));
-            LGKM3(A4, WB0, WB1);
-            STEP3(WB, A1, A2, A3, A4, DSR(A5, ra2, ROFF(5)), DSR(WA0, wa_, WOFF(2, 2, 0)), DSR(WA1, wa_, WOFF(2, 2, 1)));
-            LGKM3(A5, WA0, WA1);
-            STEP0(WA, A2, A3, A4, A5);
-#undef DSR
-#undef WOFF
-#undef ROFF
-#undef SB
-#undef MF
-#undef STEP0
-#undef STEP3
-#undef STEP6
-#undef LGKM3
-#undef LGKM6
+            I32_SLICE_MFMAS(lds0 + (s & 1) * I32_BUF_BYTES);
             if constexpr (kFuse) {
                 if (s == 0 && tid < 256) *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;  // the previous item's epilogue copied its fragments before the hand-over barrier
             }
