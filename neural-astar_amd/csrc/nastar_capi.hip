@@ -559,6 +559,21 @@ static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
     return NASTAR_OK;
 }
 
+// input assembly + 2 -> 32 + 32 -> 64 channels for 32x32 maps in one persistent kernel
+static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream)
+{
+    void (*kern)(const StemArgs) = &nastar_conv_stem32_kernel;
+    int rc = ensure_lds(kern, STEM_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const unsigned grid = (unsigned)(sa.B < n_cu ? sa.B : n_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), STEM_LDS_BYTES, stream, sa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 // 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
 static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
 {
@@ -944,16 +959,24 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         const size_t off = (size_t)b0 * H * W;
         const long long npix = (long long)nb * H * W;
         const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
-        hipLaunchKernelGGL(nastar_encoder_prep_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
-                           plus ? goal + off : map, x0, npix, plus);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
         ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
         int rc;
-        ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
-        if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
-        ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
-        if ((rc = launch_conv_auto<32, 64, true>(ca, s))) return rc;
+        if (H == 32 && W == 32 && !(enc_flags() & 17)) {  // bit 4: keep input assembly and the first two layers separate launches
+            StemArgs sa;
+            sa.map = map + off; sa.start = plus ? start + off : nullptr; sa.goal = plus ? goal + off : nullptr; sa.plus = plus; sa.B = nb;
+            sa.w1 = wpack[0]; sa.scale1 = scale[0]; sa.shift1 = shift[0]; sa.w2 = wpack[1]; sa.scale2 = scale[1]; sa.shift2 = shift[1];
+            sa.out = pong;
+            if ((rc = launch_conv_stem32(sa, s))) return rc;
+        } else {
+            hipLaunchKernelGGL(nastar_encoder_prep_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
+                               plus ? goal + off : map, x0, npix, plus);
+            ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
+            if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
+            ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
+            if ((rc = launch_conv_auto<32, 64, true>(ca, s))) return rc;
+        }
         ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
         if ((rc = launch_conv_auto<64, 128, true>(ca, s))) return rc;
         ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];

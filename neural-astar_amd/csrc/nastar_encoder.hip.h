@@ -729,6 +729,165 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const
     }
 }
 
+// ---- stem for 32x32 maps: input assembly + conv 2->32 + conv 32->64 in ONE persistent kernel -------------------------------------
+// The first two layers are latency-, not matrix-bound (a 2-slice item cannot hide its own operand loads, and the 2->32 layer is a
+// 100 MB round trip through HBM for 0.3 % of the FLOPs).  Here a workgroup walks images: it packs (map, start+goal) into a 34x34
+// bf16x2 patch in LDS, computes the 32 first-layer channels with 2 MFMAs per image row (K = 9 taps x 2 channels = 18 of 32) and
+// writes them -- scaled, ReLUed, rounded to bf16 -- straight into the two 16-channel operand tiles of the second layer, whose
+// weights (both slices, 37 KB) were staged once per workgroup.  The only global reads per image are its 12 KB of fp32 maps,
+// prefetched one image ahead; the first-layer activations never exist in HBM.
+struct StemArgs {
+    const float* map; const float* start; const float* goal;   // [B,32,32] fp32 (start/goal unused when plus == 0)
+    const uint16_t* w1; const float* scale1; const float* shift1;   // layer 1: packed [9][2][32][8] (cin padded to 16), 32 channels
+    const uint16_t* w2; const float* scale2; const float* shift2;   // layer 2: packed [9][4][64][8], 64 channels
+    uint16_t* out;                                                  // [B,32,32,64] bf16
+    int B, plus;
+};
+constexpr int STEM_RAW_BYTES = 34 * 34 * 4;
+constexpr size_t STEM_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + 8 * 4096 + STEM_RAW_BYTES + (64 + 128) * 4;
+
+__global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs a)
+{
+    constexpr int CIN = 32, COUT = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* obase = smem + 2 * I32_BUF_BYTES;                       // epilogue transpose patches, 8 x 4 KB
+    uint32_t* raw = reinterpret_cast<uint32_t*>(obase + 8 * 4096);         // [34][34] bf16x2 (map, start+goal), zero halo
+    float* ss1 = reinterpret_cast<float*>(obase + 8 * 4096 + STEM_RAW_BYTES);  // scale1[32] | shift1[32]
+    float* ss2 = ss1 + 64;                                                 // scale2[64] | shift2[64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 31, kh = lane >> 5;
+
+    for (int q = tid; q < I32_TILE_BYTES / 16; q += 512) {
+        *reinterpret_cast<uint4*>(smem + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(smem + I32_BUF_BYTES + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int q = tid; q < 34 * 34; q += 512) raw[q] = 0u;
+    if (tid < 32) { ss1[tid] = a.scale1[tid]; ss1[32 + tid] = a.shift1[tid]; }
+    if (tid < 64) { ss2[tid] = a.scale2[tid]; ss2[64 + tid] = a.shift2[tid]; }
+    // second-layer weights, both slices, once: chunk q = tid + 512 i -> n = q & 63, khalf = (q >> 6) & 1, tap = q >> 7
+    {
+        const size_t w_lane = ((size_t)((tid >> 7) * (CIN / 8) + ((tid >> 6) & 1)) * COUT + (tid & 63)) * 8;
+        constexpr size_t WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < 2 || tid < 128)
+                    *reinterpret_cast<uint4*>(smem + sl * I32_BUF_BYTES + I32_TILE_BYTES + (tid + i * 512) * 16) =
+                        *reinterpret_cast<const uint4*>(a.w2 + w_lane + i * WSTR + sl * WSL);
+    }
+    // first-layer A fragments (row = output channel px, k = (tap, channel)): k-step 0 holds taps 0..7, k-step 1 tap 8
+    bf16x8 w1a, w1b;
+    {
+        uint16_t e0[8], e1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tap = kh * 4 + (i >> 1), ch = i & 1;
+            e0[i] = a.w1[((size_t)(tap * 2) * 32 + px) * 8 + ch];
+            e1[i] = (kh == 0 && i < 2) ? a.w1[((size_t)(8 * 2) * 32 + px) * 8 + ch] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w1a[i] = (short)e0[i]; w1b[i] = (short)e1[i]; }
+    }
+    // this lane's patch offsets of the 4 taps it feeds (k-step 0) and of tap 8, relative to (image row, column px)
+    int toff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = kh * 4 + j;
+        toff[j] = (t / 3) * 34 + (t % 3) + px;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t rowb0 = i32_tile_off(wave * I32_RPW, px + 0, kh), rowb1 = i32_tile_off(wave * I32_RPW, px + 1, kh),
+                   rowb2 = i32_tile_off(wave * I32_RPW, px + 2, kh), wgtb = I32_TILE_BYTES + (kh * I32_NT + px) * 16;
+
+    // raw input prefetch: this thread owns pixels tid and tid + 512 of the image
+    float m0 = 0.f, m1 = 0.f, g0 = 0.f, g1 = 0.f;
+    auto fetch = [&](int b) {
+        const size_t o = (size_t)b * 1024 + tid;
+        m0 = a.map[o]; m1 = a.map[o + 512];
+        if (a.plus) { g0 = a.start[o] + a.goal[o]; g1 = a.start[o + 512] + a.goal[o + 512]; }
+    };
+    auto put_raw = [&]() {
+        raw[((tid >> 5) + 1) * 34 + (tid & 31) + 1] = pack_bf16x2(m0, g0);
+        raw[((tid >> 5) + 17) * 34 + (tid & 31) + 1] = pack_bf16x2(m1, g1);
+    };
+    int b = blockIdx.x;
+    if (b < a.B) fetch(b);
+    __syncthreads();   // zero fill, weights, constants
+    if (b < a.B) put_raw();
+    for (; b < a.B; b += gridDim.x) {
+        const int next = b + gridDim.x;
+        if (next < a.B) fetch(next);
+        __syncthreads();   // patch visible; every wave is past the previous image's MFMAs, the tiles may be rewritten
+        // ---- layer 1 for this wave's 4 rows -> the two operand tiles of layer 2 ---------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < I32_RPW; ++m) {
+            const int y = wave * I32_RPW + m;
+            const uint32_t* rp = raw + y * 34;
+            const uint4 q0 = make_uint4(rp[toff[0]], rp[toff[1]], rp[toff[2]], rp[toff[3]]);
+            const uint4 q1 = make_uint4(kh == 0 ? rp[2 * 34 + 2 + px] : 0u, 0u, 0u, 0u);
+            f32x16 a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, *reinterpret_cast<const bf16x8*>(&q0), a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1b, *reinterpret_cast<const bf16x8*>(&q1), a1, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // D rows 8g + 4kh + {0..3} = first-layer channels; g >> 1 = second-layer slice
+                const int c = 8 * g + 4 * kh;
+                const float4 sc = *reinterpret_cast<const float4*>(ss1 + c);
+                const float4 sh = *reinterpret_cast<const float4*>(ss1 + 32 + c);
+                const float v0 = fmaxf(a1[4 * g + 0] * sc.x + sh.x, 0.f), v1 = fmaxf(a1[4 * g + 1] * sc.y + sh.y, 0.f);
+                const float v2 = fmaxf(a1[4 * g + 2] * sc.z + sh.z, 0.f), v3 = fmaxf(a1[4 * g + 3] * sc.w + sh.w, 0.f);
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(smem + (g >> 1) * I32_BUF_BYTES + i32_tile_off(y + 1, px + 1, g & 1) + kh * 8) = o;
+            }
+        }
+        __syncthreads();   // tiles complete; the patch is free again
+        if (next < a.B) put_raw();
+        // ---- layer 2: both slices are resident, no synchronisation in between -------------------------------------------------------
+        f32x16 acc[I32_RPW][I32_NB];
+#pragma unroll
+        for (int m = 0; m < I32_RPW; ++m)
+#pragma unroll
+            for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        I32_SLICE_MFMAS(lds0);
+        I32_SLICE_MFMAS(lds0 + I32_BUF_BYTES);
+        // ---- epilogue (as in nastar_conv3x3_img32_kernel) ------------------------------------------------------------------------------
+        unsigned char* ob = obase + wave * 4096;
+#pragma unroll
+        for (int m = 0; m < I32_RPW; ++m) {
+#pragma unroll
+            for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = n * 32 + 8 * g + 4 * kh;
+                    const float4 sc = *reinterpret_cast<const float4*>(ss2 + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(ss2 + COUT + cl);
+                    const float v0 = fmaxf(acc[m][n][4 * g + 0] * sc.x + sh.x, 0.f), v1 = fmaxf(acc[m][n][4 * g + 1] * sc.y + sh.y, 0.f);
+                    const float v2 = fmaxf(acc[m][n][4 * g + 2] * sc.z + sh.z, 0.f), v3 = fmaxf(acc[m][n][4 * g + 3] * sc.w + sh.w, 0.f);
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    const int chunk = n * 4 + g;
+                    *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = j * 8 + (lane >> 3), chunk = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                const size_t pix = (size_t)b * 1024 + (wave * I32_RPW + m) * 32 + p;
+                *reinterpret_cast<uint4*>(a.out + pix * COUT + chunk * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // input assembly (astar.py:171-177): x0[b][y][x][0] = map, [1] = start + goal, channels 2..15 = 0   (bf16 NHWC, 16 ch)
 __global__ __launch_bounds__(256) void nastar_encoder_prep_kernel(const float* __restrict__ map, const float* __restrict__ start,
                                                                   const float* __restrict__ goal, uint16_t* __restrict__ x0,
