@@ -45,6 +45,23 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(one, one, one, one, 1, 128, 128, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_backward(one, one, one, one, one, 1, 8, 8, 0.5, 64, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
+    # training / data-path / encoder entry points
+    assert lib.nastar_backward_l1(None, one, None, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_backward_l1(one, one, None, one, one, one, one, 0, 8, 8, 0.5, 64, one, None, one, None) == _native.NASTAR_ERR_BAD_SHAPE
+    assert lib.nastar_l1_loss(one, None, 64, one, one, 2048, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_l1_loss(one, one, 0, one, one, 2048, None) == _native.NASTAR_ERR_BAD_SHAPE
+    assert lib.nastar_l1_loss(one, one, 64, one, one, 8, None) == _native.NASTAR_ERR_WORKSPACE
+    assert lib.nastar_policy_rollout(one, None, one, 1, 1, 8, 8, 8, one, one, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_policy_rollout(one, one, one, 1, 1, 9, 8, 8, one, one, None) == _native.NASTAR_ERR_BAD_SHAPE
+    import ctypes
+    arr = (ctypes.c_void_p * 5)(*([one] * 5))
+    assert lib.nastar_encoder_cnn_forward(None, one, one, 1, 1, 32, 32, arr, arr, arr, 1.0, one, one, 1 << 20, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_encoder_cnn_forward(one, one, one, 1, 1, 30, 32, arr, arr, arr, 1.0, one, one, 1 << 20, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_encoder_cnn_forward(one, one, one, 1, 1, 32, 32, arr, arr, arr, 1.0, one, one, 16, None) == _native.NASTAR_ERR_WORKSPACE
+    assert lib.nastar_encoder_workspace_bytes(4096, 32, 32) == 4096 * 1024 * 800 and lib.nastar_encoder_workspace_bytes(0, 32, 32) == 0
+    assert lib.nastar_conv3x3_bf16(one, one, one, one, None, 1, 32, 32, 32, 64, 1, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_pack_outputs(None, one, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_unpack_outputs(one, 0, 8, 8, one, one, None) == _native.NASTAR_ERR_BAD_SHAPE
 
 
 def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
