@@ -267,7 +267,7 @@ def data_path_ms(dev, n_maps=400, batch=100):
     return {"host_dataloader_ms_per_batch": host_ms, "device_loader_ms_per_batch": dev_ms, "batch": batch, "maps": n_maps}
 
 
-def neural_astar_forward_ms(pr, dev, reps=5):
+def neural_astar_forward_ms(pr, dev, reps=10):
     """Extra (BASELINE config 3 stand-in): NeuralAstar(CNN encoder, depth 4) forward on the bench batch with the bf16-MFMA
     HIP encoder + the HIP search, eval mode.  (The torch/MIOpen encoder is not timed here: its first call autotunes for
     minutes; DESIGN.md quotes it from tools/probe_encoder.py.)"""
@@ -295,8 +295,12 @@ def neural_astar_forward_ms(pr, dev, reps=5):
         torch.cuda.synchronize(dev)
         full_ms = e0.elapsed_time(e1) / reps
     flop = 2.0 * m.shape[0] * H * W * 9 * (2 * 32 + 32 * 64 + 64 * 128 + 128 * 256 + 256)
-    return {"encoder_ms": enc_ms, "encoder_useful_tflops": flop / enc_ms / 1e9, "forward_ms": full_ms,
-            "maps_per_s": m.shape[0] / full_ms * 1e3, "dtype": "bf16 operands / fp32 accumulate (encoder), f32 (search)"}
+    tf = flop / enc_ms / 1e9
+    return {"encoder_ms": enc_ms, "encoder_useful_tflops": tf, "forward_ms": full_ms,
+            "maps_per_s": m.shape[0] / full_ms * 1e3, "dtype": "bf16 operands / fp32 accumulate (encoder), f32 (search)",
+            "encoder_roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                                 "note": "useful FLOPs of the 5 conv layers / wall time of the whole encoder; the matrix pipe itself "
+                                         "sustains 1660 TFLOP/s on random bf16 operands at the power limit (tools/ubench/mfma_peak.hip)"}}
 
 
 def kernel_launch_ms(run, steps, dev):
