@@ -12,6 +12,9 @@
  *                              (what loss.backward() runs in utils/training.py:55-61)
  *   nastar_heuristic        <- get_heuristic                 differentiable_astar.py:26-52 (debug/parity)
  *   nastar_workspace_bytes  <- (new) workspace sizing; PyTorch owns every allocation
+ *   nastar_l1_loss / nastar_backward_l1 <- loss = nn.L1Loss()(histories, opt_trajs); loss.backward()   utils/training.py:55-61
+ *   nastar_policy_rollout   <- MazeDataset.get_opt_traj / next_loc                                      utils/data.py:171-199,222-244
+ *   nastar_encoder_cnn_forward <- NeuralAstar.encode with the CNN encoder in eval mode                  astar.py:154-180, encoder.py:32-34,60-78
  *   nastar_pack_outputs / nastar_unpack_outputs <- (new) multi-GPU collation payload, see below
  *
  * Conventions
