@@ -352,8 +352,17 @@ def main():
                     help="dev: run the N>1 collation path (pack kernel + all-gather) in a 1-rank RCCL group")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: re-launch one rank per GPU the way the driver does
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or args.force_collate:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
