@@ -61,7 +61,7 @@ def make_problem(kind: str, B: int, seed: int):
 class Runner:
     """Device-resident inputs + preallocated outputs; step() = one nastar_forward launch on torch's current stream."""
 
-    def __init__(self, pr, dev):
+    def __init__(self, pr, dev, g_ratio=G_RATIO, max_iters=None):
         from neural_astar import _native
         self.lib = _native.load()
         self._check = _native.check
@@ -70,6 +70,8 @@ class Runner:
         self.s = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
         self.g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
         self.B, self.H, self.W = self.m.shape
+        self.g_ratio = float(g_ratio)
+        self.max_iters = int(max_iters) if max_iters is not None else self.W * self.W  # eval mode: search to the goal
         self.hist = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=dev)
         self.paths = torch.empty((self.B, self.H, self.W), dtype=torch.int64, device=dev)
         self.iters = torch.empty((self.B,), dtype=torch.int32, device=dev)
@@ -86,13 +88,13 @@ class Runner:
             self._pk ^= 1  # double buffer: the previous step's payload may still be in flight in the all-gather
             rc = self.lib.nastar_forward_packed(
                 self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
-                G_RATIO, self.W * self.W, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
+                self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
                 self.status.data_ptr(), self.packed[self._pk].data_ptr(), None, 0, 0,
                 torch.cuda.current_stream(self.dev).cuda_stream)
             self._check(rc, "nastar_forward_packed")
             return
         rc = self.lib.nastar_forward(self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
-                                     self.B, self.H, self.W, G_RATIO, self.W * self.W, self.hist.data_ptr(),
+                                     self.B, self.H, self.W, self.g_ratio, self.max_iters, self.hist.data_ptr(),
                                      self.paths.data_ptr(), None,
                                      self.iters.data_ptr(), self.status.data_ptr(), None, 0, 0,
                                      torch.cuda.current_stream(self.dev).cuda_stream)
@@ -451,6 +453,18 @@ def main():
                 nbytes = 28 * run2.H * run2.W * B_PER_GPU
                 sec.append({"workload": f"{other}: {B_PER_GPU} maps of {run2.H}x{run2.W}", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
                             "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "mean_iters_per_map": float(run2.iters.float().mean().item()),
+                            "max_iters_per_map": int(run2.iters.max().item())})
+                del run2
+            # the two other readings of BASELINE.json's "tau = 0.25" (SURVEY.md section 0.3): training-mode budget Tmax = 0.25
+            # (searches truncated after 256 selections) and g_ratio = 0.8, on the headline maze batch
+            for label, kw in (("maze32, training-mode budget Tmax=0.25 (max 256 steps)", {"max_iters": int(0.25 * W * W)}),
+                              ("maze32, g_ratio=0.8 (eval mode)", {"g_ratio": 0.8})):
+                run2 = Runner(pr, dev, **kw)
+                dt2, _ = timed_loop(run2, max(10, args.steps // 4), max(2, args.warmup // 4), 1, dev)
+                a2, _, _ = kernel_launch_ms(run2, max(10, min(args.steps // 4, 50)), dev)
+                sec.append({"workload": f"{label}: {B_PER_GPU} maps of 32x32", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
+                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": BYTES_PER_MAP * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "mean_iters_per_map": float(run2.iters.float().mean().item()),
                             "max_iters_per_map": int(run2.iters.max().item())})
                 del run2
