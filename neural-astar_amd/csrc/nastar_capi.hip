@@ -6,15 +6,13 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "../../include/nastar.h"
+#include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
 #include "nastar_search_reg.hip.h"
 #include "nastar_search_global.hip.h"
-#include "nastar_encoder.hip.h"
 
 namespace nastar {
 
-constexpr size_t kMaxLdsBytes = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own all of it
 
 struct FwdArgs {
     const float* cost;
@@ -419,13 +417,7 @@ __global__ __launch_bounds__(256) void nastar_unpack_kernel(const uint8_t* __res
     }
 }
 
-static thread_local char g_last_error[256] = "";
-
-static int hip_fail(hipError_t e, const char* what)
-{
-    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
-    return NASTAR_ERR_HIP;
-}
+thread_local char g_last_error[256] = "";
 
 constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
 
@@ -450,28 +442,6 @@ static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims
     d.gr = (float)g_ratio;
     d.omg = (float)(1.0 - g_ratio);  // python evaluates (1 - g_ratio) in double, ATen casts the scalar to fp32
     d.sqrtW = (float)sqrt((double)W);  // math.sqrt(W) in double, then the fp32 scalar of the division (:207)
-    return NASTAR_OK;
-}
-
-template <typename K>
-static int ensure_lds(K kernel, size_t bytes)
-{
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    return NASTAR_OK;
-}
-
-template <typename K, typename... A>
-static int launch(K kernel, int B, size_t lds, hipStream_t stream, const A&... args)
-{
-    int rc = ensure_lds(kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(64), lds, stream, args...);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }
 
@@ -500,180 +470,6 @@ static bool fastdiv_verified(int W)
     return false;
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-// bit 0: force the tiled conv kernel even for 32x32 images (parity tests of both kernels); read per call
-static int enc_flags()
-{
-    const char* e = getenv("NASTAR_ENCODER_FLAGS");
-    return e ? atoi(e) : 0;
-}
-
-template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
-static int launch_conv(const ConvArgs& ca, hipStream_t stream)
-{
-    constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;
-    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)9 * (KS / 16) * 2 * NT * 16 + (size_t)NT * 8;
-    auto kern = &nastar_conv3x3_kernel<CIN, COUT, NT, kRelu, kFinal>;
-    int rc = ensure_lds(kern, lds);
-    if (rc) return rc;
-    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW) * (COUT / NT));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-// 32x32 images, CIN >= 32 and COUT >= 64: whole-image workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
-static int conv_cu_count(int* out)
-{
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device query");
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    *out = n_cu;
-    return NASTAR_OK;
-}
-
-// CIN >= 32 and COUT >= 64, H and W multiples of 32: persistent 32x32-tile workgroups (nastar_conv3x3_img32_kernel; 32x32 images
-// take its whole-image form), otherwise the generic tiled kernel
-template <int CIN, int COUT, bool kRelu>
-static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
-{
-    if (ca.H % 32 != 0 || ca.W % 32 != 0 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
-    const bool whole = ca.H == 32 && ca.W == 32;
-    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
-    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 0, true>;
-    int rc = ensure_lds(kern, I32_LDS_BYTES);
-    if (rc) return rc;
-    int n_cu = 0;
-    if ((rc = conv_cu_count(&n_cu))) return rc;
-    const long long items = (long long)ca.B * (ca.H / 32) * (ca.W / 32) * (COUT / I32_NT);
-    const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);  // persistent: one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-// input assembly + 2 -> 32 + 32 -> 64 channels for 32x32 maps in one persistent kernel
-static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream)
-{
-    void (*kern)(const StemArgs) = &nastar_conv_stem32_kernel;
-    int rc = ensure_lds(kern, STEM_LDS_BYTES);
-    if (rc) return rc;
-    int n_cu = 0;
-    if ((rc = conv_cu_count(&n_cu))) return rc;
-    const unsigned grid = (unsigned)(sa.B < n_cu ? sa.B : n_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), STEM_LDS_BYTES, stream, sa);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-// 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
-static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
-{
-    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
-    if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 2>;  // dev: every workgroup reads image 0 (L2 hits)
-    if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 1>;  // dev: cycle totals into the (unused) output slab
-    int rc = ensure_lds(kern, I32_LDS_BYTES);
-    if (rc) return rc;
-    int n_cu = 0;
-    if ((rc = conv_cu_count(&n_cu))) return rc;
-    const unsigned grid = (unsigned)(ca.B < n_cu ? ca.B : n_cu);  // a workgroup owns whole images
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-// ---- optimal-trajectory roll-out of the dataset path (reference utils/data.py:171-199 get_opt_traj + :222-244 next_loc) --------------
-// One thread per roll-out (map n, start s): follow argmax_a policy[n][a][cell] from the start cell until the goal cell; every visited
-// cell except the goal is set to 1.  A serial chain of at most H*W dependent 8-way loads; the batch supplies the parallelism.
-// status: 0 ok, 1 = the policy revisits a cell (the reference asserts), 2 = it walks off the map / start invalid, 3 = no goal within H*W.
-__global__ __launch_bounds__(64) void nastar_policy_rollout_kernel(const float* pol, const int* start_idx, const int* goal_idx,
-                                                                  int n_roll, int starts_per_map, int A, int H, int W,
-                                                                  float* traj, int* status)
-{
-    const int HW = H * W;
-    const int r0 = blockIdx.x * 64;
-    const int nr = (n_roll - r0 < 64) ? n_roll - r0 : 64;
-    for (long long i = threadIdx.x; i < (long long)nr * HW; i += 64) traj[(size_t)r0 * HW + i] = 0.f;
-    __syncthreads();
-    const int r = r0 + threadIdx.x;
-    if (r >= n_roll) return;
-    const int n = r / starts_per_map;
-    const float* p = pol + (size_t)n * A * HW;
-    float* t = traj + (size_t)r * HW;
-    const int goal = goal_idx[n];
-    int cur = start_idx[r];
-    int st = 0;
-    if ((unsigned)cur >= (unsigned)HW || (unsigned)goal >= (unsigned)HW) st = 2;
-    int steps = 0;
-    while (st == 0 && cur != goal) {
-        t[cur] = 1.0f;                                   // :190
-        int best = 0;
-        float bv = p[cur];
-        for (int a = 1; a < A; ++a) {                    // np.argmax: first maximum (:243)
-            const float v = p[(size_t)a * HW + cur];
-            if (v > bv) { bv = v; best = a; }
-        }
-        // action -> (dy, dx), :232-241
-        const int dy = (best == 0 || best == 4 || best == 5) ? -1 : ((best == 3 || best == 6 || best == 7) ? 1 : 0);
-        const int dx = (best == 1 || best == 4 || best == 6) ? 1 : ((best == 2 || best == 5 || best == 7) ? -1 : 0);
-        const int y = cur / W + dy, x = cur % W + dx;
-        if (best > 7 || (unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) { st = 2; break; }
-        const int nxt = y * W + x;
-        if (t[nxt] != 0.f) { st = 1; break; }            // :193-195
-        cur = nxt;
-        if (++steps > HW) st = 3;
-    }
-    status[r] = st;
-}
-
-// ---- mean |histories - opt_trajs| (nn.L1Loss, training.py:58): fixed-order two-stage reduction in double, deterministic --------
-constexpr int kL1Blocks = 256;
-__device__ __forceinline__ double block_sum_256(double v, double* sh)
-{
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
-        __syncthreads();
-    }
-    return sh[0];
-}
-__global__ __launch_bounds__(256) void nastar_l1_partial_kernel(const float* h, const float* t, long long n, double* part)
-{
-    __shared__ double sh[256];
-    double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)kL1Blocks * 256) acc += (double)fabsf(h[i] - t[i]);
-    const double tot = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(256) void nastar_l1_final_kernel(const double* part, long long n, float* loss)
-{
-    __shared__ double sh[256];
-    const double tot = block_sum_256(part[threadIdx.x], sh);
-    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)n);
-}
-
-static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
-{
-    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
-    auto kern = &nastar_conv3x3_final_kernel<256>;
-    int rc = ensure_lds(kern, lds);
-    if (rc) return rc;
-    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
 }  // namespace nastar
 
 using namespace nastar;
@@ -858,36 +654,6 @@ int nastar_backward_l1(const float* histories, const float* opt_trajs, const flo
     return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
 }
 
-int nastar_policy_rollout(const float* opt_policies, const int32_t* start_idx, const int32_t* goal_idx, int n_maps,
-                          int starts_per_map, int n_actions, int H, int W, float* opt_trajs_out, int32_t* status_out, void* stream)
-{
-    if (!opt_policies || !start_idx || !goal_idx || !opt_trajs_out || !status_out) return NASTAR_ERR_NULL;
-    if (n_maps <= 0 || starts_per_map <= 0 || H <= 0 || W <= 0 || n_actions <= 0 || n_actions > 8) return NASTAR_ERR_BAD_SHAPE;
-    const long long n_roll = (long long)n_maps * starts_per_map;
-    if (n_roll > (1ll << 30)) return NASTAR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(nastar_policy_rollout_kernel, dim3((unsigned)((n_roll + 63) / 64)), dim3(64), 0,
-                       reinterpret_cast<hipStream_t>(stream), opt_policies, start_idx, goal_idx, (int)n_roll, starts_per_map,
-                       n_actions, H, W, opt_trajs_out, status_out);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-int nastar_l1_loss(const float* histories, const float* opt_trajs, long long numel, float* loss_out, void* workspace,
-                   size_t workspace_bytes, void* stream)
-{
-    if (!histories || !opt_trajs || !loss_out || !workspace) return NASTAR_ERR_NULL;
-    if (numel <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (workspace_bytes < (size_t)kL1Blocks * sizeof(double)) return NASTAR_ERR_WORKSPACE;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    double* part = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(nastar_l1_partial_kernel, dim3(kL1Blocks), dim3(256), 0, s, histories, opt_trajs, numel, part);
-    hipLaunchKernelGGL(nastar_l1_final_kernel, dim3(1), dim3(256), 0, s, part, numel, loss_out);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
 int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out, void* stream)
 {
     if (!histories || !paths || !packed_out) return NASTAR_ERR_NULL;
@@ -914,102 +680,6 @@ int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* his
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
-}
-
-// ---- CNN encoder (eval mode, bf16 MFMA) -------------------------------------------------------------------------------
-// padded channels per layer: in 16, 32, 64, 128, 256 (layer 1: 2 real + 14 zero); out 32, 64, 128, 256, 32 (layer 5: 1 real)
-// Images per pass: the activation slabs of a pass (800 B per pixel) are far larger than the 256 MB MALL either way, so the pass is
-// sized for few launches and even work per persistent workgroup: 4 Mi pixels (4096 maps of 32x32, 3.3 GB of the 288 GB HBM).
-// NASTAR_ENCODER_CHUNK overrides it (dev).
-static int enc_chunk_images(int H, int W)
-{
-    const char* e = getenv("NASTAR_ENCODER_CHUNK");
-    if (e && atoi(e) > 0) return atoi(e);
-    const long long px = (long long)H * W;
-    const long long n = (4ll << 20) / px;
-    return n < 1 ? 1 : (int)n;
-}
-constexpr size_t kEncBytesPerPixel = (16 + 128 + 256) * 2;  // x0 + ping (<=128 ch) + pong (<=256 ch), bf16
-
-size_t nastar_encoder_workspace_bytes(int B, int H, int W)
-{
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const int cap = enc_chunk_images(H, W);
-    const int chunk = B < cap ? B : cap;  // images processed per pass
-    return (size_t)chunk * H * W * kEncBytesPerPixel;
-}
-
-int nastar_encoder_cnn_forward(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
-                               const uint16_t* const* wpack, const float* const* scale, const float* const* shift,
-                               float final_mul, float* cost_out, void* workspace, size_t workspace_bytes, void* stream)
-{
-    if (!map || !cost_out || !wpack || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_UNSUPPORTED;
-    const size_t per_img = (size_t)H * W * kEncBytesPerPixel;
-    int chunk = (int)(workspace_bytes / per_img);
-    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
-    if (chunk > B) chunk = B;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    uint16_t* x0 = static_cast<uint16_t*>(workspace);
-    uint16_t* ping = x0 + (size_t)chunk * H * W * 16;
-    uint16_t* pong = ping + (size_t)chunk * H * W * 128;
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
-        const size_t off = (size_t)b0 * H * W;
-        const long long npix = (long long)nb * H * W;
-        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
-        ConvArgs ca;
-        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
-        int rc;
-        if (H == 32 && W == 32 && !(enc_flags() & 17)) {  // bit 4: keep input assembly and the first two layers separate launches
-            StemArgs sa;
-            sa.map = map + off; sa.start = plus ? start + off : nullptr; sa.goal = plus ? goal + off : nullptr; sa.plus = plus; sa.B = nb;
-            sa.w1 = wpack[0]; sa.scale1 = scale[0]; sa.shift1 = shift[0]; sa.w2 = wpack[1]; sa.scale2 = scale[1]; sa.shift2 = shift[1];
-            sa.out = pong;
-            if ((rc = launch_conv_stem32(sa, s))) return rc;
-        } else {
-            hipLaunchKernelGGL(nastar_encoder_prep_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
-                               plus ? goal + off : map, x0, npix, plus);
-            ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
-            if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
-            ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
-            if ((rc = launch_conv_auto<32, 64, true>(ca, s))) return rc;
-        }
-        ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
-        if ((rc = launch_conv_auto<64, 128, true>(ca, s))) return rc;
-        ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
-        if (H == 32 && W == 32 && !(enc_flags() & 9)) {  // bit 3: keep the last layer a separate launch
-            ca.wfin = wpack[4]; ca.fscale = scale[4]; ca.fshift = shift[4]; ca.out_f32 = cost_out + off;
-            if ((rc = launch_conv_fused_final(ca, s))) return rc;
-            continue;
-        }
-        if ((rc = launch_conv_auto<128, 256, true>(ca, s))) return rc;
-        ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
-        if ((rc = launch_conv_final(ca, s))) return rc;
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-// One 3x3 convolution layer on its own (unit tests): in [B,H,W,CIN] bf16 -> out [B,H,W,COUT] bf16, y = relu?(acc*scale+shift).
-int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
-                        int B, int H, int W, int cin, int cout, int relu, void* stream)
-{
-    if (!in || !wpack || !scale || !shift || !out) return NASTAR_ERR_NULL;
-    if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
-    ConvArgs ca;
-    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
-    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
-    ca.B = B; ca.H = H; ca.W = W;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);
-    if (cin == 32 && cout == 64) return relu ? launch_conv_auto<32, 64, true>(ca, s) : launch_conv_auto<32, 64, false>(ca, s);
-    if (cin == 64 && cout == 128) return relu ? launch_conv_auto<64, 128, true>(ca, s) : launch_conv_auto<64, 128, false>(ca, s);
-    if (cin == 128 && cout == 256) return relu ? launch_conv_auto<128, 256, true>(ca, s) : launch_conv_auto<128, 256, false>(ca, s);
-    return NASTAR_ERR_UNSUPPORTED;
 }
 
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out)

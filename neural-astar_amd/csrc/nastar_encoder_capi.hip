@@ -1,0 +1,213 @@
+// nastar_encoder_capi.hip -- C-ABI entry points of the bf16-MFMA CNN encoder (include/nastar.h) and their launch logic.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "nastar_host.hip.h"
+#include "nastar_encoder.hip.h"
+
+namespace nastar {
+
+// bit 0: force the tiled conv kernel even for 32x32 images (parity tests of both kernels); read per call
+static int enc_flags()
+{
+    const char* e = getenv("NASTAR_ENCODER_FLAGS");
+    return e ? atoi(e) : 0;
+}
+
+template <int CIN, int COUT, int NT, bool kRelu, bool kFinal>
+static int launch_conv(const ConvArgs& ca, hipStream_t stream)
+{
+    constexpr int KS = (CIN < ENC_KS) ? CIN : ENC_KS;
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)9 * (KS / 16) * 2 * NT * 16 + (size_t)NT * 8;
+    auto kern = &nastar_conv3x3_kernel<CIN, COUT, NT, kRelu, kFinal>;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW) * (COUT / NT));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// 32x32 images, CIN >= 32 and COUT >= 64: whole-image workgroups (nastar_conv3x3_img32_kernel), otherwise the tiled kernel
+static int conv_cu_count(int* out)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hip_fail(hipGetLastError(), "device query");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    *out = n_cu;
+    return NASTAR_OK;
+}
+
+// CIN >= 32 and COUT >= 64, H and W multiples of 32: persistent 32x32-tile workgroups (nastar_conv3x3_img32_kernel; 32x32 images
+// take its whole-image form), otherwise the generic tiled kernel
+template <int CIN, int COUT, bool kRelu>
+static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
+{
+    if (ca.H % 32 != 0 || ca.W % 32 != 0 || (enc_flags() & 1)) return launch_conv<CIN, COUT, (COUT >= 64 ? 64 : 32), kRelu, false>(ca, stream);
+    const bool whole = ca.H == 32 && ca.W == 32;
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu>;
+    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 0, true>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const long long items = (long long)ca.B * (ca.H / 32) * (ca.W / 32) * (COUT / I32_NT);
+    const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);  // persistent: one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// input assembly + 2 -> 32 + 32 -> 64 channels for 32x32 maps in one persistent kernel
+static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream)
+{
+    void (*kern)(const StemArgs) = &nastar_conv_stem32_kernel;
+    int rc = ensure_lds(kern, STEM_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const unsigned grid = (unsigned)(sa.B < n_cu ? sa.B : n_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), STEM_LDS_BYTES, stream, sa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
+static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
+{
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
+    if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 2>;  // dev: every workgroup reads image 0 (L2 hits)
+    if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 1>;  // dev: cycle totals into the (unused) output slab
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const unsigned grid = (unsigned)(ca.B < n_cu ? ca.B : n_cu);  // a workgroup owns whole images
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I32_LDS_BYTES, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
+    auto kern = &nastar_conv3x3_final_kernel<256>;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_THREADS), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+}  // namespace nastar
+
+using namespace nastar;
+
+extern "C" {
+
+// ---- CNN encoder (eval mode, bf16 MFMA) -------------------------------------------------------------------------------
+// padded channels per layer: in 16, 32, 64, 128, 256 (layer 1: 2 real + 14 zero); out 32, 64, 128, 256, 32 (layer 5: 1 real)
+// Images per pass: the activation slabs of a pass (800 B per pixel) are far larger than the 256 MB MALL either way, so the pass is
+// sized for few launches and even work per persistent workgroup: 4 Mi pixels (4096 maps of 32x32, 3.3 GB of the 288 GB HBM).
+// NASTAR_ENCODER_CHUNK overrides it (dev).
+static int enc_chunk_images(int H, int W)
+{
+    const char* e = getenv("NASTAR_ENCODER_CHUNK");
+    if (e && atoi(e) > 0) return atoi(e);
+    const long long px = (long long)H * W;
+    const long long n = (4ll << 20) / px;
+    return n < 1 ? 1 : (int)n;
+}
+constexpr size_t kEncBytesPerPixel = (16 + 128 + 256) * 2;  // x0 + ping (<=128 ch) + pong (<=256 ch), bf16
+
+size_t nastar_encoder_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int cap = enc_chunk_images(H, W);
+    const int chunk = B < cap ? B : cap;  // images processed per pass
+    return (size_t)chunk * H * W * kEncBytesPerPixel;
+}
+
+int nastar_encoder_cnn_forward(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                               const uint16_t* const* wpack, const float* const* scale, const float* const* shift,
+                               float final_mul, float* cost_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!map || !cost_out || !wpack || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_UNSUPPORTED;
+    const size_t per_img = (size_t)H * W * kEncBytesPerPixel;
+    int chunk = (int)(workspace_bytes / per_img);
+    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
+    if (chunk > B) chunk = B;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    uint16_t* x0 = static_cast<uint16_t*>(workspace);
+    uint16_t* ping = x0 + (size_t)chunk * H * W * 16;
+    uint16_t* pong = ping + (size_t)chunk * H * W * 128;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const size_t off = (size_t)b0 * H * W;
+        const long long npix = (long long)nb * H * W;
+        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+        ConvArgs ca;
+        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
+        int rc;
+        if (H == 32 && W == 32 && !(enc_flags() & 17)) {  // bit 4: keep input assembly and the first two layers separate launches
+            StemArgs sa;
+            sa.map = map + off; sa.start = plus ? start + off : nullptr; sa.goal = plus ? goal + off : nullptr; sa.plus = plus; sa.B = nb;
+            sa.w1 = wpack[0]; sa.scale1 = scale[0]; sa.shift1 = shift[0]; sa.w2 = wpack[1]; sa.scale2 = scale[1]; sa.shift2 = shift[1];
+            sa.out = pong;
+            if ((rc = launch_conv_stem32(sa, s))) return rc;
+        } else {
+            hipLaunchKernelGGL(nastar_encoder_prep_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
+                               plus ? goal + off : map, x0, npix, plus);
+            ca.in = x0; ca.out = ping; ca.wpack = wpack[0]; ca.scale = scale[0]; ca.shift = shift[0];
+            if ((rc = launch_conv<16, 32, 32, true, false>(ca, s))) return rc;
+            ca.in = ping; ca.out = pong; ca.wpack = wpack[1]; ca.scale = scale[1]; ca.shift = shift[1];
+            if ((rc = launch_conv_auto<32, 64, true>(ca, s))) return rc;
+        }
+        ca.in = pong; ca.out = ping; ca.wpack = wpack[2]; ca.scale = scale[2]; ca.shift = shift[2];
+        if ((rc = launch_conv_auto<64, 128, true>(ca, s))) return rc;
+        ca.in = ping; ca.out = pong; ca.wpack = wpack[3]; ca.scale = scale[3]; ca.shift = shift[3];
+        if (H == 32 && W == 32 && !(enc_flags() & 9)) {  // bit 3: keep the last layer a separate launch
+            ca.wfin = wpack[4]; ca.fscale = scale[4]; ca.fshift = shift[4]; ca.out_f32 = cost_out + off;
+            if ((rc = launch_conv_fused_final(ca, s))) return rc;
+            continue;
+        }
+        if ((rc = launch_conv_auto<128, 256, true>(ca, s))) return rc;
+        ca.in = pong; ca.out = nullptr; ca.out_f32 = cost_out + off; ca.wpack = wpack[4]; ca.scale = scale[4]; ca.shift = shift[4];
+        if ((rc = launch_conv_final(ca, s))) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// One 3x3 convolution layer on its own (unit tests): in [B,H,W,CIN] bf16 -> out [B,H,W,COUT] bf16, y = relu?(acc*scale+shift).
+int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
+                        int B, int H, int W, int cin, int cout, int relu, void* stream)
+{
+    if (!in || !wpack || !scale || !shift || !out) return NASTAR_ERR_NULL;
+    if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
+    ConvArgs ca;
+    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
+    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
+    ca.B = B; ca.H = H; ca.W = W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);
+    if (cin == 32 && cout == 64) return relu ? launch_conv_auto<32, 64, true>(ca, s) : launch_conv_auto<32, 64, false>(ca, s);
+    if (cin == 64 && cout == 128) return relu ? launch_conv_auto<64, 128, true>(ca, s) : launch_conv_auto<64, 128, false>(ca, s);
+    if (cin == 128 && cout == 256) return relu ? launch_conv_auto<128, 256, true>(ca, s) : launch_conv_auto<128, 256, false>(ca, s);
+    return NASTAR_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"
