@@ -54,6 +54,7 @@ class HipCnnEncoder:
         self.cnn = cnn
         self.in_channels = convs[0].in_channels
         self._key = None
+        self._ws: Optional[torch.Tensor] = None
         self._refresh()
 
     def _refresh(self) -> None:
@@ -91,15 +92,16 @@ class HipCnnEncoder:
         g = goal_maps[:, 0].contiguous() if plus else None
         cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         ws_bytes = int(lib.nastar_encoder_workspace_bytes(B, H, W))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        ws = self._ws  # activation slabs, kept across calls (grown on demand) instead of re-allocated per batch
+        if ws is None or ws.device != dev or ws.numel() < ws_bytes:
+            ws = self._ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         arr = ctypes.c_void_p * 5
         mul = self._mul
         with torch.cuda.device(dev):
             rc = lib.nastar_encoder_cnn_forward(
                 m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, H, W,
                 arr(*[t.data_ptr() for t in self.wpack]), arr(*[t.data_ptr() for t in self.scale]),
-                arr(*[t.data_ptr() for t in self.shift]), mul, cost.data_ptr(), ws.data_ptr(), ws_bytes,
+                arr(*[t.data_ptr() for t in self.shift]), mul, cost.data_ptr(), ws.data_ptr(), ws.numel(),
                 torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "nastar_encoder_cnn_forward")
-        self._last_ws = ws  # (dev probes read kernel instrumentation out of it)
         return cost.unsqueeze(1)

@@ -17,8 +17,8 @@ with torch.no_grad():
 torch.cuda.synchronize()
 enc = na._hip_encoder if hasattr(na, "_hip_encoder") else None
 if enc is None:
-    enc = [v for v in vars(na).values() if hasattr(v, "_last_ws")][0]
-ws = enc._last_ws
+    enc = [v for v in vars(na).values() if hasattr(v, "_ws")][0]
+ws = enc._ws
 off = B * 1024 * (16 + 128) * 2
 d = ws[off: off + 256 * 8 * 4 * 8].view(torch.int64).cpu().numpy().reshape(256, 8, 4)
 tot, bar, main, epi = (d[..., i].astype(np.float64) for i in range(4))
