@@ -160,6 +160,19 @@ size_t nastar_encoder_workspace_bytes(int B, int H, int W);
 int nastar_encoder_cnn_forward(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
                                const uint16_t* const* wpack, const float* const* scale, const float* const* shift,
                                float final_mul, float* cost_out, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * The same encoder at fp32-grade accuracy ("f16x3": operands split into two fp16 terms, products hi*hi + lo*hi + hi*lo on the
+ * fp16 MFMA, fp32 accumulation; cost maps within 1e-5 of the reference's fp32 encoder).  H, W multiples of 32.
+ *   w1_f32   first conv weight [32][1|2][3][3] fp32 (torch layout): that layer runs in plain fp32
+ *   wsplit   5 device pointers: layers 2..4 packed over 3*cin virtual channels [W_hi | W_hi | W_lo] as fp16
+ *            ([tap][3*cin/8][cout][8]), then the last layer's W_hi and W_lo packs ([tap][256/8][32][8], channel 0 real)
+ *   scale/shift as in nastar_encoder_cnn_forward (5 layers); workspace: nastar_encoder_workspace_bytes_f16x3(B,H,W)
+ */
+size_t nastar_encoder_workspace_bytes_f16x3(int B, int H, int W);
+int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                                     const float* w1_f32, const uint16_t* const* wsplit, const float* const* scale,
+                                     const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 /* one layer of the above on its own (unit tests): (cin, cout) in {(16,32), (32,64), (64,128), (128,256)} */
 int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
                         int B, int H, int W, int cin, int cout, int relu, void* stream);

@@ -23,6 +23,16 @@ namespace nastar {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 accumulator fragment
+typedef _Float16 nastar_h8 __attribute__((ext_vector_type(8)));
+// one 32x32x16 MFMA; the operand registers hold 8 bf16 or 8 fp16 per lane
+template <bool kF16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    if constexpr (kF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<nastar_h8*>(&a), *reinterpret_cast<nastar_h8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f)
 {
@@ -39,6 +49,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     const nastar_bf16x2 b = __builtin_convertvector(v, nastar_bf16x2);
     return *reinterpret_cast<const uint32_t*>(&b);
 }
+// ---- "f16x3" precision (north-star tolerance 1e-5 on float outputs): every operand is split into two fp16 terms x = hi + lo
+// (22 significant bits) and a product is hi*hi + lo*hi + hi*lo on the fp16 MFMA with fp32 accumulation -- 3x the matrix work of the bf16
+// path for fp32-grade cost maps.  Activations are stored [hi(C) | lo(C)] per pixel, weights are packed over 3C "virtual" input channels
+// [W_hi | W_hi | W_lo] that meet the activation blocks [x_hi | x_lo | x_hi].
+typedef _Float16 nastar_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 nastar_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)  // round to nearest even
+{
+    const nastar_f16x2 b = {(_Float16)lo, (_Float16)hi};
+    return *reinterpret_cast<const uint32_t*>(&b);
+}
+__device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
+template <bool kF16>
+__device__ __forceinline__ uint32_t pack_pair(float lo, float hi) { return kF16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 constexpr int ENC_TW = 32;        // tile width  = image width handled per workgroup column block
@@ -64,6 +88,10 @@ struct ConvArgs {
     const uint16_t* wfin;   // fused last layer (img32 kernel, kFuse): its packed weights [9][COUT/8][32][8] ...
     const float* fscale;    // ... and its folded BatchNorm scale / shift (1 channel)
     const float* fshift;
+    // tap-major last-layer kernel only: channels per input pixel (0 = CIN) and multi-pass accumulation for the f16x3 form
+    int in_stride;
+    int pass_flags;         // bit 0: add zacc[pixel] to the tap sum; bit 1: store the raw sum to zacc and stop (not the last pass)
+    float* zacc;            // [B,H,W] fp32 partial sums
     float final_mul;
     int B, H, W;
 };
@@ -287,7 +315,7 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
 #define LGKM3(a_, b_, c_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_))
 #define LGKM6(a_, b_, c_, d_, e_, f_) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_), "+v"(e_), "+v"(f_))
 // one MFMA of the 4 x 2 register tile (row m of the step's window, channel block n), order pinned
-#define MF(m_, n_, W_, R_) acc[m_][n_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W_##n_, R_, acc[m_][n_], 0, 0, 0); SB
+#define MF(m_, n_, W_, R_) acc[m_][n_] = mfma16<kF16>(W_##n_, R_, acc[m_][n_]); SB   /* kF16: constant in the using kernel */
 // a step: 8 MFMAs on weights W_{0,1} x rows R0_..R3_, with the next step's fragment reads slotted one per MFMA gap
 #define STEP0(W_, R0_, R1_, R2_, R3_) \
     SB; MF(0, 0, W_, R0_); MF(0, 1, W_, R0_); MF(1, 0, W_, R1_); MF(1, 1, W_, R1_);  \
@@ -328,11 +356,17 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
 // kProbe (dev builds only): 1 = per-wave cycle totals written to the output slab, 2 = every workgroup reads image 0 (L2-hit ablation)
 // kTiled: the image is H x W with H, W multiples of 32 and a work item is one of its 32x32 tiles: the halo ring (132 pixels) is
 // then real data, loaded as a fifth chunk by threads 0..263 (zero outside the image); kTiled = false is the whole-image case above.
-template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, bool kTiled = false>
+// kF16: the f16x3 split-precision form (see pack_f16x2): in [.., 2 CIN] = [hi | lo], weights packed over 3 CIN virtual channels,
+// out [.., 2 COUT] = [hi | lo]; 3 CIN / 16 slices per item.
+template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, bool kTiled = false, bool kF16 = false>
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
     static_assert(!(kFuse && kTiled), "the fused last layer needs the whole image in one workgroup");
-    constexpr int NSLICE = CIN / I32_KS;
+    static_assert(!(kFuse && kF16), "split precision keeps the last layer a separate launch");
+    constexpr int NS1 = CIN / I32_KS;                 // slices per precision block
+    constexpr int NSLICE = (kF16 ? 3 : 1) * NS1;
+    constexpr int CINV = (kF16 ? 3 : 1) * CIN;        // virtual input channels of the packed weights
+    constexpr int IN_STRIDE = (kF16 ? 2 : 1) * CIN, OUT_STRIDE = (kF16 ? 2 : 1) * COUT;  // channels per pixel in HBM
     constexpr int NGRP = COUT / I32_NT;
     static_assert(NSLICE % 2 == 0, "buffer parity must repeat per work item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -364,14 +398,14 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     }
     // staging: chunk q = tid + 512 i.  pixels: p = q >> 1 = (tid >> 1) + 256 i -> row (tid >> 6) + 8 i, column (tid >> 1) & 31
     const int t_dst = i32_tile_off((tid >> 6) + 1, ((tid >> 1) & 31) + 1, tid & 1);
-    const size_t t_lane = ((size_t)(tid >> 6) * img_w + ((tid >> 1) & 31)) * CIN + (tid & 1) * 8;
+    const size_t t_lane = ((size_t)(tid >> 6) * img_w + ((tid >> 1) & 31)) * IN_STRIDE + (tid & 1) * 8;
     // weights: q -> n = q & 63, khalf = (q >> 6) & 1, tap = (q >> 7) = (tid >> 7) + 4 i
-    const size_t w_lane = ((size_t)((tid >> 7) * (CIN / 8) + ((tid >> 6) & 1)) * COUT + (tid & 63)) * 8;
+    const size_t w_lane = ((size_t)((tid >> 7) * (CINV / 8) + ((tid >> 6) & 1)) * COUT + (tid & 63)) * 8;
     // (named scalars, not arrays: the arrays were left in scratch memory by the compiler)
     uint4 t0, t1, t2, t3, w0, w1, w2 = make_uint4(0u, 0u, 0u, 0u);
     const bool w2on = tid < 128;
-    constexpr size_t WSTR = (size_t)4 * (CIN / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
-    const size_t TSTR = (size_t)8 * img_w * CIN;  // 8 image rows
+    constexpr size_t WSTR = (size_t)4 * (CINV / 8) * COUT * 8, WSL = (size_t)2 * COUT * 8;
+    const size_t TSTR = (size_t)8 * img_w * IN_STRIDE;  // 8 image rows
     // halo ring (kTiled): chunk tid < 264 -> ring pixel tid >> 1: top row, bottom row, left column, right column of the 34x34 tile
     uint4 hq = make_uint4(0u, 0u, 0u, 0u);
     int h_dst = 0, h_y = 0, h_x = 0;
@@ -389,14 +423,16 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
 #define I32_LOAD_SLICE(item_, s_)                                                                        \
     do {                                                                                                 \
         I32_DECODE(item_, ib_, iy_, ix_, ig_);                                                           \
-        const uint16_t* ip_ = a.in + (((size_t)ib_ * (kTiled ? a.H : 32) + iy_) * img_w + ix_) * CIN + (s_) * I32_KS; \
+        /* activation channels of virtual slice s: blocks [x_hi | x_lo | x_hi] */                         \
+        const int cs_ = (kF16 && (s_) >= 2 * NS1) ? (s_) - 2 * NS1 : (s_);                               \
+        const uint16_t* ip_ = a.in + (((size_t)ib_ * (kTiled ? a.H : 32) + iy_) * img_w + ix_) * IN_STRIDE + cs_ * I32_KS; \
         const uint16_t* tp_ = ip_ + t_lane;                                                              \
         const uint16_t* wp_ = a.wpack + w_lane + ig_ * I32_NT * 8 + (size_t)(s_) * WSL;                  \
         if constexpr (kTiled) {                                                                          \
             const int gy_ = iy_ + h_y - 1, gx_ = ix_ + h_x - 1;                                          \
             hq = make_uint4(0u, 0u, 0u, 0u);                                                             \
             if (h_on && (unsigned)gy_ < (unsigned)a.H && (unsigned)gx_ < (unsigned)a.W)                  \
-                hq = *reinterpret_cast<const uint4*>(ip_ + ((ptrdiff_t)(h_y - 1) * img_w + (h_x - 1)) * CIN + (tid & 1) * 8); \
+                hq = *reinterpret_cast<const uint4*>(ip_ + ((ptrdiff_t)(h_y - 1) * img_w + (h_x - 1)) * IN_STRIDE + (tid & 1) * 8); \
         }                                                                                                \
         t0 = *reinterpret_cast<const uint4*>(tp_);                                                       \
         t1 = *reinterpret_cast<const uint4*>(tp_ + TSTR);                                                \
@@ -558,37 +594,43 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             // ---- epilogue: scale/shift/ReLU -> bf16, transposed through a wave-private LDS patch so that 8 lanes write one pixel's
             // 128 contiguous bytes.  D layout: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel.
             unsigned char* ob = obase + wave * 4096;  // one image row: 32 pixels x 64 channels
-    #pragma unroll
+#pragma unroll
             for (int m = 0; m < I32_RPW; ++m) {
-    #pragma unroll
-                for (int n = 0; n < I32_NB; ++n)
-    #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = n0 + n * 32 + 8 * g + 4 * kh;
-                        const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                        const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
-                        float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
-                        float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
-                        float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
-                        float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
-                        if constexpr (kRelu) {
-                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+#pragma unroll
+                for (int part = 0; part < (kF16 ? 2 : 1); ++part) {  // f16x3: the hi halves, then the lo halves (v - fp16(v))
+#pragma unroll
+                    for (int n = 0; n < I32_NB; ++n)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = n0 + n * 32 + 8 * g + 4 * kh;
+                            const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                            const float4 sh = *reinterpret_cast<const float4*>(ss + COUT + cl);
+                            float v0 = acc[m][n][4 * g + 0] * sc.x + sh.x;
+                            float v1 = acc[m][n][4 * g + 1] * sc.y + sh.y;
+                            float v2 = acc[m][n][4 * g + 2] * sc.z + sh.z;
+                            float v3 = acc[m][n][4 * g + 3] * sc.w + sh.w;
+                            if constexpr (kRelu) {
+                                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                            }
+                            if (part == 1) {
+                                v0 = f16_residual(v0); v1 = f16_residual(v1); v2 = f16_residual(v2); v3 = f16_residual(v3);
+                            }
+                            uint2 o;
+                            o.x = pack_pair<kF16>(v0, v1);
+                            o.y = pack_pair<kF16>(v2, v3);
+                            const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
+                            *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
                         }
-                        uint2 o;
-                        o.x = pack_bf16x2(v0, v1);
-                        o.y = pack_bf16x2(v2, v3);
-                        const int chunk = n * 4 + g;  // 16-byte chunk of the pixel's 128 bytes, swizzled by the column
-                        *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p = j * 8 + (lane >> 3), chunk = lane & 7;
+                        const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
+                        const size_t pix = ((size_t)b * (kTiled ? a.H : 32) + ty0 + wave * I32_RPW + m) * img_w + tx0 + p;
+                        *reinterpret_cast<uint4*>(a.out + pix * OUT_STRIDE + part * COUT + n0 + chunk * 8) = v;
                     }
-                __builtin_amdgcn_wave_barrier();
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = j * 8 + (lane >> 3), chunk = lane & 7;
-                    const uint4 v = *reinterpret_cast<const uint4*>(ob + p * 128 + ((chunk ^ ((p >> 1) & 7)) << 4));
-                    const size_t pix = ((size_t)b * (kTiled ? a.H : 32) + ty0 + wave * I32_RPW + m) * img_w + tx0 + p;
-                    *reinterpret_cast<uint4*>(a.out + pix * COUT + n0 + chunk * 8) = v;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
         if constexpr (kProbe == 1) tk_epi += clock64() - tk0;
@@ -611,9 +653,10 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
 // of a 1x1 convolution:  P[p][t] = sum_c x[p][c] * w[t][c]  for every pixel p of the halo tile (MFMA rows = taps), and the
 // 3x3 convolution is the shifted sum  out[y][x] = sum_t P[(y+dy, x+dx)][t].  9x fewer MFMAs than the padded GEMM; the layer
 // becomes a pure stream over its 512-byte-per-pixel input.
-template <int CIN>
+template <int CIN, bool kF16 = false>
 __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const ConvArgs a)
 {
+    const int istr = a.in_stride > 0 ? a.in_stride : CIN;
     constexpr int KS = ENC_KS, KSTEPS = KS / 16, NSLICE = CIN / KS, CH16 = KS / 8;
     constexpr int HP = (ENC_TH + 2) * (ENC_TW + 2);       // halo pixels (612)
     constexpr int NBLK = (HP + 31) / 32;                  // 32-pixel MFMA column blocks (20)
@@ -650,10 +693,10 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const
         const int tx = p % (ENC_TW + 2), ty = p / (ENC_TW + 2);
         const int gy = y0 + ty - 1, gx = x0 + tx - 1;
         const bool ok = q < NTC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        t_src[i] = ok ? (int)(((gy * a.W + gx) * CIN) + c * 8) : -1;
+        t_src[i] = ok ? (int)(((gy * a.W + gx) * istr) + c * 8) : -1;
         t_dst[i] = q < NTC ? enc_tile_off(ty, tx, c) : -1;
     }
-    const uint16_t* in_img = a.in + (size_t)b * a.H * a.W * CIN;
+    const uint16_t* in_img = a.in + (size_t)b * a.H * a.W * istr;
     uint4 tq[NTQ];
     auto load_slice = [&](int s) {
 #pragma unroll
@@ -693,7 +736,7 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const
                 if ((wave + j * ENC_WAVES) < NBLK) {  // wave-uniform
                     const int ty = boff[j] / (ENC_TW + 2), tx = boff[j] % (ENC_TW + 2);
                     const bf16x8 xb = *reinterpret_cast<const bf16x8*>(tile + enc_tile_off(ty, tx, kk * 2 + kh));
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s * KSTEPS + kk], xb, acc[j], 0, 0, 0);
+                    acc[j] = mfma16<kF16>(wa[s * KSTEPS + kk], xb, acc[j]);
                 }
             }
         if (s + 1 < NSLICE) {
@@ -724,8 +767,14 @@ __global__ __launch_bounds__(ENC_THREADS) void nastar_conv3x3_final_kernel(const
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) z += part[((oy + dy) * (ENC_TW + 2) + ox + dx) * 9 + dy * 3 + dx];
+        const size_t pi = ((size_t)b * a.H + y0 + oy) * a.W + x0 + ox;
+        if (a.pass_flags & 1) z += a.zacc[pi];
+        if (a.pass_flags & 2) {
+            a.zacc[pi] = z;
+            continue;
+        }
         z = z * a.scale[0] + a.shift[0];
-        a.out_f32[((size_t)b * a.H + y0 + oy) * a.W + x0 + ox] = a.final_mul / (1.0f + __expf(-z));
+        a.out_f32[pi] = a.final_mul / (1.0f + (kF16 ? expf(-z) : __expf(-z)));
     }
 }
 
@@ -749,6 +798,7 @@ constexpr size_t STEM_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + 8 * 4096 + STEM_RA
 __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs a)
 {
     constexpr int CIN = 32, COUT = 64;
+    constexpr bool kF16 = false;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* obase = smem + 2 * I32_BUF_BYTES;                       // epilogue transpose patches, 8 x 4 KB
     uint32_t* raw = reinterpret_cast<uint32_t*>(obase + 8 * 4096);         // [34][34] bf16x2 (map, start+goal), zero halo
@@ -884,6 +934,55 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
                 *reinterpret_cast<uint4*>(a.out + pix * COUT + chunk * 8) = v;
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- f16x3 form of the first layer: input assembly + conv (1|2) -> 32 + BatchNorm + ReLU in plain fp32 on the vector ALU ---------------
+// 18 multiply-adds per output: not worth a matrix instruction, and exact.  One thread per pixel; output [B,H,W,64] fp16 = [hi(32) | lo(32)].
+__global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float* __restrict__ map, const float* __restrict__ start,
+                                                                   const float* __restrict__ goal, int plus, const float* __restrict__ w,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   uint16_t* __restrict__ out, int B, int H, int W)
+{
+    __shared__ float ws[32 * 2 * 9 + 64];
+    const int cin = plus ? 2 : 1;
+    for (int i = threadIdx.x; i < 32 * cin * 9; i += 256) ws[i] = w[i];  // [32][cin][3][3], the torch layout
+    if (threadIdx.x < 32) { ws[576 + threadIdx.x] = scale[threadIdx.x]; ws[608 + threadIdx.x] = shift[threadIdx.x]; }
+    __syncthreads();
+    const long long npix = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        float in[2][9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const long long j = i + (long long)(t / 3 - 1) * W + (t % 3 - 1);
+            in[0][t] = ok ? map[j] : 0.f;
+            in[1][t] = (ok && plus) ? start[j] + goal[j] : 0.f;
+        }
+        uint32_t hi[16], lo[16];
+#pragma unroll
+        for (int c = 0; c < 32; c += 2) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float* wc = ws + (c + e) * cin * 9;
+                float z = 0.f;
+                for (int ci = 0; ci < cin; ++ci)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) z += wc[ci * 9 + t] * in[ci][t];
+                v[e] = fmaxf(z * ws[576 + c + e] + ws[608 + c + e], 0.f);
+            }
+            hi[c >> 1] = pack_f16x2(v[0], v[1]);
+            lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));
+        }
+        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dst[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+            dst[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
         }
     }
 }

@@ -96,6 +96,36 @@ static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
     return NASTAR_OK;
 }
 
+// f16x3 split precision: persistent 32x32-tile kernel over 3 CIN virtual channels; H, W multiples of 32
+template <int CIN, int COUT>
+static int launch_conv_split(const ConvArgs& ca, hipStream_t stream)
+{
+    const bool whole = ca.H == 32 && ca.W == 32;
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, false, true>;
+    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, true, true>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const long long items = (long long)ca.B * (ca.H / 32) * (ca.W / 32) * (COUT / I32_NT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(items < n_cu ? items : n_cu)), dim3(512), I32_LDS_BYTES, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+static int launch_conv_final_split_pass(const ConvArgs& ca, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
+    auto kern = &nastar_conv3x3_final_kernel<256, true>;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)ca.B * (ca.H / ENC_TH) * (ca.W / ENC_TW))), dim3(ENC_THREADS), lds, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
 {
     constexpr size_t lds = (size_t)(ENC_TH + 2) * (ENC_TW + 2) * ENC_PIX_B + (size_t)(((ENC_TH + 2) * (ENC_TW + 2) + 31) / 32) * 32 * 9 * 4;
@@ -159,7 +189,7 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
+        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
         int rc;
         if (H == 32 && W == 32 && !(enc_flags() & 17)) {  // bit 4: keep input assembly and the first two layers separate launches
             StemArgs sa;
@@ -192,6 +222,67 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
     return NASTAR_OK;
 }
 
+// ---- f16x3 ("fp32-grade") form of the same encoder: every conv is hi*hi + lo*hi + hi*lo on the fp16 MFMA ----------------------------------
+constexpr size_t kSplitBytesPerPixel = (64 + 128 + 256 + 512) * 2 + 4;  // [hi|lo] fp16 outputs of layers 1..4 + the last layer's fp32 partial sum
+
+size_t nastar_encoder_workspace_bytes_f16x3(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    long long cap = (1ll << 20) / ((long long)H * W);
+    if (cap < 1) cap = 1;
+    return (size_t)(B < cap ? B : cap) * H * W * kSplitBytesPerPixel;
+}
+
+int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                                     const float* w1_f32, const uint16_t* const* wsplit, const float* const* scale,
+                                     const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                     size_t workspace_bytes, void* stream)
+{
+    if (!map || !cost_out || !w1_f32 || !wsplit || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H % 32 != 0 || W % 32 != 0) return NASTAR_ERR_UNSUPPORTED;
+    const size_t per_img = (size_t)H * W * kSplitBytesPerPixel;
+    int chunk = (int)(workspace_bytes / per_img);
+    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
+    if (chunk > B) chunk = B;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t npc = (size_t)chunk * H * W;
+    uint16_t* a1 = static_cast<uint16_t*>(workspace);   // [.., 64]
+    uint16_t* a2 = a1 + npc * 64;                       // [.., 128]
+    uint16_t* a3 = a2 + npc * 128;                      // [.., 256]
+    uint16_t* a4 = a3 + npc * 256;                      // [.., 512]
+    float* zacc = reinterpret_cast<float*>(a4 + npc * 512);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const size_t off = (size_t)b0 * H * W;
+        const long long npix = (long long)nb * H * W;
+        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+        hipLaunchKernelGGL(nastar_conv_first_f32_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
+                           plus ? goal + off : map, plus, w1_f32, scale[0], shift[0], a1, nb, H, W);
+        ConvArgs ca;
+        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+        int rc;
+        ca.in = a1; ca.out = a2; ca.wpack = wsplit[0]; ca.scale = scale[1]; ca.shift = shift[1];
+        if ((rc = launch_conv_split<32, 64>(ca, s))) return rc;
+        ca.in = a2; ca.out = a3; ca.wpack = wsplit[1]; ca.scale = scale[2]; ca.shift = shift[2];
+        if ((rc = launch_conv_split<64, 128>(ca, s))) return rc;
+        ca.in = a3; ca.out = a4; ca.wpack = wsplit[2]; ca.scale = scale[3]; ca.shift = shift[3];
+        if ((rc = launch_conv_split<128, 256>(ca, s))) return rc;
+        // last layer: three accumulating passes of the tap-major kernel: x_hi*W_hi, x_lo*W_hi, x_hi*W_lo
+        ca.out = nullptr; ca.out_f32 = cost_out + off; ca.scale = scale[4]; ca.shift = shift[4]; ca.in_stride = 512; ca.zacc = zacc;
+        ca.in = a4; ca.wpack = wsplit[3]; ca.pass_flags = 2;
+        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+        ca.in = a4 + 256; ca.wpack = wsplit[3]; ca.pass_flags = 3;
+        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+        ca.in = a4; ca.wpack = wsplit[4]; ca.pass_flags = 1;
+        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 // One 3x3 convolution layer on its own (unit tests): in [B,H,W,CIN] bf16 -> out [B,H,W,COUT] bf16, y = relu?(acc*scale+shift).
 int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
                         int B, int H, int W, int cin, int cout, int relu, void* stream)
@@ -200,7 +291,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
     if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
     ConvArgs ca;
     ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
-    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr;
+    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
     ca.B = B; ca.H = H; ca.W = W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);

@@ -49,6 +49,8 @@ EXPORTED_SYMBOLS = (
     "nastar_unpack_outputs",
     "nastar_encoder_workspace_bytes",
     "nastar_encoder_cnn_forward",
+    "nastar_encoder_workspace_bytes_f16x3",
+    "nastar_encoder_cnn_forward_f16x3",
     "nastar_conv3x3_bf16",
 )
 
@@ -106,6 +108,11 @@ def load() -> ctypes.CDLL:
     lib.nastar_encoder_cnn_forward.restype = ci
     lib.nastar_encoder_cnn_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                ctypes.POINTER(vp), ctypes.c_float, vp, vp, cz, vp]
+    lib.nastar_encoder_workspace_bytes_f16x3.restype = cz
+    lib.nastar_encoder_workspace_bytes_f16x3.argtypes = [ci, ci, ci]
+    lib.nastar_encoder_cnn_forward_f16x3.restype = ci
+    lib.nastar_encoder_cnn_forward_f16x3.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                     ctypes.POINTER(vp), ctypes.c_float, vp, vp, cz, vp]
     lib.nastar_conv3x3_bf16.restype = ci
     lib.nastar_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.nastar_debug_occupancy.restype = ci

@@ -1,4 +1,4 @@
-"""bf16-MFMA inference path of the reference's ``CNN`` encoder (``csrc/nastar_encoder.hip.h``).
+"""MFMA inference paths of the reference's ``CNN`` encoder (``csrc/nastar_encoder.hip.h``): bf16 (fast) and f16x3 (fp32-grade).
 
 ``HipCnnEncoder`` wraps a ``planner.encoder.CNN`` module (depth 4: 2 -> 32 -> 64 -> 128 -> 256 -> 1): it folds the eval-mode
 BatchNorm and the conv bias into per-channel scale/shift, packs the weights in the kernel's ``[tap][cin/8][cout][8]`` bf16
@@ -20,13 +20,27 @@ _CIN_P = (16, 32, 64, 128, 256)
 _COUT_P = (32, 64, 128, 256, 32)
 
 
-def pack_conv_weight(w: torch.Tensor, cin_p: int, cout_p: int) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] fp32 -> [9, cin_p/8, cout_p, 8] bf16 (as int16 bits), zero padded, tap = ky*3 + kx."""
+def pack_conv_weight(w: torch.Tensor, cin_p: int, cout_p: int, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 -> [9, cin_p/8, cout_p, 8] bf16 / fp16 (as int16 bits), zero padded, tap = ky*3 + kx."""
     cout, cin = w.shape[:2]
     wp = torch.zeros((cout_p, cin_p, 3, 3), dtype=torch.float32, device=w.device)
     wp[:cout, :cin] = w
     wp = wp.permute(2, 3, 1, 0).reshape(9, cin_p // 8, 8, cout_p).permute(0, 1, 3, 2).contiguous()
-    return wp.to(torch.bfloat16).view(torch.int16)
+    return wp.to(dtype).view(torch.int16)
+
+
+def split_f16(w: torch.Tensor):
+    """w = hi + lo with hi = fp16(w), lo = fp16(w - hi): 22 significant bits in two fp16 terms (both returned as fp32 tensors)."""
+    hi = w.to(torch.float16).float()
+    lo = (w - hi).to(torch.float16).float()
+    return hi, lo
+
+
+def pack_conv_weight_f16x3(w: torch.Tensor, cout_p: int) -> torch.Tensor:
+    """Weights of a layer whose input arrives as [x_hi | x_lo]: packed over 3*Cin virtual channels [W_hi | W_hi | W_lo], so that
+    the kernel's slices compute x_hi*W_hi + x_lo*W_hi + x_hi*W_lo (the lo*lo term, 2^-22 relative, is dropped)."""
+    hi, lo = split_f16(w)
+    return pack_conv_weight(torch.cat((hi, hi, lo), dim=1), 3 * w.shape[1], cout_p, torch.float16)
 
 
 def fold_bn(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], cout_p: int):
@@ -46,7 +60,13 @@ def fold_bn(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], cout_p: int):
 
 
 class HipCnnEncoder:
-    def __init__(self, cnn: nn.Module):
+    """``precision``: ``"bf16"`` (default: bf16 operands, 2.8 ms per 4096 32x32 maps, cost maps within ~1e-3 of the fp32 encoder) or
+    ``"f16x3"`` (split fp16 operands, ~3x the matrix work, cost maps within 1e-5 -- the north-star tolerance for float outputs)."""
+
+    def __init__(self, cnn: nn.Module, precision: str = "bf16"):
+        if precision not in ("bf16", "f16x3"):
+            raise ValueError(precision)
+        self.precision = precision
         layers = list(cnn.model)
         convs = [m for m in layers if isinstance(m, nn.Conv2d)]
         if [c.out_channels for c in convs] != [32, 64, 128, 256, 1] or convs[0].in_channels > 16:
@@ -74,6 +94,12 @@ class HipCnnEncoder:
             self.scale.append(sc)
             self.shift.append(sh)
             idx += 3 if li < 4 else 2  # conv, bn, relu  |  conv, bn
+        if self.precision == "f16x3":
+            convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+            self.w1 = convs[0].weight.detach().float().contiguous()
+            hi5, lo5 = split_f16(convs[4].weight.detach().float())
+            self.wsplit = [pack_conv_weight_f16x3(convs[li].weight.detach().float(), _COUT_P[li]) for li in (1, 2, 3)]
+            self.wsplit += [pack_conv_weight(hi5, 256, 32, torch.float16), pack_conv_weight(lo5, 256, 32, torch.float16)]
         const = self.cnn.const  # read back once per weight version (a per-call .item() would sync the stream)
         self._mul = float(const.detach().item()) if isinstance(const, torch.Tensor) else float(const)
         self._key = key
@@ -91,12 +117,22 @@ class HipCnnEncoder:
         s = start_maps[:, 0].contiguous() if plus else None
         g = goal_maps[:, 0].contiguous() if plus else None
         cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-        ws_bytes = int(lib.nastar_encoder_workspace_bytes(B, H, W))
+        split = self.precision == "f16x3"
+        ws_bytes = int(lib.nastar_encoder_workspace_bytes_f16x3(B, H, W) if split else lib.nastar_encoder_workspace_bytes(B, H, W))
         ws = self._ws  # activation slabs, kept across calls (grown on demand) instead of re-allocated per batch
         if ws is None or ws.device != dev or ws.numel() < ws_bytes:
             ws = self._ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         arr = ctypes.c_void_p * 5
         mul = self._mul
+        if split:
+            with torch.cuda.device(dev):
+                rc = lib.nastar_encoder_cnn_forward_f16x3(
+                    m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, H, W,
+                    self.w1.data_ptr(), arr(*[t.data_ptr() for t in self.wsplit]), arr(*[t.data_ptr() for t in self.scale]),
+                    arr(*[t.data_ptr() for t in self.shift]), mul, cost.data_ptr(), ws.data_ptr(), ws.numel(),
+                    torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(rc, "nastar_encoder_cnn_forward_f16x3")
+            return cost.unsqueeze(1)
         with torch.cuda.device(dev):
             rc = lib.nastar_encoder_cnn_forward(
                 m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, H, W,

@@ -543,3 +543,50 @@ def test_hip_encoder_map_only_input_and_learned_const():
         na.encoder.const.mul_(2.0)  # a changed parameter must be picked up (weights are re-packed per version)
         got2 = na.encode(m, s, go)
         assert torch.allclose(got2, 2.0 * got, rtol=1e-5, atol=1e-6)
+
+
+def test_f16x3_encoder_meets_the_float_tolerance_of_the_north_star():
+    """encoder_backend="hip_f16x3": split-fp16 MFMA encoder vs the reference's fp32 cost maps (shipped checkpoint, golden
+    maze32_cnncost_g050) within 1e-5 -- BASELINE.json: "within 1e-5 for float cost/loss on identical inputs" -- and the search on
+    top of it reproduces the reference's histories and paths for those cost maps where the cost maps agree to the last bit of q."""
+    from test_host_logic import _shipped_planner
+    g = G.load("maze32_cnncost_g050")
+    dev = _dev()
+    na = _shipped_planner().to(dev)
+    na.encoder_backend = "hip_f16x3"
+    m, s, go = _t(g.map_designs), _t(g.start_maps), _t(g.goal_maps)
+    ref = _t(g.cost_maps)
+    with torch.no_grad():
+        c = na.encode(m, s, go)
+        assert na._hip_encoder is not None and na._hip_encoder.precision == "f16x3"
+        err = (c - ref).abs()
+        assert float(err.max()) < 1e-5, float(err.max())
+        out = na(m, s, go)
+    assert int((na.astar.last_status != 0).sum()) == 0
+    same = (out.paths[:, 0].cpu().numpy() == g.paths[:, 0]).reshape(g.B, -1).all(1)
+    assert same.mean() >= 0.75, same      # identical plans except where a 1e-7 cost difference flips an exact tie
+
+
+@pytest.mark.parametrize("shape", [(32, 32), (64, 96)])
+def test_f16x3_encoder_random_weights_and_sizes(shape):
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    H, W = shape
+    dev = _dev()
+    pr = syn.random_obstacle_maps(20, H, W, 0.2, seed=13)
+    m, s, go = (_t(x) for x in pr)
+    torch.manual_seed(5)
+    na = NeuralAstar(encoder_arch="CNN", const=3.0).to(dev)
+    with torch.no_grad():
+        for mod in na.encoder.model:
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+    na.eval()
+    with torch.no_grad():
+        ref = na.encode(m, s, go)
+        na.encoder_backend = "hip_f16x3"
+        got = na.encode(m, s, go)
+        assert na._hip_encoder is not None and na._hip_encoder.precision == "f16x3"
+        err = (got - ref).abs()
+        assert float(err.max()) < 3e-5 and float(err.mean()) < 3e-6, (shape, float(err.max()), float(err.mean()))  # const = 3
