@@ -269,6 +269,41 @@ def data_path_ms(dev, n_maps=400, batch=100):
     return {"host_dataloader_ms_per_batch": host_ms, "device_loader_ms_per_batch": dev_ms, "batch": batch, "maps": n_maps}
 
 
+def neural_astar_f16x3_ms(pr, dev, reps=5):
+    """Extra: the same NeuralAstar forward with the fp32-grade encoder (encoder_backend="hip_f16x3": cost maps within 1e-5 of the
+    fp32 reference encoder, the north-star tolerance for float outputs)."""
+    from neural_astar.planner import NeuralAstar
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="CNN").to(dev).eval()
+    na.encoder_backend = "hip_f16x3"
+    na.astar.check_solvable = False
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        for _ in range(2):
+            na(m, s, g)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            c = na.encode(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        enc_ms = e0.elapsed_time(e1) / reps
+        e0.record()
+        for _ in range(reps):
+            na(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        full_ms = e0.elapsed_time(e1) / reps
+        na.encoder_backend = "torch"   # fp32 torch encoder on a 16-map slice only (MIOpen autotunes per shape; keep it short)
+        ref = na.encode(m[:16], s[:16], g[:16])
+        err = float((c[:16] - ref).abs().max())
+    flop = 3 * 2.0 * m.shape[0] * H * W * 9 * (32 * 64 + 64 * 128 + 128 * 256 + 256)
+    return {"encoder_ms": enc_ms, "forward_ms": full_ms, "maps_per_s": m.shape[0] / full_ms * 1e3,
+            "max_abs_diff_vs_torch_fp32_encoder_16_maps": err, "mfma_tflops_incl_split_products": flop / enc_ms / 1e9,
+            "dtype": "fp16 hi/lo split operands (3 products) / fp32 accumulate"}
+
+
 def neural_astar_forward_ms(pr, dev, reps=10):
     """Extra (BASELINE config 3 stand-in): NeuralAstar(CNN encoder, depth 4) forward on the bench batch with the bf16-MFMA
     HIP encoder + the HIP search, eval mode.  (The torch/MIOpen encoder is not timed here: its first call autotunes for
@@ -470,6 +505,7 @@ def main():
                 del run2
             out["secondary"] = sec
             out["extra"] = {"neural_astar_cnn_hip_bf16": neural_astar_forward_ms(pr, dev),
+                            "neural_astar_cnn_hip_f16x3": neural_astar_f16x3_ms(pr, dev),
                             "train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),
                             "data_path_32x32": data_path_ms(dev),
                             "train_l1_step_Tmax025": {"batch_100": l1_training_step_ms(pr, dev, 100),
