@@ -21,7 +21,7 @@ with torch.no_grad():
     e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-na.encoder_backend = "torch"
+na.encoder_backend = "torch"  # (16 maps only: MIOpen searches its kernels on the first call of a shape)
 with torch.no_grad():
-    r = na.encode(m[:256], s[:256], g[:256])
-print(f"f16x3 encoder B={B}: {ms:.3f} ms; max |err| vs torch fp32 on 256 maps: {float((c[:256] - r).abs().max()):.2e}")
+    r = na.encode(m[:16], s[:16], g[:16])
+print(f"f16x3 encoder B={B}: {ms:.3f} ms; max |err| vs torch fp32 on 16 maps: {float((c[:16] - r).abs().max()):.2e}")
