@@ -940,27 +940,24 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
 
 // ---- f16x3 form of the first layer: input assembly + conv (1|2) -> 32 + BatchNorm + ReLU in plain fp32 on the vector ALU ---------------
 // 18 multiply-adds per output: not worth a matrix instruction, and exact.  One thread per pixel; output [B,H,W,64] fp16 = [hi(32) | lo(32)].
+template <int CINR>  // real input channels: 2 ("m+": map, start+goal) or 1 ("m")
 __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float* __restrict__ map, const float* __restrict__ start,
-                                                                   const float* __restrict__ goal, int plus, const float* __restrict__ w,
+                                                                   const float* __restrict__ goal, const float* __restrict__ w,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    uint16_t* __restrict__ out, int B, int H, int W)
 {
-    __shared__ float ws[32 * 2 * 9 + 64];
-    const int cin = plus ? 2 : 1;
-    for (int i = threadIdx.x; i < 32 * cin * 9; i += 256) ws[i] = w[i];  // [32][cin][3][3], the torch layout
-    if (threadIdx.x < 32) { ws[576 + threadIdx.x] = scale[threadIdx.x]; ws[608 + threadIdx.x] = shift[threadIdx.x]; }
-    __syncthreads();
+    // weights / scale / shift are indexed with compile-time constants only: wave-uniform scalar loads, multiply-adds straight from SGPRs
     const long long npix = (long long)B * H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
         const int x = (int)(i % W), y = (int)((i / W) % H);
-        float in[2][9];
+        float in[CINR][9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
             const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             const long long j = i + (long long)(t / 3 - 1) * W + (t % 3 - 1);
             in[0][t] = ok ? map[j] : 0.f;
-            in[1][t] = (ok && plus) ? start[j] + goal[j] : 0.f;
+            if constexpr (CINR == 2) in[1][t] = ok ? start[j] + goal[j] : 0.f;
         }
         uint32_t hi[16], lo[16];
 #pragma unroll
@@ -968,12 +965,12 @@ __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float*
             float v[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float* wc = ws + (c + e) * cin * 9;
                 float z = 0.f;
-                for (int ci = 0; ci < cin; ++ci)
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) z += wc[ci * 9 + t] * in[ci][t];
-                v[e] = fmaxf(z * ws[576 + c + e] + ws[608 + c + e], 0.f);
+                for (int ci = 0; ci < CINR; ++ci)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) z += w[((c + e) * CINR + ci) * 9 + t] * in[ci][t];  // [32][cin][3][3], the torch layout
+                v[e] = fmaxf(z * scale[c + e] + shift[c + e], 0.f);
             }
             hi[c >> 1] = pack_f16x2(v[0], v[1]);
             lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));

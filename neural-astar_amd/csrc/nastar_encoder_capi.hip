@@ -257,8 +257,12 @@ int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const
         const size_t off = (size_t)b0 * H * W;
         const long long npix = (long long)nb * H * W;
         const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
-        hipLaunchKernelGGL(nastar_conv_first_f32_kernel, dim3(pg), dim3(256), 0, s, map + off, plus ? start + off : map,
-                           plus ? goal + off : map, plus, w1_f32, scale[0], shift[0], a1, nb, H, W);
+        if (plus)
+            hipLaunchKernelGGL(nastar_conv_first_f32_kernel<2>, dim3(pg), dim3(256), 0, s, map + off, start + off, goal + off, w1_f32,
+                               scale[0], shift[0], a1, nb, H, W);
+        else
+            hipLaunchKernelGGL(nastar_conv_first_f32_kernel<1>, dim3(pg), dim3(256), 0, s, map + off, map, map, w1_f32, scale[0],
+                               shift[0], a1, nb, H, W);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
         ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;

@@ -567,8 +567,8 @@ def test_f16x3_encoder_meets_the_float_tolerance_of_the_north_star():
     assert same.mean() >= 0.75, same      # identical plans except where a 1e-7 cost difference flips an exact tie
 
 
-@pytest.mark.parametrize("shape", [(32, 32), (64, 96)])
-def test_f16x3_encoder_random_weights_and_sizes(shape):
+@pytest.mark.parametrize("shape,enc_in", [((32, 32), "m+"), ((64, 96), "m+"), ((32, 32), "m")])
+def test_f16x3_encoder_random_weights_and_sizes(shape, enc_in):
     from neural_astar.planner import NeuralAstar
     from neural_astar.utils import synthetic as syn
     H, W = shape
@@ -576,7 +576,7 @@ def test_f16x3_encoder_random_weights_and_sizes(shape):
     pr = syn.random_obstacle_maps(20, H, W, 0.2, seed=13)
     m, s, go = (_t(x) for x in pr)
     torch.manual_seed(5)
-    na = NeuralAstar(encoder_arch="CNN", const=3.0).to(dev)
+    na = NeuralAstar(encoder_input=enc_in, encoder_arch="CNN", const=3.0).to(dev)
     with torch.no_grad():
         for mod in na.encoder.model:
             if isinstance(mod, torch.nn.BatchNorm2d):
