@@ -61,6 +61,7 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)  // round to 
     return *reinterpret_cast<const uint32_t*>(&b);
 }
 __device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
+__device__ __forceinline__ float f16_clamp(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 template <bool kF16>
 __device__ __forceinline__ uint32_t pack_pair(float lo, float hi) { return kF16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
@@ -612,6 +613,9 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                             if constexpr (kRelu) {
                                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                             }
+                            if constexpr (kF16) {  // fp16 range: saturate instead of producing inf (BatchNorm-ed activations are O(1..10))
+                                v0 = f16_clamp(v0); v1 = f16_clamp(v1); v2 = f16_clamp(v2); v3 = f16_clamp(v3);
+                            }
                             if (part == 1) {
                                 v0 = f16_residual(v0); v1 = f16_residual(v1); v2 = f16_residual(v2); v3 = f16_residual(v3);
                             }
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float*
                 for (int ci = 0; ci < CINR; ++ci)
 #pragma unroll
                     for (int t = 0; t < 9; ++t) z += w[((c + e) * CINR + ci) * 9 + t] * in[ci][t];  // [32][cin][3][3], the torch layout
-                v[e] = fmaxf(z * scale[c + e] + shift[c + e], 0.f);
+                v[e] = f16_clamp(fmaxf(z * scale[c + e] + shift[c + e], 0.f));
             }
             hi[c >> 1] = pack_f16x2(v[0], v[1]);
             lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));
