@@ -186,3 +186,28 @@ def test_every_import_the_reference_callers_use_resolves_here():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def test_f16x3_split_and_virtual_channel_packing():
+    """Host side of the f16x3 encoder: w = hi + lo to 2^-22, the packed weight tensor spans 3*Cin virtual channels [W_hi|W_hi|W_lo]
+    in the kernel's [tap][cin/8][cout][8] order, and the three-product identity the kernels implement holds to fp32 accuracy."""
+    import torch
+    from neural_astar.encoder_hip import pack_conv_weight, pack_conv_weight_f16x3, split_f16
+    torch.manual_seed(0)
+    w = torch.randn(64, 32, 3, 3) * 0.1
+    hi, lo = split_f16(w)
+    assert torch.equal(hi, hi.half().float()) and torch.equal(lo, lo.half().float())
+    assert float((w - (hi + lo)).abs().max()) <= float(w.abs().max()) * 2.0 ** -21
+    p = pack_conv_weight_f16x3(w, 64)
+    assert p.shape == (9, 96 // 8, 64, 8) and p.dtype == torch.int16
+    unp = p.view(torch.float16).float().permute(0, 1, 3, 2).reshape(3, 3, 96, 64).permute(3, 2, 0, 1)   # -> [cout, 3*cin, ky, kx]
+    assert torch.equal(unp[:, :32], hi) and torch.equal(unp[:, 32:64], hi) and torch.equal(unp[:, 64:], lo)
+    # x_hi*W_hi + x_lo*W_hi + x_hi*W_lo == x*W up to the dropped lo*lo term
+    x = torch.randn(2, 32, 16, 16).abs()
+    xh, xl = split_f16(x)
+    conv = torch.nn.functional.conv2d
+    full = conv(x.double(), w.double(), padding=1)
+    three = conv(xh.double(), hi.double(), padding=1) + conv(xl.double(), hi.double(), padding=1) + conv(xh.double(), lo.double(), padding=1)
+    bf = conv(x.bfloat16().double(), w.bfloat16().double(), padding=1)
+    e3, eb = float((three - full).abs().max()), float((bf - full).abs().max())
+    assert e3 < 2e-6 * float(full.abs().max()) and eb > 1000 * e3, (e3, eb)
