@@ -419,7 +419,6 @@ def main():
     collate_note = "n/a (single GPU)"
     if (world > 1 or args.force_collate) and not args.no_collate:
         from neural_astar import parallel
-        from neural_astar.planner.differentiable_astar import AstarOutput
 
         run.enable_packed()
 

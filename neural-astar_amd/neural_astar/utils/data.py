@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.utils.data as data
 
-from ..planner.differentiable_astar import AstarOutput
+from ..planner.differentiable_astar import AstarOutput  # noqa: F401  (re-exported: the reference's data.py imports it too)
 
 # action index -> (dy, dx): the dataset's "moore" action order (reference utils/data.py:232-241)
 ACTION_MOVES = ((-1, 0), (0, 1), (0, -1), (1, 0), (-1, 1), (-1, -1), (1, 1), (1, -1))

@@ -192,7 +192,7 @@ def test_f16x3_split_and_virtual_channel_packing():
     """Host side of the f16x3 encoder: w = hi + lo to 2^-22, the packed weight tensor spans 3*Cin virtual channels [W_hi|W_hi|W_lo]
     in the kernel's [tap][cin/8][cout][8] order, and the three-product identity the kernels implement holds to fp32 accuracy."""
     import torch
-    from neural_astar.encoder_hip import pack_conv_weight, pack_conv_weight_f16x3, split_f16
+    from neural_astar.encoder_hip import pack_conv_weight_f16x3, split_f16
     torch.manual_seed(0)
     w = torch.randn(64, 32, 3, 3) * 0.1
     hi, lo = split_f16(w)
