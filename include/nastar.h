@@ -173,6 +173,13 @@ int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const
                                      const float* w1_f32, const uint16_t* const* wsplit, const float* const* scale,
                                      const float* const* shift, float final_mul, float* cost_out, void* workspace,
                                      size_t workspace_bytes, void* stream);
+/* plain fp16 operands (11 significant bits instead of bf16's 8), same arguments; wpack16 = layers 2..4 packed over cin channels as
+ * fp16 + the last layer's pack (4 pointers); workspace: nastar_encoder_workspace_bytes_f16(B,H,W) */
+size_t nastar_encoder_workspace_bytes_f16(int B, int H, int W);
+int nastar_encoder_cnn_forward_f16(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                                   const float* w1_f32, const uint16_t* const* wpack16, const float* const* scale,
+                                   const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 /* one layer of the above on its own (unit tests): (cin, cout) in {(16,32), (32,64), (64,128), (128,256)} */
 int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
                         int B, int H, int W, int cin, int cout, int relu, void* stream);

@@ -359,15 +359,17 @@ __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
 // then real data, loaded as a fifth chunk by threads 0..263 (zero outside the image); kTiled = false is the whole-image case above.
 // kF16: the f16x3 split-precision form (see pack_f16x2): in [.., 2 CIN] = [hi | lo], weights packed over 3 CIN virtual channels,
 // out [.., 2 COUT] = [hi | lo]; 3 CIN / 16 slices per item.
-template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, bool kTiled = false, bool kF16 = false>
+// kF16 alone (kSplit = false): plain fp16 operands, same data flow as bf16 (11 instead of 8 significant bits).
+template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, bool kTiled = false, bool kF16 = false, bool kSplit = kF16>
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
     static_assert(!(kFuse && kTiled), "the fused last layer needs the whole image in one workgroup");
-    static_assert(!(kFuse && kF16), "split precision keeps the last layer a separate launch");
+    static_assert(!(kFuse && kF16), "the fp16 forms keep the last layer a separate launch");
+    static_assert(kF16 || !kSplit, "split precision is an fp16 form");
     constexpr int NS1 = CIN / I32_KS;                 // slices per precision block
-    constexpr int NSLICE = (kF16 ? 3 : 1) * NS1;
-    constexpr int CINV = (kF16 ? 3 : 1) * CIN;        // virtual input channels of the packed weights
-    constexpr int IN_STRIDE = (kF16 ? 2 : 1) * CIN, OUT_STRIDE = (kF16 ? 2 : 1) * COUT;  // channels per pixel in HBM
+    constexpr int NSLICE = (kSplit ? 3 : 1) * NS1;
+    constexpr int CINV = (kSplit ? 3 : 1) * CIN;      // virtual input channels of the packed weights
+    constexpr int IN_STRIDE = (kSplit ? 2 : 1) * CIN, OUT_STRIDE = (kSplit ? 2 : 1) * COUT;  // channels per pixel in HBM
     constexpr int NGRP = COUT / I32_NT;
     static_assert(NSLICE % 2 == 0, "buffer parity must repeat per work item");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
     do {                                                                                                 \
         I32_DECODE(item_, ib_, iy_, ix_, ig_);                                                           \
         /* activation channels of virtual slice s: blocks [x_hi | x_lo | x_hi] */                         \
-        const int cs_ = (kF16 && (s_) >= 2 * NS1) ? (s_) - 2 * NS1 : (s_);                               \
+        const int cs_ = (kSplit && (s_) >= 2 * NS1) ? (s_) - 2 * NS1 : (s_);                             \
         const uint16_t* ip_ = a.in + (((size_t)ib_ * (kTiled ? a.H : 32) + iy_) * img_w + ix_) * IN_STRIDE + cs_ * I32_KS; \
         const uint16_t* tp_ = ip_ + t_lane;                                                              \
         const uint16_t* wp_ = a.wpack + w_lane + ig_ * I32_NT * 8 + (size_t)(s_) * WSL;                  \
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
 #pragma unroll
             for (int m = 0; m < I32_RPW; ++m) {
 #pragma unroll
-                for (int part = 0; part < (kF16 ? 2 : 1); ++part) {  // f16x3: the hi halves, then the lo halves (v - fp16(v))
+                for (int part = 0; part < (kSplit ? 2 : 1); ++part) {  // f16x3: the hi halves, then the lo halves (v - fp16(v))
 #pragma unroll
                     for (int n = 0; n < I32_NB; ++n)
 #pragma unroll
@@ -943,8 +945,9 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
 }
 
 // ---- f16x3 form of the first layer: input assembly + conv (1|2) -> 32 + BatchNorm + ReLU in plain fp32 on the vector ALU ---------------
-// 18 multiply-adds per output: not worth a matrix instruction, and exact.  One thread per pixel; output [B,H,W,64] fp16 = [hi(32) | lo(32)].
-template <int CINR>  // real input channels: 2 ("m+": map, start+goal) or 1 ("m")
+// 18 multiply-adds per output: not worth a matrix instruction, and exact.  One thread per pixel; output [B,H,W,64] fp16 = [hi(32) | lo(32)]
+// (or [B,H,W,32] = hi only for the plain fp16 form).
+template <int CINR, bool kLo>  // CINR real input channels: 2 ("m+": map, start+goal) or 1 ("m"); kLo: also emit the lo halves
 __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float* __restrict__ map, const float* __restrict__ start,
                                                                    const float* __restrict__ goal, const float* __restrict__ w,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
@@ -979,11 +982,11 @@ __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float*
             hi[c >> 1] = pack_f16x2(v[0], v[1]);
             lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));
         }
-        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 64);
+        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * (kLo ? 64 : 32));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             dst[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
-            dst[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+            if constexpr (kLo) dst[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
         }
     }
 }

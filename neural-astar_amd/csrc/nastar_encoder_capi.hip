@@ -97,12 +97,12 @@ static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
 }
 
 // f16x3 split precision: persistent 32x32-tile kernel over 3 CIN virtual channels; H, W multiples of 32
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool kSplit>
 static int launch_conv_split(const ConvArgs& ca, hipStream_t stream)
 {
     const bool whole = ca.H == 32 && ca.W == 32;
-    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, false, true>;
-    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, true, true>;
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, false, true, kSplit>;
+    if (!whole) kern = &nastar_conv3x3_img32_kernel<CIN, COUT, true, false, 0, true, true, kSplit>;
     int rc = ensure_lds(kern, I32_LDS_BYTES);
     if (rc) return rc;
     int n_cu = 0;
@@ -138,6 +138,77 @@ static int launch_conv_final(const ConvArgs& ca, hipStream_t stream)
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }
+// ---- fp16 forms of the same encoder ------------------------------------------------------------------------------------------------------
+// f16x3 ("fp32-grade"): every conv is hi*hi + lo*hi + hi*lo on the fp16 MFMA, activations [hi | lo];  f16: plain fp16 operands.
+static size_t fp16_bytes_per_pixel(bool split) { return (size_t)(split ? 2 : 1) * (32 + 64 + 128 + 256) * 2 + 4; }  // layer outputs + fp32 partial sum
+
+static size_t fp16_workspace_bytes(int B, int H, int W, bool split)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    long long cap = (1ll << 20) / ((long long)H * W);
+    if (cap < 1) cap = 1;
+    return (size_t)(B < cap ? B : cap) * H * W * fp16_bytes_per_pixel(split);
+}
+
+template <bool kSplit>
+static int encoder_fp16_impl(const float* map, const float* start, const float* goal, int plus, int B, int H, int W, const float* w1_f32,
+                             const uint16_t* const* wts, const float* const* scale, const float* const* shift, float final_mul,
+                             float* cost_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!map || !cost_out || !w1_f32 || !wts || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H % 32 != 0 || W % 32 != 0) return NASTAR_ERR_UNSUPPORTED;
+    constexpr int M = kSplit ? 2 : 1;  // fp16 terms per activation
+    const size_t per_img = (size_t)H * W * fp16_bytes_per_pixel(kSplit);
+    int chunk = (int)(workspace_bytes / per_img);
+    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
+    if (chunk > B) chunk = B;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t npc = (size_t)chunk * H * W;
+    uint16_t* a1 = static_cast<uint16_t*>(workspace);   // [.., M*32]
+    uint16_t* a2 = a1 + npc * 32 * M;                   // [.., M*64]
+    uint16_t* a3 = a2 + npc * 64 * M;                   // [.., M*128]
+    uint16_t* a4 = a3 + npc * 128 * M;                  // [.., M*256]
+    float* zacc = reinterpret_cast<float*>(a4 + npc * 256 * M);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+        const size_t off = (size_t)b0 * H * W;
+        const long long npix = (long long)nb * H * W;
+        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+        if (plus)
+            hipLaunchKernelGGL((nastar_conv_first_f32_kernel<2, kSplit>), dim3(pg), dim3(256), 0, s, map + off, start + off, goal + off,
+                               w1_f32, scale[0], shift[0], a1, nb, H, W);
+        else
+            hipLaunchKernelGGL((nastar_conv_first_f32_kernel<1, kSplit>), dim3(pg), dim3(256), 0, s, map + off, map, map, w1_f32, scale[0],
+                               shift[0], a1, nb, H, W);
+        ConvArgs ca;
+        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+        int rc;
+        ca.in = a1; ca.out = a2; ca.wpack = wts[0]; ca.scale = scale[1]; ca.shift = shift[1];
+        if ((rc = launch_conv_split<32, 64, kSplit>(ca, s))) return rc;
+        ca.in = a2; ca.out = a3; ca.wpack = wts[1]; ca.scale = scale[2]; ca.shift = shift[2];
+        if ((rc = launch_conv_split<64, 128, kSplit>(ca, s))) return rc;
+        ca.in = a3; ca.out = a4; ca.wpack = wts[2]; ca.scale = scale[3]; ca.shift = shift[3];
+        if ((rc = launch_conv_split<128, 256, kSplit>(ca, s))) return rc;
+        ca.out = nullptr; ca.out_f32 = cost_out + off; ca.scale = scale[4]; ca.shift = shift[4]; ca.in_stride = 256 * M; ca.zacc = zacc;
+        if constexpr (kSplit) {  // last layer: three accumulating passes of the tap-major kernel: x_hi*W_hi, x_lo*W_hi, x_hi*W_lo
+            ca.in = a4; ca.wpack = wts[3]; ca.pass_flags = 2;
+            if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+            ca.in = a4 + 256; ca.wpack = wts[3]; ca.pass_flags = 3;
+            if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+            ca.in = a4; ca.wpack = wts[4]; ca.pass_flags = 1;
+            if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+        } else {
+            ca.in = a4; ca.wpack = wts[3]; ca.pass_flags = 0;
+            if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 }  // namespace nastar
 
 using namespace nastar;
@@ -222,69 +293,26 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
     return NASTAR_OK;
 }
 
-// ---- f16x3 ("fp32-grade") form of the same encoder: every conv is hi*hi + lo*hi + hi*lo on the fp16 MFMA ----------------------------------
-constexpr size_t kSplitBytesPerPixel = (64 + 128 + 256 + 512) * 2 + 4;  // [hi|lo] fp16 outputs of layers 1..4 + the last layer's fp32 partial sum
-
-size_t nastar_encoder_workspace_bytes_f16x3(int B, int H, int W)
-{
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    long long cap = (1ll << 20) / ((long long)H * W);
-    if (cap < 1) cap = 1;
-    return (size_t)(B < cap ? B : cap) * H * W * kSplitBytesPerPixel;
-}
+// ---- fp16 forms of the same encoder (implementation: encoder_fp16_impl above) ----------------------------------------------------------
+size_t nastar_encoder_workspace_bytes_f16x3(int B, int H, int W) { return fp16_workspace_bytes(B, H, W, true); }
+size_t nastar_encoder_workspace_bytes_f16(int B, int H, int W) { return fp16_workspace_bytes(B, H, W, false); }
 
 int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
                                      const float* w1_f32, const uint16_t* const* wsplit, const float* const* scale,
                                      const float* const* shift, float final_mul, float* cost_out, void* workspace,
                                      size_t workspace_bytes, void* stream)
 {
-    if (!map || !cost_out || !w1_f32 || !wsplit || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (H % 32 != 0 || W % 32 != 0) return NASTAR_ERR_UNSUPPORTED;
-    const size_t per_img = (size_t)H * W * kSplitBytesPerPixel;
-    int chunk = (int)(workspace_bytes / per_img);
-    if (chunk <= 0) return NASTAR_ERR_WORKSPACE;
-    if (chunk > B) chunk = B;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t npc = (size_t)chunk * H * W;
-    uint16_t* a1 = static_cast<uint16_t*>(workspace);   // [.., 64]
-    uint16_t* a2 = a1 + npc * 64;                       // [.., 128]
-    uint16_t* a3 = a2 + npc * 128;                      // [.., 256]
-    uint16_t* a4 = a3 + npc * 256;                      // [.., 512]
-    float* zacc = reinterpret_cast<float*>(a4 + npc * 512);
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = (B - b0 < chunk) ? B - b0 : chunk;
-        const size_t off = (size_t)b0 * H * W;
-        const long long npix = (long long)nb * H * W;
-        const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
-        if (plus)
-            hipLaunchKernelGGL(nastar_conv_first_f32_kernel<2>, dim3(pg), dim3(256), 0, s, map + off, start + off, goal + off, w1_f32,
-                               scale[0], shift[0], a1, nb, H, W);
-        else
-            hipLaunchKernelGGL(nastar_conv_first_f32_kernel<1>, dim3(pg), dim3(256), 0, s, map + off, map, map, w1_f32, scale[0],
-                               shift[0], a1, nb, H, W);
-        ConvArgs ca;
-        ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
-        int rc;
-        ca.in = a1; ca.out = a2; ca.wpack = wsplit[0]; ca.scale = scale[1]; ca.shift = shift[1];
-        if ((rc = launch_conv_split<32, 64>(ca, s))) return rc;
-        ca.in = a2; ca.out = a3; ca.wpack = wsplit[1]; ca.scale = scale[2]; ca.shift = shift[2];
-        if ((rc = launch_conv_split<64, 128>(ca, s))) return rc;
-        ca.in = a3; ca.out = a4; ca.wpack = wsplit[2]; ca.scale = scale[3]; ca.shift = shift[3];
-        if ((rc = launch_conv_split<128, 256>(ca, s))) return rc;
-        // last layer: three accumulating passes of the tap-major kernel: x_hi*W_hi, x_lo*W_hi, x_hi*W_lo
-        ca.out = nullptr; ca.out_f32 = cost_out + off; ca.scale = scale[4]; ca.shift = shift[4]; ca.in_stride = 512; ca.zacc = zacc;
-        ca.in = a4; ca.wpack = wsplit[3]; ca.pass_flags = 2;
-        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
-        ca.in = a4 + 256; ca.wpack = wsplit[3]; ca.pass_flags = 3;
-        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
-        ca.in = a4; ca.wpack = wsplit[4]; ca.pass_flags = 1;
-        if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
+    return encoder_fp16_impl<true>(map, start, goal, plus, B, H, W, w1_f32, wsplit, scale, shift, final_mul, cost_out, workspace,
+                                   workspace_bytes, stream);
+}
+
+int nastar_encoder_cnn_forward_f16(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
+                                   const float* w1_f32, const uint16_t* const* wpack16, const float* const* scale,
+                                   const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                   size_t workspace_bytes, void* stream)
+{
+    return encoder_fp16_impl<false>(map, start, goal, plus, B, H, W, w1_f32, wpack16, scale, shift, final_mul, cost_out, workspace,
+                                    workspace_bytes, stream);
 }
 
 // One 3x3 convolution layer on its own (unit tests): in [B,H,W,CIN] bf16 -> out [B,H,W,COUT] bf16, y = relu?(acc*scale+shift).

@@ -60,11 +60,12 @@ def fold_bn(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], cout_p: int):
 
 
 class HipCnnEncoder:
-    """``precision``: ``"bf16"`` (default: bf16 operands, 2.8 ms per 4096 32x32 maps, cost maps within ~1e-3 of the fp32 encoder) or
-    ``"f16x3"`` (split fp16 operands, ~3x the matrix work, cost maps within 1e-5 -- the north-star tolerance for float outputs)."""
+    """``precision``: ``"bf16"`` (default: bf16 operands, 2.8 ms per 4096 32x32 maps, cost maps within ~1e-3 of the fp32 encoder),
+    ``"f16"`` (plain fp16 operands: 8x finer than bf16, no fused stem / last layer) or ``"f16x3"`` (split fp16 operands, ~3x the
+    matrix work, cost maps within 1e-5 -- the north-star tolerance for float outputs)."""
 
     def __init__(self, cnn: nn.Module, precision: str = "bf16"):
-        if precision not in ("bf16", "f16x3"):
+        if precision not in ("bf16", "f16", "f16x3"):
             raise ValueError(precision)
         self.precision = precision
         layers = list(cnn.model)
@@ -94,6 +95,12 @@ class HipCnnEncoder:
             self.scale.append(sc)
             self.shift.append(sh)
             idx += 3 if li < 4 else 2  # conv, bn, relu  |  conv, bn
+        if self.precision == "f16":
+            convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+            self.w1 = convs[0].weight.detach().float().contiguous()
+            self.wsplit = [pack_conv_weight(convs[li].weight.detach().float(), _CIN_P[li], _COUT_P[li], torch.float16) for li in (1, 2, 3)]
+            self.wsplit += [pack_conv_weight(convs[4].weight.detach().float(), 256, 32, torch.float16)]
+            self.wsplit += [self.wsplit[-1]]  # (pointer array has 5 slots)
         if self.precision == "f16x3":
             convs = [m for m in layers if isinstance(m, nn.Conv2d)]
             self.w1 = convs[0].weight.detach().float().contiguous()
@@ -117,8 +124,10 @@ class HipCnnEncoder:
         s = start_maps[:, 0].contiguous() if plus else None
         g = goal_maps[:, 0].contiguous() if plus else None
         cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-        split = self.precision == "f16x3"
-        ws_bytes = int(lib.nastar_encoder_workspace_bytes_f16x3(B, H, W) if split else lib.nastar_encoder_workspace_bytes(B, H, W))
+        split = self.precision in ("f16", "f16x3")
+        fwd16 = lib.nastar_encoder_cnn_forward_f16x3 if self.precision == "f16x3" else lib.nastar_encoder_cnn_forward_f16
+        ws_bytes = int({"bf16": lib.nastar_encoder_workspace_bytes, "f16": lib.nastar_encoder_workspace_bytes_f16,
+                        "f16x3": lib.nastar_encoder_workspace_bytes_f16x3}[self.precision](B, H, W))
         ws = self._ws  # activation slabs, kept across calls (grown on demand) instead of re-allocated per batch
         if ws is None or ws.device != dev or ws.numel() < ws_bytes:
             ws = self._ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -126,12 +135,12 @@ class HipCnnEncoder:
         mul = self._mul
         if split:
             with torch.cuda.device(dev):
-                rc = lib.nastar_encoder_cnn_forward_f16x3(
+                rc = fwd16(
                     m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, H, W,
                     self.w1.data_ptr(), arr(*[t.data_ptr() for t in self.wsplit]), arr(*[t.data_ptr() for t in self.scale]),
                     arr(*[t.data_ptr() for t in self.shift]), mul, cost.data_ptr(), ws.data_ptr(), ws.numel(),
                     torch.cuda.current_stream(dev).cuda_stream)
-            _native.check(rc, "nastar_encoder_cnn_forward_f16x3")
+            _native.check(rc, "nastar_encoder_cnn_forward_" + self.precision)
             return cost.unsqueeze(1)
         with torch.cuda.device(dev):
             rc = lib.nastar_encoder_cnn_forward(

@@ -62,15 +62,15 @@ class NeuralAstar(VanillaAstar):
         self.g_ratio = g_ratio
         self.use_differentiable_astar = use_differentiable_astar
         # "torch" (default, fp32, differentiable), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder: eval mode,
-        # no gradients; csrc/nastar_encoder.hip.h) or "hip_f16x3" (the same kernels on split fp16 operands: 3x the matrix work,
-        # cost maps within 1e-5 of the fp32 encoder).  Not part of the reference's constructor signature.
+        # no gradients; csrc/nastar_encoder.hip.h), "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the
+        # matrix work, cost maps within 1e-5 of the fp32 encoder).  Not part of the reference's constructor signature.
         self.encoder_backend = "torch"
         self._hip_encoder = None
 
     def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
         """Predict cost maps (reference astar.py:154-180)."""
-        tile = 32 if self.encoder_backend == "hip_f16x3" else 16
-        if (self.encoder_backend in ("hip_bf16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
+        tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
+        if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % tile == 0 and map_designs.shape[-1] % 32 == 0
                 and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)):

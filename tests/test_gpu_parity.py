@@ -590,3 +590,21 @@ def test_f16x3_encoder_random_weights_and_sizes(shape, enc_in):
         assert na._hip_encoder is not None and na._hip_encoder.precision == "f16x3"
         err = (got - ref).abs()
         assert float(err.max()) < 3e-5 and float(err.mean()) < 3e-6, (shape, float(err.max()), float(err.mean()))  # const = 3
+
+
+def test_f16_encoder_is_an_order_of_magnitude_closer_than_bf16():
+    """encoder_backend="hip_f16": plain fp16 operands (11 significant bits) -- between bf16 and f16x3 in accuracy, bf16-like cost."""
+    from test_host_logic import _shipped_planner
+    g = G.load("maze32_cnncost_g050")
+    dev = _dev()
+    na = _shipped_planner().to(dev)
+    m, s, go = _t(g.map_designs), _t(g.start_maps), _t(g.goal_maps)
+    ref = _t(g.cost_maps)
+    errs = {}
+    with torch.no_grad():
+        for backend in ("hip_bf16", "hip_f16", "hip_f16x3"):
+            na.encoder_backend = backend
+            c = na.encode(m, s, go)
+            assert na._hip_encoder is not None and na._hip_encoder.precision == backend[4:]
+            errs[backend] = float((c - ref).abs().max())
+    assert errs["hip_f16x3"] < 1e-5 < errs["hip_f16"] < 5e-3 and errs["hip_f16"] * 4 < errs["hip_bf16"] < 3e-2, errs
