@@ -173,8 +173,8 @@ int nastar_encoder_cnn_forward_f16x3(const float* map, const float* start, const
                                      const float* w1_f32, const uint16_t* const* wsplit, const float* const* scale,
                                      const float* const* shift, float final_mul, float* cost_out, void* workspace,
                                      size_t workspace_bytes, void* stream);
-/* plain fp16 operands (11 significant bits instead of bf16's 8), same arguments; wpack16 = layers 2..4 packed over cin channels as
- * fp16 + the last layer's pack (4 pointers); workspace: nastar_encoder_workspace_bytes_f16(B,H,W) */
+/* plain fp16 operands (11 significant bits instead of bf16's 8), same arguments; wpack16 = the five layers packed exactly as for
+ * nastar_encoder_cnn_forward but in fp16 (w1_f32 serves sizes other than 32x32); workspace: nastar_encoder_workspace_bytes_f16(B,H,W) */
 size_t nastar_encoder_workspace_bytes_f16(int B, int H, int W);
 int nastar_encoder_cnn_forward_f16(const float* map, const float* start, const float* goal, int plus, int B, int H, int W,
                                    const float* w1_f32, const uint16_t* const* wpack16, const float* const* scale,

@@ -63,6 +63,8 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)  // round to 
 __device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
 __device__ __forceinline__ float f16_clamp(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 template <bool kF16>
+__device__ __forceinline__ float f16_sat(float v) { return kF16 ? f16_clamp(v) : v; }  // fp16 range guard (no-op for bf16)
+template <bool kF16>
 __device__ __forceinline__ uint32_t pack_pair(float lo, float hi) { return kF16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
@@ -364,7 +366,7 @@ template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, boo
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
     static_assert(!(kFuse && kTiled), "the fused last layer needs the whole image in one workgroup");
-    static_assert(!(kFuse && kF16), "the fp16 forms keep the last layer a separate launch");
+    static_assert(!(kFuse && kSplit), "split precision keeps the last layer a separate launch");
     static_assert(kF16 || !kSplit, "split precision is an fp16 form");
     constexpr int NS1 = CIN / I32_KS;                 // slices per precision block
     constexpr int NSLICE = (kSplit ? 3 : 1) * NS1;
@@ -560,11 +562,11 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                             if constexpr (kRelu) {
                                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                             }
-                            yw[2 * h + 0] = pack_bf16x2(v0, v1);
-                            yw[2 * h + 1] = pack_bf16x2(v2, v3);
+                            yw[2 * h + 0] = pack_pair<kF16>(f16_sat<kF16>(v0), f16_sat<kF16>(v1));
+                            yw[2 * h + 1] = pack_pair<kF16>(f16_sat<kF16>(v2), f16_sat<kF16>(v3));
                         }
                         const uint4 yq = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-                        pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa, 0, 0, 0);
+                        pa = mfma16<kF16>(fa[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa);
                     }
                 // D row = tap = (reg & 3) + 8 (reg >> 2) + 4 kh: taps 0-3 / 8 in the lower half-wave, 4-7 in the upper
                 float* pp = P + ((wave * I32_RPW + m) * 32 + px) * 9 + 4 * kh;
@@ -801,10 +803,10 @@ struct StemArgs {
 constexpr int STEM_RAW_BYTES = 34 * 34 * 4;
 constexpr size_t STEM_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + 8 * 4096 + STEM_RAW_BYTES + (64 + 128) * 4;
 
+template <bool kF16 = false>   // operands bf16 or plain fp16 (weights packed accordingly by the host)
 __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs a)
 {
     constexpr int CIN = 32, COUT = 64;
-    constexpr bool kF16 = false;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* obase = smem + 2 * I32_BUF_BYTES;                       // epilogue transpose patches, 8 x 4 KB
     uint32_t* raw = reinterpret_cast<uint32_t*>(obase + 8 * 4096);         // [34][34] bf16x2 (map, start+goal), zero halo
@@ -864,8 +866,8 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
         if (a.plus) { g0 = a.start[o] + a.goal[o]; g1 = a.start[o + 512] + a.goal[o + 512]; }
     };
     auto put_raw = [&]() {
-        raw[((tid >> 5) + 1) * 34 + (tid & 31) + 1] = pack_bf16x2(m0, g0);
-        raw[((tid >> 5) + 17) * 34 + (tid & 31) + 1] = pack_bf16x2(m1, g1);
+        raw[((tid >> 5) + 1) * 34 + (tid & 31) + 1] = pack_pair<kF16>(m0, g0);
+        raw[((tid >> 5) + 17) * 34 + (tid & 31) + 1] = pack_pair<kF16>(m1, g1);
     };
     int b = blockIdx.x;
     if (b < a.B) fetch(b);
@@ -885,8 +887,8 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
             f32x16 a1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1a, *reinterpret_cast<const bf16x8*>(&q0), a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1b, *reinterpret_cast<const bf16x8*>(&q1), a1, 0, 0, 0);
+            a1 = mfma16<kF16>(w1a, *reinterpret_cast<const bf16x8*>(&q0), a1);
+            a1 = mfma16<kF16>(w1b, *reinterpret_cast<const bf16x8*>(&q1), a1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {  // D rows 8g + 4kh + {0..3} = first-layer channels; g >> 1 = second-layer slice
                 const int c = 8 * g + 4 * kh;
@@ -895,8 +897,8 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
                 const float v0 = fmaxf(a1[4 * g + 0] * sc.x + sh.x, 0.f), v1 = fmaxf(a1[4 * g + 1] * sc.y + sh.y, 0.f);
                 const float v2 = fmaxf(a1[4 * g + 2] * sc.z + sh.z, 0.f), v3 = fmaxf(a1[4 * g + 3] * sc.w + sh.w, 0.f);
                 uint2 o;
-                o.x = pack_bf16x2(v0, v1);
-                o.y = pack_bf16x2(v2, v3);
+                o.x = pack_pair<kF16>(f16_sat<kF16>(v0), f16_sat<kF16>(v1));
+                o.y = pack_pair<kF16>(f16_sat<kF16>(v2), f16_sat<kF16>(v3));
                 *reinterpret_cast<uint2*>(smem + (g >> 1) * I32_BUF_BYTES + i32_tile_off(y + 1, px + 1, g & 1) + kh * 8) = o;
             }
         }
@@ -926,8 +928,8 @@ __global__ __launch_bounds__(512) void nastar_conv_stem32_kernel(const StemArgs 
                     const float v0 = fmaxf(acc[m][n][4 * g + 0] * sc.x + sh.x, 0.f), v1 = fmaxf(acc[m][n][4 * g + 1] * sc.y + sh.y, 0.f);
                     const float v2 = fmaxf(acc[m][n][4 * g + 2] * sc.z + sh.z, 0.f), v3 = fmaxf(acc[m][n][4 * g + 3] * sc.w + sh.w, 0.f);
                     uint2 o;
-                    o.x = pack_bf16x2(v0, v1);
-                    o.y = pack_bf16x2(v2, v3);
+                    o.x = pack_pair<kF16>(f16_sat<kF16>(v0), f16_sat<kF16>(v1));
+                    o.y = pack_pair<kF16>(f16_sat<kF16>(v2), f16_sat<kF16>(v3));
                     const int chunk = n * 4 + g;
                     *reinterpret_cast<uint2*>(ob + px * 128 + ((chunk ^ ((px >> 1) & 7)) << 4) + kh * 8) = o;
                 }

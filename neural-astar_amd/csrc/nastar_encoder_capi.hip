@@ -65,9 +65,9 @@ static int launch_conv_auto(const ConvArgs& ca, hipStream_t stream)
 }
 
 // input assembly + 2 -> 32 + 32 -> 64 channels for 32x32 maps in one persistent kernel
-static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream)
+static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream, bool f16 = false)
 {
-    void (*kern)(const StemArgs) = &nastar_conv_stem32_kernel;
+    void (*kern)(const StemArgs) = f16 ? &nastar_conv_stem32_kernel<true> : &nastar_conv_stem32_kernel<false>;
     int rc = ensure_lds(kern, STEM_LDS_BYTES);
     if (rc) return rc;
     int n_cu = 0;
@@ -80,9 +80,10 @@ static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream)
 }
 
 // 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
-static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream)
+static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream, bool f16 = false)
 {
     void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
+    if (f16) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 0, false, true, false>;
     if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 2>;  // dev: every workgroup reads image 0 (L2 hits)
     if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 1>;  // dev: cycle totals into the (unused) output slab
     int rc = ensure_lds(kern, I32_LDS_BYTES);
@@ -170,11 +171,35 @@ static int encoder_fp16_impl(const float* map, const float* start, const float* 
     uint16_t* a3 = a2 + npc * 64 * M;                   // [.., M*128]
     uint16_t* a4 = a3 + npc * 128 * M;                  // [.., M*256]
     float* zacc = reinterpret_cast<float*>(a4 + npc * 256 * M);
+    // weight pointers: split form = {layer 2, 3, 4 over 3*cin virtual channels, last layer hi, lo}; plain fp16 = the five standard packs
+    const uint16_t* w2 = kSplit ? wts[0] : wts[1];
+    const uint16_t* w3 = kSplit ? wts[1] : wts[2];
+    const uint16_t* w4 = kSplit ? wts[2] : wts[3];
+    const uint16_t* w5 = kSplit ? wts[3] : wts[4];
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0 < chunk) ? B - b0 : chunk;
         const size_t off = (size_t)b0 * H * W;
         const long long npix = (long long)nb * H * W;
         const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+        if constexpr (!kSplit) {
+            if (H == 32 && W == 32 && !(enc_flags() & 25)) {  // plain fp16 on 32x32 maps: stem + 64->128 + fused 128->256(+1), as the bf16 form
+                StemArgs sa;
+                sa.map = map + off; sa.start = plus ? start + off : nullptr; sa.goal = plus ? goal + off : nullptr; sa.plus = plus; sa.B = nb;
+                sa.w1 = wts[0]; sa.scale1 = scale[0]; sa.shift1 = shift[0]; sa.w2 = w2; sa.scale2 = scale[1]; sa.shift2 = shift[1];
+                sa.out = a2;
+                int rc;
+                if ((rc = launch_conv_stem32(sa, s, true))) return rc;
+                ConvArgs ca;
+                ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
+                ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+                ca.in = a2; ca.out = a3; ca.wpack = w3; ca.scale = scale[2]; ca.shift = shift[2];
+                if ((rc = launch_conv_split<64, 128, false>(ca, s))) return rc;
+                ca.in = a3; ca.out = a4; ca.wpack = w4; ca.scale = scale[3]; ca.shift = shift[3];
+                ca.wfin = w5; ca.fscale = scale[4]; ca.fshift = shift[4]; ca.out_f32 = cost_out + off;
+                if ((rc = launch_conv_fused_final(ca, s, true))) return rc;
+                continue;
+            }
+        }
         if (plus)
             hipLaunchKernelGGL((nastar_conv_first_f32_kernel<2, kSplit>), dim3(pg), dim3(256), 0, s, map + off, start + off, goal + off,
                                w1_f32, scale[0], shift[0], a1, nb, H, W);
@@ -185,11 +210,11 @@ static int encoder_fp16_impl(const float* map, const float* start, const float* 
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
         ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
         int rc;
-        ca.in = a1; ca.out = a2; ca.wpack = wts[0]; ca.scale = scale[1]; ca.shift = shift[1];
+        ca.in = a1; ca.out = a2; ca.wpack = w2; ca.scale = scale[1]; ca.shift = shift[1];
         if ((rc = launch_conv_split<32, 64, kSplit>(ca, s))) return rc;
-        ca.in = a2; ca.out = a3; ca.wpack = wts[1]; ca.scale = scale[2]; ca.shift = shift[2];
+        ca.in = a2; ca.out = a3; ca.wpack = w3; ca.scale = scale[2]; ca.shift = shift[2];
         if ((rc = launch_conv_split<64, 128, kSplit>(ca, s))) return rc;
-        ca.in = a3; ca.out = a4; ca.wpack = wts[2]; ca.scale = scale[3]; ca.shift = shift[3];
+        ca.in = a3; ca.out = a4; ca.wpack = w4; ca.scale = scale[3]; ca.shift = shift[3];
         if ((rc = launch_conv_split<128, 256, kSplit>(ca, s))) return rc;
         ca.out = nullptr; ca.out_f32 = cost_out + off; ca.scale = scale[4]; ca.shift = shift[4]; ca.in_stride = 256 * M; ca.zacc = zacc;
         if constexpr (kSplit) {  // last layer: three accumulating passes of the tap-major kernel: x_hi*W_hi, x_lo*W_hi, x_hi*W_lo
@@ -200,7 +225,7 @@ static int encoder_fp16_impl(const float* map, const float* start, const float* 
             ca.in = a4; ca.wpack = wts[4]; ca.pass_flags = 1;
             if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
         } else {
-            ca.in = a4; ca.wpack = wts[3]; ca.pass_flags = 0;
+            ca.in = a4; ca.wpack = w5; ca.pass_flags = 0;
             if ((rc = launch_conv_final_split_pass(ca, s))) return rc;
         }
     }

@@ -61,7 +61,7 @@ def fold_bn(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], cout_p: int):
 
 class HipCnnEncoder:
     """``precision``: ``"bf16"`` (default: bf16 operands, 2.8 ms per 4096 32x32 maps, cost maps within ~1e-3 of the fp32 encoder),
-    ``"f16"`` (plain fp16 operands: 8x finer than bf16, no fused stem / last layer) or ``"f16x3"`` (split fp16 operands, ~3x the
+    ``"f16"`` (plain fp16 operands: 8x finer than bf16 at the same speed; activations must stay below 65504) or ``"f16x3"`` (split fp16 operands, ~3x the
     matrix work, cost maps within 1e-5 -- the north-star tolerance for float outputs)."""
 
     def __init__(self, cnn: nn.Module, precision: str = "bf16"):
@@ -98,9 +98,7 @@ class HipCnnEncoder:
         if self.precision == "f16":
             convs = [m for m in layers if isinstance(m, nn.Conv2d)]
             self.w1 = convs[0].weight.detach().float().contiguous()
-            self.wsplit = [pack_conv_weight(convs[li].weight.detach().float(), _CIN_P[li], _COUT_P[li], torch.float16) for li in (1, 2, 3)]
-            self.wsplit += [pack_conv_weight(convs[4].weight.detach().float(), 256, 32, torch.float16)]
-            self.wsplit += [self.wsplit[-1]]  # (pointer array has 5 slots)
+            self.wsplit = [pack_conv_weight(convs[li].weight.detach().float(), _CIN_P[li], _COUT_P[li], torch.float16) for li in range(5)]
         if self.precision == "f16x3":
             convs = [m for m in layers if isinstance(m, nn.Conv2d)]
             self.w1 = convs[0].weight.detach().float().contiguous()

@@ -608,3 +608,37 @@ def test_f16_encoder_is_an_order_of_magnitude_closer_than_bf16():
             assert na._hip_encoder is not None and na._hip_encoder.precision == backend[4:]
             errs[backend] = float((c - ref).abs().max())
     assert errs["hip_f16x3"] < 1e-5 < errs["hip_f16"] < 5e-3 and errs["hip_f16"] * 4 < errs["hip_bf16"] < 3e-2, errs
+
+
+def test_f16_encoder_routes_agree():
+    """hip_f16: the stem + fused-last-layer route (32x32 default), the layer-by-layer route (NASTAR_ENCODER_FLAGS=16) and the
+    32x32-tile route (64x96 maps) against the fp32 torch encoder."""
+    import os
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    torch.manual_seed(6)
+    na = NeuralAstar(encoder_arch="CNN").to(dev)
+    with torch.no_grad():
+        for mod in na.encoder.model:
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+    na.eval()
+    for (H, W) in ((32, 32), (64, 96)):
+        pr = syn.random_obstacle_maps(12, H, W, 0.2, seed=15)
+        m, s, go = (_t(x) for x in pr)
+        with torch.no_grad():
+            na.encoder_backend = "torch"
+            ref = na.encode(m, s, go)
+            na.encoder_backend = "hip_f16"
+            got = na.encode(m, s, go)
+            assert na._hip_encoder.precision == "f16"
+            assert float((got - ref).abs().max()) < 5e-3 and float((got - ref).abs().mean()) < 5e-4
+            if (H, W) == (32, 32):
+                try:
+                    os.environ["NASTAR_ENCODER_FLAGS"] = "16"
+                    alt = na.encode(m, s, go)
+                finally:
+                    os.environ.pop("NASTAR_ENCODER_FLAGS", None)
+                assert 0.0 < float((alt - got).abs().max()) < 2e-3      # different kernels, same fp16 operands
