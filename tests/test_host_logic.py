@@ -211,3 +211,27 @@ def test_f16x3_split_and_virtual_channel_packing():
     bf = conv(x.bfloat16().double(), w.bfloat16().double(), padding=1)
     e3, eb = float((three - full).abs().max()), float((bf - full).abs().max())
     assert e3 < 2e-6 * float(full.abs().max()) and eb > 1000 * e3, (e3, eb)
+
+
+def test_hip_encoder_backends_fall_back_to_torch_when_gradients_are_needed():
+    """The MFMA encoders are inference kernels: in training mode, or with autograd recording, `encode` silently stays on the
+    differentiable torch encoder whatever `encoder_backend` says (so a training loop can leave the flag set)."""
+    import torch
+    from neural_astar.planner import NeuralAstar
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="CNN")
+    m = (torch.rand(2, 1, 32, 32) > 0.2).float()
+    s = torch.zeros_like(m); s[:, 0, 1, 1] = 1
+    g = torch.zeros_like(m); g[:, 0, 30, 30] = 1
+    na.eval()
+    with torch.no_grad():
+        ref = na.encode(m, s, g)
+    for backend in ("hip_bf16", "hip_f16", "hip_f16x3"):
+        na.encoder_backend = backend
+        na.eval()
+        c = na.encode(m, s, g)                       # autograd is recording -> torch path (runs on the CPU)
+        assert c.requires_grad and torch.allclose(c, ref)
+        na.train()
+        with torch.no_grad():
+            c2 = na.encode(m, s, g)                  # training mode (batch-statistics BatchNorm) -> torch path
+        assert c2.shape == ref.shape and na._hip_encoder is None
