@@ -231,7 +231,8 @@ def test_hip_encoder_backends_fall_back_to_torch_when_gradients_are_needed():
         na.eval()
         c = na.encode(m, s, g)                       # autograd is recording -> torch path (runs on the CPU)
         assert c.requires_grad and torch.allclose(c, ref)
-        na.train()
+        import copy
+        nt = copy.deepcopy(na).train()               # (a copy: training-mode BatchNorm updates its running statistics)
         with torch.no_grad():
-            c2 = na.encode(m, s, g)                  # training mode (batch-statistics BatchNorm) -> torch path
-        assert c2.shape == ref.shape and na._hip_encoder is None
+            c2 = nt.encode(m, s, g)                  # training mode (batch-statistics BatchNorm) -> torch path
+        assert c2.shape == ref.shape and nt._hip_encoder is None and na._hip_encoder is None
