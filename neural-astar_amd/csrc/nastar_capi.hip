@@ -10,6 +10,7 @@
 #include "nastar_search.hip.h"
 #include "nastar_search_reg.hip.h"
 #include "nastar_search_global.hip.h"
+#include "nastar_search_compact.hip.h"
 
 namespace nastar {
 
@@ -92,6 +93,92 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
     if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off,
                          a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
+    if (lane == 0) {
+        a.iters[b] = iters;
+        a.status[b] = status;
+    }
+}
+
+// ---- forward, compact LDS state (nastar_search_compact.hip.h): the default for every map that fits LDS ------------------
+struct FwdCArgs {
+    const float* cost;
+    const float* start;
+    const float* goal;
+    const float* passable;
+    float* hist;
+    long long* paths;
+    int* sel_log;
+    int* iters;
+    int* status;
+    uint8_t* packed;
+    int max_iters;
+    CompactDims d;
+};
+
+// LOGH > 0 && LOGW > 0: the map is exactly (1<<LOGH) x (1<<LOGW) (compile-time sizes, immediate ds offsets).
+// CPL_T: chunk minima per lane (1 or 4) when known at compile time, 0 = runtime.
+template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog>
+__global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    CompactDims d = a.d;
+    if constexpr (LOGH > 0 && LOGW > 0) {
+        d.H = 1 << LOGH;
+        d.W = 1 << LOGW;
+        d.HW = 1 << (LOGH + LOGW);
+        d.nchunks = d.HW >> CCL;
+        d.HWp = d.HW;
+        d.CPL = (d.nchunks + 63) / 64;
+        d.NCp = d.CPL * 64;
+        d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
+    }
+    const CompactLds l = carve_compact_lds(smem, d);
+    const size_t off = (size_t)b * (size_t)d.HW;
+
+    int start_idx, goal_idx;
+    compact_load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    const int gi = goal_idx < 0 ? 0 : goal_idx;
+    const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
+    const int goal_c = gi - goal_r * d.W;
+
+    const CompactLane lc = make_compact_lane(d, lane);
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    if (start_idx < 0 || goal_idx < 0) {
+        status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
+    } else {
+        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
+        int s = 0;
+        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
+            uint2 mine;
+            s = compact_select<CPL_T>(d, l, lane, mine);
+            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
+            if constexpr (kLog) {
+                if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            }
+            ++iters;
+            compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
+        }
+        if (iters < a.max_iters) {
+            if (s < 0) {
+                status = NASTAR_ERR_UNSOLVABLE;
+            } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
+                if constexpr (kLog) {
+                    if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+                }
+                ++iters;
+                solved = true;
+                if (lane == 0) l.gc[s].x = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
+            }
+        }
+    }
+    wave_sync();
+    if (goal_idx >= 0) compact_backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    compact_store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off,
+                                 a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
@@ -421,11 +508,40 @@ thread_local char g_last_error[256] = "";
 
 constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
 
+static int make_cdims(int B, int H, int W, int max_iters, double g_ratio, CompactDims& d)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H > 65535 || W > 65535 || (long long)H * W > 65535 - CCSZ) return NASTAR_ERR_UNSUPPORTED;
+    d.H = H;
+    d.W = W;
+    d.HW = H * W;
+    d.nchunks = (d.HW + CCSZ - 1) / CCSZ;
+    d.HWp = d.nchunks * CCSZ;
+    d.CPL = (d.nchunks + 63) / 64;
+    d.NCp = d.CPL * 64;
+    d.magicW = (uint32_t)((1ull << 32) / (unsigned)W) + 1u;
+    d.gr = (float)g_ratio;
+    d.omg = (float)(1.0 - g_ratio);  // python evaluates (1 - g_ratio) in double, ATen casts the scalar to fp32
+    d.sqrtW = (float)sqrt((double)W);  // math.sqrt(W) in double, then the fp32 scalar of the division (:207)
+    return NASTAR_OK;
+}
+
+// maps whose compact state (9 B/cell, nastar_search_compact.hip.h) does not fit the 160 KiB of one CU keep it in HBM
 static bool needs_global_state(int H, int W)
 {
     const long long HW = (long long)H * W;
+    if (HW > 65535 - CCSZ) return true;
+    const long long nchunks = (HW + CCSZ - 1) / CCSZ;
+    return compact_lds_bytes((int)(nchunks * CCSZ), (int)(((nchunks + 63) / 64) * 64)) > kMaxLdsBytes;
+}
+
+// round-1 layout (17 B/cell, 64-cell chunks): kept behind NASTAR_FLAG_FORCE_LDS for A/B measurements
+static bool fits_legacy_lds(int H, int W)
+{
+    const long long HW = (long long)H * W;
+    if (HW > 65535) return false;
     const long long nchunks = (HW + 63) / 64;
-    return map_lds_bytes((int)(nchunks * 64), (int)(((nchunks + 63) / 64) * 64)) > kMaxLdsBytes;
+    return map_lds_bytes((int)(nchunks * 64), (int)(((nchunks + 63) / 64) * 64)) <= kMaxLdsBytes;
 }
 
 static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
@@ -516,6 +632,41 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
         return NASTAR_OK;
     }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool legacy = (flags & (NASTAR_FLAG_FORCE_LDS | NASTAR_FLAG_FORCE_REG)) && B > 0 && H > 0 && W > 0 && fits_legacy_lds(H, W);
+    if (!legacy) {
+        FwdCArgs c;
+        int rc = make_cdims(B, H, W, max_iters, g_ratio, c.d);
+        if (rc) return rc;
+        const size_t lds = compact_lds_bytes(c.d.HWp, c.d.NCp);
+        if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
+        c.cost = cost; c.start = start; c.goal = goal; c.passable = passable;
+        c.hist = histories_out; c.paths = reinterpret_cast<long long*>(paths_out);
+        c.sel_log = sel_log_out; c.iters = iters_out; c.status = status_out; c.max_iters = max_iters;
+        c.packed = nullptr;
+        const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
+                          aligned16(histories_out) && aligned16(paths_out);
+        if (packed_out && vec4 && (c.d.HW % 8 == 0)) {  // fused emission of the bit-packed masks
+            c.packed = packed_out;
+            *packed_done = true;
+        }
+        const float rcp = 1.0f / c.d.sqrtW;
+        const bool fast = fastdiv_verified(W);
+        const bool lg = sel_log_out != nullptr;
+        void (*kern)(const FwdCArgs, const float) = nullptr;
+#define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
+    kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
+        if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
+        else if (vec4 && fast && H == 64 && W == 64) { NASTAR_CPICK(true, 6, 6, 4, true); }
+        else if (vec4 && fast && H == 16 && W == 16) { NASTAR_CPICK(true, 4, 4, 1, true); }
+        else if (vec4 && fast && c.d.CPL == 1) { NASTAR_CPICK(true, 0, 0, 1, true); }
+        else if (vec4 && fast) { NASTAR_CPICK(true, 0, 0, 0, true); }
+        else if (vec4) { NASTAR_CPICK(true, 0, 0, 0, false); }
+        else if (fast) { NASTAR_CPICK(false, 0, 0, 0, true); }
+        else { NASTAR_CPICK(false, 0, 0, 0, false); }
+#undef NASTAR_CPICK
+        return launch(kern, B, lds, s, c, rcp);
+    }
     FwdArgs a;
     int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
     if (rc) return rc;
@@ -528,7 +679,6 @@ static int forward_impl(const float* cost, const float* start, const float* goal
     const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                       aligned16(histories_out) && aligned16(paths_out);
     const bool multi = a.d.nchunks > 64;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nstep = reg_max_slot_steps(H, W);
     if (a.d.HW <= REG_MAX_CELLS && nstep <= 3 && (flags & NASTAR_FLAG_FORCE_REG)) {
         const float rcp = 1.0f / a.d.sqrtW;
@@ -684,12 +834,14 @@ int nastar_unpack_outputs(const uint8_t* packed, int B, int H, int W, float* his
 
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out)
 {
-    MapDims d;
-    if (make_dims(1, H, W, 1, 0.5, d)) return -1;
-    const size_t lds = map_lds_bytes(d.HWp, d.NCp);
+    CompactDims d;
+    if (make_cdims(1, H, W, 1, 0.5, d)) return -1;
+    const size_t lds = compact_lds_bytes(d.HWp, d.NCp);
     if (lds_bytes_out) *lds_bytes_out = (int)lds;
     if (lds > kMaxLdsBytes) return 0;
-    void (*kern)(const FwdArgs, const float) = &nastar_forward_kernel<true, false, 0, false, false>;
+    void (*kern)(const FwdCArgs, const float) = &nastar_forward_compact_kernel<true, 0, 0, 0, false, false>;
+    if (H == 32 && W == 32) kern = &nastar_forward_compact_kernel<true, 5, 5, 1, true, false>;
+    if (H == 64 && W == 64) kern = &nastar_forward_compact_kernel<true, 6, 6, 4, true, false>;
     if (ensure_lds(kern, lds)) return -1;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, lds) != hipSuccess) return -1;

@@ -196,10 +196,63 @@ def data_golden():
     print("data_maze32.npz: starts", np.stack(starts)[:2].tolist())
 
 
+def grad_goldens_other_sizes(ref):
+    """grad_* vectors for every size class the backward launcher distinguishes (nastar_capi.hip backward_impl): 64x64 (config 4),
+    12x12 all-passable with start (0,0) / goal (-1,-1) (WarCraft, data.py WarCraftDataset), 16x16, the odd 20x45 and 24x40, a 7x5
+    scalar-load case, and 96x96 / 100x100 (larger than the LDS-resident backward state).  eval (run to the goal, uneven finishing
+    times inside the batch -> the batch-coupled fixed-point terms) and train mode with Tmax = 0.25 (budget-truncated)."""
+    rng = np.random.Generator(np.random.PCG64(2025))
+
+    def one(name, pr, cost, gr, Tmax=1.0, training=False, passable=None):
+        B, _, H, W = pr.map_designs.shape
+        up = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+        pa = pr.map_designs if passable is None else passable
+        out, grad = run_ref(ref, cost, pr.start_maps, pr.goal_maps, pa, gr, Tmax=Tmax, training=training, want_grad=up)
+        save(name, pr, cost, out, gr, Tmax=Tmax, training=training, grad_up=up, grad=grad, passable=passable)
+
+    r64 = syn.random_obstacle_maps(4, 64, 64, 0.20, seed=640)
+    c64 = syn.random_costs(4, 64, 64, seed=641)
+    one("grad_rand64_eval_g050", r64, c64, 0.5)
+    one("grad_rand64_train_T025", r64, c64, 0.5, Tmax=0.25, training=True)
+    # long searches at 64x64: the reference's fixture (block obstacle, corner to corner) under random costs, one run to the goal
+    # with a second, much shorter map in the batch (fixed-point steps), one truncated by the budget (Tmax = 0.05 -> 204 steps)
+    fx = syn.fixture_block(2, 64, 64)
+    fs = fx.start_maps.copy(); fs[1] = 0; fs[1, 0, 40, 50] = 1  # map 1 starts close to the goal
+    fx2 = syn.Problems(fx.map_designs, fs, fx.goal_maps)
+    cf = syn.random_costs(2, 64, 64, seed=642)
+    one("grad_fixture64_eval_g050", fx2, cf, 0.5)
+    one("grad_fixture64_train_T005", fx2, cf, 0.5, Tmax=0.05, training=True)
+    # WarCraft geometry: 12x12, everything passable (learn_obstacles: passable = ones), start top-left, goal bottom-right
+    B = 8
+    ones = np.ones((B, 1, 12, 12), np.float32)
+    s = np.zeros_like(ones); g = np.zeros_like(ones)
+    s[:, 0, 0, 0] = 1; g[:, 0, -1, -1] = 1
+    wc = syn.Problems(ones, s, g)
+    cw = syn.random_costs(B, 12, 12, seed=120)
+    one("grad_warcraft12_eval_g050", wc, cw, 0.5, passable=ones)
+    one("grad_warcraft12_train_T025", wc, cw, 0.5, Tmax=0.25, training=True, passable=ones)
+    r16 = syn.random_obstacle_maps(8, 16, 16, 0.2, seed=160)
+    one("grad_rand16_eval_g080", r16, syn.random_costs(8, 16, 16, seed=161), 0.8)
+    r2 = syn.random_obstacle_maps(4, 20, 45, 0.2, seed=2045)
+    one("grad_rand20x45_eval_g050", r2, syn.random_costs(4, 20, 45, seed=2046), 0.5)
+    r3 = syn.random_obstacle_maps(4, 24, 40, 0.2, seed=2440)
+    one("grad_rand24x40_train_T025", r3, syn.random_costs(4, 24, 40, seed=2441), 0.5, Tmax=0.25, training=True)
+    r4 = syn.random_obstacle_maps(4, 7, 5, 0.1, seed=75)
+    one("grad_rand7x5_eval_g050", r4, syn.random_costs(4, 7, 5, seed=76), 0.5)
+    # larger than the LDS-resident backward state (HBM-workspace route)
+    r96 = syn.random_obstacle_maps(2, 96, 96, 0.2, seed=960)
+    one("grad_rand96_train_T005", r96, syn.random_costs(2, 96, 96, seed=961), 0.5, Tmax=0.05, training=True)
+    r100 = syn.random_obstacle_maps(2, 100, 100, 0.15, seed=1001)
+    one("grad_rand100_eval_g050", r100, syn.random_costs(2, 100, 100, seed=1002), 0.5)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "grad-sizes":  # round 2 addition; leaves the round-1 files untouched
+        grad_goldens_other_sizes(ref)
+        return
 
     # 1. the reference's own fixture (tests/astar_test.py:5-14) -- known answers of SURVEY 8(c)
     fx = syn.fixture_block(2, 64, 64)
@@ -297,6 +350,7 @@ def main():
     save("grad_maze32_cnn_train_T025", mg, cmz, out, 0.5, Tmax=0.25, training=True, grad_up=upl, grad=grad)
     out, grad = run_ref(ref, cmz, mg.start_maps, mg.goal_maps, mg.map_designs, 0.2, want_grad=upl)
     save("grad_maze32_cnn_eval_g020", mg, cmz, out, 0.2, grad_up=upl, grad=grad)
+    grad_goldens_other_sizes(ref)
 
 
 if __name__ == "__main__":
