@@ -76,6 +76,7 @@ class Runner:
         self.paths = torch.empty((self.B, self.H, self.W), dtype=torch.int64, device=dev)
         self.iters = torch.empty((self.B,), dtype=torch.int32, device=dev)
         self.status = torch.empty((self.B,), dtype=torch.int32, device=dev)
+        self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))  # dev A/B switch (include/nastar.h NASTAR_FLAG_*)
         self.packed = None  # set by enable_packed(): the step then also emits the bit-packed masks (all-gather payload)
 
     def enable_packed(self):
@@ -89,14 +90,14 @@ class Runner:
             rc = self.lib.nastar_forward_packed(
                 self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
                 self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
-                self.status.data_ptr(), self.packed[self._pk].data_ptr(), None, 0, 0,
+                self.status.data_ptr(), self.packed[self._pk].data_ptr(), None, 0, self.flags,
                 torch.cuda.current_stream(self.dev).cuda_stream)
             self._check(rc, "nastar_forward_packed")
             return
         rc = self.lib.nastar_forward(self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
                                      self.B, self.H, self.W, self.g_ratio, self.max_iters, self.hist.data_ptr(),
                                      self.paths.data_ptr(), None,
-                                     self.iters.data_ptr(), self.status.data_ptr(), None, 0, 0,
+                                     self.iters.data_ptr(), self.status.data_ptr(), None, 0, self.flags,
                                      torch.cuda.current_stream(self.dev).cuda_stream)
         self._check(rc, "nastar_forward")
 

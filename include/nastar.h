@@ -51,8 +51,9 @@ extern "C" {
 
 /* flags for nastar_workspace_bytes / nastar_forward / nastar_backward */
 #define NASTAR_FLAG_NONE 0
-#define NASTAR_FLAG_FORCE_LDS 1 /* forward: always use the LDS-resident kernel */
+#define NASTAR_FLAG_FORCE_LDS 1 /* forward: round-1 LDS layout (17 B/cell, one map per wavefront); A/B measurements only */
 #define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
+#define NASTAR_FLAG_SINGLE_MAP 4 /* forward: compact state but ONE map per wavefront (default: two where both fit LDS) */
 
 int nastar_version(void);
 

@@ -11,6 +11,7 @@
 #include "nastar_search_reg.hip.h"
 #include "nastar_search_global.hip.h"
 #include "nastar_search_compact.hip.h"
+#include "nastar_search_duo.hip.h"
 
 namespace nastar {
 
@@ -112,6 +113,7 @@ struct FwdCArgs {
     int* status;
     uint8_t* packed;
     int max_iters;
+    int B;
     CompactDims d;
 };
 
@@ -182,6 +184,87 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
+    }
+}
+
+// ---- forward, two maps per wavefront (nastar_search_duo.hip.h): the default wherever two compact states fit one CU's LDS ----
+// a.d.CPL / a.d.NCp count chunk minima per 32-lane half here.
+template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog>
+__global__ __launch_bounds__(64) void nastar_forward_duo_kernel(const FwdCArgs a, const float rcp_sqrtW)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, hl = lane & 31;
+    const int bq = 2 * (int)blockIdx.x + half;
+    const bool valid = bq < a.B;            // odd B: the second half of the last wavefront shadows the first (stores masked)
+    const int b = valid ? bq : a.B - 1;
+    CompactDims d = a.d;
+    if constexpr (LOGH > 0 && LOGW > 0) {
+        d.H = 1 << LOGH;
+        d.W = 1 << LOGW;
+        d.HW = 1 << (LOGH + LOGW);
+        d.nchunks = d.HW >> CCL;
+        d.HWp = d.HW;
+        d.CPL = (d.nchunks + 31) / 32;
+        d.NCp = d.CPL * 32;
+        d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
+    }
+    const CompactLds l = carve_duo_lds(smem, d, half);
+    const size_t off = (size_t)b * (size_t)d.HW;
+
+    int start_idx, goal_idx;
+    duo_load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, hl, start_idx, goal_idx);
+    const int gi = goal_idx < 0 ? 0 : goal_idx;
+    const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
+    const int goal_c = gi - goal_r * d.W;
+
+    const DuoLane lc = make_duo_lane(d, hl);
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    bool live = (start_idx >= 0) & (goal_idx >= 0);
+    if (!live) status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
+    if (live & (hl == 0)) {  // open list = {start} (:187), g[start] = 0 (:193)
+        const int r = (int)div_magic((uint32_t)start_idx, d.magicW);
+        const int c = start_idx - r * d.W;
+        const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + l.gc[start_idx].y);
+        const uint32_t k0 = compact_key<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
+        l.gc[start_idx].x = 0.0f;
+        l.cmin[start_idx >> CCL] = cmin_entry(k0, (uint32_t)start_idx);
+        l.pdir[start_idx] = (uint8_t)(PARENT_UNSET | P_PASS);  // the start is expanded even if it sits on an obstacle
+    }
+    wave_sync();
+    int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
+    for (;;) {
+        const bool can = live & (iters < a.max_iters);  // :203 for t in range(Tmax)
+        if (__ballot(can) == 0) break;
+        bool empty;
+        uint2 e0, e1;
+        int s = duo_select<CPL_T>(d, l, half, hl, empty, e0, e1);
+        const bool hit = can & (empty | (s == goal_idx));  // open list empty (:68 would divide by zero) or goal selected
+        const bool reached = hit & !empty;
+        const bool act = can & !hit;
+        if (hit & empty) status = NASTAR_ERR_UNSOLVABLE;
+        if (reached) solved = true;  // :219-220,:251: every later step of the reference is a fixed point
+        if constexpr (kLog) {
+            if ((act | reached) & (hl == 0) & valid) log_row[iters] = s;
+        }
+        if (act | reached) ++iters;
+        if (reached & (hl == 0)) l.gc[s].x = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
+        if (hit) live = false;
+        if (__ballot(act) == 0) continue;
+        s = act ? s : 0;
+        duo_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, half, hl, s, act, goal_r, goal_c, rcp_sqrtW, e0, e1);
+    }
+    wave_sync();
+    duo_backtrack(d, l, hl, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    if (valid) {
+        duo_store_outputs<kVec4>(d, l, hl, a.hist + off, a.paths + off,
+                                 a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
+        if (hl == 0) {
+            a.iters[b] = iters;
+            a.status[b] = status;
+        }
     }
 }
 
@@ -654,6 +737,27 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const bool fast = fastdiv_verified(W);
         const bool lg = sel_log_out != nullptr;
         void (*kern)(const FwdCArgs, const float) = nullptr;
+        c.B = B;
+        // two maps per wavefront wherever two states fit (up to ~8.9 k cells per map); NASTAR_FLAG_SINGLE_MAP opts out
+        const int dcpl = (c.d.nchunks + 31) / 32;
+        const size_t dlds = duo_lds_bytes(c.d.HWp, dcpl * 32);
+        if (dlds <= kMaxLdsBytes && !(flags & NASTAR_FLAG_SINGLE_MAP)) {
+            c.d.CPL = dcpl;
+            c.d.NCp = dcpl * 32;
+#define NASTAR_DPICK(V4, LW, LH, CPL, FD) \
+    kern = lg ? &nastar_forward_duo_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_duo_kernel<V4, LW, LH, CPL, FD, false>
+            if (vec4 && fast && H == 32 && W == 32) { NASTAR_DPICK(true, 5, 5, 2, true); }
+            else if (vec4 && fast && H == 64 && W == 64) { NASTAR_DPICK(true, 6, 6, 8, true); }
+            else if (vec4 && fast && H == 16 && W == 16) { NASTAR_DPICK(true, 4, 4, 1, true); }
+            else if (vec4 && fast && dcpl == 1) { NASTAR_DPICK(true, 0, 0, 1, true); }
+            else if (vec4 && fast && dcpl == 2) { NASTAR_DPICK(true, 0, 0, 2, true); }
+            else if (vec4 && fast) { NASTAR_DPICK(true, 0, 0, 0, true); }
+            else if (vec4) { NASTAR_DPICK(true, 0, 0, 0, false); }
+            else if (fast) { NASTAR_DPICK(false, 0, 0, 0, true); }
+            else { NASTAR_DPICK(false, 0, 0, 0, false); }
+#undef NASTAR_DPICK
+            return launch(kern, (B + 1) / 2, dlds, s, c, rcp);
+        }
 #define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
     kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
         if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }

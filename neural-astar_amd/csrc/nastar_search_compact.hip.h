@@ -181,10 +181,17 @@ __device__ __forceinline__ int compact_select(const CompactDims& d, const Compac
         const int cpl = CPL_T > 0 ? CPL_T : d.CPL;
         const uint2* p = reinterpret_cast<const uint2*>(l.cmin) + lane * cpl;
         best = p[0];
+        if constexpr (CPL_T > 0) {
 #pragma unroll
-        for (int c = 1; c < cpl; ++c) {
-            const uint2 e = p[c];
-            if (e.y < best.y) best = e;  // strict: the earlier chunk wins ties
+            for (int c = 1; c < CPL_T; ++c) {
+                const uint2 e = p[c];
+                if (e.y < best.y) best = e;  // strict: the earlier chunk wins ties
+            }
+        } else {
+            for (int c = 1; c < cpl; ++c) {
+                const uint2 e = p[c];
+                if (e.y < best.y) best = e;
+            }
         }
     }
     mine = best;
