@@ -119,7 +119,7 @@ struct FwdCArgs {
 
 // LOGH > 0 && LOGW > 0: the map is exactly (1<<LOGH) x (1<<LOGW) (compile-time sizes, immediate ds offsets).
 // CPL_T: chunk minima per lane (1 or 4) when known at compile time, 0 = runtime.
-template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog>
+template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, int ABL = 0>
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,13 +156,17 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         int s = 0;
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
-            s = compact_select<CPL_T>(d, l, lane, mine);
-            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
+            s = compact_select<CPL_T, ABL>(d, l, lane, mine);
+            if constexpr (ABL != 0) {  // timing probe: always run the whole budget
+                if (s < 0 || s >= d.HW) s = iters & (d.HW - 1);
+            } else {
+                if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
+            }
             if constexpr (kLog) {
                 if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
             }
             ++iters;
-            compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
+            compact_expand<LOGW, kFastDiv, CPL_T, ABL>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
         }
         if (iters < a.max_iters) {
             if (s < 0) {
@@ -760,6 +764,17 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         }
 #define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
     kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
+        static const int ablate = getenv("NASTAR_ABLATE") ? atoi(getenv("NASTAR_ABLATE")) : 0;  // dev timing probe only
+        if (ablate && vec4 && fast && H == 32 && W == 32 && !lg) {
+            switch (ablate) {
+#define NASTAR_ABL(N) case N: kern = &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, N>; break;
+                NASTAR_ABL(128) NASTAR_ABL(129) NASTAR_ABL(130) NASTAR_ABL(132) NASTAR_ABL(136) NASTAR_ABL(144) NASTAR_ABL(160) NASTAR_ABL(192)
+                NASTAR_ABL(142) NASTAR_ABL(175) NASTAR_ABL(255)
+#undef NASTAR_ABL
+                default: return NASTAR_ERR_UNSUPPORTED;
+            }
+            return launch(kern, B, lds, s, c, rcp);
+        }
         if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
         else if (vec4 && fast && H == 64 && W == 64) { NASTAR_CPICK(true, 6, 6, 4, true); }
         else if (vec4 && fast && H == 16 && W == 16) { NASTAR_CPICK(true, 4, 4, 1, true); }
