@@ -53,7 +53,8 @@ extern "C" {
 #define NASTAR_FLAG_NONE 0
 #define NASTAR_FLAG_FORCE_LDS 1 /* forward: round-1 LDS layout (17 B/cell, one map per wavefront); A/B measurements only */
 #define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
-#define NASTAR_FLAG_SINGLE_MAP 4 /* forward: compact state but ONE map per wavefront (default: two where both fit LDS) */
+#define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
+#define NASTAR_FLAG_DUO 4        /* forward: two maps per wavefront (nastar_search_duo.hip.h), a measured non-improvement */
 
 int nastar_version(void);
 

@@ -12,6 +12,7 @@
 #include "nastar_search_global.hip.h"
 #include "nastar_search_compact.hip.h"
 #include "nastar_search_duo.hip.h"
+#include "nastar_search_asm.hip.h"
 
 namespace nastar {
 
@@ -119,6 +120,7 @@ struct FwdCArgs {
 
 // LOGH > 0 && LOGW > 0: the map is exactly (1<<LOGH) x (1<<LOGW) (compile-time sizes, immediate ds offsets).
 // CPL_T: chunk minima per lane (1 or 4) when known at compile time, 0 = runtime.
+// ABL == -1: the selection/expansion loop is the hand-scheduled instruction stream of nastar_search_asm.hip.h
 template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, int ABL = 0>
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
@@ -154,6 +156,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     } else {
         compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
         int s = 0;
+        if constexpr (ABL == -1) {
+            static_assert(LOGW > 0 && LOGW == LOGH && CPL_T == 1 && kFastDiv, "asm loop: square power-of-two maps of <= 1024 cells");
+            s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW,
+                                                    kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr);
+        } else
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
             s = compact_select<CPL_T, ABL>(d, l, lane, mine);
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             ++iters;
             compact_expand<LOGW, kFastDiv, CPL_T, ABL>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
         }
-        if (iters < a.max_iters) {
+        if ((ABL == -1) ? (s != -2) : (iters < a.max_iters)) {
             if (s < 0) {
                 status = NASTAR_ERR_UNSOLVABLE;
             } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
@@ -742,10 +749,11 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const bool lg = sel_log_out != nullptr;
         void (*kern)(const FwdCArgs, const float) = nullptr;
         c.B = B;
-        // two maps per wavefront wherever two states fit (up to ~8.9 k cells per map); NASTAR_FLAG_SINGLE_MAP opts out
+        // two maps per wavefront (opt-in, NASTAR_FLAG_DUO): measured no faster in bulk and slower per step than one map per
+        // wavefront, kept for the record
         const int dcpl = (c.d.nchunks + 31) / 32;
         const size_t dlds = duo_lds_bytes(c.d.HWp, dcpl * 32);
-        if (dlds <= kMaxLdsBytes && !(flags & NASTAR_FLAG_SINGLE_MAP)) {
+        if (dlds <= kMaxLdsBytes && (flags & NASTAR_FLAG_DUO)) {
             c.d.CPL = dcpl;
             c.d.NCp = dcpl * 32;
 #define NASTAR_DPICK(V4, LW, LH, CPL, FD) \
@@ -775,7 +783,12 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             }
             return launch(kern, B, lds, s, c, rcp);
         }
-        if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
+        const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
+        if (use_asm && vec4 && fast && H == 32 && W == 32)
+            kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, -1>;
+        else if (use_asm && vec4 && fast && H == 16 && W == 16)
+            kern = lg ? &nastar_forward_compact_kernel<true, 4, 4, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 4, 4, 1, true, false, -1>;
+        else if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
         else if (vec4 && fast && H == 64 && W == 64) { NASTAR_CPICK(true, 6, 6, 4, true); }
         else if (vec4 && fast && H == 16 && W == 16) { NASTAR_CPICK(true, 4, 4, 1, true); }
         else if (vec4 && fast && c.d.CPL == 1) { NASTAR_CPICK(true, 0, 0, 1, true); }
