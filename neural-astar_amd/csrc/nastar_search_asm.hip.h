@@ -36,10 +36,12 @@ struct AsmLayout {
 
 #define NASTAR_ASM_SELECT \
         "s_cmp_ge_u32 %[it], %[maxit]\n\t" \
-        "s_cbranch_scc1 .Lbudget%=\n" \
+        "s_cbranch_scc1 .Lbudget%=\n\t" \
+        "v_mov_b32 v48, -1\n\t" \
+        "v_mov_b32 v49, -1\n\t" \
+        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n" /* v20 = cell index, v21 = key of this lane's chunk */ \
         ".Lloop%=:\n\t" \
- /* ---- select: first cell of the minimal (key, index) chunk entry ------------------------------------------- */ \
-        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n\t" /* v20 = cell index, v21 = key of this lane's chunk */ \
+ /* ---- select: first cell of the minimal (key, index) chunk entry (its read was issued at the end of the previous step) */ \
         "s_waitcnt lgkmcnt(0)\n\t" \
         "v_min_u32_dpp v22, v21, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
         "s_nop 1\n\t" \
@@ -118,44 +120,34 @@ struct AsmLayout {
         "v_mul_f32 v42, %[crcp], v41\n\t" /* :207 f / sqrt(W), correctly rounded (tools/fastdiv_check.c) */ \
         "v_fma_f32 v43, -v42, %[csq], v41\n\t" \
         "v_fma_f32 v42, v43, %[crcp], v42\n\t" \
-        "v_cmp_lt_f32_e64 vcc, |v30|, %[vinf]\n\t" /* open <=> finite g */ \
         "v_ashrrev_i32 v43, 31, v42\n\t" \
-        "v_bitop3_b32 v47, v43, v42, %[msb] bitop3:0x36\n\t" /* order-preserving u32 key */ \
-        "v_cndmask_b32 v43, -1, v47, vcc\n\t" /* chunk lanes: key of open cells, KEY_INF otherwise */ \
         "v_cmp_eq_u32 vcc, s46, %[lane]\n\t" \
+        "v_bitop3_b32 v47, v43, v42, %[msb] bitop3:0x36\n\t" /* order-preserving u32 key: [v46:v47] = (cell, key) */ \
         "v_cndmask_b32_e64 v45, %[vinf], v40, s[54:55]\n\t" /* value to beat: g2 for in-map neighbour lanes, +inf elsewhere */ \
+        "v_cndmask_b32 v44, %[loc], %[vinf], vcc\n\t" /* chunk lanes: -inf (any finite g is open), +inf for s* itself and other lanes */ \
         "v_lshrrev_b32 v50, 4, v46\n\t" \
-        "v_cndmask_b32_e64 v43, v43, -1, vcc\n\t" /* ... without s* itself */ \
         "v_lshlrev_b32 v50, 3, v50\n\t" /* byte offset of cmin[chunk of il] */ \
         "v_mov_b32 v52, s47\n\t" \
- /* minimum of the chunk of s* without it: row reduction over lanes 16..31, wait states filled */ \
-        "v_min_u32_dpp v44, v43, v43 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
-        "s_nop 1\n\t" \
-        "v_min_u32_dpp v44, v44, v44 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
-        "s_nop 1\n\t" \
-        "v_min_u32_dpp v44, v44, v44 row_half_mirror row_mask:0xf bank_mask:0xf\n\t" \
-        "s_nop 1\n\t" \
-        "v_min_u32_dpp v44, v44, v44 row_mirror row_mask:0xf bank_mask:0xf\n\t" \
-        "v_cmp_eq_u32 vcc, v43, v44\n\t" \
-        "v_readlane_b32 s51, v44, 16\n\t" /* minimal key of the chunk without s* */ \
-        "s_lshr_b32 s50, vcc_lo, 16\n\t" \
-        "s_ff1_i32_b32 s50, s50\n\t" /* first cell of the chunk with that key (0 when none is open) */ \
-        "s_add_u32 s52, s45, s50\n\t" \
-        "v_mov_b32 v48, s52\n\t" \
-        "v_mov_b32 v49, s51\n\t" \
- /* stores: lane 8 closes s* (:222-225) and publishes the chunk's new entry, then the relaxed neighbours (:238-249) */ \
+ /* lane 8 closes s* (:222-225) and empties its chunk's entry; the chunk's open cells (without s*) then re-enter it through \
+    the same 64-bit atomic minimum the relaxed neighbours use: (key, cell) lexicographic = first flat index on ties */ \
         "s_mov_b64 exec, 0x100\n\t" \
         "ds_write_b32 v27, %[vminf]\n\t" \
         "ds_write_b64 v52, v[48:49] offset:%[CMIN]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_cmpx_gt_f32 vcc, v30, v44\n\t" /* chunk lanes other than s* whose g > -inf ... */ \
+        "v_cmpx_ge_f32 vcc, 0x7f7fffff, v30\n\t" /* ... and finite: open */ \
+        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" \
         "s_mov_b64 exec, -1\n\t" \
         "v_cmpx_gt_f32 vcc, v30, v45\n\t" /* :229,:235 g[n] > g2 on in-map neighbour lanes */ \
         "ds_write_b32 v26, v40\n\t" /* :238 g[n] = g2 */ \
         "ds_write_b8 v46, %[pcode] offset:%[PDIR]\n\t" /* :246-249 parent = s* */ \
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 (key, n) enters its chunk's minimum */ \
         "s_mov_b64 exec, -1\n\t" \
+        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n\t" /* next step's chunk minima */ \
         "s_cmp_lt_u32 %[it], %[maxit]\n\t" \
         "s_cbranch_scc1 .Lloop%=\n" \
         ".Lbudget%=:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" /* the prefetched chunk minima must have landed before v20/v21 are released */ \
         "s_mov_b32 %[sel], -2\n\t" \
         "s_branch .Lend%=\n" \
         ".Lempty%=:\n\t" \
@@ -167,7 +159,7 @@ struct AsmLayout {
 #define NASTAR_ASM_OPERANDS \
         : [it] "+s"(it), [sel] "=s"(sel) \
         : [l8] "v"(v_l8), [lane] "v"(lane), [dr] "v"(v_dr), [dc] "v"(v_dc), [off] "v"(v_off), [pcode] "v"(v_pcode), \
-          [vinf] "v"(v_inf), [vminf] "v"(v_minf), [goal] "s"(goal_idx), [gr] "s"(goal_r), [gc] "s"(goal_c), \
+          [vinf] "v"(v_inf), [vminf] "v"(v_minf), [loc] "v"(v_loc), [goal] "s"(goal_idx), [gr] "s"(goal_r), [gc] "s"(goal_c), \
           [maxit] "s"(max_iters), [cgr] "s"(d.gr), [comg] "s"(d.omg), [csq] "s"(d.sqrtW), [crcp] "s"(rcp_sqrtW), \
           [mnb] "s"(m_nb), [mchk] "s"(m_chk), [msb] "s"(msb), [logp] "s"(logp), \
           [CMIN] "i"(L::CMIN), [PDIR] "i"(L::PDIR), [LOGW] "i"(LOGW), [WM1] "i"(L::W - 1), [W] "i"(L::W) \
@@ -191,6 +183,7 @@ __device__ __forceinline__ int compact_search_loop_asm(const CompactDims& d, int
     const uint32_t v_pcode = P_PASS | (uint32_t)(lane & 7);
     const uint32_t v_l8 = (uint32_t)lane * 8u;
     const float v_inf = NASTAR_POS_INF, v_minf = NASTAR_NEG_INF;
+    const float v_loc = is_chk ? NASTAR_NEG_INF : NASTAR_POS_INF;  // lower bound of "open" for the chunk re-insertion
     const unsigned long long m_nb = 0xFFull, m_chk = 0xFFFF0000ull;
     const uint32_t msb = 0x80000000u;
     int it = __builtin_amdgcn_readfirstlane(iters);
