@@ -110,6 +110,24 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
                     size_t workspace_bytes, int flags, void* stream);
 
 /*
+ * The same gradient by REPLAY of the forward's selection log (sel_log_out of nastar_forward, required): no selection is
+ * repeated and the softmax is accounted per open-list event, O(9) work per step instead of O(open list)
+ * (csrc/nastar_backward_replay.hip.h).  Any map of up to 65519 cells: the per-map state lives in LDS up to ~11.6 k cells and in
+ * the workspace beyond.  workspace: nastar_backward_workspace_bytes(B,H,W,max_iters) bytes (per-step history of the running
+ * sums, 16 B per executed step, + the state slabs of maps too large for LDS).  grad_cost_out is fully written.
+ * nastar_backward_l1_replay: the fused-L1 form (see nastar_backward_l1).
+ */
+size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters);
+int nastar_backward_replay(const float* grad_histories, const float* cost, const float* start, const float* goal,
+                           const float* passable, const int32_t* sel_log, int B, int H, int W, double g_ratio, int max_iters,
+                           const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
+                           size_t workspace_bytes, int flags, void* stream);
+int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
+                              const float* start, const float* goal, const float* passable, const int32_t* sel_log, int B, int H,
+                              int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
+                              float* grad_cost_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Training step with the loss fused in (SURVEY.md 8f "next #3"; reference utils/training.py:55-61):
  *   loss = nn.L1Loss()(outputs.histories, opt_trajs); loss.backward()
  * nastar_l1_loss: loss_out[0] = mean |histories - opt_trajs| over numel elements (fixed-order double reduction, bitwise

@@ -1,0 +1,250 @@
+// nastar_backward_replay.hip.h -- backward of DifferentiableAstar.forward (differentiable_astar.py:203-252 under autograd),
+// round-2 algorithm: REPLAY the search from the forward's selection log and account the softmax gradient per EVENT.
+//
+//     dL/dcost = sum_t kfac * y_t * (G - <G, y_t>),   y_t = v / S_t over the open list,  v_i = exp(-q_i),  kfac = (1-g_ratio)(-1/sqrt(W))
+//
+// The round-1 kernels re-evaluated the whole softmax (two wave sums, one exp per open cell) before EVERY selection: O(open list)
+// per step, 3.7x the cost of a forward step.  Between two re-keyings a cell's v_i is constant, so its gradient over an interval
+// [t0, t1] of steps on the open list is   kfac * v_i * (G_i * (A(t1) - A(t0)) - (B(t1) - B(t0)))   with the running sums
+//     A(t) = sum_{tau <= t} w_tau / S_tau,      B(t) = sum_{tau <= t} w_tau * D_tau / S_tau^2,      D_t = sum_open v * G
+// and S, D change by at most 9 cells per step (the closed node and its <= 8 relaxed neighbours): O(9) per step.
+//   * S, D live in LDS as doubles and are updated with ds_add_f64 by the <= 9 lanes that change them; a cell's v enters and
+//     leaves with the identical fp32 value, and fp64 adds fp32 terms exactly, so S and D carry no drift (the reference sums in fp32).
+//   * A, B are doubles in registers (wave-uniform).  Every step appends (A, B) to a per-map history in the HBM workspace; a cell
+//     stores the step that opened it (u16 in LDS) and its interval is closed with one 16-byte history load, consumed one step later
+//     (software-pipelined: never on the replay's critical path).
+//   * contributions go to grad_cost with global_atomic_add_f32 (fire and forget); cells still open at the end are flushed by a sweep.
+//   * no selection at all: s_t comes from the forward's sel_log, so a step is one LDS round trip.
+// w_tau = 1 except for the reference's batch-coupled fixed-point steps (`extra`, see nastar_backward in include/nastar.h).
+// Prototype with the same arithmetic, checked against the reference's autograd: tools/proto_backward_events.py.
+#pragma once
+#include "nastar_search_compact.hip.h"
+#include "nastar_search_global.hip.h"
+
+namespace nastar {
+
+struct BwdRArgs {
+    const float* grad_hist;  // upstream dL/dhistories, or nullptr: L1 loss fused (l1_* below)
+    const float* l1_hist;
+    const float* l1_traj;
+    const float* l1_up;
+    float l1_scale;
+    const float* cost;
+    const float* start;
+    const float* goal;
+    const float* passable;
+    const int* sel_log;   // [B, max_iters] selections of the forward
+    const int* iters;     // [B]
+    const int* t_batch;   // device scalar or nullptr
+    float* grad_cost;     // [B,H,W], fully written by this kernel
+    double* hist;         // workspace: [B][hist_len][2]  (A, B) after each step; entry 0 = (0, 0)
+    unsigned char* state; // workspace for maps whose state does not fit LDS (kGlobal), else nullptr
+    size_t state_stride;
+    int max_iters;
+    int hist_len;  // history entries per map = min(max_iters, HW + 1) + 2
+    float kfac;
+    CompactDims d;
+};
+
+__host__ __device__ inline size_t bwdr_state_bytes(int HWp) { return (size_t)HWp * 14 + 64; }  // gc 8 + G 4 + t0 2 per cell, + (S, D)
+
+__device__ __forceinline__ float bwdr_upstream(const BwdRArgs& a, size_t i)
+{
+    if (a.grad_hist != nullptr) return a.grad_hist[i];
+    const float dlt = a.l1_hist[i] - a.l1_traj[i];  // fused L1 (training.py:58): sign(histories - opt_trajs) * grad / numel
+    const float sg = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+    return sg * (a.l1_scale * (a.l1_up != nullptr ? *a.l1_up : 1.f));
+}
+
+// state accessors: LDS (plain) or the HBM workspace (agent-scope relaxed atomics = sc1, served by L2; see nastar_search_global.hip.h)
+template <bool kGlobal, typename T>
+__device__ __forceinline__ T st_ld(const T* p)
+{
+    if constexpr (kGlobal) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool kGlobal, typename T>
+__device__ __forceinline__ void st_st(T* p, T v)
+{
+    if constexpr (kGlobal) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// q = fl(f / fl32(sqrt(W))) of a cell with g-value G and hh = (1-g_ratio)(h0 + cost)   (:206-207); exp(-q) by v_exp_f32
+__device__ __forceinline__ float bwdr_v(const CompactDims& d, float G, float hh)
+{
+    const float f = d.gr * G + hh;
+    const float q = f / d.sqrtW;
+    return __builtin_amdgcn_exp2f(q * -1.4426950408889634f);
+}
+
+template <bool kGlobal>
+__global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const CompactDims d = a.d;
+    unsigned char* base = kGlobal ? a.state + (size_t)b * a.state_stride : smem;
+    float* g = reinterpret_cast<float*>(base);                 // [HWp] g-value / node state (sign of infinity, as the forward)
+    float* cst = g + d.HWp;                                     // [HWp] cost
+    float* G = cst + d.HWp;                                     // [HWp] upstream gradient
+    unsigned short* t0 = reinterpret_cast<unsigned short*>(G + d.HWp);  // [HWp] history index at which the cell was (re)opened
+    double* sd = reinterpret_cast<double*>(smem + (kGlobal ? 0 : (size_t)d.HWp * 14));  // S, D: always in LDS
+    const size_t off = (size_t)b * (size_t)d.HW;
+    double* hist = a.hist + (size_t)b * (size_t)a.hist_len * 2;
+    float* gout = a.grad_cost + off;
+
+    int sidx = -1, gidx = -1;
+    for (int i = lane; i < d.HW; i += 64) {
+        if (a.start[off + i] != 0.f) sidx = i;
+        if (a.goal[off + i] != 0.f) gidx = i;
+        st_st<kGlobal>(&g[i], a.passable[off + i] != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF);
+        st_st<kGlobal>(&cst[i], a.cost[off + i]);
+        st_st<kGlobal>(&G[i], bwdr_upstream(a, off + i));
+        st_st<kGlobal>(&t0[i], (unsigned short)0);
+        gout[i] = 0.f;
+    }
+    sidx = wave_max_i32(sidx);
+    gidx = wave_max_i32(gidx);
+    if (lane == 0) {
+        sd[0] = 0.0;
+        sd[1] = 0.0;
+        __hip_atomic_store(&hist[0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hist[1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    global_step_fence();  // the zeroed gradient and history entry 0 are in L2 before any atomic / load touches them
+    wave_sync();
+    if (sidx < 0 || gidx < 0) return;
+
+    const int goal_r = gidx / d.W, goal_c = gidx - goal_r * d.W;
+    const int n_steps = a.iters[b];
+    // The reference keeps stepping a finished map at its fixed point until the slowest map of the batch is done (:251):
+    // extra = t_batch - tau such steps; the goal cell is then re-selected while closed and torch.clamp's backward (:223) zeroes
+    // its upstream gradient.
+    int extra = 0;
+    if (a.t_batch != nullptr) extra = *a.t_batch - (n_steps - 1);
+    if (lane == 0) {
+        if (extra > 0) st_st<kGlobal>(&G[gidx], 0.f);
+        // open list = {start} (:187), g[start] = 0 (:193): the start is open from history index 0
+        const int r = sidx / d.W, c = sidx - r * d.W;
+        const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + st_ld<kGlobal>(&cst[sidx]));
+        const float v = bwdr_v(d, 0.0f, hh);
+        st_st<kGlobal>(&g[sidx], 0.0f);
+        sd[0] = (double)v;
+        sd[1] = (double)(st_ld<kGlobal>(&G[sidx]) * v);
+    }
+    if constexpr (kGlobal) global_step_fence();
+    wave_sync();
+
+    int dr, dc;
+    neighbour_delta(lane & 7, dr, dc);
+    const bool is_nb = lane < 8;
+    const int noff = dr * d.W + dc;
+    const int* log = a.sel_log + (size_t)b * (size_t)a.max_iters;
+    double A = 0.0, B = 0.0;
+    // pending interval (closed in the previous step, its history entry still in flight)
+    bool pend = false;
+    float pv = 0.f, pG = 0.f;
+    int pcell = 0;
+    double pA0 = 0.0, pB0 = 0.0, pA = 0.0, pB = 0.0;
+    int logv = 0;
+    bool goal_fixed_point = false;
+    for (int t = 0; t < n_steps; ++t) {
+        if ((t & 63) == 0) logv = (t + lane < n_steps) ? log[t + lane] : 0;
+        const int s = __builtin_amdgcn_readlane(logv, t & 63);
+        // everything issued so far has landed: the history entry of the previous step, the loads of the pending intervals,
+        // and (kGlobal) the state stores of the previous step
+        global_step_fence();
+        if (pend) {
+            const float dA = (float)(pA - pA0), dB = (float)(pB - pB0);
+            unsafeAtomicAdd(&gout[pcell], (a.kfac * pv) * (pG * dA - dB));
+        }
+        // softmax of step t over the current open list: A += 1/S, B += D/S^2   (y_t = v/S, <G,y_t> = D/S)
+        const double S = sd[0], D = sd[1];
+        const float rS = 1.0f / (float)S;
+        A += (double)rS;
+        B += (double)((float)D * rS * rS);
+        const bool goal_step = s == gidx;
+        if (goal_step && extra <= 0) {
+            pend = false;
+            break;
+        }
+        // expansion of s (:222-249): lanes 0..7 relax the neighbours, lane 8 closes s (the goal stays open, :224)
+        const int r = s / d.W, c = s - r * d.W;
+        const int nr = r + dr, nc = c + dc;
+        const bool inb = is_nb & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+        const int il = inb ? s + noff : s;
+        const float gs = st_ld<kGlobal>(&g[s]), cs = st_ld<kGlobal>(&cst[s]);
+        const float gl = st_ld<kGlobal>(&g[il]), cl = st_ld<kGlobal>(&cst[il]);
+        const float Gl = st_ld<kGlobal>(&G[il]);
+        const int tl = st_ld<kGlobal>(&t0[il]);
+        const int rl = il / d.W, cc = il - rl * d.W;
+        const float hh = d.omg * (heuristic0_fast(rl, cc, goal_r, goal_c) + cl);
+        const float g2 = gs + cs;
+        const bool upd = inb & (gl > g2);
+        const bool was_open = fabsf(gl) < NASTAR_POS_INF;
+        const bool flushing = (upd & was_open) | ((lane == 8) & !goal_step);
+        const float v_old = bwdr_v(d, gl, hh);
+        const float v_new = bwdr_v(d, g2, hh);
+        if (upd | flushing) {
+            const double dS = (upd ? (double)v_new : 0.0) - (flushing ? (double)v_old : 0.0);
+            const double dD = (upd ? (double)(Gl * v_new) : 0.0) - (flushing ? (double)(Gl * v_old) : 0.0);
+            atomicAdd(&sd[0], dS);
+            atomicAdd(&sd[1], dD);
+        }
+        if (upd) {
+            st_st<kGlobal>(&g[il], g2);
+            st_st<kGlobal>(&t0[il], (unsigned short)(t + 1));
+        }
+        if ((lane == 8) & !goal_step) st_st<kGlobal>(&g[s], NASTAR_NEG_INF);
+        if (lane == 0) {  // history entry t+1 = (A, B) after step t
+            __hip_atomic_store(&hist[2 * (t + 1)], A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hist[2 * (t + 1) + 1], B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // close the interval of every cell that left the open list or was re-keyed: load its opening stamp, consume next step
+        pend = flushing;
+        pv = v_old;
+        pG = Gl;
+        pcell = il;
+        pA = A;
+        pB = B;
+        if (flushing) {
+            pA0 = __hip_atomic_load(&hist[2 * tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pB0 = __hip_atomic_load(&hist[2 * tl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wave_order();
+        if (goal_step) {  // extra > 0: `extra` more identical steps on the open list left by the goal's own expansion
+            goal_fixed_point = true;
+            break;
+        }
+    }
+    global_step_fence();
+    if (pend) {
+        const float dA = (float)(pA - pA0), dB = (float)(pB - pB0);
+        unsafeAtomicAdd(&gout[pcell], (a.kfac * pv) * (pG * dA - dB));
+    }
+    wave_sync();
+    if (goal_fixed_point) {
+        const double S = sd[0], D = sd[1];
+        const float rS = 1.0f / (float)S;
+        A += (double)extra * (double)rS;
+        B += (double)extra * (double)((float)D * rS * rS);
+    }
+    // cells still on the open list: close their intervals at the final (A, B)
+    for (int i = lane; i < d.HW; i += 64) {
+        const float gi = st_ld<kGlobal>(&g[i]);
+        if (fabsf(gi) < NASTAR_POS_INF) {
+            const int ti = st_ld<kGlobal>(&t0[i]);
+            const double A0 = __hip_atomic_load(&hist[2 * ti], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double B0 = __hip_atomic_load(&hist[2 * ti + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ri = i / d.W, ci = i - ri * d.W;
+            const float hh = d.omg * (heuristic0_fast(ri, ci, goal_r, goal_c) + st_ld<kGlobal>(&cst[i]));
+            const float v = bwdr_v(d, gi, hh);
+            const float dA = (float)(A - A0), dB = (float)(B - B0);
+            unsafeAtomicAdd(&gout[i], (a.kfac * v) * (st_ld<kGlobal>(&G[i]) * dA - dB));
+        }
+    }
+}
+
+}  // namespace nastar

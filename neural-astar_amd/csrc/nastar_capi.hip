@@ -13,6 +13,7 @@
 #include "nastar_search_compact.hip.h"
 #include "nastar_search_duo.hip.h"
 #include "nastar_search_asm.hip.h"
+#include "nastar_backward_replay.hip.h"
 
 namespace nastar {
 
@@ -934,6 +935,72 @@ int nastar_backward_l1(const float* histories, const float* opt_trajs, const flo
     a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
     a.l1_scale = (float)(1.0 / ((double)B * H * W));
     return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
+}
+
+// ---- backward by replay of the forward's selection log (nastar_backward_replay.hip.h) ------------------------------------
+static int bwdr_hist_len(int HW, int max_iters) { return (max_iters < HW + 1 ? max_iters : HW + 1) + 2; }
+static bool bwdr_fits_lds(int HW) { return bwdr_state_bytes(((HW + 63) / 64) * 64) <= kMaxLdsBytes; }
+
+size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0 || (long long)H * W > 65535 - CCSZ) return 0;
+    const int HW = H * W, HWp = ((HW + 63) / 64) * 64;
+    size_t n = (size_t)B * (size_t)bwdr_hist_len(HW, max_iters) * 16;
+    if (!bwdr_fits_lds(HW)) n += (size_t)B * ((bwdr_state_bytes(HWp) + 255) & ~(size_t)255);
+    return n;
+}
+
+static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* start, const float* goal, const float* passable,
+                                const int32_t* sel_log, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
+                                const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cost || !start || !goal || !passable || !sel_log || !iters || !grad_cost_out || !workspace) return NASTAR_ERR_NULL;
+    int rc = make_cdims(B, H, W, max_iters, g_ratio, a.d);
+    if (rc) return rc;
+    if (workspace_bytes < nastar_backward_workspace_bytes(B, H, W, max_iters)) return NASTAR_ERR_WORKSPACE;
+    a.d.HWp = ((a.d.HW + 63) / 64) * 64;
+    a.cost = cost; a.start = start; a.goal = goal; a.passable = passable; a.sel_log = sel_log; a.iters = iters;
+    a.t_batch = t_batch_dev; a.grad_cost = grad_cost_out; a.max_iters = max_iters;
+    a.kfac = a.d.omg * (-1.0f / a.d.sqrtW);
+    a.hist = static_cast<double*>(workspace);
+    // the kernel indexes the history by step: a search executes at most HW + 1 selections whatever the budget
+    const int hlen = bwdr_hist_len(a.d.HW, max_iters);
+    a.max_iters = max_iters;
+    a.state = nullptr;
+    a.state_stride = 0;
+    a.hist_len = hlen;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (bwdr_fits_lds(a.d.HW)) return launch(nastar_backward_replay_kernel<false>, B, bwdr_state_bytes(a.d.HWp), s, a);
+    a.state_stride = (bwdr_state_bytes(a.d.HWp) + 255) & ~(size_t)255;
+    a.state = static_cast<unsigned char*>(workspace) + (size_t)B * (size_t)hlen * 16;
+    return launch(nastar_backward_replay_kernel<true>, B, 64, s, a);
+}
+
+int nastar_backward_replay(const float* grad_histories, const float* cost, const float* start, const float* goal,
+                           const float* passable, const int32_t* sel_log, int B, int H, int W, double g_ratio, int max_iters,
+                           const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
+                           size_t workspace_bytes, int flags, void* stream)
+{
+    (void)flags;
+    if (!grad_histories) return NASTAR_ERR_NULL;
+    BwdRArgs a;
+    a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
+    return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
+                                grad_cost_out, workspace, workspace_bytes, stream);
+}
+
+int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
+                              const float* start, const float* goal, const float* passable, const int32_t* sel_log, int B, int H,
+                              int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
+                              float* grad_cost_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!histories || !opt_trajs) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    BwdRArgs a;
+    a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
+    a.l1_scale = (float)(1.0 / ((double)B * H * W));
+    return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
+                                grad_cost_out, workspace, workspace_bytes, stream);
 }
 
 int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out, void* stream)

@@ -41,6 +41,9 @@ EXPORTED_SYMBOLS = (
     "nastar_forward_packed",
     "nastar_backward",
     "nastar_backward_l1",
+    "nastar_backward_workspace_bytes",
+    "nastar_backward_replay",
+    "nastar_backward_l1_replay",
     "nastar_l1_loss",
     "nastar_policy_rollout",
     "nastar_heuristic",
@@ -95,6 +98,12 @@ def load() -> ctypes.CDLL:
     lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_backward_l1.restype = ci
     lib.nastar_backward_l1.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp]
+    lib.nastar_backward_workspace_bytes.restype = cz
+    lib.nastar_backward_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_backward_replay.restype = ci
+    lib.nastar_backward_replay.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_backward_l1_replay.restype = ci
+    lib.nastar_backward_l1_replay.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, vp]
     lib.nastar_l1_loss.restype = ci
     lib.nastar_l1_loss.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, cz, vp]
     lib.nastar_policy_rollout.restype = ci

@@ -13,7 +13,7 @@ import torch
 
 from . import _native
 
-__all__ = ["astar_forward", "astar_backward", "astar_backward_l1", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
+__all__ = ["astar_forward", "astar_backward", "astar_backward_replay", "astar_backward_l1", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
 
 
 def max_iters_for(W: int, Tmax: float, training: bool) -> int:
@@ -34,6 +34,8 @@ def _require_device(*tensors: torch.Tensor) -> None:
 
 # development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
+# development knob: NASTAR_BACKWARD=reselect keeps the round-1 backward kernels (A/B measurements)
+BACKWARD_MODE = os.environ.get("NASTAR_BACKWARD", "replay")
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -106,23 +108,57 @@ def _(grad_hist, cost, start, goal, passable, g_ratio, max_iters, iters, t_batch
     return torch.empty_like(cost)
 
 
+@torch.library.custom_op("nastar::astar_backward_replay", mutates_args=())
+def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
+                          passable: torch.Tensor, sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
+                          t_batch: Optional[torch.Tensor]) -> torch.Tensor:
+    """dL/dcost by replaying the forward's selection log (csrc/nastar_backward_replay.hip.h): any map size the forward takes
+    up to 65519 cells, O(9) accounting work per step."""
+    _require_device(grad_hist, cost, start, goal, passable)
+    lib = _native.load()
+    grad_hist, cost, start, goal, passable, sel_log = (x.contiguous() for x in (grad_hist, cost, start, goal, passable, sel_log))
+    B, H, W = cost.shape
+    dev = cost.device
+    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    ws_bytes = int(lib.nastar_backward_workspace_bytes(B, H, W, int(max_iters)))
+    if ws_bytes == 0:
+        raise RuntimeError(f"nastar_backward_replay: unsupported map size {H}x{W}")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_backward_replay(grad_hist.data_ptr(), cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
+                                        passable.data_ptr(), sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters),
+                                        iters.data_ptr(), t_batch.data_ptr() if t_batch is not None else None,
+                                        grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, 0, _stream_ptr(dev))
+    _native.check(rc, "nastar_backward_replay")
+    return grad_cost
+
+
+@astar_backward_replay.register_fake
+def _(grad_hist, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch):
+    return torch.empty_like(cost)
+
+
 def _setup_context(ctx, inputs, output):
     cost, start, goal, passable, g_ratio, max_iters, _ = inputs
-    _, _, iters, _, _ = output
-    ctx.save_for_backward(cost, start, goal, passable, iters)
+    _, _, iters, _, sel_log = output
+    ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
     ctx.g_ratio = g_ratio
     ctx.max_iters = max_iters
 
 
 def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
-    cost, start, goal, passable, iters = ctx.saved_tensors
+    cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
     if g_hist is None:
         return None, None, None, None, None, None, None
     # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
     # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
     t_batch = BatchCoupling.t_batch(iters)
-    grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
-                                                ctx.max_iters, iters, t_batch)
+    if sel_log.numel() > 0 and BACKWARD_MODE != "reselect":  # the forward logged its selections: replay them
+        grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
+                                                           ctx.g_ratio, ctx.max_iters, iters, t_batch)
+    else:  # round-1 kernels: repeat the selection and sweep the open list every step (LDS-resident maps only)
+        grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
+                                                    ctx.max_iters, iters, t_batch)
     return grad_cost, None, None, None, None, None, None
 
 
@@ -198,24 +234,60 @@ def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, g_ratio, max
     return torch.empty_like(cost)
 
 
+@torch.library.custom_op("nastar::astar_backward_l1_replay", mutates_args=())
+def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, grad_loss: Optional[torch.Tensor],
+                             cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
+                             sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
+                             t_batch: Optional[torch.Tensor]) -> torch.Tensor:
+    """astar_backward_l1 through the replay kernel (the sign gradient is formed while loading)."""
+    _require_device(histories, opt_trajs, cost, start, goal, passable)
+    lib = _native.load()
+    histories, opt_trajs, cost, start, goal, passable, sel_log = (
+        x.contiguous() for x in (histories, opt_trajs, cost, start, goal, passable, sel_log))
+    B, H, W = cost.shape
+    dev = cost.device
+    gl = grad_loss.reshape(1).to(torch.float32).contiguous() if grad_loss is not None else None
+    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    ws_bytes = int(lib.nastar_backward_workspace_bytes(B, H, W, int(max_iters)))
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_backward_l1_replay(histories.data_ptr(), opt_trajs.data_ptr(), gl.data_ptr() if gl is not None else None,
+                                           cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(),
+                                           sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
+                                           t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(),
+                                           ws.data_ptr(), ws_bytes, _stream_ptr(dev))
+    _native.check(rc, "nastar_backward_l1_replay")
+    return grad_cost
+
+
+@astar_backward_l1_replay.register_fake
+def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch):
+    return torch.empty_like(cost)
+
+
 class _AstarL1Loss(torch.autograd.Function):
     """search + L1 loss as ONE autograd node: forward = nastar_forward + nastar_l1_loss, backward = nastar_backward_l1."""
 
     @staticmethod
     def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters):
         with torch.no_grad():
-            hist, paths, iters, status, _ = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, False)
+            want_log = BACKWARD_MODE != "reselect"
+            hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log)
             loss = torch.ops.nastar.l1_loss(hist, opt_trajs)
-        ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters)
+        ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(hist, paths, iters, status)
         return loss.reshape(()), hist, paths, iters, status
 
     @staticmethod
     def backward(ctx, g_loss, g_hist, g_paths, g_iters, g_status):
-        cost, start, goal, passable, opt_trajs, hist, iters = ctx.saved_tensors
-        grad_cost = torch.ops.nastar.astar_backward_l1(hist, opt_trajs, g_loss, cost, start, goal, passable, ctx.g_ratio,
-                                                       ctx.max_iters, iters, BatchCoupling.t_batch(iters))
+        cost, start, goal, passable, opt_trajs, hist, iters, sel_log = ctx.saved_tensors
+        if sel_log.numel() > 0:
+            grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
+                                                                  ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters))
+        else:
+            grad_cost = torch.ops.nastar.astar_backward_l1(hist, opt_trajs, g_loss, cost, start, goal, passable, ctx.g_ratio,
+                                                           ctx.max_iters, iters, BatchCoupling.t_batch(iters))
         return grad_cost, None, None, None, None, None, None
 
 

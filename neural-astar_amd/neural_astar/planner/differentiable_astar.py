@@ -67,8 +67,12 @@ class DifferentiableAstar(nn.Module):
         W = cost.shape[-1]
         max_iters = ops.max_iters_for(W, self.Tmax, self.training)
 
+        # the selection log doubles as the tape of the backward (replayed by nastar_backward_replay): keep it whenever
+        # autograd will need it
+        want_log = bool(store_intermediate_results) or (
+            torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
         hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
-            cost, start, goal, passable, float(self.g_ratio), max_iters, bool(store_intermediate_results))
+            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log)
         self.last_status, self.last_iters = status, iters
         if self.check_solvable and bool((status != 0).any()):
             bad = torch.nonzero(status != 0).flatten().tolist()

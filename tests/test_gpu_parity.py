@@ -65,10 +65,19 @@ def test_forward_matches_reference_golden(name):
             assert np.array_equal(log[b, :n], g.sel_log[b, :n])
 
 
+@pytest.mark.parametrize("mode", ["replay", "reselect"])
 @pytest.mark.parametrize("name", [n for n in G.names() if n.startswith("grad_")])
-def test_backward_matches_reference_autograd(name):
+def test_backward_matches_reference_autograd(name, mode, monkeypatch):
+    """dL/dcost of the reference's autograd (differentiable_astar.py:203-252) for every size class of the backward launchers:
+    32x32 (register kernel), 64x64 / 12x12 / 16x16 / 20x45 / 24x40 / 7x5 (generic kernels) and 96x96 / 100x100 (replay only:
+    the round-1 `reselect` kernels keep their state + three softmax arrays in LDS and stop at ~5.4 k cells).
+    replay = nastar_backward_replay (selection log + event accounting), reselect = nastar_backward (round 1)."""
+    from neural_astar import ops
     from neural_astar.planner.differentiable_astar import DifferentiableAstar
     g = G.load(name)
+    if mode == "reselect" and g.H * g.W > 5400:
+        pytest.skip("round-1 backward kernels: LDS-resident maps only")
+    monkeypatch.setattr(ops, "BACKWARD_MODE", mode)
     m = DifferentiableAstar(g_ratio=g.g_ratio, Tmax=g.Tmax).to(_dev())
     m.train(g.training)
     cost = _t(g.cost_maps).requires_grad_(True)
@@ -79,6 +88,25 @@ def test_backward_matches_reference_autograd(name):
     err = float(np.abs(got - g.grad_cost).max())
     assert err <= GRAD_TOL * scale, f"grad max abs err {err:.3e}"
     assert np.array_equal(out.histories.detach().cpu().numpy(), g.histories)
+
+
+def test_backward_replay_large_map_matches_oracle():
+    """Backward of a map whose state does not fit LDS (150x200 = 30 k cells: HBM-workspace state) against the oracle's literal
+    reverse-mode restatement, and the fused-L1 replay against autograd's L1Loss on the same maps."""
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    H, W, B = 150, 200, 2
+    pr = syn.random_obstacle_maps(B, H, W, 0.2, seed=15200)
+    cost_np = syn.random_costs(B, H, W, seed=15201)
+    up = np.random.Generator(np.random.PCG64(3)).standard_normal((B, 1, H, W)).astype(np.float32)
+    m = DifferentiableAstar(g_ratio=0.5, Tmax=1.0).to(_dev()).eval()
+    cost = _t(cost_np).requires_grad_(True)
+    out = m(cost, _t(pr.start_maps), _t(pr.goal_maps), _t(pr.map_designs))
+    (out.histories * _t(up)).sum().backward()
+    ref = O.backward(up, cost_np, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, W * W)
+    err = float(np.abs(cost.grad[:, 0].cpu().numpy() - ref).max())
+    assert err <= GRAD_TOL * max(1.0, float(np.abs(ref).max())), f"grad max abs err {err:.3e}"
 
 
 @pytest.mark.parametrize("H,W,B,p,gr,ucost", [

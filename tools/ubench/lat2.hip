@@ -77,6 +77,27 @@ __global__ void k_lds_wr_rd64(uint64_t* t, uint32_t* o)
     if (threadIdx.x == 0) t[0] = b - a;
     o[threadIdx.x] = (uint32_t)e;
 }
+
+// same-address LDS atomics: `nsame` lanes of row 1 hit one word, the other lanes are inactive; followed by a dependent read
+template <int NSAME>
+__global__ void k_lds_min64_same(uint64_t* t, uint32_t* o)
+{
+    __shared__ unsigned long long sm[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) sm[i] = ~0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long* base = sm + wv * 64;
+    unsigned long long e = ((unsigned long long)(lane * 7919u) << 32) | (unsigned)lane;
+    uint64_t a = __builtin_readcyclecounter();
+    for (int i = 0; i < N * 10; ++i) {
+        if (lane >= 16 && lane < 16 + NSAME) atomicMin(&base[5], e);
+        e += base[(lane + 1) & 63] & 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint64_t b = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) t[0] = b - a;
+    o[threadIdx.x] = (uint32_t)e;
+}
 // loop with a taken backward branch per iteration and a one-instruction body
 __global__ void k_loop(uint64_t* t, uint32_t* o, int n)
 {
@@ -130,6 +151,10 @@ int main()
     run("2x ds_read_b64 + 2 valu", k_lds_rd64x2, U);
     run("ds_min_u64 -> ds_read_b64", k_lds_min64_rd, U);
     run("ds_write_b64 -> ds_read_b64", k_lds_wr_rd64, U);
+    run("ds_min_u64 1 lane  -> read", k_lds_min64_same<1>, U);
+    run("ds_min_u64 4 same  -> read", k_lds_min64_same<4>, U);
+    run("ds_min_u64 8 same  -> read", k_lds_min64_same<8>, U);
+    run("ds_min_u64 16 same -> read", k_lds_min64_same<16>, U);
     printf("%-30s", "loop: s_add + taken branch");
     for (int k : waves) {
         uint64_t h = 0;
