@@ -70,16 +70,39 @@ __device__ __forceinline__ void st_st(T* p, T v)
     else *p = v;
 }
 
+template <bool kLds>
+__device__ __forceinline__ double hist_ld(const double* p)
+{
+    if constexpr (kLds) return *p;
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kLds>
+__device__ __forceinline__ void hist_st(double* p, double v)
+{
+    if constexpr (kLds) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // q = fl(f / fl32(sqrt(W))) of a cell with g-value G and hh = (1-g_ratio)(h0 + cost)   (:206-207); exp(-q) by v_exp_f32
-__device__ __forceinline__ float bwdr_v(const CompactDims& d, float G, float hh)
+template <bool kFastDiv>
+__device__ __forceinline__ float bwdr_v(const CompactDims& d, float G, float hh, float rcp_sqrtW)
 {
     const float f = d.gr * G + hh;
-    const float q = f / d.sqrtW;
+    float q;
+    if constexpr (kFastDiv) {  // correctly rounded f / sqrt(W) for the verified widths (tools/fastdiv_check.c)
+        const float q0 = f * rcp_sqrtW;
+        const float rem = __builtin_fmaf(-q0, d.sqrtW, f);
+        q = __builtin_fmaf(rem, rcp_sqrtW, q0);
+    } else {
+        q = f / d.sqrtW;
+    }
     return __builtin_amdgcn_exp2f(q * -1.4426950408889634f);
 }
 
-template <bool kGlobal>
-__global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a)
+// kHistLds: the (A, B) history lives in LDS behind the state (16 B per executed step): no global round trip inside the loop
+// (an HBM history costs a write-through store + a vmcnt(0) drain per step, ~1 us).  kFastDiv: see compact_key.
+template <bool kGlobal, bool kHistLds, bool kFastDiv>
+__global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -92,7 +115,8 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     unsigned short* t0 = reinterpret_cast<unsigned short*>(G + d.HWp);  // [HWp] history index at which the cell was (re)opened
     double* sd = reinterpret_cast<double*>(smem + (kGlobal ? 0 : (size_t)d.HWp * 14));  // S, D: always in LDS
     const size_t off = (size_t)b * (size_t)d.HW;
-    double* hist = a.hist + (size_t)b * (size_t)a.hist_len * 2;
+    static_assert(!(kGlobal && kHistLds), "a map too large for LDS keeps its history in the workspace as well");
+    double* hist = kHistLds ? reinterpret_cast<double*>(smem + (size_t)d.HWp * 14 + 16) : a.hist + (size_t)b * (size_t)a.hist_len * 2;
     float* gout = a.grad_cost + off;
 
     int sidx = -1, gidx = -1;
@@ -110,8 +134,8 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     if (lane == 0) {
         sd[0] = 0.0;
         sd[1] = 0.0;
-        __hip_atomic_store(&hist[0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hist[1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hist_st<kHistLds>(&hist[0], 0.0);
+        hist_st<kHistLds>(&hist[1], 0.0);
     }
     global_step_fence();  // the zeroed gradient and history entry 0 are in L2 before any atomic / load touches them
     wave_sync();
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         // open list = {start} (:187), g[start] = 0 (:193): the start is open from history index 0
         const int r = sidx / d.W, c = sidx - r * d.W;
         const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + st_ld<kGlobal>(&cst[sidx]));
-        const float v = bwdr_v(d, 0.0f, hh);
+        const float v = bwdr_v<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
         st_st<kGlobal>(&g[sidx], 0.0f);
         sd[0] = (double)v;
         sd[1] = (double)(st_ld<kGlobal>(&G[sidx]) * v);
@@ -153,16 +177,16 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     for (int t = 0; t < n_steps; ++t) {
         if ((t & 63) == 0) logv = (t + lane < n_steps) ? log[t + lane] : 0;
         const int s = __builtin_amdgcn_readlane(logv, t & 63);
-        // everything issued so far has landed: the history entry of the previous step, the loads of the pending intervals,
-        // and (kGlobal) the state stores of the previous step
-        global_step_fence();
+        // HBM history / state: everything issued so far has landed -- the history entry of the previous step, the loads of the
+        // pending intervals, the state stores of the previous step.  (LDS executes a wave's operations in order: nothing to do.)
+        if constexpr (kGlobal || !kHistLds) global_step_fence();
         if (pend) {
             const float dA = (float)(pA - pA0), dB = (float)(pB - pB0);
             unsafeAtomicAdd(&gout[pcell], (a.kfac * pv) * (pG * dA - dB));
         }
         // softmax of step t over the current open list: A += 1/S, B += D/S^2   (y_t = v/S, <G,y_t> = D/S)
         const double S = sd[0], D = sd[1];
-        const float rS = 1.0f / (float)S;
+        const float rS = __builtin_amdgcn_rcpf((float)S);
         A += (double)rS;
         B += (double)((float)D * rS * rS);
         const bool goal_step = s == gidx;
@@ -185,13 +209,15 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         const bool upd = inb & (gl > g2);
         const bool was_open = fabsf(gl) < NASTAR_POS_INF;
         const bool flushing = (upd & was_open) | ((lane == 8) & !goal_step);
-        const float v_old = bwdr_v(d, gl, hh);
-        const float v_new = bwdr_v(d, g2, hh);
+        const float v_old = bwdr_v<kFastDiv>(d, gl, hh, rcp_sqrtW);
+        const float v_new = bwdr_v<kFastDiv>(d, g2, hh, rcp_sqrtW);
         if (upd | flushing) {
             const double dS = (upd ? (double)v_new : 0.0) - (flushing ? (double)v_old : 0.0);
             const double dD = (upd ? (double)(Gl * v_new) : 0.0) - (flushing ? (double)(Gl * v_old) : 0.0);
-            atomicAdd(&sd[0], dS);
-            atomicAdd(&sd[1], dD);
+            // ds_add_f64 issued directly: for a wave-uniform address hipcc's atomic optimizer would first reduce the lanes in a
+            // scalar loop (one iteration per active lane); the LDS unit serialises the <= 9 same-address adds much faster
+            const uint32_t sda = (uint32_t)(uintptr_t)sd;
+            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:8" ::"v"(sda), "v"(dS), "v"(dD) : "memory");
         }
         if (upd) {
             st_st<kGlobal>(&g[il], g2);
@@ -199,8 +225,8 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         }
         if ((lane == 8) & !goal_step) st_st<kGlobal>(&g[s], NASTAR_NEG_INF);
         if (lane == 0) {  // history entry t+1 = (A, B) after step t
-            __hip_atomic_store(&hist[2 * (t + 1)], A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&hist[2 * (t + 1) + 1], B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hist_st<kHistLds>(&hist[2 * (t + 1)], A);
+            hist_st<kHistLds>(&hist[2 * (t + 1) + 1], B);
         }
         // close the interval of every cell that left the open list or was re-keyed: load its opening stamp, consume next step
         pend = flushing;
@@ -210,8 +236,8 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         pA = A;
         pB = B;
         if (flushing) {
-            pA0 = __hip_atomic_load(&hist[2 * tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pB0 = __hip_atomic_load(&hist[2 * tl + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pA0 = hist_ld<kHistLds>(&hist[2 * tl]);
+            pB0 = hist_ld<kHistLds>(&hist[2 * tl + 1]);
         }
         wave_order();
         if (goal_step) {  // extra > 0: `extra` more identical steps on the open list left by the goal's own expansion
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     wave_sync();
     if (goal_fixed_point) {
         const double S = sd[0], D = sd[1];
-        const float rS = 1.0f / (float)S;
+        const float rS = __builtin_amdgcn_rcpf((float)S);
         A += (double)extra * (double)rS;
         B += (double)extra * (double)((float)D * rS * rS);
     }
@@ -236,11 +262,11 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         const float gi = st_ld<kGlobal>(&g[i]);
         if (fabsf(gi) < NASTAR_POS_INF) {
             const int ti = st_ld<kGlobal>(&t0[i]);
-            const double A0 = __hip_atomic_load(&hist[2 * ti], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double B0 = __hip_atomic_load(&hist[2 * ti + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double A0 = hist_ld<kHistLds>(&hist[2 * ti]);
+            const double B0 = hist_ld<kHistLds>(&hist[2 * ti + 1]);
             const int ri = i / d.W, ci = i - ri * d.W;
             const float hh = d.omg * (heuristic0_fast(ri, ci, goal_r, goal_c) + st_ld<kGlobal>(&cst[i]));
-            const float v = bwdr_v(d, gi, hh);
+            const float v = bwdr_v<kFastDiv>(d, gi, hh, rcp_sqrtW);
             const float dA = (float)(A - A0), dB = (float)(B - B0);
             unsafeAtomicAdd(&gout[i], (a.kfac * v) * (st_ld<kGlobal>(&G[i]) * dA - dB));
         }

@@ -970,10 +970,21 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
     a.state_stride = 0;
     a.hist_len = hlen;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (bwdr_fits_lds(a.d.HW)) return launch(nastar_backward_replay_kernel<false>, B, bwdr_state_bytes(a.d.HWp), s, a);
+    const float rcp = 1.0f / a.d.sqrtW;
+    const bool fast = fastdiv_verified(W);
+    if (bwdr_fits_lds(a.d.HW)) {
+        // history in LDS as long as at least 2 maps (or what the state alone allows) stay resident per CU
+        const size_t st = bwdr_state_bytes(a.d.HWp), with_hist = st + (size_t)hlen * 16;
+        const bool hist_lds = with_hist <= kMaxLdsBytes && (kMaxLdsBytes / with_hist >= 2 || kMaxLdsBytes / st < 2);
+        if (hist_lds) return fast ? launch(nastar_backward_replay_kernel<false, true, true>, B, with_hist, s, a, rcp)
+                                  : launch(nastar_backward_replay_kernel<false, true, false>, B, with_hist, s, a, rcp);
+        return fast ? launch(nastar_backward_replay_kernel<false, false, true>, B, st, s, a, rcp)
+                    : launch(nastar_backward_replay_kernel<false, false, false>, B, st, s, a, rcp);
+    }
     a.state_stride = (bwdr_state_bytes(a.d.HWp) + 255) & ~(size_t)255;
     a.state = static_cast<unsigned char*>(workspace) + (size_t)B * (size_t)hlen * 16;
-    return launch(nastar_backward_replay_kernel<true>, B, 64, s, a);
+    return fast ? launch(nastar_backward_replay_kernel<true, false, true>, B, 64, s, a, rcp)
+                : launch(nastar_backward_replay_kernel<true, false, false>, B, 64, s, a, rcp);
 }
 
 int nastar_backward_replay(const float* grad_histories, const float* cost, const float* start, const float* goal,
