@@ -30,11 +30,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-H = W = 32
+H = W = 32  # headline workload; `Runner` carries the size of whatever workload it was given
 B_PER_GPU = 4096
 G_RATIO = 0.5
 BYTES_PER_MAP = 28 * H * W  # reads cost+start+goal+passable (4x4 B/cell), writes fp32 hist + int64 paths
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_ROTATE = 3  # distinct input/output batch sets cycled by the timed loop: 3 x 100 MB > the 256 MB MALL, so HBM is what is read
 
 
 def make_problem(kind: str, B: int, seed: int):
@@ -58,26 +59,58 @@ def make_problem(kind: str, B: int, seed: int):
     return pr
 
 
-class Runner:
-    """Device-resident inputs + preallocated outputs; step() = one nastar_forward launch on torch's current stream."""
+def make_problem_rows(kind: str, total: int, seed: int, rows: np.ndarray):
+    """Rows `rows` of a `total`-map global batch that is defined chunk-wise (1024 maps per chunk, chunk c seeded from (seed, c)),
+    so that a rank only synthesises the chunks its shard touches and every N sees the same global batch."""
+    from neural_astar.utils import synthetic as syn
+    CH = 1024
+    rows = np.asarray(rows)
+    assert (np.diff(rows) > 0).all(), "rows must be ascending"
+    parts = []
+    for c in np.unique(rows // CH):
+        n = min(CH, total - int(c) * CH)
+        pr = make_problem(kind, n, seed=seed * 100003 + int(c))
+        sel = rows[(rows // CH) == c] - int(c) * CH
+        parts.append(tuple(x[sel] for x in pr))
+    return syn.Problems(*(np.concatenate([p[k] for p in parts]) for k in range(3)))
 
-    def __init__(self, pr, dev, g_ratio=G_RATIO, max_iters=None):
+
+class Runner:
+    """Device-resident inputs + preallocated outputs; step() = one nastar_forward launch on torch's current stream.
+
+    `prs` may be a list of problem sets (same shape): step i works on set i % len(prs), each with its own input AND output
+    buffers, so consecutive timed steps do not re-read a cache-resident batch (>256 MB in rotation)."""
+
+    def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None):
         from neural_astar import _native
         self.lib = _native.load()
         self._check = _native.check
         self.dev = dev
-        self.m = torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous()
-        self.s = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
-        self.g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
-        self.B, self.H, self.W = self.m.shape
+        if not isinstance(prs, (list, tuple)) or hasattr(prs, "map_designs"):
+            prs = [prs]
+        self.sets = []
+        for pr in prs:
+            m = torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous()
+            st = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
+            g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
+            B, Hh, Ww = m.shape
+            self.sets.append(dict(m=m, s=st, g=g,
+                                  hist=torch.empty((B, Hh, Ww), dtype=torch.float32, device=dev),
+                                  paths=torch.empty((B, Hh, Ww), dtype=torch.int64, device=dev),
+                                  iters=torch.empty((B,), dtype=torch.int32, device=dev),
+                                  status=torch.empty((B,), dtype=torch.int32, device=dev)))
+        self.B, self.H, self.W = self.sets[0]["m"].shape
         self.g_ratio = float(g_ratio)
         self.max_iters = int(max_iters) if max_iters is not None else self.W * self.W  # eval mode: search to the goal
-        self.hist = torch.empty((self.B, self.H, self.W), dtype=torch.float32, device=dev)
-        self.paths = torch.empty((self.B, self.H, self.W), dtype=torch.int64, device=dev)
-        self.iters = torch.empty((self.B,), dtype=torch.int32, device=dev)
-        self.status = torch.empty((self.B,), dtype=torch.int32, device=dev)
         self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))  # dev A/B switch (include/nastar.h NASTAR_FLAG_*)
         self.packed = None  # set by enable_packed(): the step then also emits the bit-packed masks (all-gather payload)
+        self._i = 0
+        self._bind(0)
+
+    def _bind(self, k):
+        z = self.sets[k]
+        self.m, self.s, self.g = z["m"], z["s"], z["g"]
+        self.hist, self.paths, self.iters, self.status = z["hist"], z["paths"], z["iters"], z["status"]
 
     def enable_packed(self):
         nb = (self.H * self.W + 7) // 8
@@ -85,6 +118,8 @@ class Runner:
         self._pk = 0
 
     def step(self):
+        self._bind(self._i % len(self.sets))
+        self._i += 1
         if self.packed is not None:
             self._pk ^= 1  # double buffer: the previous step's payload may still be in flight in the all-gather
             rc = self.lib.nastar_forward_packed(
@@ -187,19 +222,26 @@ def training_step_ms(pr, dev, reps=10):
     gh = torch.randn_like(hist)
     tb = (iters.amax() - 1).to(torch.int32).reshape(1)
 
-    def once():
+    def replay():  # round 2: the forward logs its selections, the backward replays them (nastar_backward_replay)
+        h, _, it, _, log = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, True)
+        torch.ops.nastar.astar_backward_replay(gh, cost, s, g, m, log, G_RATIO, mi, it, tb)
+
+    def reselect():  # round 1 kernels
         h, _, it, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
         torch.ops.nastar.astar_backward(gh, cost, s, g, m, G_RATIO, mi, it, tb)
-    for _ in range(2):
-        once()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        once()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / reps
+    out = {}
+    for name, once in (("replay_ms", replay), ("round1_reselect_ms", reselect)):
+        for _ in range(2):
+            once()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            once()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = e0.elapsed_time(e1) / reps
+    return out
 
 
 def l1_training_step_ms(pr, dev, batch, reps=20):
@@ -355,21 +397,31 @@ def kernel_launch_ms(run, steps, dev):
     return sum(d) / len(d), d[len(d) // 2], d[0]
 
 
-def cpu_baseline(pr, gpu_hist, gpu_paths):
+def oracle_check(pr, gpu_hist, gpu_paths, n, g_ratio=G_RATIO):
+    """Parity of the first n maps of a bench batch against the CPU oracle (the checker, never the thing measured)."""
+    from oracle import oracle as O
+    O.build()
+    Ww = pr.map_designs.shape[-1]
+    o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], g_ratio, Ww * Ww)
+    return bool(np.array_equal(o.histories, gpu_hist[:n]) and np.array_equal(o.paths, gpu_paths[:n]))
+
+
+def cpu_baseline_port(pr, gpu_hist, gpu_paths):
     """Time the CPU oracle (literal C port of the reference's tensor program, OpenMP over maps) on a bounded sample
     of the SAME workload, and use its outputs to parity-check the GPU results of those maps."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     O.build()
+    Ww = pr.map_designs.shape[-1]
     n0 = min(512, pr.map_designs.shape[0])
-    O.forward(pr.map_designs[:8], pr.start_maps[:8], pr.goal_maps[:8], pr.map_designs[:8], G_RATIO, W * W)  # spin up the OpenMP team
+    O.forward(pr.map_designs[:8], pr.start_maps[:8], pr.goal_maps[:8], pr.map_designs[:8], G_RATIO, Ww * Ww)  # spin up the OpenMP team
     t0 = time.perf_counter()
-    O.forward(pr.map_designs[:n0], pr.start_maps[:n0], pr.goal_maps[:n0], pr.map_designs[:n0], G_RATIO, W * W)
+    O.forward(pr.map_designs[:n0], pr.start_maps[:n0], pr.goal_maps[:n0], pr.map_designs[:n0], G_RATIO, Ww * Ww)
     rate0 = n0 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 15.0)))  # aim at ~15 s of CPU work (bounded by the batch)
+    n = int(min(pr.map_designs.shape[0], max(n0, rate0 * 10.0)))  # aim at ~10 s of CPU work (bounded by the batch)
     t0 = time.perf_counter()
-    o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], G_RATIO, W * W)
+    o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], G_RATIO, Ww * Ww)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(o.histories, gpu_hist[:n]) and np.array_equal(o.paths, gpu_paths[:n]))
     return {"value": n / dt, "unit": "maps/s", "cores": cores, "kind": "port",
@@ -377,12 +429,92 @@ def cpu_baseline(pr, gpu_hist, gpu_paths):
             "gpu_matches_oracle_on_sample": ok}
 
 
+REF_STAGED = os.path.join(ROOT, "oracle", "_ref", "differentiable_astar.py")
+
+
+def cpu_baseline_reference(pr, gpu_hist, gpu_paths):
+    """The reference's OWN DifferentiableAstar.forward() (eval mode, no_grad) on this box's host cores: the module file staged
+    into the git-ignored oracle/_ref/ by `__graft_entry__.build()` in the authoring container (it is torch-only and travels with
+    gpurun like a built .so; /root/reference itself is never read here).  Bounded sample: whole-batch calls of growing size until
+    ~15 s are spent; torch.set_num_threads(cores)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_differentiable_astar", REF_STAGED)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    planner = ref.DifferentiableAstar(g_ratio=G_RATIO, Tmax=1.0).eval()
+    best = None
+    with torch.no_grad():
+        n = 64
+        spent = 0.0
+        while True:
+            n = min(n, pr.map_designs.shape[0])
+            m, s_, g = (torch.from_numpy(x[:n]) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+            t0 = time.perf_counter()
+            out = planner(m, s_, g, m)
+            dt = time.perf_counter() - t0
+            spent += dt
+            ok = bool(np.array_equal(out.histories[:, 0].numpy(), gpu_hist[:n]) and np.array_equal(out.paths[:, 0].numpy(), gpu_paths[:n]))
+            if best is None or n / dt > best[0]:
+                best = (n / dt, n, dt, ok)
+            if n >= pr.map_designs.shape[0] or spent + 4 * dt > 15.0:
+                break
+            n *= 4
+    rate, n, dt, ok = best
+    return {"value": rate, "unit": "maps/s", "cores": cores, "kind": "reference",
+            "sample": f"reference DifferentiableAstar.forward (torch {torch.__version__} CPU, {cores} threads, eval, no_grad) on the first "
+                      f"{n} maps of the bench batch in one call, {dt:.2f} s (best of the growing-batch calls that fit ~15 s)",
+            "gpu_matches_reference_on_sample": ok}
+
+
+def cpu_baseline(pr, gpu_hist, gpu_paths):
+    port = cpu_baseline_port(pr, gpu_hist, gpu_paths)
+    if os.path.exists(REF_STAGED):
+        try:
+            ref = cpu_baseline_reference(pr, gpu_hist, gpu_paths)
+            ref["port"] = port
+            ref["gpu_matches_oracle_on_sample"] = port["gpu_matches_oracle_on_sample"]
+            return ref
+        except Exception as e:  # reported, not hidden
+            port["reference_error"] = f"{type(e).__name__}: {e}"
+    return port
+
+
+def through_module_ms(pr, dev, reps=30):
+    """End to end through the drop-in boundary: ms per VanillaAstar.forward() call on the bench batch -- torch custom-op
+    dispatch, output allocation, the launch, and (check_solvable=True, the default) one device->host status sync per call."""
+    from neural_astar.planner import VanillaAstar
+    m, s_, g = (torch.from_numpy(x).to(dev) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    out = {}
+    for label, chk in (("check_solvable_true", True), ("check_solvable_false", False)):
+        va = VanillaAstar().to(dev).eval()
+        va.astar.check_solvable = chk
+        with torch.no_grad():
+            for _ in range(3):
+                va(m, s_, g)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                va(m, s_, g)
+            torch.cuda.synchronize(dev)
+        out[label] = (time.perf_counter() - t0) / reps * 1e3
+    out["unit"] = "ms per VanillaAstar.forward() call, wall clock, same input batch each call"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="maze32", choices=["maze32", "rand32"])
+    ap.add_argument("--workload", default="maze32", choices=["maze32", "rand32", "rand64"],
+                    help="maze32 = BASELINE config 2 (headline); rand64 = the 64x64 maps of config 4")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many maps in total, global_batch/N rows per rank (config 4: --workload rand64 "
+                         "--global-batch 32768); default 0 = weak scaling, 4096 maps per GPU")
+    ap.add_argument("--shard", default="contiguous", choices=["contiguous", "interleaved"],
+                    help="strong scaling: which rows a rank owns (parallel.shard_rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (clean kernel profiles)")
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
@@ -413,8 +545,21 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    pr = make_problem(args.workload, B_PER_GPU, seed=1234 + rank)
-    run = Runner(pr, dev)
+    strong = args.global_batch > 0
+    if strong:
+        # strong scaling: ONE global batch (seeded independently of N), every rank searches its rows of it
+        from neural_astar import parallel as _par
+        assert args.global_batch % n_gpus == 0, "--global-batch must be a multiple of the number of GPUs"
+        b_rank = args.global_batch // n_gpus
+        rows = _par.shard_rows(args.global_batch, n_gpus, rank, args.shard).numpy()
+        prs = [make_problem_rows(args.workload, args.global_batch, 1234 + 1000 * k, rows) for k in range(N_ROTATE)]
+    else:
+        b_rank = B_PER_GPU
+        prs = [make_problem(args.workload, B_PER_GPU, seed=1234 + rank + 1000 * k) for k in range(N_ROTATE)]
+    pr = prs[0]
+    run = Runner(prs, dev)
+    Hh, Ww = run.H, run.W
+    bytes_per_map = 28 * Hh * Ww
 
     collate = None
     collate_note = "n/a (single GPU)"
@@ -440,16 +585,17 @@ def main():
             collate_note = f"FAILED ({type(e).__name__}: {e}); steps timed without the all-gather"
 
     dt, dev_ms = timed_loop(run, args.steps, args.warmup, world, dev, collate)
-    total_maps = n_gpus * B_PER_GPU * args.steps
+    total_maps = n_gpus * b_rank * args.steps
     value = total_maps / dt
 
     if rank == 0:
+        run._bind(0)
         hist = run.hist.cpu().numpy()
         paths = run.paths.cpu().numpy()
-        iters = run.iters.cpu().numpy()
-        assert int(run.status.abs().sum().item()) == 0, "unsolvable map in the synthetic batch"
+        iters = torch.cat([z["iters"] for z in run.sets]).cpu().numpy()
+        assert all(int(z["status"].abs().sum().item()) == 0 for z in run.sets), "unsolvable map in the synthetic batch"
         avg_ms, med_ms, min_ms = kernel_launch_ms(run, min(args.steps, 100), dev)
-        achieved = BYTES_PER_MAP * B_PER_GPU / (avg_ms * 1e-3) / 1e9
+        achieved = bytes_per_map * b_rank / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
@@ -457,53 +603,61 @@ def main():
                 tj = json.load(f)
             traffic = tj.get(args.workload, {}).get("bytes_per_launch")
         out = {
-            "metric": "map-instances/s (forward A*) 32x32 Moore-8 @batch 4096",
+            "metric": f"map-instances/s (forward A*) {Hh}x{Ww} Moore-8 @batch {b_rank * n_gpus if strong else B_PER_GPU}",
             "value": value, "unit": "maps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {B_PER_GPU} maps/GPU of 32x32 Moore-8, cost=map (VanillaAstar), "
-                                   f"g_ratio={G_RATIO}, eval mode (search to goal), seed 1234+rank",
-                       "batch_per_gpu": B_PER_GPU, "global_batch": n_gpus * B_PER_GPU, "H": H, "W": W,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {b_rank} maps/GPU of {Hh}x{Ww} Moore-8, cost=map (VanillaAstar), "
+                                   f"g_ratio={G_RATIO}, eval mode (search to goal), {N_ROTATE} distinct batch sets in rotation "
+                                   f"({N_ROTATE * 25 * Hh * Ww * b_rank / 1e6:.0f} MB of inputs+outputs per GPU), "
+                                   + (f"global batch {args.global_batch} seeded 1234+1000k, {args.shard} shards"
+                                      if strong else "seeds 1234+rank+1000k"),
+                       "batch_per_gpu": b_rank, "global_batch": n_gpus * b_rank, "H": Hh, "W": Ww,
                        "parallelism": f"shard{n_gpus}" if n_gpus > 1 else "single", "collate": collate_note},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nastar_forward_kernel<vec4,single-chunk>",
-                         "algorithmic_bytes_per_launch": BYTES_PER_MAP * B_PER_GPU,
+                         "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop for 32x32)",
+                         "algorithmic_bytes_per_launch": bytes_per_map * b_rank,
                          "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms},
-            "expansions_per_s": float(iters.sum()) * n_gpus * args.steps / dt,
+            "expansions_per_s": float(iters.sum()) / len(run.sets) * n_gpus * args.steps / dt,
             "mean_iters_per_map": float(iters.mean()), "max_iters_per_map": int(iters.max()),
             "device_ms_per_step": dev_ms / args.steps,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pr, hist, paths)
+            out["through_module"] = through_module_ms(pr, dev)
         if n_gpus == 1 and not args.no_secondary:
             # secondary workloads on the same GPU (not the headline): short searches and the 64x64 shard of config 4
             sec = []
             for other in ("maze32", "rand32", "rand64"):
                 if other == args.workload:
                     continue
-                run2 = Runner(make_problem(other, B_PER_GPU, seed=1234), dev)
+                pr2 = make_problem(other, B_PER_GPU, seed=1234)
+                run2 = Runner(pr2, dev)
                 dt2, _ = timed_loop(run2, max(10, args.steps // 4), max(2, args.warmup // 4), 1, dev)
                 a2, _, _ = kernel_launch_ms(run2, max(10, min(args.steps // 4, 50)), dev)
                 nbytes = 28 * run2.H * run2.W * B_PER_GPU
                 sec.append({"workload": f"{other}: {B_PER_GPU} maps of {run2.H}x{run2.W}", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
                             "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "mean_iters_per_map": float(run2.iters.float().mean().item()),
-                            "max_iters_per_map": int(run2.iters.max().item())})
-                del run2
+                            "max_iters_per_map": int(run2.iters.max().item()),
+                            "gpu_matches_oracle_on_sample": oracle_check(pr2, run2.hist.cpu().numpy(), run2.paths.cpu().numpy(), 256),
+                            "oracle_sample": "first 256 maps"})
+                del run2, pr2
             # the two other readings of BASELINE.json's "tau = 0.25" (SURVEY.md section 0.3): training-mode budget Tmax = 0.25
             # (searches truncated after 256 selections) and g_ratio = 0.8, on the headline maze batch
-            for label, kw in (("maze32, training-mode budget Tmax=0.25 (max 256 steps)", {"max_iters": int(0.25 * W * W)}),
-                              ("maze32, g_ratio=0.8 (eval mode)", {"g_ratio": 0.8})):
+            for label, kw in ((("maze32, training-mode budget Tmax=0.25 (max 256 steps)", {"max_iters": int(0.25 * W * W)}),
+                               ("maze32, g_ratio=0.8 (eval mode)", {"g_ratio": 0.8})) if args.workload == "maze32" and not strong else ()):
                 run2 = Runner(pr, dev, **kw)
                 dt2, _ = timed_loop(run2, max(10, args.steps // 4), max(2, args.warmup // 4), 1, dev)
                 a2, _, _ = kernel_launch_ms(run2, max(10, min(args.steps // 4, 50)), dev)
                 sec.append({"workload": f"{label}: {B_PER_GPU} maps of 32x32", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
-                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": BYTES_PER_MAP * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": bytes_per_map * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "mean_iters_per_map": float(run2.iters.float().mean().item()),
                             "max_iters_per_map": int(run2.iters.max().item())})
                 del run2
             out["secondary"] = sec
+        if n_gpus == 1 and not args.no_secondary and Hh == 32 and Ww == 32 and not strong:
             out["extra"] = {"neural_astar_cnn_hip_bf16": neural_astar_forward_ms(pr, dev),
                             "neural_astar_cnn_hip_f16x3": neural_astar_f16x3_ms(pr, dev),
                             "train_fwd_bwd_ms_per_4096_maps_Tmax025": training_step_ms(pr, dev),

@@ -80,7 +80,9 @@ class HipCnnEncoder:
 
     def _refresh(self) -> None:
         layers = list(self.cnn.model)
-        key = tuple(int(p._version) for p in self.cnn.parameters()) + tuple(int(b._version) for b in self.cnn.buffers())
+        # version counters miss module.to(device) / .half() / .float() / `param.data = ...`: key on storage, device and dtype too
+        key = tuple((int(t._version), t.data_ptr(), str(t.device), t.dtype)
+                    for t in list(self.cnn.parameters()) + list(self.cnn.buffers()))
         if key == self._key:
             return
         self.wpack: List[torch.Tensor] = []

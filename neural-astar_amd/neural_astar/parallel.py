@@ -29,6 +29,30 @@ def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def shard_rows(n: int, world_size: int, rank: int, mode: str = "contiguous") -> torch.Tensor:
+    """Row indices (ascending, int64) of the global batch that rank ``rank`` plans.
+
+    ``contiguous``: the block of :func:`shard_bounds`.  ``interleaved``: rows ``b`` with ``b % world_size == rank`` -- searches
+    differ 10-100x in length (SURVEY.md section 8e caveat 2) and batches are often ordered (by dataset file, by difficulty), so
+    striding the rows spreads long searches over the ranks instead of handing one rank a hard block; it costs nothing, the
+    collated order is restored by :func:`collated_order`."""
+    if mode == "contiguous":
+        lo, hi = shard_bounds(n, world_size, rank)
+        return torch.arange(lo, hi, dtype=torch.int64)
+    if mode == "interleaved":
+        return torch.arange(rank, n, world_size, dtype=torch.int64)
+    raise ValueError(f"unknown sharding mode {mode!r}")
+
+
+def collated_order(n: int, world_size: int, mode: str = "contiguous") -> torch.Tensor:
+    """Permutation ``perm`` such that ``gathered[perm]`` is the global batch in its original row order, where ``gathered`` is
+    the rank-major concatenation an all-gather of the per-rank shards produces.  Requires equal shard sizes."""
+    rows = torch.cat([shard_rows(n, world_size, r, mode) for r in range(world_size)])
+    perm = torch.empty_like(rows)
+    perm[rows] = torch.arange(rows.numel(), dtype=torch.int64)
+    return perm
+
+
 def pack_masks(histories: torch.Tensor, paths: torch.Tensor) -> torch.Tensor:
     """[B,1,H,W] fp32 0/1 + [B,1,H,W] int64 0/1 -> [B, 2*ceil(HW/8)] uint8 (histories bits, then path bits).
 
@@ -85,18 +109,33 @@ def unpack_masks(packed: torch.Tensor, H: int, W: int) -> Tuple[torch.Tensor, to
     return un(packed[:, :nb]).to(torch.float32), un(packed[:, nb:]).to(torch.int64)
 
 
+def _equal_shards(n_local: int, group: Optional[dist.ProcessGroup], device: torch.device) -> None:
+    """all_gather_into_tensor needs the same number of rows on every rank (a ragged last DataLoader batch or n % world != 0
+    would otherwise end in an RCCL error or a hang): check it with one tiny all-reduce and fail with a clear message."""
+    t = torch.tensor([n_local, -n_local], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t[0]) != -int(t[1]):
+        raise ValueError(f"sharded collation needs equally sized shards on every rank: this rank has {n_local} rows, the "
+                         f"group has between {-int(t[1])} and {int(t[0])}; pad the batch or drop the ragged tail")
+
+
 def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = None,
-                      async_op: bool = False, unpack: bool = True):
+                      async_op: bool = False, unpack: bool = True, order: Optional[torch.Tensor] = None,
+                      check_sizes: bool = True):
     """Collate the per-rank ``AstarOutput`` of equally sized shards with ONE all-gather (RCCL on GPUs).
 
-    Returns ``AstarOutput`` of the full batch (rank-major row order), or, with ``async_op=True``, a tuple
-    ``(work, finish)`` where ``finish()`` waits and returns the collated output -- lets the caller overlap the
-    collective with the next batch's search on the compute stream.  ``unpack=False`` keeps the collated batch in its
-    bit-packed form (``[world*B, 2*ceil(HW/8)] uint8``; :func:`unpack_masks` materialises the reference's fp32 / int64
-    tensors on demand): expanding 2 bits per cell to 12 bytes per cell for the whole global batch on every rank is the
-    expensive part of the collation and few consumers need it."""
+    Returns ``AstarOutput`` of the full batch (rank-major row order, or the original order when ``order`` =
+    :func:`collated_order` is given), or, with ``async_op=True``, a tuple ``(work, finish)`` where ``finish()`` waits and
+    returns the collated output -- lets the caller overlap the collective with the next batch's search on the compute stream.
+    ``unpack=False`` keeps the collated batch in its bit-packed form (``[world*B, 2*ceil(HW/8)] uint8``;
+    :func:`unpack_masks` materialises the reference's fp32 / int64 tensors on demand): expanding 2 bits per cell to 12 bytes
+    per cell for the whole global batch on every rank is the expensive part of the collation and few consumers need it.
+    The collated output carries no autograd graph (masks only) and, like the differentiable path of the reference, an empty
+    ``intermediate_results`` list."""
     H, W = out.histories.shape[-2:]
     packed = pack_masks(out.histories.detach(), out.paths)
+    if check_sizes:
+        _equal_shards(packed.shape[0], group, packed.device)
     world = dist.get_world_size(group)
     gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.uint8, device=packed.device)
     work = dist.all_gather_into_tensor(gathered, packed, group=group, async_op=async_op)
@@ -104,10 +143,11 @@ def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = Non
     def finish():
         if work is not None:
             work.wait()
+        g = gathered if order is None else gathered[order.to(gathered.device)]
         if not unpack:
-            return gathered
-        h, p = unpack_masks(gathered, H, W)
-        return AstarOutput(h, p, None)
+            return g
+        h, p = unpack_masks(g, H, W)
+        return AstarOutput(h, p, [])
 
     if async_op:
         return work, finish
@@ -143,20 +183,31 @@ def global_t_batch(group: Optional[dist.ProcessGroup] = None):
 
 
 class ShardedPlanner(torch.nn.Module):
-    """Wraps a planner (``VanillaAstar`` / ``NeuralAstar``): each rank plans ITS rows of the batch; ``gather=True``
-    collates the full-batch output on every rank with one all-gather.
+    """Wraps a planner (``VanillaAstar`` / ``NeuralAstar``): each rank plans ITS rows of the batch; in eval mode the full-batch
+    output is collated on every rank with one all-gather.
 
-    ``forward`` takes the rank-local shard (the usual data-parallel convention: every rank's DataLoader yields its
-    own rows)."""
+    ``forward`` takes the rank-local shard (the usual data-parallel convention: every rank's DataLoader yields its own rows;
+    :func:`shard_rows` says which rows of a global batch those are for ``sharding`` = "contiguous" | "interleaved").
+    ``gather``: True / False, or None (default) = collate only when not training -- the collated output is a pair of masks
+    without an autograd graph, so a training step keeps the local rows (whose ``histories`` carry the gradient) and lets the
+    data-parallel wrapper all-reduce parameter gradients.  ``global_batch`` (rows of the whole batch) restores the original row
+    order after an interleaved gather."""
 
-    def __init__(self, planner: torch.nn.Module, group: Optional[dist.ProcessGroup] = None, gather: bool = True):
+    def __init__(self, planner: torch.nn.Module, group: Optional[dist.ProcessGroup] = None, gather: Optional[bool] = None,
+                 sharding: str = "contiguous"):
         super().__init__()
         self.planner = planner
         self.group = group
         self.gather = gather
+        self.sharding = sharding
 
     def forward(self, map_designs, start_maps, goal_maps, store_intermediate_results: bool = False) -> AstarOutput:
         out = self.planner(map_designs, start_maps, goal_maps, store_intermediate_results)
-        if not self.gather or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        gather = (not self.training) if self.gather is None else self.gather
+        if not gather or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return out
-        return all_gather_output(out, self.group)
+        world = dist.get_world_size(self.group)
+        order = None
+        if self.sharding != "contiguous":
+            order = collated_order(world * out.histories.shape[0], world, self.sharding)
+        return all_gather_output(out, self.group, order=order)

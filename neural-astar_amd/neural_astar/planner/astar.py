@@ -2,7 +2,12 @@
 
 Same constructors, attributes (``astar``, ``encoder``, ``g_ratio``, ``encode``, ``perform_astar``) and state-dict
 keys (``astar.neighbor_filter``, ``encoder.model.<n>.*``) as the reference (astar.py:17-46,105-152), so
-``scripts/train.py``, ``scripts/create_gif.py`` and ``utils/training.py`` run unchanged against this package.
+``scripts/train.py`` and ``utils/training.py`` run unchanged against this package.
+
+Not drop-in (by design): ``use_differentiable_astar=False`` (the reference's CPU ``pq_astar``, a
+different algorithm; the reference's own ``tests/astar_test.py::test_pq_astar`` therefore needs the reference package) raises;
+CPU tensors raise (no CPU fallback), so ``scripts/create_gif.py``, which never moves the planner or its data to a device, needs
+a one-line ``.cuda()`` on both to run.
 """
 from __future__ import annotations
 
@@ -11,6 +16,13 @@ import torch.nn as nn
 
 from . import encoder
 from .differentiable_astar import AstarOutput, DifferentiableAstar
+
+
+def _is_depth4_cnn(enc: nn.Module) -> bool:
+    """The HIP encoder kernels implement the reference's default depth-4 CNN (.. -> 32 -> 64 -> 128 -> 256 -> 1) only; any other
+    depth keeps the torch encoder."""
+    convs = [m for m in enc.model if isinstance(m, nn.Conv2d)]
+    return [c.out_channels for c in convs] == [32, 64, 128, 256, 1] and convs[0].in_channels <= 16
 
 
 class VanillaAstar(nn.Module):
@@ -73,7 +85,8 @@ class NeuralAstar(VanillaAstar):
         if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % tile == 0 and map_designs.shape[-1] % 32 == 0
-                and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)):
+                and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
+                and _is_depth4_cnn(self.encoder)):
             precision = self.encoder_backend[4:]
             if self._hip_encoder is None or self._hip_encoder.precision != precision:
                 from ..encoder_hip import HipCnnEncoder

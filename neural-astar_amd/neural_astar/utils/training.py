@@ -110,6 +110,12 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
 
     Works for ``VanillaAstar`` and ``NeuralAstar`` (whose ``encode`` supplies the cost map); search budget and mode follow
     ``planner.astar`` exactly as in ``planner.forward`` (``Tmax`` applies in training mode only)."""
+    # The fused node computes mean|histories - opt_trajs| for ONE trajectory per map.  The reference's L1Loss broadcasts
+    # histories [B,1,H,W] against opt_trajs [B,S,H,W] when num_starts S > 1 (training.py:58), and use_differentiable_astar=False
+    # selects another planner altogether: both go through the planner's own forward + nn.L1Loss, exactly like the reference.
+    if opt_trajs.shape[1] != 1 or opt_trajs.shape[-2:] != start_maps.shape[-2:] or not getattr(planner, "use_differentiable_astar", True):
+        outputs = planner(map_designs, start_maps, goal_maps)
+        return nn.L1Loss()(outputs.histories, opt_trajs), outputs
     if hasattr(planner, "encode"):
         cost_maps = planner.encode(map_designs, start_maps, goal_maps)
         obstacles = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
@@ -121,4 +127,8 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
     loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
                                                          opt_trajs[:, 0], astar.g_ratio, max_iters)
     astar.last_status, astar.last_iters = status, iters
+    if astar.check_solvable and bool((status != 0).any()):  # same contract as DifferentiableAstar.forward (one sync per call)
+        from ..planner.differentiable_astar import UnsolvableMapError
+        bad = torch.nonzero(status != 0).flatten().tolist()
+        raise UnsolvableMapError(f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map (batch rows {bad[:16]})")
     return loss, AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), [])

@@ -74,6 +74,10 @@ def test_pack_unpack_roundtrip_and_shard_bounds():
         lo, hi = parallel.shard_bounds(10, 3, r)
         cover += list(range(lo, hi))
     assert cover == list(range(10))
+    for mode in ("contiguous", "interleaved"):
+        rows = torch.cat([parallel.shard_rows(12, 4, r, mode) for r in range(4)])
+        assert sorted(rows.tolist()) == list(range(12))
+        assert torch.equal(rows[parallel.collated_order(12, 4, mode)], torch.arange(12))
 
 
 def _gloo_worker(rank, world, port, tmp):
@@ -95,7 +99,7 @@ def _gloo_worker(rank, world, port, tmp):
             o = O.forward(m.numpy(), s.numpy(), g.numpy(), m.numpy(), 0.5, 1024, mode="sm")
             return AstarOutput(torch.from_numpy(o.histories).unsqueeze(1), torch.from_numpy(o.paths).unsqueeze(1), None)
 
-    sp = parallel.ShardedPlanner(OraclePlanner())
+    sp = parallel.ShardedPlanner(OraclePlanner()).eval()
     out = sp(*(torch.from_numpy(x[lo:hi]) for x in pr))
     full = O.forward(pr.map_designs, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, 1024, mode="sm")
     ok = (np.array_equal(out.histories[:, 0].numpy(), full.histories) and np.array_equal(out.paths[:, 0].numpy(), full.paths)
@@ -106,6 +110,36 @@ def _gloo_worker(rank, world, port, tmp):
     ok = ok and torch.equal(out2.histories, out.histories) and torch.equal(out2.paths, out.paths)
     t = parallel.global_t_batch()(torch.from_numpy(full.iters[lo:hi]))
     ok = ok and int(t.item()) == int(full.iters.max()) - 1
+    # interleaved sharding (rows b % world == rank spread long searches over the ranks): the collated order is restored
+    rows = parallel.shard_rows(B, world, rank, "interleaved")
+    spi = parallel.ShardedPlanner(OraclePlanner(), sharding="interleaved").eval()
+    outi = spi(*(torch.from_numpy(x[rows.numpy()]) for x in pr))
+    ok = ok and np.array_equal(outi.histories[:, 0].numpy(), full.histories) and np.array_equal(outi.paths[:, 0].numpy(), full.paths)
+    ok = ok and outi.intermediate_results == []
+    # training mode keeps the local rows (autograd graph), no collective
+    spt = parallel.ShardedPlanner(OraclePlanner()).train()
+    ok = ok and spt(*(torch.from_numpy(x[lo:hi]) for x in pr)).histories.shape[0] == hi - lo
+    # gradients of a sharded batch with the batch coupling all-reduced (BatchCoupling.mode = global_t_batch) equal the rows of
+    # the single-process gradient of the whole batch: oracle backward as the CPU stand-in, t_batch as the only exchanged scalar
+    cost = syn.random_costs(B, 32, 32, seed=43)
+    up = np.random.Generator(np.random.PCG64(44)).standard_normal((B, 1, 32, 32)).astype(np.float32)
+    whole = O.backward(up, cost, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, 1024)
+    fw = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, 1024, mode="sm")
+    tg = int(parallel.global_t_batch()(torch.from_numpy(fw.iters[lo:hi])).item())
+    ok = ok and tg == int(fw.iters.max()) - 1
+    # a local-only t_batch would differ whenever the slowest map is on the other rank: the oracle's dense backward couples
+    # through t_batch only, so padding the shard with the globally slowest map reproduces the global coupling exactly
+    slow = int(np.argmax(fw.iters))
+    idx = list(range(lo, hi)) + ([slow] if not (lo <= slow < hi) else [])
+    part = O.backward(up[idx], cost[idx], pr.start_maps[idx], pr.goal_maps[idx], pr.map_designs[idx], 0.5, 1024)[:hi - lo]
+    ok = ok and float(np.abs(part - whole[lo:hi]).max()) <= 1e-6 * max(1.0, float(np.abs(whole).max()))
+    # ragged shards are refused with a clear error instead of hanging in the collective
+    try:
+        n_bad = (hi - lo) - (1 if rank == 0 else 0)
+        parallel.all_gather_output(sp.planner(*(torch.from_numpy(x[lo:lo + n_bad]) for x in pr)))
+        ok = False
+    except ValueError:
+        pass
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
