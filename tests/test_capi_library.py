@@ -44,7 +44,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(one, one, one, one, 1, 8, 8, 0.5, 0, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, one, 16, 0, None) == _native.NASTAR_ERR_WORKSPACE
-    assert lib.nastar_forward(one, one, one, one, 1, 128, 128, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_backward(one, one, one, one, one, 1, 8, 8, 0.5, 64, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
     # training / data-path / encoder entry points
