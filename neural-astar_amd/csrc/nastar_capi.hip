@@ -14,6 +14,7 @@
 #include "nastar_search_duo.hip.h"
 #include "nastar_search_asm.hip.h"
 #include "nastar_backward_replay.hip.h"
+#include "nastar_backward_replay_asm.hip.h"
 
 namespace nastar {
 
@@ -952,7 +953,8 @@ size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters)
 
 static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* start, const float* goal, const float* passable,
                                 const int32_t* sel_log, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
-                                const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes, void* stream)
+                                const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes, void* stream,
+                                int flags = 0)
 {
     if (!cost || !start || !goal || !passable || !sel_log || !iters || !grad_cost_out || !workspace) return NASTAR_ERR_NULL;
     int rc = make_cdims(B, H, W, max_iters, g_ratio, a.d);
@@ -972,6 +974,14 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float rcp = 1.0f / a.d.sqrtW;
     const bool fast = fastdiv_verified(W);
+    const int max_steps = hlen - 2;
+    if ((flags & NASTAR_FLAG_NO_ASM) == 0 && fast && H == W && (W == 32 || W == 16) && aligned16(cost) && aligned16(start) &&
+        aligned16(goal) && aligned16(passable) && aligned16(grad_cost_out) && bwdr_asm_lds_bytes(a.d.HW, max_steps) <= kMaxLdsBytes) {
+        // hand-scheduled replay loop (nastar_backward_replay_asm.hip.h): the reference's training sizes
+        const size_t lds = bwdr_asm_lds_bytes(a.d.HW, max_steps);
+        return W == 32 ? launch(nastar_backward_replay_asm_kernel<5>, B, lds, s, a, rcp)
+                       : launch(nastar_backward_replay_asm_kernel<4>, B, lds, s, a, rcp);
+    }
     if (bwdr_fits_lds(a.d.HW)) {
         // history in LDS as long as at least 2 maps (or what the state alone allows) stay resident per CU
         const size_t st = bwdr_state_bytes(a.d.HWp), with_hist = st + (size_t)hlen * 16;
@@ -992,12 +1002,11 @@ int nastar_backward_replay(const float* grad_histories, const float* cost, const
                            const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
                            size_t workspace_bytes, int flags, void* stream)
 {
-    (void)flags;
     if (!grad_histories) return NASTAR_ERR_NULL;
     BwdRArgs a;
     a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
-                                grad_cost_out, workspace, workspace_bytes, stream);
+                                grad_cost_out, workspace, workspace_bytes, stream, flags);
 }
 
 int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
