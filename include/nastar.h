@@ -200,6 +200,21 @@ int nastar_encoder_cnn_forward_f16(const float* map, const float* start, const f
                                    const float* w1_f32, const uint16_t* const* wpack16, const float* const* scale,
                                    const float* const* shift, float final_mul, float* cost_out, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/*
+ * CNNDownSize encoder of NeuralAstar in eval mode (reference planner/encoder.py:81-97 + :32-34 and the input assembly of
+ * astar.py:171-177; the WarCraft configuration scripts/config/train_warcraft.yaml:6-10 is C = 3, plus = 1, depth = 3, 96x96 -> 12x12)
+ * on the f32-input MFMA (fp32 accuracy: csrc/nastar_encoder_downsize.hip.h):
+ *     x = cat(image, upsample_nearest(start + goal));  depth x [conv3x3, BN, ReLU, maxpool 2x2];  cost = sigmoid(BN(conv3x3(x))) * final_mul
+ *   image [B,C,H,W] fp32 (NCHW, C + plus <= 4), start/goal [B,h,w] fp32 (NULL when plus == 0), cost_out [B, H>>depth, W>>depth] fp32;
+ *   H, W multiples of 2^depth.  wts[l] device fp32 [9][CINp][COUTp] (tap = ky*3+kx; CINp = 2|4, 32, 64, 128; COUTp = 32, 64, 128,
+ *   256 for the hidden blocks and 32 (channel 0 real) for the last one), scale/shift [COUTp] = eval-mode BatchNorm and conv bias folded;
+ *   wts/scale/shift are HOST arrays of depth+1 device pointers.  workspace: nastar_encoder_downsize_workspace_bytes(B, C+plus, H, W, depth).
+ */
+size_t nastar_encoder_downsize_workspace_bytes(int B, int C, int H, int W, int depth);
+int nastar_encoder_cnn_downsize_forward(const float* image, const float* start, const float* goal, int plus, int B, int C, int H,
+                                        int W, int h, int w, int depth, const float* const* wts, const float* const* scale,
+                                        const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 /* one layer of the above on its own (unit tests): (cin, cout) in {(16,32), (32,64), (64,128), (128,256)} */
 int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
                         int B, int H, int W, int cin, int cout, int relu, void* stream);

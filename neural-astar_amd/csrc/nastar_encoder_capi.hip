@@ -4,6 +4,7 @@
 
 #include "nastar_host.hip.h"
 #include "nastar_encoder.hip.h"
+#include "nastar_encoder_downsize.hip.h"
 
 namespace nastar {
 
@@ -356,6 +357,83 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
     if (cin == 64 && cout == 128) return relu ? launch_conv_auto<64, 128, true>(ca, s) : launch_conv_auto<64, 128, false>(ca, s);
     if (cin == 128 && cout == 256) return relu ? launch_conv_auto<128, 256, true>(ca, s) : launch_conv_auto<128, 256, false>(ca, s);
     return NASTAR_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"
+
+// ---- CNNDownSize (WarCraft) on the f32-input MFMA: nastar_encoder_downsize.hip.h -----------------------------------------------
+namespace nastar {
+template <int CIN, int COUTP, bool kPool, bool kFinal>
+static int launch_ds_conv(const DsConvArgs& a, hipStream_t s)
+{
+    auto kern = &nastar_conv3x3_f32mfma_kernel<CIN, COUTP, kPool, kFinal>;
+    const size_t lds = (size_t)(DS_TR + 2) * (DS_TC + 2) * CIN * sizeof(float);
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((size_t)a.B * ((a.H + DS_TR - 1) / DS_TR) * ((a.W + DS_TC - 1) / DS_TC));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (COUTP / 32)), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+static int ds_cin_pad(int c) { return c <= 2 ? 2 : 4; }
+}  // namespace nastar
+
+extern "C" {
+
+size_t nastar_encoder_downsize_workspace_bytes(int B, int C, int H, int W, int depth)
+{
+    if (B <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0 || depth < 1 || depth > 4) return 0;
+    size_t n = (size_t)B * H * W * nastar::ds_cin_pad(C);
+    int h = H, w = W, ch = 32;
+    for (int l = 0; l < depth; ++l) {
+        h /= 2; w /= 2;
+        n += (size_t)B * h * w * ch;
+        ch *= 2;
+    }
+    return n * sizeof(float);
+}
+
+int nastar_encoder_cnn_downsize_forward(const float* image, const float* start, const float* goal, int plus, int B, int C, int H,
+                                        int W, int h, int w, int depth, const float* const* wts, const float* const* scale,
+                                        const float* const* shift, float final_mul, float* cost_out, void* workspace,
+                                        size_t workspace_bytes, void* stream)
+{
+    using namespace nastar;
+    if (!image || !cost_out || !wts || !scale || !shift || !workspace || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    const int Cin = C + (plus ? 1 : 0);
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || depth < 1 || depth > 4 || Cin > 4) return NASTAR_ERR_BAD_SHAPE;
+    if (H % (1 << depth) != 0 || W % (1 << depth) != 0 || (plus && (h <= 0 || w <= 0))) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < nastar_encoder_downsize_workspace_bytes(B, Cin, H, W, depth)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int cp = ds_cin_pad(Cin);
+    float* x = static_cast<float*>(workspace);
+    const long long npix = (long long)B * H * W;
+    const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nastar_downsize_prep_kernel, dim3(pg), dim3(256), 0, s, image, plus ? start : image, plus ? goal : image, x, B, C,
+                       H, W, plus ? h : 1, plus ? w : 1, plus, cp);
+    DsConvArgs a;
+    a.B = B; a.H = H; a.W = W; a.final_mul = final_mul;
+    a.in = x;
+    float* nxt = x + (size_t)npix * cp;
+    int rc = NASTAR_OK;
+    for (int l = 0; l < depth; ++l) {  // hidden blocks: conv + BN + ReLU + 2x2 max-pool (encoder.py:91-95)
+        a.w = wts[l]; a.scale = scale[l]; a.shift = shift[l]; a.out = nxt;
+        if (l == 0) rc = cp == 2 ? launch_ds_conv<2, 32, true, false>(a, s) : launch_ds_conv<4, 32, true, false>(a, s);
+        else if (l == 1) rc = launch_ds_conv<32, 64, true, false>(a, s);
+        else if (l == 2) rc = launch_ds_conv<64, 128, true, false>(a, s);
+        else rc = launch_ds_conv<128, 256, true, false>(a, s);
+        if (rc) return rc;
+        a.H /= 2; a.W /= 2;
+        a.in = nxt;
+        nxt += (size_t)B * a.H * a.W * (32 << l);
+    }
+    a.w = wts[depth]; a.scale = scale[depth]; a.shift = shift[depth]; a.out = cost_out;  // last block + sigmoid * const
+    if (depth == 1) rc = launch_ds_conv<32, 32, false, true>(a, s);
+    else if (depth == 2) rc = launch_ds_conv<64, 32, false, true>(a, s);
+    else if (depth == 3) rc = launch_ds_conv<128, 32, false, true>(a, s);
+    else rc = launch_ds_conv<256, 32, false, true>(a, s);
+    return rc;
 }
 
 }  // extern "C"

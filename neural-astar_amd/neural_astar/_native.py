@@ -57,6 +57,8 @@ EXPORTED_SYMBOLS = (
     "nastar_encoder_workspace_bytes_f16",
     "nastar_encoder_cnn_forward_f16",
     "nastar_conv3x3_bf16",
+    "nastar_encoder_downsize_workspace_bytes",
+    "nastar_encoder_cnn_downsize_forward",
 )
 
 
@@ -128,6 +130,11 @@ def load() -> ctypes.CDLL:
     lib.nastar_encoder_workspace_bytes_f16.argtypes = [ci, ci, ci]
     lib.nastar_encoder_cnn_forward_f16.restype = ci
     lib.nastar_encoder_cnn_forward_f16.argtypes = lib.nastar_encoder_cnn_forward_f16x3.argtypes
+    lib.nastar_encoder_downsize_workspace_bytes.restype = cz
+    lib.nastar_encoder_downsize_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
+    lib.nastar_encoder_cnn_downsize_forward.restype = ci
+    lib.nastar_encoder_cnn_downsize_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(vp),
+                                                        ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_float, vp, vp, cz, vp]
     lib.nastar_conv3x3_bf16.restype = ci
     lib.nastar_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.nastar_debug_occupancy.restype = ci

@@ -150,3 +150,81 @@ class HipCnnEncoder:
                 torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "nastar_encoder_cnn_forward")
         return cost.unsqueeze(1)
+
+
+def pack_conv_weight_f32(weight: torch.Tensor, cin_p: int, cout_p: int) -> torch.Tensor:
+    """torch conv weight [cout, cin, 3, 3] -> fp32 [9][cin_p][cout_p] (tap = ky*3+kx, output channel contiguous), zero padded:
+    the B-operand order of nastar_conv3x3_f32mfma_kernel."""
+    cout, cin = weight.shape[:2]
+    w = torch.zeros((9, cin_p, cout_p), dtype=torch.float32, device=weight.device)
+    w[:, :cin, :cout] = weight.detach().float().permute(2, 3, 1, 0).reshape(9, cin, cout)
+    return w.contiguous()
+
+
+class HipCnnDownSizeEncoder:
+    """Eval-mode ``CNNDownSize`` (reference planner/encoder.py:81-97; the WarCraft encoder) through
+    ``nastar_encoder_cnn_downsize_forward``: f32-input MFMA, fp32 accuracy (csrc/nastar_encoder_downsize.hip.h)."""
+
+    def __init__(self, cnn: nn.Module):
+        convs = [m for m in cnn.model if isinstance(m, nn.Conv2d)]
+        self.depth = len(convs) - 1
+        if not (1 <= self.depth <= 4) or [c.out_channels for c in convs] != [32, 64, 128, 256][:self.depth] + [1] \
+                or convs[0].in_channels > 4:
+            raise NotImplementedError("the HIP CNNDownSize encoder implements input (<= 4 ch) -> 32 -> 64 -> 128 -> 256 (depth 1..4) -> 1")
+        self.cnn = cnn
+        self.in_channels = convs[0].in_channels
+        self._key = None
+        self._ws: Optional[torch.Tensor] = None
+        self._refresh()
+
+    def _refresh(self) -> None:
+        key = tuple((int(t._version), t.data_ptr(), str(t.device), t.dtype)
+                    for t in list(self.cnn.parameters()) + list(self.cnn.buffers()))
+        if key == self._key:
+            return
+        layers = list(self.cnn.model)
+        convs = [i for i, m in enumerate(layers) if isinstance(m, nn.Conv2d)]
+        self.w, self.scale, self.shift = [], [], []
+        for k, i in enumerate(convs):
+            conv = layers[i]
+            bn = layers[i + 1] if i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d) else None
+            cin_p = (2 if conv.in_channels <= 2 else 4) if k == 0 else conv.in_channels
+            cout_p = conv.out_channels if k < self.depth else 32
+            self.w.append(pack_conv_weight_f32(conv.weight, cin_p, cout_p))
+            sc, sh = fold_bn(conv, bn, cout_p)
+            self.scale.append(sc)
+            self.shift.append(sh)
+        const = self.cnn.const
+        self._mul = float(const.detach().item()) if isinstance(const, torch.Tensor) else float(const)
+        self._key = key
+
+    def __call__(self, images: torch.Tensor, start_maps: Optional[torch.Tensor], goal_maps: Optional[torch.Tensor],
+                 plus: bool) -> torch.Tensor:
+        """images [B,C,H,W] fp32, start/goal [B,1,h,w] -> cost [B,1,H>>depth,W>>depth] fp32 = sigmoid(model(x)) * const."""
+        if self.cnn.training:
+            raise RuntimeError("HipCnnDownSizeEncoder is inference only (eval-mode BatchNorm is folded into the kernel)")
+        self._refresh()
+        lib = _native.load()
+        x = images.contiguous()
+        B, C, H, W = x.shape
+        if C + (1 if plus else 0) != self.in_channels:
+            raise ValueError(f"encoder expects {self.in_channels} input channels, got {C} + {int(plus)}")
+        dev = x.device
+        s = start_maps[:, 0].contiguous() if plus else None
+        g = goal_maps[:, 0].contiguous() if plus else None
+        h, w = (s.shape[-2], s.shape[-1]) if plus else (1, 1)
+        Ho, Wo = H >> self.depth, W >> self.depth
+        cost = torch.empty((B, Ho, Wo), dtype=torch.float32, device=dev)
+        ws_bytes = int(lib.nastar_encoder_downsize_workspace_bytes(B, self.in_channels, H, W, self.depth))
+        ws = self._ws
+        if ws is None or ws.device != dev or ws.numel() < ws_bytes:
+            ws = self._ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        arr = ctypes.c_void_p * (self.depth + 1)
+        with torch.cuda.device(dev):
+            rc = lib.nastar_encoder_cnn_downsize_forward(
+                x.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus), B, C, H, W, h, w,
+                self.depth, arr(*[t.data_ptr() for t in self.w]), arr(*[t.data_ptr() for t in self.scale]),
+                arr(*[t.data_ptr() for t in self.shift]), self._mul, cost.data_ptr(), ws.data_ptr(), ws.numel(),
+                torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "nastar_encoder_cnn_downsize_forward")
+        return cost.unsqueeze(1)

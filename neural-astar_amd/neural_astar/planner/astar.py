@@ -25,6 +25,11 @@ def _is_depth4_cnn(enc: nn.Module) -> bool:
     return [c.out_channels for c in convs] == [32, 64, 128, 256, 1] and convs[0].in_channels <= 16
 
 
+def _downsize_cls():
+    from ..encoder_hip import HipCnnDownSizeEncoder
+    return HipCnnDownSizeEncoder
+
+
 class VanillaAstar(nn.Module):
     def __init__(self, g_ratio: float = 0.5, use_differentiable_astar: bool = True):
         """Vanilla A*: cost map = obstacle map = ``map_designs`` (reference astar.py:17-46,93-94).
@@ -81,6 +86,18 @@ class NeuralAstar(VanillaAstar):
 
     def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
         """Predict cost maps (reference astar.py:154-180)."""
+        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+                and isinstance(self.encoder, encoder.CNNDownSize)):
+            # CNNDownSize (WarCraft): f32-input MFMA kernels at fp32 accuracy whatever the hip_* precision asked for
+            convs = [m for m in self.encoder.model if isinstance(m, nn.Conv2d)]
+            depth = len(convs) - 1
+            plus = "+" in self.encoder_input
+            if (1 <= depth <= 4 and [c.out_channels for c in convs] == [32, 64, 128, 256][:depth] + [1] and convs[0].in_channels <= 4
+                    and map_designs.shape[1] + int(plus) == convs[0].in_channels
+                    and map_designs.shape[-2] % (1 << depth) == 0 and map_designs.shape[-1] % (1 << depth) == 0):
+                if not isinstance(self._hip_encoder, _downsize_cls()):
+                    self._hip_encoder = _downsize_cls()(self.encoder)
+                return self._hip_encoder(map_designs, start_maps, goal_maps, plus)
         tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
         if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
@@ -88,7 +105,7 @@ class NeuralAstar(VanillaAstar):
                 and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
                 and _is_depth4_cnn(self.encoder)):
             precision = self.encoder_backend[4:]
-            if self._hip_encoder is None or self._hip_encoder.precision != precision:
+            if getattr(self._hip_encoder, "precision", None) != precision:
                 from ..encoder_hip import HipCnnEncoder
                 self._hip_encoder = HipCnnEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)

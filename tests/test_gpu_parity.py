@@ -670,3 +670,42 @@ def test_f16_encoder_routes_agree():
                 finally:
                     os.environ.pop("NASTAR_ENCODER_FLAGS", None)
                 assert 0.0 < float((alt - got).abs().max()) < 2e-3      # different kernels, same fp16 operands
+
+
+@pytest.mark.parametrize("enc_in,C,H,W,depth,const", [("rgb+", 3, 96, 96, 3, 10.0), ("m+", 1, 64, 32, 2, None), ("rgb", 3, 32, 48, 4, 2.0)])
+def test_cnn_downsize_encoder_f32_mfma_matches_torch_fp32(enc_in, C, H, W, depth, const):
+    """CNNDownSize (reference planner/encoder.py:81-97; WarCraft: rgb+, depth 3, 96x96 -> 12x12, const 10) on the f32-input MFMA
+    vs the fp32 torch module with random weights and non-trivial BatchNorm statistics: the north-star float tolerance 1e-5
+    (scaled by const), and the search downstream picks the same paths."""
+    from neural_astar.planner import NeuralAstar
+    torch.manual_seed(7)
+    dev = _dev()
+    na = NeuralAstar(encoder_input=enc_in, encoder_arch="CNNDownSize", encoder_depth=depth, const=const, learn_obstacles=True).to(dev)
+    with torch.no_grad():
+        for m in na.encoder.model:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    na.eval()
+    B = 5
+    h, w = H >> depth, W >> depth
+    img = torch.rand((B, C, H, W), device=dev)
+    s = torch.zeros((B, 1, h, w), device=dev)
+    g = torch.zeros((B, 1, h, w), device=dev)
+    s[:, 0, 0, 0] = 1
+    g[:, 0, -1, -1] = 1
+    with torch.no_grad():
+        ref = na.encode(img, s, g)
+        na.encoder_backend = "hip_f16x3"
+        got = na.encode(img, s, g)
+        assert got.shape == ref.shape == (B, 1, h, w)
+        scale = float(const) if const is not None else 1.0
+        err = float((got - ref).abs().max())
+        assert err <= 1e-5 * max(1.0, scale), f"max |cost - torch fp32| = {err:.3e}"
+        out_hip = na(img, s, g)
+        na.encoder_backend = "torch"
+        out_ref = na(img, s, g)
+    same = (out_hip.paths == out_ref.paths).flatten(1).all(1).float().mean().item()
+    assert same >= 0.8, f"only {same:.0%} of the maps keep the fp32 encoder's path"
