@@ -1,0 +1,121 @@
+"""Data-parallel training of a planner on several MI355X GPUs: one process per GPU, ``torch.distributed`` over RCCL / xGMI.
+
+The reference trains on ONE device through Lightning (``scripts/train.py`` / ``scripts/train_warcraft.py``: ``pl.Trainer`` without
+``devices`` / ``strategy``); BASELINE.json config 5 asks for its WarCraft loop on 8 GPUs.  What has to cross GPUs in that loop:
+
+* nothing during the search or its backward -- every rank plans its own rows of the batch (``neural_astar.parallel``);
+* ONE all-reduce of the parameter gradients per step.  The encoders are small (CNNDownSize depth 3: 98 k parameters, 0.4 MB;
+  CNN depth 4: 392 k, 1.6 MB), so all gradients travel as ONE flat fp32 bucket: over point-to-point xGMI a ring all-reduce is
+  per-link latency-bound at this size and one collective beats per-layer buckets (torch DDP's default 25 MB bucket would also
+  be one bucket, but DDP's hooks expect the wrapped ``forward`` to run, and the training step here is the fused
+  ``utils.training.fused_l1_step`` node that calls ``planner.encode`` + the search ops directly);
+* optionally ONE int32 all-reduce (MAX) of the step count so that the reference's batch-coupled gradient terms see the global batch
+  (``coupling="global"``, ``parallel.global_t_batch``); the default ``coupling="none"`` makes every map its own batch, which is
+  independent of how the batch is sharded.
+
+Launch: ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 your_script.py`` with a loop like
+``tests/test_distributed_training.py`` (RCCL when every rank has its own GPU, gloo otherwise).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .training import fused_l1_step
+
+__all__ = ["init_distributed", "broadcast_parameters", "allreduce_gradients", "DataParallelTrainer"]
+
+
+def init_distributed(backend: Optional[str] = None) -> torch.device:
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run's environment).
+    backend: "nccl" (= RCCL on ROCm; default when every local rank has its own GPU) or "gloo"."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this driver stack
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % max(n_dev, 1)) if n_dev else torch.device("cpu")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    if backend is None:
+        backend = "nccl" if dev.type == "cuda" and n_dev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo"
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dev
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Every rank starts from rank ``src``'s parameters and buffers (one flat broadcast each)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for tensors in (list(module.parameters()), [b for b in module.buffers() if b.is_floating_point()]):
+        if not tensors:
+            continue
+        flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        with torch.no_grad():
+            for t in tensors:
+                t.copy_(flat[o:o + t.numel()].reshape(t.shape))
+                o += t.numel()
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None) -> None:
+    """Average the gradients over the ranks with ONE all-reduce of one flat fp32 bucket (see the module docstring).
+    Parameters without a gradient on this rank contribute zeros, so every rank reduces the same layout."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    world = dist.get_world_size(group)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
+    o = 0
+    for p in params:
+        g = flat[o:o + p.numel()].reshape(p.shape).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        o += p.numel()
+
+
+class DataParallelTrainer:
+    """The reference's training step (utils/training.py:55-61: planner forward, L1 loss on histories, RMSprop) data-parallel
+    over the process group: each rank runs ``fused_l1_step`` on ITS rows, gradients are averaged with one flat all-reduce.
+
+    ``coupling``: "none" (default) = shard-size independent gradients; "global" = the reference's batch-coupled terms over the
+    GLOBAL batch (one extra scalar all-reduce per step); "local" = coupled within each rank's shard."""
+
+    def __init__(self, planner: torch.nn.Module, lr: float = 1e-3, group: Optional[dist.ProcessGroup] = None,
+                 coupling: str = "none"):
+        self.planner = planner
+        self.group = group
+        self.optimizer = torch.optim.RMSprop(planner.parameters(), lr)  # reference training.py:52-53
+        if coupling not in ("none", "global", "local"):
+            raise ValueError(coupling)
+        self.coupling = coupling
+        broadcast_parameters(planner, 0, group)
+
+    def train_step(self, map_designs, start_maps, goal_maps, opt_trajs) -> torch.Tensor:
+        from .. import parallel
+        self.planner.train()
+        prev = ops.BatchCoupling.mode
+        ops.BatchCoupling.mode = {"none": "none", "local": "batch",
+                                  "global": parallel.global_t_batch(self.group) if dist.is_initialized() else "batch"}[self.coupling]
+        try:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss, _ = fused_l1_step(self.planner, map_designs, start_maps, goal_maps, opt_trajs)
+            loss.backward()
+        finally:
+            ops.BatchCoupling.mode = prev
+        allreduce_gradients(self.planner.parameters(), self.group)
+        self.optimizer.step()
+        return loss.detach()
