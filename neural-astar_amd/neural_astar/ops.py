@@ -62,8 +62,8 @@ def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, p
     paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
-    sel_log = (torch.full((B, max_iters), -1, dtype=torch.int32, device=dev) if want_log
-               else torch.empty((0,), dtype=torch.int32, device=dev))
+    # entries at positions >= iters[b] are never read (the backward replays iters[b] steps, _intermediate_results masks by iters)
+    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
     ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, FORWARD_FLAGS))  # > 0 only for maps too large for LDS
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     with torch.cuda.device(dev):

@@ -1,30 +1,66 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): kernel-trace stats + HBM traffic counters for the bench workload.
-# Usage: tools/profile_round.sh r01   -> writes gpurun_out/profiles_<tag>/...
+# Run on the GPU box (via gpurun): the evidence the bench line's roofline block is checked against.
+#   1. rocprofv3 kernel trace + stats of the exact default bench command (N=1)          -> kernel_stats
+#   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slot limit), kernel-trace only
+#   3. SQ counters of the shipped forward kernel and, for comparison, of the round-1 LDS layout (NASTAR_FORWARD_FLAGS=1)
+#   4. kernel stats of the fused training step (forward with selection log + replay backward), 4096 maps, Tmax = 0.25
+# Usage: tools/profile_round.sh r02   -> writes gpurun_out/profiles_<tag>/ (copy the summaries into profiles/<tag>/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. kernel trace + stats of the exact bench command (N=1)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.log 2>&1
-# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot limit), kernel-trace only
+B="python $R/bench.py --no-cpu-baseline --no-secondary"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $B --steps 50 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/pmc_$C.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- $B --steps 20 --warmup 2 > $OUT/pmc_$C.log 2>&1
 done
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+SQ2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU"
+for V in 0 1; do
+  NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ --kernel-trace -d $OUT/sq_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq_f$V.log 2>&1
+  NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ2 --kernel-trace -d $OUT/sq2_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq2_f$V.log 2>&1
+done
+cat > /tmp/train_step.py <<PY
+import sys
+sys.path[:0] = ["$R/neural-astar_amd", "$R"]
+import torch
+from neural_astar import ops
+from neural_astar.utils import synthetic as syn
+dev = torch.device("cuda:0")
+pr = syn.maze_maps(4096, 32, seed=1234)
+m, s, g = (torch.from_numpy(x[:, 0]).to(dev).contiguous() for x in pr)
+traj = ((torch.rand_like(m) < 0.2).float() * m).contiguous()
+cost = torch.from_numpy(syn.random_costs(4096, 32, 32, seed=3)[:, 0]).to(dev).requires_grad_(True)
+for _ in range(20):
+    cost.grad = None
+    ops.astar_l1_loss(cost, s, g, m, traj, 0.5, 256)[0].backward()
+torch.cuda.synchronize()
+PY
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train --output-format csv -- python /tmp/train_step.py > $OUT/train.log 2>&1
 python - <<PY
 import csv, glob, json, collections
 out = {}
-for f in glob.glob("$OUT/trace/*kernel_stats.csv"):
-    rows = list(csv.DictReader(open(f)))
-    out["kernel_stats"] = rows[:8]
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    acc = collections.defaultdict(list)
-    for f in glob.glob("$OUT/pmc_%s/*counter_collection.csv" % c):
+for tag, pat in (("bench_kernel_stats", "$OUT/trace/**/*kernel_stats.csv"), ("train_step_kernel_stats", "$OUT/train/**/*kernel_stats.csv")):
+    for f in glob.glob(pat, recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        out[tag] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in rows[:6]]
+        open("$OUT/%s.csv" % tag, "w").write(open(f).read())
+def counters(pat):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
-    out[c] = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items()}
+            acc[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items() if "nastar" in k}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    out[c] = counters("$OUT/pmc_%s/**/*counter_collection.csv" % c)
+for V in ("0", "1"):
+    d = counters("$OUT/sq_f%s/**/*counter_collection.csv" % V)
+    d2 = counters("$OUT/sq2_f%s/**/*counter_collection.csv" % V)
+    for k in d2:
+        d.setdefault(k, {}).update(d2[k])
+    out["sq_flags" + V] = d
 json.dump(out, open("$OUT/summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+print(json.dumps(out, indent=1)[:5000])
 PY
