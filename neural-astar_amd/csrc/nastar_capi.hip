@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
         int s = 0;
         if constexpr (ABL == -1) {
-            static_assert(LOGW > 0 && LOGW == LOGH && CPL_T == 1 && kFastDiv, "asm loop: square power-of-two maps of <= 1024 cells");
+            static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
             s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW,
                                                     kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr);
         } else
@@ -790,6 +790,8 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, -1>;
         else if (use_asm && vec4 && fast && H == 16 && W == 16)
             kern = lg ? &nastar_forward_compact_kernel<true, 4, 4, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 4, 4, 1, true, false, -1>;
+        else if (use_asm && vec4 && fast && H == 64 && W == 64)
+            kern = lg ? &nastar_forward_compact_kernel<true, 6, 6, 4, true, true, -1> : &nastar_forward_compact_kernel<true, 6, 6, 4, true, false, -1>;
         else if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
         else if (vec4 && fast && H == 64 && W == 64) { NASTAR_CPICK(true, 6, 6, 4, true); }
         else if (vec4 && fast && H == 16 && W == 16) { NASTAR_CPICK(true, 4, 4, 1, true); }

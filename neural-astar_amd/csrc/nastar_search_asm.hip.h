@@ -1,5 +1,5 @@
 // nastar_search_asm.hip.h -- the selection/expansion loop of the compact forward kernel (nastar_search_compact.hip.h) as ONE
-// hand-scheduled gfx950 instruction stream, for square power-of-two maps of <= 1024 cells (32x32: the headline configuration).
+// hand-scheduled gfx950 instruction stream, for square power-of-two maps: 16x16, 32x32 (the headline configuration) and 64x64.
 //
 // Why assembly: a map's search is a serial chain of steps executed by ONE wavefront, and for the 4096-map batch every map is
 // resident from t = 0 (16 per CU), so the launch lasts as long as the longest chain (472 steps) x the latency of one step.
@@ -30,19 +30,41 @@ template <int LOGW>
 struct AsmLayout {
     static constexpr int W = 1 << LOGW;
     static constexpr int HW = W * W;
+    static constexpr int CPL = (HW / 16 + 63) / 64;  // chunk minima per lane: 1 (<= 1024 cells) or 4 (64x64)
     static constexpr int CMIN = HW * 8;
-    static constexpr int PDIR = CMIN + 64 * 8 + 256;
+    static constexpr int PDIR = CMIN + CPL * 64 * 8 + 256;
 };
 
-#define NASTAR_ASM_SELECT \
+#define NASTAR_ASM_ENTRY \
         "s_cmp_ge_u32 %[it], %[maxit]\n\t" \
         "s_cbranch_scc1 .Lbudget%=\n\t" \
         "v_mov_b32 v48, -1\n\t" \
-        "v_mov_b32 v49, -1\n\t" \
-        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n" /* v20 = cell index, v21 = key of this lane's chunk */ \
+        "v_mov_b32 v49, -1\n\t"
+/* this lane's chunk minima: one entry (<= 1024 cells) or four contiguous entries (4096 cells); .x = cell index, .y = key */ \
+
+#define NASTAR_ASM_READ_1 \
+        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n\t"
+#define NASTAR_ASM_READ_4 \
+        "ds_read_b128 v[12:15], %[l8] offset:%[CMIN]\n\t" \
+        "ds_read_b128 v[16:19], %[l8] offset:%[CMIN16]\n\t"
+#define NASTAR_ASM_LOOPTOP \
         ".Lloop%=:\n\t" \
- /* ---- select: first cell of the minimal (key, index) chunk entry (its read was issued at the end of the previous step) */ \
-        "s_waitcnt lgkmcnt(0)\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" /* the read was issued at the end of the previous step */
+#define NASTAR_ASM_LOCALMIN_1
+/* first minimal entry of the lane's four (the earlier chunk wins ties): v20 = cell index, v21 = key */ \
+
+#define NASTAR_ASM_LOCALMIN_4 \
+        "v_min_u32 v21, v13, v15\n\t" \
+        "v_min3_u32 v21, v21, v17, v19\n\t" \
+        "v_mov_b32 v20, v18\n\t" \
+        "v_cmp_eq_u32 vcc, v21, v17\n\t" \
+        "v_cmp_eq_u32_e64 s[48:49], v21, v15\n\t" \
+        "v_cmp_eq_u32_e64 s[50:51], v21, v13\n\t" \
+        "v_cndmask_b32 v20, v20, v16, vcc\n\t" \
+        "v_cndmask_b32_e64 v20, v20, v14, s[48:49]\n\t" \
+        "v_cndmask_b32_e64 v20, v20, v12, s[50:51]\n\t"
+#define NASTAR_ASM_SELECT \
+ /* ---- select: first cell of the minimal (key, index) chunk entry ------------------------------------------- */ \
         "v_min_u32_dpp v22, v21, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
         "s_nop 1\n\t" \
         "v_min_u32_dpp v22, v22, v22 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
@@ -59,7 +81,7 @@ struct AsmLayout {
         "s_cmp_eq_u32 s40, -1\n\t" \
         "s_cbranch_scc1 .Lempty%=\n\t" /* open list empty */ \
         "v_cmp_eq_u32 vcc, s40, v21\n\t" \
-        "s_ff1_i32_b64 s41, vcc\n\t" /* first chunk with the minimum */ \
+        "s_ff1_i32_b64 s41, vcc\n\t" /* first lane (= first chunks) with the minimum */ \
         "v_readlane_b32 s42, v20, s41\n\t" /* s* (its entry names the chunk's first minimal cell) */ \
         "s_cmp_eq_u32 s42, %[goal]\n\t" \
         "s_cbranch_scc1 .Lgoal%=\n\t"
@@ -142,8 +164,8 @@ struct AsmLayout {
         "ds_write_b32 v26, v40\n\t" /* :238 g[n] = g2 */ \
         "ds_write_b8 v46, %[pcode] offset:%[PDIR]\n\t" /* :246-249 parent = s* */ \
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 (key, n) enters its chunk's minimum */ \
-        "s_mov_b64 exec, -1\n\t" \
-        "ds_read_b64 v[20:21], %[l8] offset:%[CMIN]\n\t" /* next step's chunk minima */ \
+        "s_mov_b64 exec, -1\n\t"
+#define NASTAR_ASM_LOOPEND \
         "s_cmp_lt_u32 %[it], %[maxit]\n\t" \
         "s_cbranch_scc1 .Lloop%=\n" \
         ".Lbudget%=:\n\t" \
@@ -162,10 +184,10 @@ struct AsmLayout {
           [vinf] "v"(v_inf), [vminf] "v"(v_minf), [loc] "v"(v_loc), [goal] "s"(goal_idx), [gr] "s"(goal_r), [gc] "s"(goal_c), \
           [maxit] "s"(max_iters), [cgr] "s"(d.gr), [comg] "s"(d.omg), [csq] "s"(d.sqrtW), [crcp] "s"(rcp_sqrtW), \
           [mnb] "s"(m_nb), [mchk] "s"(m_chk), [msb] "s"(msb), [logp] "s"(logp), \
-          [CMIN] "i"(L::CMIN), [PDIR] "i"(L::PDIR), [LOGW] "i"(LOGW), [WM1] "i"(L::W - 1), [W] "i"(L::W) \
+          [CMIN] "i"(L::CMIN), [CMIN16] "i"(L::CMIN + 16), [PDIR] "i"(L::PDIR), [LOGW] "i"(LOGW), [WM1] "i"(L::W - 1), [W] "i"(L::W) \
         : "memory", "vcc", "scc", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
           "v34", "v35", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v52", "s40", "s41", "s42", \
-          "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s54", "s55", "s53", "v53", "v54"
+          "s43", "s44", "s45", "s46", "s47", "s50", "s51", "s52", "s54", "s55", "s53", "v53", "v54", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "s48", "s49"
 
 // Runs selection steps until the goal is selected, the open list is empty or `max_iters` steps were executed.
 // Returns the goal index (goal selected, not yet counted in iters), -1 (open list empty) or -2 (budget exhausted).
@@ -174,14 +196,14 @@ __device__ __forceinline__ int compact_search_loop_asm(const CompactDims& d, int
                                                        int max_iters, int& iters, float rcp_sqrtW, int* log_row)
 {
     using L = AsmLayout<LOGW>;
-    static_assert(L::HW <= 1024 && L::HW >= 256, "one chunk minimum per lane, chunks inside one map row");
+    static_assert((L::CPL == 1 || L::CPL == 4) && L::HW >= 256, "1 or 4 chunk minima per lane, chunks inside one map row");
     int dr, dc;
     neighbour_delta(lane & 7, dr, dc);
     const bool is_nb = lane < 8, is_chk = (lane & 48) == 16;
     const int v_dr = is_nb ? dr : 0, v_dc = is_nb ? dc : 0;
     const int v_off = is_nb ? dr * L::W + dc : (is_chk ? (lane & 15) : 0);
     const uint32_t v_pcode = P_PASS | (uint32_t)(lane & 7);
-    const uint32_t v_l8 = (uint32_t)lane * 8u;
+    const uint32_t v_l8 = (uint32_t)lane * 8u * L::CPL;
     const float v_inf = NASTAR_POS_INF, v_minf = NASTAR_NEG_INF;
     const float v_loc = is_chk ? NASTAR_NEG_INF : NASTAR_POS_INF;  // lower bound of "open" for the chunk re-insertion
     const unsigned long long m_nb = 0xFFull, m_chk = 0xFFFF0000ull;
@@ -193,11 +215,17 @@ __device__ __forceinline__ int compact_search_loop_asm(const CompactDims& d, int
     max_iters = __builtin_amdgcn_readfirstlane(max_iters);
     int sel;
     unsigned long long logp = reinterpret_cast<unsigned long long>(log_row);
-    if constexpr (kLog) {
-        asm volatile(NASTAR_ASM_SELECT NASTAR_ASM_LOG NASTAR_ASM_EXPAND NASTAR_ASM_OPERANDS);
+#define NASTAR_ASM_BODY(N, LOGPART) \
+    NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N NASTAR_ASM_LOOPTOP NASTAR_ASM_LOCALMIN_##N NASTAR_ASM_SELECT LOGPART NASTAR_ASM_EXPAND \
+        NASTAR_ASM_READ_##N NASTAR_ASM_LOOPEND
+    if constexpr (L::CPL == 1) {
+        if constexpr (kLog) asm volatile(NASTAR_ASM_BODY(1, NASTAR_ASM_LOG) NASTAR_ASM_OPERANDS);
+        else asm volatile(NASTAR_ASM_BODY(1, ) NASTAR_ASM_OPERANDS);
     } else {
-        asm volatile(NASTAR_ASM_SELECT NASTAR_ASM_EXPAND NASTAR_ASM_OPERANDS);
+        if constexpr (kLog) asm volatile(NASTAR_ASM_BODY(4, NASTAR_ASM_LOG) NASTAR_ASM_OPERANDS);
+        else asm volatile(NASTAR_ASM_BODY(4, ) NASTAR_ASM_OPERANDS);
     }
+#undef NASTAR_ASM_BODY
     iters = it;
     return sel;
 }
