@@ -212,9 +212,39 @@ def test_full_size_properties_b4096():
     perm = np.random.Generator(np.random.PCG64(3)).permutation(B)
     h2, p2, _, _, _ = _run_capi(pr.map_designs[perm], pr.start_maps[perm], pr.goal_maps[perm], pr.map_designs[perm], 0.5, 1024)
     assert np.array_equal(h2, hist[perm]) and np.array_equal(p2, paths[perm])
-    # and a 256-row slice against the dense oracle
+    # a 256-row slice against the dense oracle (the literal tensor program) and ALL 4096 rows against its state-machine twin
+    # (test_oracle_golden pins both readings to the reference's vectors and to each other)
     o = O.forward(pr.map_designs[:256], pr.start_maps[:256], pr.goal_maps[:256], pr.map_designs[:256], 0.5, 1024)
     assert np.array_equal(hist[:256], o.histories) and np.array_equal(paths[:256], o.paths)
+    o = O.forward(pr.map_designs, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, 1024, mode="sm")
+    assert np.array_equal(hist, o.histories) and np.array_equal(paths, o.paths) and np.array_equal(iters, o.iters)
+
+
+@pytest.mark.parametrize("kind,H,B", [("maze", 32, 4096), ("rand", 64, 1024)])
+def test_full_size_bench_batches_match_oracle_on_every_row(kind, H, B):
+    """The bench workloads themselves (maze32 headline batch, a 1024-map slice of config 4's 64x64 shard), every row, against the
+    oracle's state-machine reading; U(0,1) costs on the same maps as well (the NeuralAstar convention cost != passable)."""
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.20, seed=1234)
+    for cost in (pr.map_designs, syn.random_costs(B, H, H, seed=5)):
+        hist, paths, iters, status, _ = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, H * H)
+        o = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, H * H, mode="sm")
+        assert (status == 0).all()
+        assert np.array_equal(hist, o.histories) and np.array_equal(paths, o.paths) and np.array_equal(iters, o.iters)
+
+
+def test_neural_astar_unet_runs_on_device():
+    """BASELINE config 3's architecture (Unet vgg16_bn encoder, from-scratch definition, torch convolutions) in front of the HIP search."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    torch.manual_seed(0)
+    pr = syn.maze_maps(8, 32, seed=3)
+    na = NeuralAstar(encoder_arch="Unet", encoder_depth=4, Tmax=0.25).to(_dev())
+    out = na(_t(pr.map_designs), _t(pr.start_maps), _t(pr.goal_maps))
+    torch.nn.L1Loss()(out.histories, torch.zeros_like(out.histories)).backward()
+    assert out.histories.shape == (8, 1, 32, 32) and out.paths.dtype == torch.int64
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in na.encoder.model.segmentation_head.parameters())
 
 
 def test_pack_unpack_kernels_match_host_expression():

@@ -270,3 +270,27 @@ def test_hip_encoder_backends_fall_back_to_torch_when_gradients_are_needed():
         with torch.no_grad():
             c2 = nt.encode(m, s, g)                  # training mode (batch-statistics BatchNorm) -> torch path
         assert c2.shape == ref.shape and nt._hip_encoder is None and na._hip_encoder is None
+
+
+def test_unet_vgg16_bn_encoder_constructs_and_runs_without_smp():
+    """BASELINE config 3 names Unet(vgg16_bn): the from-scratch VggUnet (reference encoder.py:37-57 structure, parity unpinned)."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.planner.encoder import VggUnet
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="Unet", encoder_depth=4)
+    assert isinstance(na.encoder.model, VggUnet) or type(na.encoder.model).__name__ == "Unet"
+    if isinstance(na.encoder.model, VggUnet):
+        keys = set(na.encoder.state_dict())
+        assert {"model.encoder.features.0.weight", "model.decoder.center.0.0.weight", "model.decoder.blocks.0.conv1.0.weight",
+                "model.decoder.blocks.3.conv2.1.running_mean", "model.segmentation_head.0.weight"} <= keys
+        # vgg16_bn stages up to stride 16 (13 convs less the 3 of the last stage kept unused) + centre + 4 decoder blocks + head
+        n = sum(p.numel() for p in na.encoder.parameters())
+        assert 20e6 < n < 30e6
+    na.eval()
+    x = torch.rand(2, 2, 32, 32)
+    with torch.no_grad():
+        y = na.encoder(x)
+    assert y.shape == (2, 1, 32, 32) and float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    na.train()
+    na.encoder(x).sum().backward()
+    assert all(p.grad is not None for p in na.encoder.model.decoder.parameters())
