@@ -537,6 +537,10 @@ def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--ref-worker":
         _reference_worker(sys.argv[2])
         return
+    # stdout carries exactly ONE line (the JSON): anything a library prints there meanwhile (RCCL / c10d notices) goes to stderr
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -561,7 +565,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        sys.exit(subprocess.call(cmd, env=env))
+        sys.exit(subprocess.call(cmd, env=env, stdout=real_stdout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != max(args.gpus, 1) and rank == 0:
@@ -710,7 +714,8 @@ def main():
             out["extra"] = {**ex,
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "
                                     "not the headline value, which times strictly serial launches on one stream"}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_collate:
         dist.barrier()
         dist.destroy_process_group()
