@@ -144,7 +144,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     const size_t off = (size_t)b * (size_t)d.HW;
 
     int start_idx, goal_idx;
-    compact_load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    constexpr int kLoadIter = (kVec4 && LOGH > 0 && LOGW > 0 && LOGH + LOGW >= 8) ? (1 << (LOGH + LOGW - 8)) : 0;
+    compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
     const int gi = goal_idx < 0 ? 0 : goal_idx;
     const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
     const int goal_c = gi - goal_r * d.W;

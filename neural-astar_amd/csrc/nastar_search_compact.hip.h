@@ -91,7 +91,9 @@ __device__ __forceinline__ float heuristic0_fast(int r, int c, int goal_r, int g
     return cheb + 0.001f * euc;
 }
 
-template <bool kVec4>
+// ITER > 0: the map has exactly ITER * 256 cells (compile-time size): the loads of up to 4 iterations (16 x 16 B per lane) are all
+// issued before the first is consumed, so a map costs ~one HBM latency to load instead of one per iteration.
+template <bool kVec4, int ITER = 0>
 __device__ __forceinline__ void compact_load_map(const CompactDims& d, const CompactLds& l, const float* __restrict__ cost,
                                                  const float* __restrict__ start, const float* __restrict__ goal,
                                                  const float* __restrict__ passable, int lane, int& start_idx, int& goal_idx)
@@ -102,12 +104,7 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
         const float4* g4 = reinterpret_cast<const float4*>(goal);
         const float4* c4 = reinterpret_cast<const float4*>(cost);
         const float4* p4 = reinterpret_cast<const float4*>(passable);
-        const int n4 = d.HW >> 2;
-        for (int q = lane; q < n4; q += 64) {
-            const float4 sv = s4[q];
-            const float4 gv = g4[q];
-            const float4 cv = c4[q];
-            const float4 pv = p4[q];
+        auto place = [&](int q, const float4& sv, const float4& gv, const float4& cv, const float4& pv) {
             const int i = q << 2;
             if (sv.x != 0.f) sidx = i;
             if (sv.y != 0.f) sidx = i + 1;
@@ -132,6 +129,26 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
                                ((PARENT_UNSET | (pv.z != 0.f ? P_PASS : 0u)) << 16) |
                                ((PARENT_UNSET | (pv.w != 0.f ? P_PASS : 0u)) << 24);
             *reinterpret_cast<uint32_t*>(l.pdir + i) = m;
+        };
+        if constexpr (ITER > 0) {
+            constexpr int G = ITER < 4 ? ITER : 4;
+            static_assert(ITER % G == 0, "groups of up to 4 iterations");
+            for (int base = 0; base < ITER; base += G) {
+                float4 sv[G], gv[G], cv[G], pv[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int q = lane + (base + k) * 64;
+                    sv[k] = s4[q];
+                    gv[k] = g4[q];
+                    cv[k] = c4[q];
+                    pv[k] = p4[q];
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) place(lane + (base + k) * 64, sv[k], gv[k], cv[k], pv[k]);
+            }
+        } else {
+            const int n4 = d.HW >> 2;
+            for (int q = lane; q < n4; q += 64) place(q, s4[q], g4[q], c4[q], p4[q]);
         }
     } else {
         for (int i = lane; i < d.HW; i += 64) {
