@@ -219,6 +219,34 @@ int nastar_encoder_cnn_downsize_forward(const float* image, const float* start, 
 int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out,
                         int B, int H, int W, int cin, int cout, int relu, void* stream);
 
+/*
+ * Generic 3x3 convolution layer (padding 1) on the fp16 MFMA for any image size and channel count: the building block of the
+ * U-Net encoder (reference planner/encoder.py:37-57: segmentation_models_pytorch Unet(vgg16_bn); VGG stages at 32x32 ... 2x2 pixels,
+ * decoder blocks = nearest x2 upsampling + skip concatenation + two conv-BN-ReLU) and of layers the fixed-shape kernels above do not
+ * cover (csrc/nastar_conv_flat.hip.h).  Activations are NHWC fp16; with NASTAR_CONV_SPLIT every pixel is [hi(C) | lo(C)] (two fp16
+ * terms per value, "f16x3": products hi*hi + lo*hi + hi*lo, fp32-grade results).
+ *   y[b,y,x,n] = act(scale[n] * sum_{tap,c} w[tap][c][n] * x[b, y+dy, x+dx, c] + shift[n]),  x = cat(in (upsampled), in2)
+ *   in   [B, H, W, c1]  (NASTAR_CONV_UPSAMPLE: [B, H/2, W/2, c1], read at (y/2, x/2))      in2  [B, H, W, c2] or NULL (c2 = 0)
+ *   wpack  fp16 [9][CINV/8][cout][8], tap = ky*3+kx, CINV = c1+c2 input channels -- or 3*(c1+c2) virtual channels
+ *          [W_hi | W_hi | W_lo] with NASTAR_CONV_SPLIT;   scale/shift fp32 [cout] (folded eval-mode BatchNorm / bias)
+ *   out  [B, H, W, cout] fp16 (x2 when split), or with NASTAR_CONV_FINAL out_f32 [B,H,W] = sigmoid(y[..., 0]) * final_mul (cout == 32,
+ *        channel 0 real: reference encoder.py:32-34)
+ *   c1, c2 multiples of 32, cout a multiple of 32, W <= 94, B*H*W*max(channels) < 2^31 (chunk the batch above that).
+ */
+#define NASTAR_CONV_RELU 1
+#define NASTAR_CONV_FINAL 2
+#define NASTAR_CONV_UPSAMPLE 4
+#define NASTAR_CONV_SPLIT 8
+int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* wpack, const float* scale, const float* shift,
+                       uint16_t* out, float* out_f32, int B, int H, int W, int c1, int c2, int cout, int flags, float final_mul,
+                       void* stream);
+/* 2x2 max-pool of an NHWC fp16 tensor [B,H,W,C] -> [B,H/2,W/2,C] (split: [hi | lo] pairs, the pair with the larger hi + lo wins) */
+int nastar_maxpool2x2_f16(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, int split, void* stream);
+/* input assembly of NeuralAstar.encode (reference astar.py:171-177): (map, start + goal, 0, ...) as cp-channel NHWC fp16
+ * (split: followed by cp zero lo halves); map/start/goal fp32 [npix], start/goal may be NULL when plus == 0 */
+int nastar_encoder_prep_f16(const float* map, const float* start, const float* goal, int plus, long long npix, int cp, int split,
+                            uint16_t* out, void* stream);
+
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */
 int nastar_debug_occupancy(int H, int W, int* lds_bytes_out);

@@ -5,6 +5,7 @@
 #include "nastar_host.hip.h"
 #include "nastar_encoder.hip.h"
 #include "nastar_encoder_downsize.hip.h"
+#include "nastar_conv_flat.hip.h"
 
 namespace nastar {
 
@@ -434,6 +435,80 @@ int nastar_encoder_cnn_downsize_forward(const float* image, const float* start, 
     else if (depth == 3) rc = launch_ds_conv<128, 32, false, true>(a, s);
     else rc = launch_ds_conv<256, 32, false, true>(a, s);
     return rc;
+}
+
+}  // extern "C"
+
+// ---- generic fp16 / f16x3 building blocks (nastar_conv_flat.hip.h): any image size, any channel count -------------------------------
+namespace nastar {
+
+template <int NT, bool kFinal, bool kSplit>
+static int launch_flat(const FlatConvArgs& fa, hipStream_t s)
+{
+    auto kern = &nastar_conv3x3_flat_kernel<NT, kFinal, kSplit>;
+    const size_t lds = (size_t)FC_PIXB + (size_t)(FC_TP + 2 * (fa.W + 1)) * FC_PIXB + (size_t)9 * 4 * NT * 16 + (size_t)NT * 8;
+    int rc = ensure_lds(kern, lds);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)(((fa.ntiles + 7) / 8) * 8 * (fa.COUT / NT));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FC_THREADS), lds, s, fa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+}  // namespace nastar
+
+extern "C" {
+
+int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* wpack, const float* scale, const float* shift,
+                       uint16_t* out, float* out_f32, int B, int H, int W, int c1, int c2, int cout, int flags, float final_mul,
+                       void* stream)
+{
+    const bool relu = flags & NASTAR_CONV_RELU, fin = flags & NASTAR_CONV_FINAL, ups = flags & NASTAR_CONV_UPSAMPLE,
+               split = flags & NASTAR_CONV_SPLIT;
+    if (!in || !wpack || !scale || !shift || (fin ? !out_f32 : !out) || (c2 > 0 && !in2)) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || c1 <= 0 || c2 < 0 || cout <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (c1 % FC_KS || c2 % FC_KS || cout % 32 || W > FC_MAXW || (fin && cout != 32) || (ups && ((H | W) & 1))) return NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    const long long widest = (long long)(split ? 2 : 1) * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout));
+    if (npix * widest >= (1ll << 31)) return NASTAR_ERR_UNSUPPORTED;  // 32-bit element offsets: the caller chunks the batch
+    if (!aligned16(in) || (in2 && !aligned16(in2)) || !aligned16(wpack) || (out && !aligned16(out))) return NASTAR_ERR_BAD_SHAPE;
+    FlatConvArgs fa;
+    fa.in = in; fa.in2 = in2; fa.wpack = wpack; fa.scale = scale; fa.shift = shift; fa.out = out; fa.out_f32 = out_f32;
+    fa.final_mul = final_mul; fa.B = B; fa.H = H; fa.W = W; fa.C1 = c1; fa.C2 = c2; fa.COUT = cout; fa.npix = (int)npix;
+    fa.ups = ups ? 1 : 0; fa.relu = relu ? 1 : 0; fa.ntiles = (int)((npix + FC_TP - 1) / FC_TP);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (fin) return split ? launch_flat<32, true, true>(fa, s) : launch_flat<32, true, false>(fa, s);
+    if (cout % 64 == 0) return split ? launch_flat<64, false, true>(fa, s) : launch_flat<64, false, false>(fa, s);
+    return split ? launch_flat<32, false, true>(fa, s) : launch_flat<32, false, false>(fa, s);
+}
+
+int nastar_maxpool2x2_f16(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, int split, void* stream)
+{
+    if (!in || !out) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((H | W) & 1 || C % 8) return NASTAR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (split) hipLaunchKernelGGL(nastar_maxpool2x2_f16_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C);
+    else hipLaunchKernelGGL(nastar_maxpool2x2_f16_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, B, H, W, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_encoder_prep_f16(const float* map, const float* start, const float* goal, int plus, long long npix, int cp, int split,
+                            uint16_t* out, void* stream)
+{
+    if (!map || !out || (plus && (!start || !goal))) return NASTAR_ERR_NULL;
+    if (npix <= 0 || cp < 2 || cp % 8) return NASTAR_ERR_BAD_SHAPE;
+    const unsigned grid = (unsigned)((npix + 255) / 256 < 65536 ? (npix + 255) / 256 : 65536);
+    hipLaunchKernelGGL(nastar_encoder_prep_f16_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), map, start, goal,
+                       out, npix, plus, cp, split);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
 }
 
 }  // extern "C"

@@ -59,6 +59,9 @@ EXPORTED_SYMBOLS = (
     "nastar_conv3x3_bf16",
     "nastar_encoder_downsize_workspace_bytes",
     "nastar_encoder_cnn_downsize_forward",
+    "nastar_conv3x3_f16",
+    "nastar_maxpool2x2_f16",
+    "nastar_encoder_prep_f16",
 )
 
 
@@ -137,6 +140,12 @@ def load() -> ctypes.CDLL:
                                                         ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_float, vp, vp, cz, vp]
     lib.nastar_conv3x3_bf16.restype = ci
     lib.nastar_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.nastar_conv3x3_f16.restype = ci
+    lib.nastar_conv3x3_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    lib.nastar_maxpool2x2_f16.restype = ci
+    lib.nastar_maxpool2x2_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.nastar_encoder_prep_f16.restype = ci
+    lib.nastar_encoder_prep_f16.argtypes = [vp, vp, vp, ci, ctypes.c_longlong, ci, ci, vp, vp]
     lib.nastar_debug_occupancy.restype = ci
     lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib

@@ -228,3 +228,177 @@ class HipCnnDownSizeEncoder:
                 torch.cuda.current_stream(dev).cuda_stream)
         _native.check(rc, "nastar_encoder_cnn_downsize_forward")
         return cost.unsqueeze(1)
+
+
+# ---- U-Net (vgg16_bn) encoder on the generic fp16 / f16x3 MFMA convolution (csrc/nastar_conv_flat.hip.h) ---------------------------------
+CONV_RELU, CONV_FINAL, CONV_UPSAMPLE, CONV_SPLIT = 1, 2, 4, 8  # include/nastar.h
+
+
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def pack_flat_conv(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], split: bool):
+    """(wpack, scale, shift, cin_p, cout_p) of one conv(+BN) layer for ``nastar_conv3x3_f16``: input / output channels zero padded to
+    multiples of 32, weights ``[9][cin_v/8][cout_p][8]`` fp16 with cin_v = cin_p, or 3*cin_p virtual channels [W_hi | W_hi | W_lo]
+    in the split ("f16x3") form; eval-mode BatchNorm and bias folded into per-channel scale / shift."""
+    cout, cin = conv.weight.shape[:2]
+    cin_p, cout_p = _pad32(cin), _pad32(cout)
+    w = torch.zeros((cout, cin_p, 3, 3), dtype=torch.float32, device=conv.weight.device)
+    w[:, :cin] = conv.weight.detach().float()
+    wpack = pack_conv_weight_f16x3(w, cout_p) if split else pack_conv_weight(w, cin_p, cout_p, torch.float16)
+    scale, shift = fold_bn(conv, bn, cout_p)
+    return wpack, scale, shift, cin_p, cout_p
+
+
+def unet_layer_plan(model: nn.Module):
+    """The launch sequence of a ``planner.encoder.VggUnet`` (reference encoder.py:37-57 via this package's from-scratch definition) as a
+    list of steps over named activation buffers ("x0" = the assembled input; ``div`` = resolution divisor of the step's OUTPUT):
+        ("conv", dst, src, skip|None, conv, bn|None, flags, div)     flags: CONV_RELU | CONV_UPSAMPLE | CONV_FINAL
+        ("pool", dst, src, None, div_in)"""
+    steps = []
+    depth = model.depth
+    x, div, n = "x0", 1, 0
+    feats = []
+    for si, stage in enumerate(model._stages()[: depth + 1]):
+        mods = list(stage)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.MaxPool2d):
+                steps.append(("pool", f"p{si}", x, None, div))
+                x, div = f"p{si}", div * 2
+                i += 1
+            elif isinstance(m, nn.Conv2d):
+                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d) else None
+                n += 1
+                steps.append(("conv", f"e{n}", x, None, m, bn, CONV_RELU, div))
+                x = f"e{n}"
+                i += 3 if bn is not None else 2
+            else:
+                i += 1
+        feats.append((x, div))
+    skips = feats[1:][::-1]  # the full-resolution stage is not a skip (VggUnet.decoder)
+    x, div = skips[0]
+    for k, blk in enumerate(model.decoder.center):
+        steps.append(("conv", f"c{k}", x, None, blk[0], blk[1], CONV_RELU, div))
+        x = f"c{k}"
+    for k, blk in enumerate(model.decoder.blocks):
+        skip = skips[k + 1][0] if k + 1 < len(skips) else None
+        div //= 2
+        steps.append(("conv", f"d{k}a", x, skip, blk.conv1[0], blk.conv1[1], CONV_RELU | CONV_UPSAMPLE, div))
+        steps.append(("conv", f"d{k}b", f"d{k}a", None, blk.conv2[0], blk.conv2[1], CONV_RELU, div))
+        x = f"d{k}b"
+    assert div == 1, "decoder must return to the input resolution (encoder_depth decoder blocks)"
+    steps.append(("conv", "cost", x, None, model.segmentation_head[0], None, CONV_FINAL, 1))
+    return steps
+
+
+class HipUnetEncoder:
+    """Eval-mode ``planner.encoder.Unet`` (from-scratch VggUnet definition; reference planner/encoder.py:37-57) on the MFMA through
+    the layer-level C ABI ``nastar_conv3x3_f16`` / ``nastar_maxpool2x2_f16`` / ``nastar_encoder_prep_f16``.
+
+    ``precision``: ``"f16"`` (plain fp16 operands, fp32 accumulation -- BASELINE config 3) or ``"f16x3"`` (split operands, results
+    within ~1e-5 of the fp32 torch module).  Inference only; upsampling, skip concatenation, BatchNorm, ReLU, bias, sigmoid * const are
+    all fused into the convolution launches (26 + 4 pooling launches per forward at depth 4)."""
+
+    def __init__(self, unet: nn.Module, precision: str = "f16"):
+        from .planner.encoder import VggUnet
+        if precision not in ("f16", "f16x3"):
+            raise ValueError(precision)
+        if not isinstance(unet.model, VggUnet):
+            raise NotImplementedError("HipUnetEncoder implements this package's VggUnet definition of Unet(vgg16_bn)")
+        self.unet = unet
+        self.precision = precision
+        self.split = precision == "f16x3"
+        self._key = None
+        self._bufs = {}
+        self._refresh()
+
+    def _refresh(self) -> None:
+        key = tuple((int(t._version), t.data_ptr(), str(t.device), t.dtype)
+                    for t in list(self.unet.parameters()) + list(self.unet.buffers()))
+        if key == self._key:
+            return
+        self.steps = []
+        for st in unet_layer_plan(self.unet.model):
+            if st[0] == "conv":
+                _, dst, src, skip, conv, bn, flags, div = st
+                wpack, scale, shift, cin_p, cout_p = pack_flat_conv(conv, bn, self.split)
+                self.steps.append(("conv", dst, src, skip, wpack, scale, shift, cin_p, cout_p, flags, div))
+            else:
+                self.steps.append(st)
+        const = self.unet.const
+        self._mul = float(const.detach().item()) if isinstance(const, torch.Tensor) else float(const)
+        self._key = key
+
+    def flops(self, H: int, W: int) -> float:
+        """useful multiply-add FLOPs of the conv layers per image (real channel counts)"""
+        total = 0.0
+        for st in unet_layer_plan(self.unet.model):
+            if st[0] == "conv":
+                conv, div = st[4], st[7]
+                total += 2.0 * 9 * conv.in_channels * conv.out_channels * (H // div) * (W // div)
+        return total
+
+    def _buf(self, name: str, numel: int, dev) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or t.device != dev or t.numel() < numel:
+            t = self._bufs[name] = torch.empty((numel,), dtype=torch.int16, device=dev)
+        return t
+
+    def __call__(self, map_designs: torch.Tensor, start_maps: Optional[torch.Tensor], goal_maps: Optional[torch.Tensor],
+                 plus: bool) -> torch.Tensor:
+        """map/start/goal [B,1,H,W] fp32 on the device -> cost [B,1,H,W] fp32 = sigmoid(model(x)) * const."""
+        if self.unet.training:
+            raise RuntimeError("HipUnetEncoder is inference only (eval-mode BatchNorm is folded into the kernels)")
+        self._refresh()
+        lib = _native.load()
+        m = map_designs[:, 0].contiguous()
+        B, H, W = m.shape
+        depth = self.unet.model.depth
+        if H % (1 << depth) or W % (1 << depth) or W > 94:
+            raise NotImplementedError(f"H, W must be multiples of {1 << depth} and W <= 94")
+        dev = m.device
+        s = start_maps[:, 0].contiguous() if plus else None
+        g = goal_maps[:, 0].contiguous() if plus else None
+        cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        mult = 2 if self.split else 1
+        # 32-bit element offsets inside a launch: chunk the batch so that the widest full-resolution tensor stays below 2^31 elements
+        per_image = max(st[8] * (H // st[10]) * (W // st[10]) for st in self.steps if st[0] == "conv") * mult
+        chunk = max(1, min(B, ((1 << 31) - 1) // per_image))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        sflag = CONV_SPLIT if self.split else 0
+        with torch.cuda.device(dev):
+            for b0 in range(0, B, chunk):
+                nb = min(chunk, B - b0)
+                chans = {"x0": 32}
+                x0 = self._buf("x0", nb * H * W * 32 * mult, dev)
+                rc = lib.nastar_encoder_prep_f16(m[b0:].data_ptr(), s[b0:].data_ptr() if plus else None,
+                                                 g[b0:].data_ptr() if plus else None, int(plus), nb * H * W, 32, int(self.split),
+                                                 x0.data_ptr(), stream)
+                _native.check(rc, "nastar_encoder_prep_f16")
+                for st in self.steps:
+                    if st[0] == "pool":
+                        _, dst, src, _, div = st
+                        c = chans[src]
+                        h, w = H // div, W // div
+                        out = self._buf(dst, nb * (h // 2) * (w // 2) * c * mult, dev)
+                        rc = lib.nastar_maxpool2x2_f16(self._bufs[src].data_ptr(), out.data_ptr(), nb, h, w, c, int(self.split), stream)
+                        _native.check(rc, "nastar_maxpool2x2_f16")
+                        chans[dst] = c
+                        continue
+                    _, dst, src, skip, wpack, scale, shift, cin_p, cout_p, flags, div = st
+                    h, w = H // div, W // div
+                    c1 = chans[src]
+                    c2 = chans[skip] if skip is not None else 0
+                    assert c1 + c2 == cin_p, (dst, c1, c2, cin_p)
+                    final = bool(flags & CONV_FINAL)
+                    out = None if final else self._buf(dst, nb * h * w * cout_p * mult, dev)
+                    rc = lib.nastar_conv3x3_f16(
+                        self._bufs[src].data_ptr(), self._bufs[skip].data_ptr() if skip is not None else None, wpack.data_ptr(),
+                        scale.data_ptr(), shift.data_ptr(), None if final else out.data_ptr(), cost[b0:].data_ptr() if final else None,
+                        nb, h, w, c1, c2, cout_p, flags | sflag, self._mul, stream)
+                    _native.check(rc, f"nastar_conv3x3_f16({dst})")
+                    chans[dst] = cout_p
+        return cost.unsqueeze(1)

@@ -98,6 +98,17 @@ class NeuralAstar(VanillaAstar):
                 if not isinstance(self._hip_encoder, _downsize_cls()):
                     self._hip_encoder = _downsize_cls()(self.encoder)
                 return self._hip_encoder(map_designs, start_maps, goal_maps, plus)
+        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+                and isinstance(self.encoder, encoder.Unet) and isinstance(self.encoder.model, encoder.VggUnet)
+                and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
+                and map_designs.shape[-2] % (1 << self.encoder.model.depth) == 0
+                and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0 and map_designs.shape[-1] <= 94):
+            # Unet(vgg16_bn): generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h); "hip_f16x3" = split operands, fp32-grade
+            precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
+            from ..encoder_hip import HipUnetEncoder
+            if not isinstance(self._hip_encoder, HipUnetEncoder) or self._hip_encoder.precision != precision:
+                self._hip_encoder = HipUnetEncoder(self.encoder, precision)
+            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
         if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
