@@ -392,6 +392,52 @@ def neural_astar_forward_ms(pr, dev, reps=10):
                                          "sustains 1660 TFLOP/s on random bf16 operands at the power limit (tools/ubench/mfma_peak.hip)"}}
 
 
+def neural_astar_unet_ms(pr, dev, precision, reps=5):
+    """Extra (BASELINE config 3 literally: NeuralAstar UNet encoder + diff-A* on 32x32 mazes, fp16, batch 4096): Unet(vgg16_bn)
+    through the generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h) + the HIP search, eval mode, random-init weights with
+    calibrated BatchNorm statistics.  ``precision``: "f16" (plain fp16 operands) or "f16x3" (split operands, fp32-grade)."""
+    from neural_astar.planner import NeuralAstar
+    torch.manual_seed(0)
+    na = NeuralAstar(encoder_arch="Unet", encoder_depth=4).to(dev)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():  # BatchNorm running statistics = batch statistics of 64 bench maps (activations stay O(1) through 26 layers)
+        for mod in na.encoder.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.momentum = 1.0
+        na.train()
+        na.encoder(torch.cat((m[:64], s[:64] + g[:64]), dim=1))
+    na.eval()
+    na.astar.check_solvable = False
+    with torch.no_grad():
+        ref = na.encode(m[:64], s[:64], g[:64])
+        na.encoder_backend = "hip_" + precision
+        err = float((na.encode(m[:64], s[:64], g[:64]) - ref).abs().max())
+        for _ in range(2):
+            na(m, s, g)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            na.encode(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        enc_ms = e0.elapsed_time(e1) / reps
+        e0.record()
+        for _ in range(reps):
+            na(m, s, g)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        full_ms = e0.elapsed_time(e1) / reps
+    tf = na._hip_encoder.flops(H, W) * m.shape[0] / enc_ms / 1e9
+    products = 3 if precision == "f16x3" else 1
+    return {"encoder_ms": enc_ms, "encoder_useful_tflops": tf, "forward_ms": full_ms, "maps_per_s": m.shape[0] / full_ms * 1e3,
+            "max_abs_diff_vs_torch_fp32_encoder_64_maps": err,
+            "dtype": ("fp16 hi/lo split operands (3 products)" if products == 3 else "fp16 operands") + " / fp32 accumulate (encoder), f32 (search)",
+            "encoder_roofline": {"bound": "mfma", "achieved": tf * products, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf * products / 2500.0,
+                                 "note": "FLOPs of the 24 conv layers (real channel counts" + (", x3 split products" if products == 3 else "")
+                                         + ") / wall time of the whole encoder incl. pooling and input assembly launches"}}
+
+
 def kernel_launch_ms(run, steps, dev):
     """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
     (torch's current stream), one event pair per launch."""
@@ -703,6 +749,8 @@ def main():
             ex = {}
             for name, fn in (("neural_astar_cnn_hip_bf16", lambda: neural_astar_forward_ms(pr, dev)),
                              ("neural_astar_cnn_hip_f16x3", lambda: neural_astar_f16x3_ms(pr, dev)),
+                             ("neural_astar_unet_hip_f16", lambda: neural_astar_unet_ms(pr, dev, "f16")),
+                             ("neural_astar_unet_hip_f16x3", lambda: neural_astar_unet_ms(pr, dev, "f16x3")),
                              ("train_fwd_bwd_ms_per_4096_maps_Tmax025", lambda: training_step_ms(pr, dev)),
                              ("data_path_32x32", lambda: data_path_ms(dev)),
                              ("train_l1_step_Tmax025", lambda: {"batch_100": l1_training_step_ms(pr, dev, 100),

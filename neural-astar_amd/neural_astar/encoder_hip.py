@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes
 from typing import List, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -238,16 +239,30 @@ def _pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-def pack_flat_conv(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], split: bool):
+def pack_flat_conv(conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], split: bool, in_scale: float = 1.0, out_scale: float = 1.0):
     """(wpack, scale, shift, cin_p, cout_p) of one conv(+BN) layer for ``nastar_conv3x3_f16``: input / output channels zero padded to
     multiples of 32, weights ``[9][cin_v/8][cout_p][8]`` fp16 with cin_v = cin_p, or 3*cin_p virtual channels [W_hi | W_hi | W_lo]
-    in the split ("f16x3") form; eval-mode BatchNorm and bias folded into per-channel scale / shift."""
+    in the split ("f16x3") form; eval-mode BatchNorm and bias folded into per-channel scale / shift.
+
+    Split form only: the weights are multiplied by a power of two 2^s that brings max|w| to ~2^14 before they are split, and 2^-s is
+    folded into ``scale`` (exact).  Conv weights are ~1e-2, so their lo terms (~2^-12 |w|) would otherwise be fp16 SUBNORMALS
+    (< 6.1e-5, absolute quantum 6e-8): 19 significant bits instead of 22.  ``in_scale`` / ``out_scale`` (powers of two) say that the
+    layer's input activations arrive multiplied by ``in_scale`` and that its output must leave multiplied by ``out_scale`` -- the same
+    cure for the activations' lo terms (ReLU and max-pool commute with a positive factor)."""
     cout, cin = conv.weight.shape[:2]
     cin_p, cout_p = _pad32(cin), _pad32(cout)
     w = torch.zeros((cout, cin_p, 3, 3), dtype=torch.float32, device=conv.weight.device)
     w[:, :cin] = conv.weight.detach().float()
-    wpack = pack_conv_weight_f16x3(w, cout_p) if split else pack_conv_weight(w, cin_p, cout_p, torch.float16)
     scale, shift = fold_bn(conv, bn, cout_p)
+    if split:
+        wmax = float(w.abs().max())
+        s = 0 if wmax == 0.0 else max(0, min(24, int(np.floor(np.log2(16384.0 / wmax)))))
+        wpack = pack_conv_weight_f16x3(w * (2.0 ** s), cout_p)
+        scale = scale * (2.0 ** -s)
+    else:
+        wpack = pack_conv_weight(w, cin_p, cout_p, torch.float16)
+    scale = (scale * (out_scale / in_scale)).contiguous()
+    shift = (shift * out_scale).contiguous()
     return wpack, scale, shift, cin_p, cout_p
 
 
@@ -324,7 +339,10 @@ class HipUnetEncoder:
         for st in unet_layer_plan(self.unet.model):
             if st[0] == "conv":
                 _, dst, src, skip, conv, bn, flags, div = st
-                wpack, scale, shift, cin_p, cout_p = pack_flat_conv(conv, bn, self.split)
+                # split form: hidden activations travel multiplied by 16 (their lo terms stay out of the fp16 subnormal range)
+                a = 16.0 if self.split else 1.0
+                wpack, scale, shift, cin_p, cout_p = pack_flat_conv(conv, bn, self.split, 1.0 if src == "x0" else a,
+                                                                    1.0 if flags & CONV_FINAL else a)
                 self.steps.append(("conv", dst, src, skip, wpack, scale, shift, cin_p, cout_p, flags, div))
             else:
                 self.steps.append(st)

@@ -71,7 +71,8 @@ def test_flat_conv_emulation_matches_torch_conv2d(case):
     if c2:
         xin = torch.cat((xin, seen(xb)), dim=1)
     y = nn.functional.conv2d(xin.double(), seen(conv.weight.detach()).double(), None, padding=1)
-    y = y * scale[:cout_real].double().view(1, -1, 1, 1) + shift[:cout_real].double().view(1, -1, 1, 1)
+    rscale, rshift = E.fold_bn(conv, None, cout)  # the module's own scale / shift (the split pack folds 2^-s into the kernel's)
+    y = y * (1.5 * rscale[:cout_real]).double().view(1, -1, 1, 1) + rshift[:cout_real].double().view(1, -1, 1, 1)
     if relu:
         y = y.clamp_min(0)
     if final:
@@ -111,4 +112,10 @@ def test_unet_launch_plan_and_packing():
     hi, hi2, lo = w[:, :cin_p], w[:, cin_p:2 * cin_p], w[:, 2 * cin_p:]
     assert torch.equal(hi, hi2)
     ref = conv.weight.detach().permute(2, 3, 1, 0).reshape(9, conv.in_channels, conv.out_channels)
-    assert float(((hi + lo)[:, :conv.in_channels, :conv.out_channels] - ref).abs().max()) <= 2.0 ** -21 * float(ref.abs().max()) * 2
+    # the pack holds w * 2^s (max|w| brought to ~2^14 so that the lo terms are normal fp16 numbers), 2^-s sits in `scale`
+    k = float(hi.abs().max() / ref.abs().max())
+    s_exp = round(np.log2(k))
+    assert abs(k / 2.0 ** s_exp - 1) < 1e-3 and 8192 <= float(hi.abs().max()) <= 16384
+    assert float(((hi + lo)[:, :conv.in_channels, :conv.out_channels] * 2.0 ** -s_exp - ref).abs().max()) <= 2.0 ** -22 * float(ref.abs().max())
+    sc_plain = E.pack_flat_conv(conv, convs[1][5], False)[1]
+    assert torch.allclose(sc * 2.0 ** s_exp, sc_plain, rtol=1e-6)

@@ -100,8 +100,11 @@ def test_flat_conv_matches_torch(case):
         xin = nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
     if c2:
         xin = torch.cat((xin, _seen(xb, split)), dim=1)
-    y = nn.functional.conv2d(xin.double(), _seen(conv.weight.detach(), split).double(), None, padding=1)
-    _, scale, shift, _, cout_p = E.pack_flat_conv(conv, bn, split)
+    # split form: the kernel's weight operands are 22-bit accurate (scaled into the normal fp16 range): compare with the exact weights
+    wref = conv.weight.detach() if split else _seen(conv.weight.detach(), False)
+    y = nn.functional.conv2d(xin.double(), wref.double(), None, padding=1)
+    cout_p = E._pad32(cout)
+    scale, shift = E.fold_bn(conv, bn, cout_p)  # the module's own eval-mode BatchNorm (the split pack folds a 2^-s into the kernel's)
     y = y * scale[:cout].double().view(1, -1, 1, 1) + shift[:cout].double().view(1, -1, 1, 1)
     if relu:
         y = y.clamp_min(0)
@@ -172,7 +175,7 @@ def _truth64(unet, m, s, g):
         return u64(torch.cat((m.cpu().double(), (s + g).cpu().double()), dim=1)).float()
 
 
-@pytest.mark.parametrize("precision,tol_truth,tol_torch", [("f16x3", 1e-5, 4e-5), ("f16", 3e-2, 3e-2)])
+@pytest.mark.parametrize("precision,tol_truth,tol_torch", [("f16x3", 1.5e-5, 4e-5), ("f16", 3e-2, 3e-2)])
 def test_unet_encoder_matches_torch(precision, tol_truth, tol_torch):
     from neural_astar.planner import NeuralAstar
     from neural_astar.utils import synthetic as syn
