@@ -237,6 +237,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
 #define NASTAR_CONV_FINAL 2
 #define NASTAR_CONV_UPSAMPLE 4
 #define NASTAR_CONV_SPLIT 8
+#define NASTAR_CONV_RAW 16 /* with NASTAR_CONV_FINAL: out_f32 = y[..., 0] itself (no sigmoid): the training path, BatchNorm follows */
 int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* wpack, const float* scale, const float* shift,
                        uint16_t* out, float* out_f32, int B, int H, int W, int c1, int c2, int cout, int flags, float final_mul,
                        void* stream);
@@ -246,6 +247,26 @@ int nastar_maxpool2x2_f16(const uint16_t* in, uint16_t* out, int B, int H, int W
  * (split: followed by cp zero lo halves); map/start/goal fp32 [npix], start/goal may be NULL when plus == 0 */
 int nastar_encoder_prep_f16(const float* map, const float* start, const float* goal, int plus, long long npix, int cp, int split,
                             uint16_t* out, void* stream);
+
+/*
+ * Encoder TRAINING kernels (autograd of reference planner/encoder.py:60-78 as utils/training.py:55-61 runs it): together with
+ * nastar_conv3x3_f16 (forward, and the input gradient = the same convolution with transposed, flipped weights) they make the
+ * conv + batch-statistics BatchNorm + ReLU stack differentiable on the device without torch.nn.  NHWC fp16 tensors, `split` as above.
+ *
+ * nastar_conv3x3_wgrad_f16: dw[tap][ci][co] = out_scale * sum_{b,y,x} dz[b,y,x,co] * a[b,y+dy,x+dx,ci]  (tap = (dy+1)*3 + (dx+1), zero
+ *   padding) on the fp16 MFMA with gfx950's LDS transpose reads; dw fp32 [9][ci][co] is zeroed and accumulated inside the call
+ *   (csrc/nastar_conv_wgrad.hip.h).  W must divide 64 (2..64), H % (64/W) == 0, co % 32 == ci % 32 == 0.
+ * nastar_chan_stats_f16: per-channel sums over all pixels in double: sums[c] = (sum v, sum v^2), or with u != NULL
+ *   (sum u*m, sum u*m*v), m = [ms[c]*v + mt[c] > 0] (the ReLU mask).  sums double [C][2], zeroed inside the call.
+ * nastar_chan_affine_f16: out = k1[c]*u*[ms[c]*v + mt[c] > 0] + k2[c]*v + k3[c], optional ReLU; u == NULL drops the first term
+ *   (forward: BatchNorm folded to k2, k3 + ReLU; backward: ReLU mask + closed-form BatchNorm backward).
+ */
+int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, int B, int H, int W, int co, int ci, int split,
+                             float out_scale, void* stream);
+int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, long long npix, int C,
+                          int split, void* stream);
+int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1, const float* k2, const float* k3, const float* ms,
+                           const float* mt, uint16_t* out, long long npix, int C, int relu, int split, void* stream);
 
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */

@@ -55,6 +55,7 @@ struct FlatConvArgs {
     int npix;              // B*H*W
     int ups;               // 1: `in` is [B, H/2, W/2, C1], nearest-upsampled x2 on the fly
     int relu;
+    int raw;               // kFinal: store y[channel 0] itself instead of sigmoid(y) * final_mul (training: BatchNorm follows)
     int ntiles;            // ceil(npix / FC_TP)
 };
 
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
         if constexpr (kFinal) {
             if (kh == 0 && nblk == 0) {
                 const float z = acc[pb][0][0] * ss[0] + ss[NT];
-                a.out_f32[p] = a.final_mul / (1.0f + __expf(-z));
+                a.out_f32[p] = a.raw ? z : a.final_mul / (1.0f + __expf(-z));
             }
         } else {
             const size_t ob = (size_t)p * (kSplit ? 2 * a.COUT : a.COUT);

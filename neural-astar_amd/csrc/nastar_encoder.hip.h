@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float*
 }
 
 // input assembly (astar.py:171-177): x0[b][y][x][0] = map, [1] = start + goal, channels 2..15 = 0   (bf16 NHWC, 16 ch)
-__global__ __launch_bounds__(256) void nastar_encoder_prep_kernel(const float* __restrict__ map, const float* __restrict__ start,
+__attribute__((unused)) static __global__ __launch_bounds__(256) void nastar_encoder_prep_kernel(const float* __restrict__ map, const float* __restrict__ start,
                                                                   const float* __restrict__ goal, uint16_t* __restrict__ x0,
                                                                   long long npix, int plus)
 {

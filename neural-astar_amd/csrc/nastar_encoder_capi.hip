@@ -476,7 +476,7 @@ int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* 
     FlatConvArgs fa;
     fa.in = in; fa.in2 = in2; fa.wpack = wpack; fa.scale = scale; fa.shift = shift; fa.out = out; fa.out_f32 = out_f32;
     fa.final_mul = final_mul; fa.B = B; fa.H = H; fa.W = W; fa.C1 = c1; fa.C2 = c2; fa.COUT = cout; fa.npix = (int)npix;
-    fa.ups = ups ? 1 : 0; fa.relu = relu ? 1 : 0; fa.ntiles = (int)((npix + FC_TP - 1) / FC_TP);
+    fa.ups = ups ? 1 : 0; fa.relu = relu ? 1 : 0; fa.raw = (flags & NASTAR_CONV_RAW) ? 1 : 0; fa.ntiles = (int)((npix + FC_TP - 1) / FC_TP);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (fin) return split ? launch_flat<32, true, true>(fa, s) : launch_flat<32, true, false>(fa, s);
     if (cout % 64 == 0) return split ? launch_flat<64, false, true>(fa, s) : launch_flat<64, false, false>(fa, s);

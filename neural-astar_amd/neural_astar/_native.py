@@ -62,6 +62,9 @@ EXPORTED_SYMBOLS = (
     "nastar_conv3x3_f16",
     "nastar_maxpool2x2_f16",
     "nastar_encoder_prep_f16",
+    "nastar_conv3x3_wgrad_f16",
+    "nastar_chan_stats_f16",
+    "nastar_chan_affine_f16",
 )
 
 
@@ -146,6 +149,12 @@ def load() -> ctypes.CDLL:
     lib.nastar_maxpool2x2_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.nastar_encoder_prep_f16.restype = ci
     lib.nastar_encoder_prep_f16.argtypes = [vp, vp, vp, ci, ctypes.c_longlong, ci, ci, vp, vp]
+    lib.nastar_conv3x3_wgrad_f16.restype = ci
+    lib.nastar_conv3x3_wgrad_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    lib.nastar_chan_stats_f16.restype = ci
+    lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
+    lib.nastar_chan_affine_f16.restype = ci
+    lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_debug_occupancy.restype = ci
     lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib

@@ -109,6 +109,15 @@ class NeuralAstar(VanillaAstar):
             if not isinstance(self._hip_encoder, HipUnetEncoder) or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
+        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled()
+                and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
+                and _is_depth4_cnn(self.encoder) and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]):
+            # TRAINING: convolutions, batch-statistics BatchNorm, ReLU and all their gradients on the MI355X kernels
+            # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade)
+            from ..encoder_train import cnn_train_forward, supported_shape
+            if supported_shape(map_designs.shape[-2], map_designs.shape[-1]):
+                return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
+                                         "f16" if self.encoder_backend == "hip_f16" else "f16x3")
         tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
         if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
