@@ -231,7 +231,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
  *          [W_hi | W_hi | W_lo] with NASTAR_CONV_SPLIT;   scale/shift fp32 [cout] (folded eval-mode BatchNorm / bias)
  *   out  [B, H, W, cout] fp16 (x2 when split), or with NASTAR_CONV_FINAL out_f32 [B,H,W] = sigmoid(y[..., 0]) * final_mul (cout == 32,
  *        channel 0 real: reference encoder.py:32-34)
- *   c1, c2 multiples of 32, cout a multiple of 32, W <= 94, B*H*W*max(channels) < 2^31 (chunk the batch above that).
+ *   c1, c2 multiples of 32, cout a multiple of 32, W <= 94, B*H*W*max(fp16 per pixel) < 2^34 (32 GiB per tensor).
  */
 #define NASTAR_CONV_RELU 1
 #define NASTAR_CONV_FINAL 2
@@ -253,20 +253,46 @@ int nastar_encoder_prep_f16(const float* map, const float* start, const float* g
  * nastar_conv3x3_f16 (forward, and the input gradient = the same convolution with transposed, flipped weights) they make the
  * conv + batch-statistics BatchNorm + ReLU stack differentiable on the device without torch.nn.  NHWC fp16 tensors, `split` as above.
  *
- * nastar_conv3x3_wgrad_f16: dw[tap][ci][co] = out_scale * sum_{b,y,x} dz[b,y,x,co] * a[b,y+dy,x+dx,ci]  (tap = (dy+1)*3 + (dx+1), zero
- *   padding) on the fp16 MFMA with gfx950's LDS transpose reads; dw fp32 [9][ci][co] is zeroed and accumulated inside the call
- *   (csrc/nastar_conv_wgrad.hip.h).  W must divide 64 (2..64), H % (64/W) == 0, co % 32 == ci % 32 == 0.
+ * nastar_conv3x3_wgrad_f16: dw[co][ci][ky][kx] = (out_scale / *grad_scale_dev) * sum_{b,y,x} dz[b,y,x,co] * a[b,y+ky-1,x+kx-1,ci]  (zero
+ *   padding) on the fp16 MFMA with gfx950's LDS transpose reads (csrc/nastar_conv_wgrad.hip.h).  dz [B,H,W,co], a [B,H,W,ci] with co, ci the
+ *   PADDED channel counts (multiples of 32); dw fp32 [co_real][ci_real][3][3] = torch's weight layout, cropped.  grad_scale_dev: device
+ *   float holding the power-of-two gradient scale to divide out, or NULL.  Deterministic (per-workgroup partial sums in `workspace`,
+ *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  W must divide 64 (2..64), H % (64/W) == 0.
  * nastar_chan_stats_f16: per-channel sums over all pixels in double: sums[c] = (sum v, sum v^2), or with u != NULL
- *   (sum u*m, sum u*m*v), m = [ms[c]*v + mt[c] > 0] (the ReLU mask).  sums double [C][2], zeroed inside the call.
+ *   (sum u*m, sum u*m*v), m = [ms[c]*v + mt[c] > 0] (the ReLU mask).  sums double [C][2], zeroed inside the call; amax_out
+ *   (optional device float): max |u*m| over the tensor (feeds the power-of-two gradient re-scaling).
  * nastar_chan_affine_f16: out = k1[c]*u*[ms[c]*v + mt[c] > 0] + k2[c]*v + k3[c], optional ReLU; u == NULL drops the first term
  *   (forward: BatchNorm folded to k2, k3 + ReLU; backward: ReLU mask + closed-form BatchNorm backward).
  */
-int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, int B, int H, int W, int co, int ci, int split,
-                             float out_scale, void* stream);
-int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, long long npix, int C,
-                          int split, void* stream);
+size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci);
+int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, int B, int H, int W, int co, int ci, int co_real,
+                             int ci_real, int split, float out_scale, const float* grad_scale_dev, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
+                          long long npix, int C, int split, void* stream);
 int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1, const float* k2, const float* k3, const float* ms,
                            const float* mt, uint16_t* out, long long npix, int C, int relu, int split, void* stream);
+/*
+ * Device-side glue of a training step (one or two tiny launches each, no host synchronisation; at the reference's batch of 100 maps the
+ * step is launch-bound, so nothing between the big kernels is left to framework ops):
+ * nastar_pack_conv_weight_f16: torch conv weight w fp32 [co][ci][3][3] -> the wpack of nastar_conv3x3_f16 (channels padded to 32;
+ *   transpose_flip = the input-gradient form W'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]; split = [W_hi | W_hi | W_lo] of w * 2^s with
+ *   2^s bringing max|w| to ~2^14), scale_out[cout_p] = 2^-s, shift_out[cout_p] = bias (or 0), scal_out[2] = (2^-s, 2^s).
+ * nastar_bn_coef_fwd: batch sums [C][2] (nastar_chan_stats_f16) -> k2 = gamma*invstd, k3 = beta - mean*k2, mean / invstd (double [C]),
+ *   running_mean / running_var updated like nn.BatchNorm2d in training mode (may be NULL).
+ * nastar_bn_coef_bwd: backward sums + amax|dy| + forward mean / invstd -> dgamma, dbeta (already divided by the gradient scale
+ *   gscale[0]), the closed-form BatchNorm-backward coefficients c1, c2, c3 multiplied by a fresh power of two, gscale[0] updated.
+ * nastar_grad_seed_f16: d fp32 [npix] (dL/dz of the 1-channel last block) -> dzb [npix][32 (x2)] fp16, channel 0 = d * S, S = 2^floor(log2(
+ *   1024 / max|d|)) written to gscale[0]; amax_scratch: one device float.
+ */
+int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
+                                float* scale_out, float* shift_out, float* scal_out, void* stream);
+int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta, double eps, long long npix, double momentum,
+                       float* running_mean, float* running_var, float* k2, float* k3, double* mean_out, double* invstd_out, int C,
+                       void* stream);
+int nastar_bn_coef_bwd(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
+                       long long npix, float* gscale, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C, void* stream);
+int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dzb, float* gscale, float* amax_scratch, void* stream);
 
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */

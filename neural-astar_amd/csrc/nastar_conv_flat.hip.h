@@ -94,7 +94,9 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     if (tid < 16) reinterpret_cast<uint32_t*>(smem)[tid] = 0u;  // the zero slot
 
     // ---- staging plan (once): thread t moves chunks idx = t + i*256, idx = slot*4 + c ----
-    int src1[FC_NTQ], src2[FC_NTQ];  // element offsets into in / in2 of (pixel, chunk) at channel 0 of the source; -1 = zero fill
+    // offsets into in / in2 of (pixel, chunk) at channel 0 of the source, in 16-BYTE UNITS (pixel strides are multiples of 32 fp16, so
+    // 32-bit offsets reach 32 GiB tensors); -1 = zero fill
+    int src1[FC_NTQ], src2[FC_NTQ];
 #pragma unroll
     for (int i = 0; i < FC_NTQ; ++i) {
         const int idx = tid + i * FC_THREADS;
@@ -106,11 +108,11 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
             if (a.ups) {
                 const int b = q / HW, r = q - b * HW;
                 const int y = r / a.W, x = r - y * a.W;
-                o1 = ((b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * st1 + c * 8;
+                o1 = ((b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * (st1 >> 3) + c;
             } else {
-                o1 = q * st1 + c * 8;
+                o1 = q * (st1 >> 3) + c;
             }
-            o2 = q * st2 + c * 8;
+            o2 = q * (st2 >> 3) + c;
         }
         src1[i] = o1;
         src2[i] = o2;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
         for (int i = 0; i < FC_NTQ; ++i) {
             const int o = first ? src1[i] : src2[i];
             tq[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (o >= 0) tq[i] = *reinterpret_cast<const uint4*>(base + o);
+            if (o >= 0) tq[i] = *reinterpret_cast<const uint4*>(base + (size_t)o * 8);
         }
         const uint16_t* wb = a.wpack + (size_t)s * (FC_KS / 8) * a.COUT * 8;
 #pragma unroll

@@ -1,6 +1,6 @@
 // nastar_conv_wgrad.hip.h -- weight gradient of a 3x3 convolution (padding 1) on the fp16 MFMA, straight from NHWC activations:
 //
-//   dW[tap][ci][co] = out_scale * sum_p dz[p][co] * a[p + tap][ci]              (autograd of reference planner/encoder.py:60-78's convs)
+//   dW[co][ci][tap] = out_scale * sum_p dz[p][co] * a[p + tap][ci]              (autograd of reference planner/encoder.py:60-78's convs)
 //
 // As a GEMM the reduction index is the PIXEL, but NHWC keeps channels contiguous: an MFMA operand wants 8 consecutive k (pixels) of one
 // row (channel) per lane, i.e. the transpose of what a coalesced load delivers.  gfx950's LDS transpose read does that on the fly:
@@ -9,16 +9,18 @@
 // of a pixel-major LDS tile, lane i ends up with channel c0 + i of pixels P0 .. P0+3: two such reads are the 8-pixel MFMA fragment of
 // "its" channel for BOTH operands (same pixel <-> k assignment on the dz and on the activation side), no transposed copies in HBM.
 //
-//   * a workgroup owns a (COB x 32) x (CIB x 32) channel tile of dW for all 9 taps and a strided set of pixel chunks; wavefront
-//     (wco, wci) holds the 9 accumulators (one per tap) of its 32 x 32 block: 144 VGPRs;
+//   * a workgroup owns a (COB x 32) x (CIB x 32) channel tile of dW for all 9 taps and a strided set of pixel chunks; it runs
+//     3 x COB x CIB wavefronts: wavefront (wco, wci, wdy) holds the 3 accumulators (dx = -1, 0, 1) of its 32 x 32 block and tap row
+//     dy: 48 accumulator registers, which leaves room to PREFETCH the next chunk into registers while the matrix pipe works;
 //   * a chunk = RC whole image rows (RC * W = 64 pixels: 4 MFMA k-steps of 16 pixels): dz rows pixel-major in LDS, the activation rows
 //     with a one-pixel ZERO frame around them ((RC+2) x (W+2) slots, rows outside the image zero): a tap is a constant LDS offset,
-//     conv2d's zero padding costs nothing in the loop, and every fragment address is a per-lane constant computed once;
+//     conv2d's zero padding costs nothing in the loop, and every staging / fragment address is a per-thread constant computed once;
 //   * pixel rows in LDS are padded by 64 bytes (row stride = 64 mod 256) so that the 4 pixels x 64 bytes a 32-lane pass of the
 //     transpose read touches fall into 4 different bank quarters;
 //   * kSplit ("f16x3"): operands are [hi | lo] fp16 pairs; per tap dz_hi*a_hi + dz_lo*a_hi + dz_hi*a_lo (fp32 accumulation);
-//   * epilogue: acc * out_scale (undoes the power-of-two gradient scale) -> fp32 atomic adds into dW [9][CI][CO] (the caller zeroes
-//     it; pixel splits and all workgroups of a tile add into the same words).
+//   * no atomics: every workgroup stores its partial tile to part[split][tap][ci][co]; nastar_wgrad_reduce_kernel sums the splits in
+//     a fixed order (bitwise reproducible), applies out_scale (undoes the power-of-two gradient scale read from device memory) and
+//     writes torch's [co][ci][3][3] layout cropped to the real channel counts.
 // Shapes: W in {2,4,...,64} dividing 64, H a multiple of RC = 64 / W; CO, CI multiples of 32 (zero padded).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,12 +33,13 @@ namespace nastar {
 struct WgradArgs {
     const uint16_t* dz;  // [P][CO (x2)] fp16 NHWC
     const uint16_t* a;   // [P][CI (x2)] fp16 NHWC (the layer's input activations)
-    float* dw;           // [9][CI][CO] fp32, accumulated with atomics
-    float out_scale;
+    float* part;         // [nsplit][9][CI][CO] fp32 partial sums
     int B, H, W, CO, CI;
     int nchunk;          // B*H*W / 64
     int nsplit;          // pixel splits: gridDim.x = nsplit * (CO/(32 COB)) * (CI/(32 CIB))
 };
+
+constexpr int WG_MAX_SLOTS = 198;  // (RC+2)*(W+2) for W = 64; 136 for W = 32
 
 typedef __fp16 nastar_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -52,20 +55,23 @@ __device__ __forceinline__ bf16x8 wg_tr_read2(uint32_t addr0, uint32_t addr1)
 }
 
 template <int COB, int CIB, bool kSplit>
-__global__ __launch_bounds__(64 * COB * CIB, 2) void nastar_conv3x3_wgrad_kernel(const WgradArgs g)
+__global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(const WgradArgs g)
 {
-    constexpr int NTHR = 64 * COB * CIB;
+    constexpr int NTHR = 192 * COB * CIB;
     constexpr int M = kSplit ? 2 : 1;
     constexpr int RDZ = COB * 64 * M + 64;  // bytes per pixel row of the dz tile (32 channels = 64 B per block and precision half) + pad
     constexpr int RA = CIB * 64 * M + 64;
+    constexpr int CPZ = M * COB * 4, CPA = M * CIB * 4;            // 16-byte chunks per pixel
+    constexpr int NZ = (64 * CPZ + NTHR - 1) / NTHR;               // staged chunks per thread
+    constexpr int NA = (WG_MAX_SLOTS * CPA + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, RC = 64 / W, PW = W + 2;
     unsigned char* dzt = smem;                    // [64][RDZ]
-    unsigned char* at = smem + 64 * RDZ;          // [(RC+2)*(W+2)][RA]
+    // activation tile [(RC+2)*(W+2)][RA] follows at smem + 64 * RDZ
     const int nslot_a = (RC + 2) * PW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wco = wave % COB, wci = wave / COB;
+    const int wdy = wave % 3, wco = (wave / 3) % COB, wci = wave / (3 * COB);
     const int ntco = g.CO / (32 * COB), ntci = g.CI / (32 * CIB);
     int t = blockIdx.x;
     const int split = t % g.nsplit; t /= g.nsplit;
@@ -74,6 +80,31 @@ __global__ __launch_bounds__(64 * COB * CIB, 2) void nastar_conv3x3_wgrad_kernel
     if (tci >= ntci) return;
     const int co0 = tco * 32 * COB, ci0 = tci * 32 * CIB;
     const int sdz = M * g.CO, sa = M * g.CI;      // fp16 elements per pixel in HBM
+
+    // ---- staging plan (constants per thread): global element offset relative to the chunk's first pixel, LDS byte offset ----
+    int zsrc[NZ], zdst[NZ], asrc[NA], adst[NA], arow[NA];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const int q = tid + i * NTHR;
+        const int pix = q / CPZ, c = q - pix * CPZ;
+        const int half = c / (COB * 4), cc = c - half * (COB * 4);
+        const bool ok = q < 64 * CPZ;
+        zsrc[i] = ok ? pix * sdz + half * g.CO + co0 + cc * 8 : -1;
+        zdst[i] = pix * RDZ + half * (COB * 64) + cc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q = tid + i * NTHR;
+        const int slot = q / CPA, c = q - slot * CPA;
+        const int half = c / (CIB * 4), cc = c - half * (CIB * 4);
+        const int sr = slot / PW, sc = slot - sr * PW;
+        const bool ok = q < nslot_a * CPA;
+        const bool inx = sc >= 1 && sc <= W;
+        // relative to the chunk's first pixel (row y0, column 0): (sr - 1) rows up/down, column sc - 1
+        asrc[i] = ((sr - 1) * W + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
+        adst[i] = ok ? 64 * RDZ + slot * RA + half * (CIB * 64) + cc * 16 : -1;
+        arow[i] = (ok && inx) ? sr - 1 : -(1 << 28);  // image row offset of the slot; hugely negative = always zero (frame column / unused)
+    }
 
     // ---- per-lane fragment addresses (constants): k-step ks, read half tt: pixel = 16 ks + 8 kh + 4 tt + (r16 >> 2) ----
     const int r16 = lane & 15, grp = (lane >> 4) & 1, kh = lane >> 5;
@@ -87,74 +118,96 @@ __global__ __launch_bounds__(64 * COB * CIB, 2) void nastar_conv3x3_wgrad_kernel
             const int chan = 16 * grp + 4 * (r16 & 3);
             adz[ks][tt] = lds0 + pix * RDZ + wco * 64 + chan * 2;
             const int row = pix / W, col = pix - row * W;
-            aa[ks][tt] = lds0 + 64 * RDZ + ((row + 1) * PW + col + 1) * RA + wci * 64 + chan * 2;
+            // tap row dy = wdy - 1 is folded in here; the three dx taps are +-RA around it
+            aa[ks][tt] = lds0 + 64 * RDZ + ((row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2;
         }
 
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
     const int rows_per_img = g.H / RC;  // chunks per image
-    for (int ch = split; ch < g.nchunk; ch += g.nsplit) {
+    uint4 zq[NZ], aq[NA];
+    auto load_chunk = [&](int ch) {
         const int b = ch / rows_per_img, y0 = (ch - b * rows_per_img) * RC;
         const size_t p0 = ((size_t)b * g.H + y0) * W;
+        const uint16_t* zb = g.dz + p0 * sdz;
+        const uint16_t* ab = g.a + (ptrdiff_t)p0 * sa;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            zq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (zsrc[i] >= 0) zq[i] = *reinterpret_cast<const uint4*>(zb + zsrc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            aq[i] = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)(y0 + arow[i]) < (unsigned)g.H) aq[i] = *reinterpret_cast<const uint4*>(ab + asrc[i]);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            if (zsrc[i] >= 0) *reinterpret_cast<uint4*>(dzt + zdst[i]) = zq[i];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (adst[i] >= 0) *reinterpret_cast<uint4*>(smem + adst[i]) = aq[i];
+    };
+
+    if (split < g.nchunk) load_chunk(split);
+    for (int ch = split; ch < g.nchunk; ch += g.nsplit) {
         __syncthreads();  // the previous chunk's fragments are consumed
-        // ---- stage dz: 64 pixels x (M * COB * 64) bytes, 16-byte chunks ----
-        {
-            constexpr int CPP = M * COB * 4;  // chunks per pixel
-            for (int q = tid; q < 64 * CPP; q += NTHR) {
-                const int pix = q / CPP, c = q - pix * CPP;
-                const int half = c / (COB * 4), cc = c - half * (COB * 4);
-                const uint4 v = *reinterpret_cast<const uint4*>(g.dz + (p0 + pix) * sdz + half * g.CO + co0 + cc * 8);
-                *reinterpret_cast<uint4*>(dzt + pix * RDZ + half * (COB * 64) + cc * 16) = v;
-            }
-        }
-        // ---- stage a: (RC+2) x (W+2) slots, zero outside the image ----
-        {
-            constexpr int CPP = M * CIB * 4;
-            for (int q = tid; q < nslot_a * CPP; q += NTHR) {
-                const int slot = q / CPP, c = q - slot * CPP;
-                const int half = c / (CIB * 4), cc = c - half * (CIB * 4);
-                const int sr = slot / PW, sc = slot - sr * PW;
-                const int y = y0 + sr - 1, x = sc - 1;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)W)
-                    v = *reinterpret_cast<const uint4*>(g.a + (((size_t)b * g.H + y) * W + x) * sa + half * g.CI + ci0 + cc * 8);
-                *reinterpret_cast<uint4*>(at + slot * RA + half * (CIB * 64) + cc * 16) = v;
-            }
-        }
+        store_chunk();
         __syncthreads();
+        if (ch + g.nsplit < g.nchunk) load_chunk(ch + g.nsplit);  // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 zh = wg_tr_read2(adz[ks][0], adz[ks][1]);
             bf16x8 zl = zh;
             if constexpr (kSplit) zl = wg_tr_read2(adz[ks][0] + COB * 64, adz[ks][1] + COB * 64);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * RA;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int toff = (dx - 1) * RA;
                 const bf16x8 xh = wg_tr_read2(aa[ks][0] + toff, aa[ks][1] + toff);
-                acc[tap] = mfma16<true>(zh, xh, acc[tap]);
+                acc[dx] = mfma16<true>(zh, xh, acc[dx]);
                 if constexpr (kSplit) {
                     const bf16x8 xl = wg_tr_read2(aa[ks][0] + toff + CIB * 64, aa[ks][1] + toff + CIB * 64);
-                    acc[tap] = mfma16<true>(zl, xh, acc[tap]);
-                    acc[tap] = mfma16<true>(zh, xl, acc[tap]);
+                    acc[dx] = mfma16<true>(zl, xh, acc[dx]);
+                    acc[dx] = mfma16<true>(zh, xl, acc[dx]);
                 }
             }
         }
     }
-    // ---- epilogue: D[row = co][col = ci]; row = (reg & 3) + 8 (reg >> 2) + 4 kh, col = lane & 31 ----
+    // ---- epilogue: D[row = co][col = ci]; row = (reg & 3) + 8 (reg >> 2) + 4 kh, col = lane & 31; 4 consecutive co per store ----
     const int ci = ci0 + wci * 32 + (lane & 31);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        float* dst = g.dw + ((size_t)tap * g.CI + ci) * g.CO + co0 + wco * 32;
+    for (int dx = 0; dx < 3; ++dx) {
+        const int tap = wdy * 3 + dx;
+        float* dst = g.part + (((size_t)split * 9 + tap) * g.CI + ci) * g.CO + co0 + wco * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            unsafeAtomicAdd(dst + co, acc[tap][r] * g.out_scale);
-        }
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q + 4 * kh) = make_float4(acc[dx][4 * q], acc[dx][4 * q + 1], acc[dx][4 * q + 2], acc[dx][4 * q + 3]);
     }
+}
+
+// dw[co][ci][tap] (torch layout, real channel counts) = scale * sum_split part[split][tap][ci_p][co_p];  scale = out_scale / *unscale_dev
+__global__ __launch_bounds__(256) void nastar_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
+                                                                  int CO, int CI, int co_real, int ci_real, float out_scale,
+                                                                  const float* __restrict__ grad_scale_dev)
+{
+    const int total = 9 * CI * CO;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int co = i % CO;
+    int r = i / CO;
+    const int ci = r % CI;
+    const int tap = r / CI;
+    if (co >= co_real || ci >= ci_real) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
+    const float sc = grad_scale_dev ? out_scale / *grad_scale_dev : out_scale;
+    dw[((size_t)co * ci_real + ci) * 9 + tap] = s * sc;
 }
 
 }  // namespace nastar

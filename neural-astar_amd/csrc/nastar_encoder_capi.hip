@@ -471,7 +471,7 @@ int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* 
     if (c1 % FC_KS || c2 % FC_KS || cout % 32 || W > FC_MAXW || (fin && cout != 32) || (ups && ((H | W) & 1))) return NASTAR_ERR_UNSUPPORTED;
     const long long npix = (long long)B * H * W;
     const long long widest = (long long)(split ? 2 : 1) * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout));
-    if (npix * widest >= (1ll << 31)) return NASTAR_ERR_UNSUPPORTED;  // 32-bit element offsets: the caller chunks the batch
+    if (npix >= (1ll << 31) || npix * widest >= (1ll << 34)) return NASTAR_ERR_UNSUPPORTED;  // 32-bit offsets in 16-byte units
     if (!aligned16(in) || (in2 && !aligned16(in2)) || !aligned16(wpack) || (out && !aligned16(out))) return NASTAR_ERR_BAD_SHAPE;
     FlatConvArgs fa;
     fa.in = in; fa.in2 = in2; fa.wpack = wpack; fa.scale = scale; fa.shift = shift; fa.out = out; fa.out_f32 = out_f32;

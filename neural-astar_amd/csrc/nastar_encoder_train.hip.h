@@ -45,18 +45,20 @@ __device__ __forceinline__ void store8(uint16_t* base, size_t pix, int stride, i
     if constexpr (kSplit) *reinterpret_cast<nastar_f16x8*>(base + pix * stride + C + c8 * 8) = lo;
 }
 
-// sums[c][0], sums[c][1] (double, accumulated with atomics: the caller zeroes them).  u == nullptr: (sum v, sum v^2);
+// sums[c][0], sums[c][1] (double, accumulated with atomics: the caller zeroes them); amax_bits (optional): max |u*m| as float bits.  u == nullptr: (sum v, sum v^2);
 // otherwise (sum u*m, sum u*m*v) with the ReLU mask m = [ms[c]*v + mt[c] > 0].  256 threads = (256 / (C/8)) pixel lanes x C/8 channel groups.
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                 const float* __restrict__ ms, const float* __restrict__ mt,
-                                                                double* __restrict__ sums, long long npix, int C)
+                                                                double* __restrict__ sums, unsigned int* __restrict__ amax_bits,
+                                                                long long npix, int C)
 {
     __shared__ double red[256][2];
     const int stride = kSplit ? 2 * C : C;
     const int CG = C >> 3;                 // 8-channel groups (C/8 <= 256 and divides 256: C in {8, 16, 32, 64, ... 2048})
     const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
     double s0[8], s1[8];
+    float amax = 0.f;  // max |u * mask| seen by this thread (backward form only)
 #pragma unroll
     for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.0;
     float fs[8], ft[8];
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float dy = (fs[e] * x[e] + ft[e] > 0.f) ? d[e] : 0.f;
+                amax = fmaxf(amax, fabsf(dy));
                 s0[e] += (double)dy;
                 s1[e] += (double)dy * (double)x[e];
             }
@@ -86,6 +89,11 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
                 s1[e] += (double)x[e] * (double)x[e];
             }
         }
+    }
+    if (amax_bits) {  // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
     }
     // reduce over the pixel lanes of the workgroup (fixed order), then one atomic pair per channel and workgroup
 #pragma unroll
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
 }
 
 // out = k1*u*[ms*v + mt > 0] + k2*v + k3, optionally ReLU'd.  u == nullptr drops the first term (forward: a = relu(k2*z + k3)).
+// A thread keeps ONE 8-channel group (its coefficients live in registers) and walks pixels: 256 threads = (256 / (C/8)) pixel lanes.
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                  const float* __restrict__ k1, const float* __restrict__ k2,
@@ -116,26 +125,195 @@ __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t*
 {
     const int stride = kSplit ? 2 * C : C;
     const int CG = C >> 3;
-    const long long total = npix * CG;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % CG);
-        const size_t p = (size_t)(i / CG);
-        float x[8], r[8];
-        load8<kSplit>(v, p, stride, C, c8, x);
+    const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
+    float f1[8], f2[8], f3[8], fs[8], ft[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = k2[c8 * 8 + e] * x[e] + k3[c8 * 8 + e];
+    for (int e = 0; e < 8; ++e) {
+        f2[e] = k2[c8 * 8 + e];
+        f3[e] = k3[c8 * 8 + e];
+        f1[e] = u ? k1[c8 * 8 + e] : 0.f;
+        fs[e] = u ? ms[c8 * 8 + e] : 0.f;
+        ft[e] = u ? mt[c8 * 8 + e] : 0.f;
+    }
+    for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += (long long)gridDim.x * NPL) {
+        float x[8], r[8];
+        load8<kSplit>(v, (size_t)p, stride, C, c8, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = f2[e] * x[e] + f3[e];
         if (u) {
             float d[8];
-            load8<kSplit>(u, p, stride, C, c8, d);
+            load8<kSplit>(u, (size_t)p, stride, C, c8, d);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (ms[c8 * 8 + e] * x[e] + mt[c8 * 8 + e] > 0.f) r[e] += k1[c8 * 8 + e] * d[e];
+                if (fs[e] * x[e] + ft[e] > 0.f) r[e] += f1[e] * d[e];
         }
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) r[e] = fmaxf(r[e], 0.f);
         }
-        store8<kSplit>(out, p, stride, C, c8, r);
+        store8<kSplit>(out, (size_t)p, stride, C, c8, r);
+    }
+}
+
+// ---- small host-replacing kernels: everything a training step needs between the big launches runs on the device, in ONE launch each,
+// so that a step is ~100 launches instead of ~600 tiny framework ops (at the reference's batch of 100 maps the step is launch-bound) ------
+
+__device__ __forceinline__ float block_max_256(float v, float* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, red[k]);
+    return m;
+}
+
+// power of two 2^floor(log2(target / amax)), clamped to [2^lo, 2^hi]; amax == 0 -> 1
+__device__ __forceinline__ float pow2_scale(float amax, float target, int lo, int hi)
+{
+    if (!(amax > 0.f)) return 1.f;
+    int e = (int)floorf(log2f(target / amax));
+    e = e < lo ? lo : (e > hi ? hi : e);
+    return ldexpf(1.f, e);
+}
+
+// Weight pack for nastar_conv3x3_f16 from torch's [co][ci][3][3] fp32 weight, ONE workgroup pass for the maximum + a grid pass for
+// the pack.  transpose_flip: the input-gradient form W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (logical cout = ci, cin = co).
+// scal[0] = 2^-s (to fold into the conv's epilogue scale), scal[1] = 2^s.
+__global__ __launch_bounds__(256) void nastar_pack_amax_kernel(const float* __restrict__ w, int n, int split, float* __restrict__ scal,
+                                                               float* __restrict__ scale_out, const float* __restrict__ bias,
+                                                               float* __restrict__ shift_out, int cout_l, int cout_p)
+{
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    m = block_max_256(m, red);
+    const float sc = split ? pow2_scale(m, 16384.f, 0, 24) : 1.f;
+    if (threadIdx.x == 0) {
+        scal[0] = 1.f / sc;
+        scal[1] = sc;
+    }
+    for (int c = threadIdx.x; c < cout_p; c += 256) {
+        scale_out[c] = 1.f / sc;
+        shift_out[c] = (bias && c < cout_l) ? bias[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void nastar_pack_weight_kernel(const float* __restrict__ w, int co, int ci, int transpose_flip, int split,
+                                                                 const float* __restrict__ scal, uint16_t* __restrict__ wpack)
+{
+    const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
+    const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
+    const int cinv = split ? 3 * cin_p : cin_p;
+    const int total = 9 * cinv * cout_p;  // elements of [tap][cinv/8][cout_p][8]
+    const float sc = scal[1];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int e = i & 7;
+        int r = i >> 3;
+        const int n = r % cout_p; r /= cout_p;
+        const int cv8 = r % (cinv >> 3);
+        const int tap = r / (cinv >> 3);
+        const int v = cv8 * 8 + e;
+        const int seg = v / cin_p, c = v - seg * cin_p;
+        float x = 0.f;
+        if (n < cout_l && c < cin_l) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            x = transpose_flip ? w[((size_t)c * ci + n) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((size_t)n * ci + c) * 9 + tap];
+            x *= sc;
+        }
+        const _Float16 hi = (_Float16)x;
+        const _Float16 val = (seg == 2) ? (_Float16)(x - (float)hi) : hi;
+        wpack[i] = *reinterpret_cast<const uint16_t*>(&val);
+    }
+}
+
+// forward BatchNorm coefficients from the batch sums (one workgroup): k2 = gamma * invstd, k3 = beta - mean * k2; mean / invstd kept in
+// double for the backward; running statistics updated like nn.BatchNorm2d in training mode (unbiased variance, momentum).
+__global__ __launch_bounds__(256) void nastar_bn_coef_fwd_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, double eps, double npix, double momentum,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float* __restrict__ k2, float* __restrict__ k3,
+                                                                 double* __restrict__ mean_out, double* __restrict__ invstd_out, int C)
+{
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double mean = sums[2 * c] / npix;
+        double var = sums[2 * c + 1] / npix - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double invstd = 1.0 / sqrt(var + eps);
+        const double g = (double)gamma[c];
+        k2[c] = (float)(g * invstd);
+        k3[c] = (float)((double)beta[c] - mean * g * invstd);
+        mean_out[c] = mean;
+        invstd_out[c] = invstd;
+        if (running_mean) {
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * var * (npix / (npix > 1.0 ? npix - 1.0 : 1.0)));
+        }
+    }
+}
+
+// backward BatchNorm coefficients (one workgroup): from (sum dy, sum dy z) * S_in, the forward's mean / invstd and gamma:
+//   dgamma = sum dy xhat / S_in, dbeta = sum dy / S_in,  dz = c1 dy + c2 z + c3  (closed-form BatchNorm backward) times a NEW power of
+// two r chosen so that |dz| <~ 2 max|k1| max|dy| lands near 2^10; gscale[0] (S) is updated to S_in * r for the next block.
+__global__ __launch_bounds__(256) void nastar_bn_coef_bwd_kernel(const double* __restrict__ sums, const float* __restrict__ amax_dy,
+                                                                 const double* __restrict__ mean, const double* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, double npix, float* __restrict__ gscale,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, int C)
+{
+    __shared__ float red[4];
+    const double S = (double)gscale[0];
+    float kmax = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) kmax = fmaxf(kmax, fabsf((float)((double)gamma[c] * invstd[c])));
+    kmax = block_max_256(kmax, red);
+    const float r = pow2_scale(2.f * kmax * amax_dy[0], 1024.f, -40, 40);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double sdy = sums[2 * c], sdyz = sums[2 * c + 1];
+        const double sdyx = (sdyz - mean[c] * sdy) * invstd[c];
+        dgamma[c] = (float)(sdyx / S);
+        dbeta[c] = (float)(sdy / S);
+        const double k1 = (double)gamma[c] * invstd[c];
+        const double m1 = sdy / npix, m2 = sdyx / npix;
+        c1[c] = (float)(k1 * r);
+        c2[c] = (float)(-k1 * m2 * invstd[c] * r);
+        c3[c] = (float)((-k1 * m1 + k1 * m2 * mean[c] * invstd[c]) * r);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) gscale[0] = (float)(S * (double)r);
+}
+
+// gradient seed: d [P] fp32 (dL/dz of the 1-channel last block) -> dzb [P][32 (x2)] fp16 with channel 0 = d * S, the rest zero;
+// S = 2^floor(log2(1024 / max|d|)) is written to gscale[0].  Two launches: maximum (atomicMax on float bits), then the scatter.
+__global__ __launch_bounds__(256) void nastar_absmax_kernel(const float* __restrict__ d, long long n, unsigned int* __restrict__ amax_bits)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(d[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_grad_seed_kernel(const float* __restrict__ d, long long npix, const float* __restrict__ amax,
+                                                               float* __restrict__ gscale, uint16_t* __restrict__ dzb)
+{
+    const float S = pow2_scale(amax[0], 1024.f, -60, 60);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gscale[0] = S;
+    constexpr int CH = kSplit ? 8 : 4;  // 16-byte chunks per pixel row (32 or 64 fp16)
+    const long long total = npix * CH;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / CH;
+        const int c = (int)(i - p * CH);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c == 0 || (kSplit && c == 4)) {
+            const float x = d[p] * S;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 h = (c == 0) ? hi : (_Float16)(x - (float)hi);
+            v.x = (uint32_t)(*reinterpret_cast<const uint16_t*>(&h));
+        }
+        *reinterpret_cast<uint4*>(dzb + i * 8) = v;
     }
 }
 

@@ -9,6 +9,16 @@
 
 namespace nastar {
 
+static int wgrad_nsplit(int nchunk, int co, int ci)
+{
+    const int cob = co % 64 == 0 ? 2 : 1, cib = ci % 64 == 0 ? 2 : 1;
+    const int tiles = (co / (32 * cob)) * (ci / (32 * cib));
+    int nsplit = 512 / tiles;                      // ~2 workgroups per CU in flight
+    if (nsplit > nchunk / 4) nsplit = nchunk / 4;  // ... but at least 4 chunks of 64 pixels per workgroup
+    if (nsplit < 1) nsplit = 1;
+    return nsplit;
+}
+
 template <int COB, int CIB, bool kSplit>
 static int launch_wgrad(WgradArgs g, hipStream_t s)
 {
@@ -19,11 +29,7 @@ static int launch_wgrad(WgradArgs g, hipStream_t s)
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
     const int tiles = (g.CO / (32 * COB)) * (g.CI / (32 * CIB));
-    int nsplit = 1024 / tiles;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > g.nchunk) nsplit = g.nchunk;
-    g.nsplit = nsplit;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nsplit * tiles)), dim3(64 * COB * CIB), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.nsplit * tiles)), dim3(192 * COB * CIB), lds, s, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
@@ -35,47 +41,66 @@ using namespace nastar;
 
 extern "C" {
 
-int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, int B, int H, int W, int co, int ci, int split,
-                             float out_scale, void* stream)
+size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci)
 {
-    if (!dz || !a || !dw) return NASTAR_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (co % 32 || ci % 32 || W < 2 || W > 64 || 64 % W || H % (64 / W)) return NASTAR_ERR_UNSUPPORTED;
-    if (!aligned16(dz) || !aligned16(a)) return NASTAR_ERR_BAD_SHAPE;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)9 * ci * co * sizeof(float), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dw)");
-    WgradArgs g;
-    g.dz = dz; g.a = a; g.dw = dw; g.out_scale = out_scale; g.B = B; g.H = H; g.W = W; g.CO = co; g.CI = ci;
-    g.nchunk = (int)(((long long)B * H * W) / 64); g.nsplit = 1;
-    const bool co2 = co % 64 == 0, ci2 = ci % 64 == 0;
-    if (split) {
-        if (co2 && ci2) return launch_wgrad<2, 2, true>(g, s);
-        if (co2) return launch_wgrad<2, 1, true>(g, s);
-        if (ci2) return launch_wgrad<1, 2, true>(g, s);
-        return launch_wgrad<1, 1, true>(g, s);
-    }
-    if (co2 && ci2) return launch_wgrad<2, 2, false>(g, s);
-    if (co2) return launch_wgrad<2, 1, false>(g, s);
-    if (ci2) return launch_wgrad<1, 2, false>(g, s);
-    return launch_wgrad<1, 1, false>(g, s);
+    if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0 || co % 32 || ci % 32) return 0;
+    const int nchunk = (int)(((long long)B * H * W) / 64);
+    return (size_t)wgrad_nsplit(nchunk, co, ci) * 9 * ci * co * sizeof(float);
 }
 
-int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, long long npix, int C,
-                          int split, void* stream)
+int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, int B, int H, int W, int co, int ci, int co_real,
+                             int ci_real, int split, float out_scale, const float* grad_scale_dev, void* workspace,
+                             size_t workspace_bytes, void* stream)
+{
+    if (!dz || !a || !dw || !workspace) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0 || co_real <= 0 || ci_real <= 0 || co_real > co || ci_real > ci) return NASTAR_ERR_BAD_SHAPE;
+    if (co % 32 || ci % 32 || W < 2 || W > 64 || 64 % W || H % (64 / W)) return NASTAR_ERR_UNSUPPORTED;
+    if (!aligned16(dz) || !aligned16(a) || !aligned16(workspace)) return NASTAR_ERR_BAD_SHAPE;
+    if (workspace_bytes < nastar_conv3x3_wgrad_workspace_bytes(B, H, W, co, ci)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    WgradArgs g;
+    g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.W = W; g.CO = co; g.CI = ci;
+    g.nchunk = (int)(((long long)B * H * W) / 64);
+    g.nsplit = wgrad_nsplit(g.nchunk, co, ci);
+    const bool co2 = co % 64 == 0, ci2 = ci % 64 == 0;
+    int rc;
+    if (split) {
+        if (co2 && ci2) rc = launch_wgrad<2, 2, true>(g, s);
+        else if (co2) rc = launch_wgrad<2, 1, true>(g, s);
+        else if (ci2) rc = launch_wgrad<1, 2, true>(g, s);
+        else rc = launch_wgrad<1, 1, true>(g, s);
+    } else {
+        if (co2 && ci2) rc = launch_wgrad<2, 2, false>(g, s);
+        else if (co2) rc = launch_wgrad<2, 1, false>(g, s);
+        else if (ci2) rc = launch_wgrad<1, 2, false>(g, s);
+        else rc = launch_wgrad<1, 1, false>(g, s);
+    }
+    if (rc) return rc;
+    const int total = 9 * ci * co;
+    hipLaunchKernelGGL(nastar_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g.part, dw, g.nsplit, co, ci,
+                       co_real, ci_real, out_scale, grad_scale_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
+                          long long npix, int C, int split, void* stream)
 {
     if (!v || !sums || (u && (!ms || !mt))) return NASTAR_ERR_NULL;
     if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
     if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(sums, 0, (size_t)C * 2 * sizeof(double), s);
+    if (e == hipSuccess && amax_out) e = hipMemsetAsync(amax_out, 0, sizeof(float), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(sums)");
     const long long per = 256 / (C / 8);
     long long grid = (npix + per * 64 - 1) / (per * 64);  // ~64 pixels per pixel lane
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
-    if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, npix, C);
-    else hipLaunchKernelGGL(nastar_chan_stats_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, npix, C);
+    unsigned int* ab = reinterpret_cast<unsigned int*>(amax_out);
+    if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, ab, npix, C);
+    else hipLaunchKernelGGL(nastar_chan_stats_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, ab, npix, C);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
@@ -86,13 +111,75 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
 {
     if (!v || !out || !k2 || !k3 || (u && (!k1 || !ms || !mt))) return NASTAR_ERR_NULL;
     if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (C % 8) return NASTAR_ERR_UNSUPPORTED;
-    const long long total = npix * (C / 8);
-    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    const long long per = 256 / (C / 8);
+    long long grid = (npix + per * 16 - 1) / (per * 16);  // ~16 pixels per pixel lane
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (split) hipLaunchKernelGGL(nastar_chan_affine_kernel<true>, dim3(grid), dim3(256), 0, s, u, v, k1, k2, k3, ms, mt, out, npix, C, relu);
-    else hipLaunchKernelGGL(nastar_chan_affine_kernel<false>, dim3(grid), dim3(256), 0, s, u, v, k1, k2, k3, ms, mt, out, npix, C, relu);
+    if (split) hipLaunchKernelGGL(nastar_chan_affine_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, u, v, k1, k2, k3, ms, mt, out, npix, C, relu);
+    else hipLaunchKernelGGL(nastar_chan_affine_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, u, v, k1, k2, k3, ms, mt, out, npix, C, relu);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
+                                float* scale_out, float* shift_out, float* scal_out, void* stream)
+{
+    if (!w || !wpack || !scale_out || !shift_out || !scal_out) return NASTAR_ERR_NULL;
+    if (co <= 0 || ci <= 0) return NASTAR_ERR_BAD_SHAPE;
+    const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
+    const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(nastar_pack_amax_kernel, dim3(1), dim3(256), 0, s, w, co * ci * 9, split, scal_out, scale_out, bias, shift_out, cout_l, cout_p);
+    const int total = 9 * (split ? 3 : 1) * cin_p * cout_p;
+    hipLaunchKernelGGL(nastar_pack_weight_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, w,
+                       co, ci, transpose_flip, split, scal_out, wpack);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta, double eps, long long npix, double momentum,
+                       float* running_mean, float* running_var, float* k2, float* k3, double* mean_out, double* invstd_out, int C,
+                       void* stream)
+{
+    if (!sums || !gamma || !beta || !k2 || !k3 || !mean_out || !invstd_out || (running_mean && !running_var)) return NASTAR_ERR_NULL;
+    if (C <= 0 || npix <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_bn_coef_fwd_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums, gamma, beta, eps,
+                       (double)npix, momentum, running_mean, running_var, k2, k3, mean_out, invstd_out, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn_coef_bwd(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
+                       long long npix, float* gscale, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C, void* stream)
+{
+    if (!sums || !amax_dy || !mean || !invstd || !gamma || !gscale || !dgamma || !dbeta || !c1 || !c2 || !c3) return NASTAR_ERR_NULL;
+    if (C <= 0 || npix <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_bn_coef_bwd_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums, amax_dy, mean, invstd,
+                       gamma, (double)npix, gscale, dgamma, dbeta, c1, c2, c3, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dzb, float* gscale, float* amax_scratch, void* stream)
+{
+    if (!d || !dzb || !gscale || !amax_scratch) return NASTAR_ERR_NULL;
+    if (npix <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(amax_scratch, 0, sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    const unsigned g1 = (unsigned)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
+    hipLaunchKernelGGL(nastar_absmax_kernel, dim3(g1), dim3(256), 0, s, d, npix, reinterpret_cast<unsigned int*>(amax_scratch));
+    const long long total = npix * (split ? 8 : 4);
+    const unsigned g2 = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (split) hipLaunchKernelGGL(nastar_grad_seed_kernel<true>, dim3(g2), dim3(256), 0, s, d, npix, amax_scratch, gscale, dzb);
+    else hipLaunchKernelGGL(nastar_grad_seed_kernel<false>, dim3(g2), dim3(256), 0, s, d, npix, amax_scratch, gscale, dzb);
+    e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }

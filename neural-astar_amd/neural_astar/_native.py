@@ -62,9 +62,14 @@ EXPORTED_SYMBOLS = (
     "nastar_conv3x3_f16",
     "nastar_maxpool2x2_f16",
     "nastar_encoder_prep_f16",
+    "nastar_conv3x3_wgrad_workspace_bytes",
     "nastar_conv3x3_wgrad_f16",
     "nastar_chan_stats_f16",
     "nastar_chan_affine_f16",
+    "nastar_pack_conv_weight_f16",
+    "nastar_bn_coef_fwd",
+    "nastar_bn_coef_bwd",
+    "nastar_grad_seed_f16",
 )
 
 
@@ -150,11 +155,21 @@ def load() -> ctypes.CDLL:
     lib.nastar_encoder_prep_f16.restype = ci
     lib.nastar_encoder_prep_f16.argtypes = [vp, vp, vp, ci, ctypes.c_longlong, ci, ci, vp, vp]
     lib.nastar_conv3x3_wgrad_f16.restype = ci
-    lib.nastar_conv3x3_wgrad_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    lib.nastar_conv3x3_wgrad_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp, vp, cz, vp]
+    lib.nastar_conv3x3_wgrad_workspace_bytes.restype = cz
+    lib.nastar_conv3x3_wgrad_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
     lib.nastar_chan_stats_f16.restype = ci
-    lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
+    lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
     lib.nastar_chan_affine_f16.restype = ci
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
+    lib.nastar_pack_conv_weight_f16.restype = ci
+    lib.nastar_pack_conv_weight_f16.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.nastar_bn_coef_fwd.restype = ci
+    lib.nastar_bn_coef_fwd.argtypes = [vp, vp, vp, cd, ctypes.c_longlong, cd, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_bn_coef_bwd.restype = ci
+    lib.nastar_bn_coef_bwd.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_grad_seed_f16.restype = ci
+    lib.nastar_grad_seed_f16.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp]
     lib.nastar_debug_occupancy.restype = ci
     lib.nastar_debug_occupancy.argtypes = [ci, ci, ctypes.POINTER(ci)]
     _lib = lib

@@ -382,9 +382,9 @@ class HipUnetEncoder:
         g = goal_maps[:, 0].contiguous() if plus else None
         cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         mult = 2 if self.split else 1
-        # 32-bit element offsets inside a launch: chunk the batch so that the widest full-resolution tensor stays below 2^31 elements
+        # 32-bit offsets in 16-byte units inside a launch: chunk the batch so that the widest tensor stays below 2^34 fp16 elements
         per_image = max(st[8] * (H // st[10]) * (W // st[10]) for st in self.steps if st[0] == "conv") * mult
-        chunk = max(1, min(B, ((1 << 31) - 1) // per_image))
+        chunk = max(1, min(B, ((1 << 34) - 1) // per_image))
         stream = torch.cuda.current_stream(dev).cuda_stream
         sflag = CONV_SPLIT if self.split else 0
         with torch.cuda.device(dev):

@@ -34,7 +34,7 @@ from .encoder_hip import CONV_FINAL, CONV_RELU, CONV_SPLIT, _pad32, pack_conv_we
 CONV_RAW = 16  # include/nastar.h
 
 
-def pack_flat_weight(w: torch.Tensor, split: bool):
+def pack_flat_weight(w: torch.Tensor, split: bool):  # torch-op reference of nastar_pack_conv_weight_f16 (tests compare the two)
     """[cout, cin, 3, 3] fp32 -> (wpack, unscale): channels zero padded to multiples of 32, the kernel's ``[9][cin_v/8][cout][8]`` fp16
     order; split form: weights times 2^s (max|w| -> ~2^14, keeps the lo terms normal fp16 numbers), ``unscale`` = 2^-s as a DEVICE
     scalar (computed without a host sync: weights change every optimiser step)."""
@@ -50,10 +50,6 @@ def pack_flat_weight(w: torch.Tensor, split: bool):
     return pack_conv_weight_f16x3(wp * scale, cout_p), 1.0 / scale
 
 
-def _split_view(buf: torch.Tensor, npix: int, C: int, split: bool) -> torch.Tensor:
-    return buf.view(npix, (2 if split else 1) * C)
-
-
 class _Lib:
     """thin typed wrappers over the C ABI (all tensors on the current device, launches on torch's current stream)"""
 
@@ -62,17 +58,39 @@ class _Lib:
         self.dev = dev
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
+    def f32(self, n):
+        return torch.empty((n,), dtype=torch.float32, device=self.dev)
+
+    def pack(self, w, transpose_flip, split, bias=None):
+        """device-side weight pack: (wpack, scale[cout_p], shift[cout_p])"""
+        co, ci = w.shape[:2]
+        cout_l, cin_l = (ci, co) if transpose_flip else (co, ci)
+        cin_p, cout_p = _pad32(cin_l), _pad32(cout_l)
+        wpack = torch.empty((9 * (3 if split else 1) * cin_p * cout_p,), dtype=torch.int16, device=self.dev)
+        scale, shift, scal = self.f32(cout_p), self.f32(cout_p), self.f32(2)
+        wc = w.detach()
+        wc = wc if wc.is_contiguous() and wc.dtype == torch.float32 else wc.float().contiguous()
+        bc = None
+        if bias is not None:
+            bc = bias.detach()
+            bc = bc if bc.is_contiguous() and bc.dtype == torch.float32 else bc.float().contiguous()
+        rc = self.lib.nastar_pack_conv_weight_f16(wc.data_ptr(), co, ci, int(transpose_flip), int(split),
+                                                  bc.data_ptr() if bc is not None else None, wpack.data_ptr(), scale.data_ptr(),
+                                                  shift.data_ptr(), scal.data_ptr(), self.stream)
+        _native.check(rc, "nastar_pack_conv_weight_f16")
+        return wpack, scale, shift
+
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None):
         rc = self.lib.nastar_conv3x3_f16(src.data_ptr(), None, wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                          out.data_ptr() if out is not None else None,
                                          out_f32.data_ptr() if out_f32 is not None else None, B, H, W, cin, 0, cout, flags, 1.0, self.stream)
         _native.check(rc, "nastar_conv3x3_f16")
 
-    def stats(self, u, v, ms, mt, npix, C, split):
+    def stats(self, u, v, ms, mt, npix, C, split, amax=None):
         sums = torch.empty((C, 2), dtype=torch.float64, device=self.dev)
         rc = self.lib.nastar_chan_stats_f16(u.data_ptr() if u is not None else None, v.data_ptr(),
                                             ms.data_ptr() if ms is not None else None, mt.data_ptr() if mt is not None else None,
-                                            sums.data_ptr(), npix, C, int(split), self.stream)
+                                            sums.data_ptr(), amax.data_ptr() if amax is not None else None, npix, C, int(split), self.stream)
         _native.check(rc, "nastar_chan_stats_f16")
         return sums
 
@@ -82,11 +100,15 @@ class _Lib:
                                              int(split), self.stream)
         _native.check(rc, "nastar_chan_affine_f16")
 
-    def wgrad(self, dz, a, B, H, W, co, ci, split):
-        dw = torch.empty((9, ci, co), dtype=torch.float32, device=self.dev)
-        rc = self.lib.nastar_conv3x3_wgrad_f16(dz.data_ptr(), a.data_ptr(), dw.data_ptr(), B, H, W, co, ci, int(split), 1.0, self.stream)
+    def wgrad(self, dz, a, B, H, W, co, ci, co_real, ci_real, split, gscale):
+        """dW in torch's [co_real, ci_real, 3, 3] layout, already divided by the device-side gradient scale"""
+        dw = torch.empty((co_real, ci_real, 3, 3), dtype=torch.float32, device=self.dev)
+        nbytes = int(self.lib.nastar_conv3x3_wgrad_workspace_bytes(B, H, W, co, ci))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_conv3x3_wgrad_f16(dz.data_ptr(), a.data_ptr(), dw.data_ptr(), B, H, W, co, ci, co_real, ci_real, int(split),
+                                               1.0, gscale.data_ptr(), ws.data_ptr(), nbytes, self.stream)
         _native.check(rc, "nastar_conv3x3_wgrad_f16")
-        return dw.view(3, 3, ci, co).permute(3, 2, 0, 1)  # -> [co, ci, 3, 3]
+        return dw
 
 
 def supported_shape(H: int, W: int) -> bool:
@@ -96,7 +118,7 @@ def supported_shape(H: int, W: int) -> bool:
 
 class _CnnTrunk(torch.autograd.Function):
     """(map, start+goal inputs, conv / BatchNorm parameters of the 4 hidden blocks, last conv) -> z5 [B,1,H,W] fp32 (raw output of the
-    last convolution, bias included).  ``cfg``: dict(split, plus, eps[4], bns[4] for the running statistics, training momentum)."""
+    last convolution, bias included).  ``cfg``: dict(split, plus, eps[4], bns[4] for the running statistics)."""
 
     @staticmethod
     def forward(ctx, cfg, m, s, g, *params):
@@ -107,7 +129,7 @@ class _CnnTrunk(torch.autograd.Function):
         L = _Lib(dev)
         mult = 2 if split else 1
         sflag = CONV_SPLIT if split else 0
-        ws = list(params[0:20:4]) + []      # conv weights of blocks 1..5
+        ws = list(params[0:20:4])           # conv weights of blocks 1..5
         bs = list(params[1:20:4])           # conv biases
         gammas = list(params[2:16:4])       # BatchNorm weights of blocks 1..4
         betas = list(params[3:16:4])
@@ -120,33 +142,31 @@ class _CnnTrunk(torch.autograd.Function):
             for l in range(4):
                 w = ws[l]
                 cout, cin_p = w.shape[0], _pad32(w.shape[1])
-                wpack, unscale = pack_flat_weight(w, split)
-                scale = unscale.expand(cout).contiguous().float()
+                wpack, scale, shift = L.pack(w, False, split, bs[l])
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
-                L.conv(acts[-1], wpack, scale, bs[l].detach().float().contiguous(), B, H, W, cin_p, cout, sflag, out=z)
+                L.conv(acts[-1], wpack, scale, shift, B, H, W, cin_p, cout, sflag, out=z)
                 sums = L.stats(None, z, None, None, npix, cout, split)
-                mean = sums[:, 0] / npix
-                var = (sums[:, 1] / npix - mean * mean).clamp_min(0.0)
-                invstd = torch.rsqrt(var + cfg["eps"][l])
-                k2 = (gammas[l].detach().double() * invstd).float().contiguous()
-                k3 = (betas[l].detach().double() - mean * gammas[l].detach().double() * invstd).float().contiguous()
+                k2, k3 = L.f32(cout), L.f32(cout)
+                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
+                bn = cfg["bns"][l]
+                track = bn is not None and bn.track_running_stats and bn.running_mean is not None
+                mom = 0.0
+                if track:  # nn.BatchNorm2d's training-mode side effect (unbiased variance), done inside the coefficient kernel
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+                    bn.num_batches_tracked += 1
+                gam, bet = gammas[l].detach(), betas[l].detach()
+                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix, float(mom),
+                                              bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                              k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
+                _native.check(rc, "nastar_bn_coef_fwd")
                 a = torch.empty_like(z)
                 L.affine(None, z, None, k2, k3, None, None, a, npix, cout, True, split)
-                bn = cfg["bns"][l]
-                if bn is not None and bn.track_running_stats:  # nn.BatchNorm2d's training-mode side effect (unbiased variance)
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    bn.running_mean.mul_(1 - mom).add_(mean.float() * mom)
-                    bn.running_var.mul_(1 - mom).add_((var * (npix / max(npix - 1, 1))).float() * mom)
-                    bn.num_batches_tracked += 1
                 zs.append(z)
                 acts.append(a)
                 coef.append((mean, invstd, k2, k3))
             w5 = ws[4]
-            wpack5, unscale5 = pack_flat_weight(w5, split)  # cout 1 -> 32
-            scale5 = torch.zeros(32, device=dev)
-            scale5[0] = unscale5
-            shift5 = torch.zeros(32, device=dev)
-            shift5[0] = bs[4].detach().float()[0]
+            wpack5, scale5, shift5 = L.pack(w5, False, split, bs[4])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
             z5 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
             L.conv(acts[-1], wpack5, scale5, shift5, B, H, W, w5.shape[1], 32, sflag | CONV_FINAL | CONV_RAW, out_f32=z5)
         ctx.cfg = cfg
@@ -170,57 +190,39 @@ class _CnnTrunk(torch.autograd.Function):
         sflag = CONV_SPLIT if split else 0
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         with torch.cuda.device(dev):
-            d = dz5.reshape(npix).float()
-            # power-of-two gradient scale from the device-side maximum: scaled gradients peak near 2^10 (fp16: no overflow, and 2^-24
-            # of the peak is still a representable hi term)
-            amax = d.abs().max().clamp_min(1e-30)
-            S = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-60, 60))
-            ds = d * S
-            dzb = torch.zeros((npix, 32 * mult), dtype=torch.float16, device=dev)
-            hi = ds.to(torch.float16)
-            dzb[:, 0] = hi
-            if split:
-                dzb[:, 32] = (ds - hi.float()).to(torch.float16)
-            dzb = dzb.view(torch.int16).reshape(-1)
+            d = dz5.reshape(npix)
+            d = d if d.is_contiguous() and d.dtype == torch.float32 else d.float().contiguous()
+            # gradients travel multiplied by a power of two S (device scalar `gscale`, re-centred per block): scaled values peak near
+            # 2^10, so fp16 neither overflows nor loses the small terms; S is divided out inside the weight-gradient / coefficient kernels
+            gscale, amax = L.f32(1), L.f32(1)
+            dzb = torch.empty((npix * 32 * mult,), dtype=torch.int16, device=dev)
+            rc = L.lib.nastar_grad_seed_f16(d.data_ptr(), npix, int(split), dzb.data_ptr(), gscale.data_ptr(), amax.data_ptr(), L.stream)
+            _native.check(rc, "nastar_grad_seed_f16")
             cur_co = 32  # padded channel count of the current dz
             for l in range(4, -1, -1):
                 w = ws[l]
                 cout, cin = w.shape[:2]
                 cin_p = _pad32(cin)
-                a_prev = ctx.acts[l]
-                dw = L.wgrad(dzb, a_prev, B, H, W, cur_co, cin_p, split)            # [cur_co, cin_p, 3, 3] * S
-                grads[4 * l] = (dw[:cout, :cin] / S).contiguous()
+                grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, H, W, cur_co, cin_p, cout, cin, split, gscale)
                 grads[4 * l + 1] = torch.zeros_like(params[4 * l + 1])             # conv bias in front of a BatchNorm: exactly 0
                 if l == 0:
                     break
-                # input gradient: the same convolution with W^T flipped (cin <-> cout)
-                wd = w.detach().float().transpose(0, 1).flip(2, 3)                  # [cin, cout, 3, 3]
-                if cur_co != cout:                                                  # last block: cout 1 padded to 32 input channels
-                    wd = torch.cat((wd, torch.zeros((cin, cur_co - cout, 3, 3), device=dev)), dim=1)
-                wpack, unscale = pack_flat_weight(wd, split)
+                # input gradient: the same convolution with W^T flipped (cin <-> cout; cout 1 of the last block padded to 32 inputs)
+                wpack, scale, shift = L.pack(w, True, split)
                 da = torch.empty((npix * cin_p * mult,), dtype=torch.int16, device=dev)
-                L.conv(dzb, wpack, unscale.expand(cin_p).contiguous().float(), torch.zeros(cin_p, device=dev), B, H, W, cur_co, cin_p,
-                       sflag, out=da)
+                L.conv(dzb, wpack, scale, shift, B, H, W, cur_co, cin_p, sflag, out=da)
                 # ReLU mask + BatchNorm backward of block l (its output is a_l = acts[l], pre-activation zs[l-1])
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
                 C = cin_p
-                sums = L.stats(da, z, k2f, k3f, npix, C, split)                     # (sum dy, sum dy z) * S
-                sdy, sdyz = sums[:, 0], sums[:, 1]
-                sdyx = (sdyz - mean * sdy) * invstd                                  # sum dy * xhat
-                gam = gammas[l - 1].detach().double()
-                grads[4 * (l - 1) + 2] = (sdyx / S).float()
-                grads[4 * (l - 1) + 3] = (sdy / S).float()
-                k1 = gam * invstd
-                m1, m2 = sdy / npix, sdyx / npix
-                # re-centre the gradient scale for the next block: |dz| <~ 2 max|k1| max|da| (BatchNorm backward amplifies by
-                # gamma / std, which can be far from 1); one reduction over da, all on the device
-                amax_da = da.view(torch.float16).abs().max().double().clamp_min(1e-30)
-                r = torch.exp2(torch.floor(torch.log2(1024.0 / (2.0 * k1.abs().max().clamp_min(1e-30) * amax_da))).clamp(-40, 40))
-                S = S * r
-                c1 = (k1 * r).float().contiguous()
-                c2 = (-k1 * m2 * invstd * r).float().contiguous()
-                c3 = ((-k1 * m1 + k1 * m2 * mean * invstd) * r).float().contiguous()
+                sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)         # (sum dy, sum dy z) * S, max|dy| * S
+                dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
+                rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                              gammas[l - 1].detach().data_ptr(), npix, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                              c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
+                _native.check(rc, "nastar_bn_coef_bwd")
+                grads[4 * (l - 1) + 2] = dgamma
+                grads[4 * (l - 1) + 3] = dbeta
                 dzb = torch.empty_like(da)
                 L.affine(da, z, c1, c2, c3, k2f, k3f, dzb, npix, C, False, split)
                 cur_co = C
@@ -242,14 +244,23 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     params = []
     for l in range(5):
         params += [convs[l].weight, convs[l].bias, bns[l].weight, bns[l].bias]
+    if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+        raise NotImplementedError("fp32 contiguous parameters expected")
     cfg = {"split": precision == "f16x3", "plus": bool(plus), "eps": [bn.eps for bn in bns[:4]], "bns": bns[:4]}
     m = map_designs[:, 0].contiguous()
     s = start_maps[:, 0].contiguous() if plus else m
     g = goal_maps[:, 0].contiguous() if plus else m
     z5 = _CnnTrunk.apply(cfg, m, s, g, *params[:18])
+    # last block's 1-channel BatchNorm (batch statistics) + sigmoid * const as plain tensor ops on [B,1,H,W]: torch's autograd serves
+    # bn5.weight / bias and const (MIOpen's spatial BatchNorm kernels are slow on a single channel)
     bn5 = bns[4]
-    y = nn.functional.batch_norm(z5, bn5.running_mean, bn5.running_var, bn5.weight, bn5.bias, True,
-                                 bn5.momentum if bn5.momentum is not None else 0.1, bn5.eps)
-    if bn5.track_running_stats:
-        bn5.num_batches_tracked += 1
+    var, mean = torch.var_mean(z5, unbiased=False)
+    y = (z5 - mean) * torch.rsqrt(var + bn5.eps) * bn5.weight + bn5.bias
+    if bn5.track_running_stats and bn5.running_mean is not None:
+        with torch.no_grad():
+            n = z5.numel()
+            mom = bn5.momentum if bn5.momentum is not None else 1.0 / float(int(bn5.num_batches_tracked) + 1)
+            bn5.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
+            bn5.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
+            bn5.num_batches_tracked += 1
     return torch.sigmoid(y) * cnn.const

@@ -65,10 +65,10 @@ def run(inp, inp2, wpack, scale, shift, B, H, W, C1, C2, COUT, relu, final, ups,
                 r = q - b * HW
                 y = r // W
                 x = r - y * W
-                o1 = ((b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * st1 + c * 8
+                o1 = ((b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * (st1 >> 3) + c  # 16-byte units
             else:
-                o1 = q * st1 + c * 8
-            o2 = q * st2 + c * 8
+                o1 = q * (st1 >> 3) + c
+            o2 = q * (st2 >> 3) + c
             src1[i] = np.where(ok, o1, -1)
             src2[i] = np.where(ok, o2, -1)
         wsrc = np.full((NWQ, FC_THREADS), -1, np.int64)
@@ -96,7 +96,7 @@ def run(inp, inp2, wpack, scale, shift, B, H, W, C1, C2, COUT, relu, final, ups,
                     c, slot = idx & 3, idx >> 2
                     if slot >= nslot:
                         continue
-                    o = srcs[i, t]
+                    o = srcs[i, t] * 8
                     v = arr[base + o: base + o + 8] if o >= 0 else np.zeros(8, np.float16)
                     a = slot_off(slot, c) // 2
                     smem[a:a + 8] = v

@@ -59,14 +59,21 @@ def test_wgrad_matches_torch_autograd(case):
     if co == 32 and ci == 256:
         dz[:, 1:] = 0
     da_, dz_ = _nhwc(a, split).to(dev), _nhwc(dz, split).to(dev)
-    dw = torch.empty((9, ci, co), dtype=torch.float32, device=dev)
-    rc = lib.nastar_conv3x3_wgrad_f16(dz_.data_ptr(), da_.data_ptr(), dw.data_ptr(), B, H, W, co, ci, int(split), 0.5,
-                                      torch.cuda.current_stream(dev).cuda_stream)
-    _native.check(rc, "nastar_conv3x3_wgrad_f16")
-    got = dw.view(3, 3, ci, co).permute(3, 2, 0, 1).cpu().double() * 2.0
+    co_r, ci_r = (1, ci) if (co == 32 and ci == 256) else (co - 3, ci - 5)  # cropped outputs (padded channels are not written)
+    dw = torch.full((co_r, ci_r, 3, 3), 7.0, dtype=torch.float32, device=dev)
+    nbytes = int(lib.nastar_conv3x3_wgrad_workspace_bytes(B, H, W, co, ci))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    gscale = torch.full((1,), 4.0, device=dev)
+    for _ in range(2):  # twice: deterministic (fixed-order partial sums), bitwise equal
+        rc = lib.nastar_conv3x3_wgrad_f16(dz_.data_ptr(), da_.data_ptr(), dw.data_ptr(), B, H, W, co, ci, co_r, ci_r, int(split), 2.0,
+                                          gscale.data_ptr(), ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(rc, "nastar_conv3x3_wgrad_f16")
+        first = dw.clone() if _ == 0 else first
+    assert torch.equal(first, dw)
+    got = dw.cpu().double() * 2.0  # out_scale / gscale = 0.5
     w = torch.zeros((co, ci, 3, 3), dtype=torch.float64, requires_grad=True)
     nn.functional.conv2d(_seen(a, split).double(), w, None, padding=1).backward(_seen(dz, split).double())
-    ref = w.grad
+    ref = w.grad[:co_r, :ci_r]
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err <= (2e-6 if split else 1e-5), err  # same operands, fp32 accumulation over B*H*W pixels vs float64
 
@@ -88,13 +95,15 @@ def test_chan_stats_and_affine(split):
     zs, das = _seen(z, split).double(), _seen(da, split).double()
     st = torch.cuda.current_stream(dev).cuda_stream
     sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
-    _native.check(lib.nastar_chan_stats_f16(None, z_.data_ptr(), None, None, sums.data_ptr(), npix, C, int(split), st), "stats")
+    _native.check(lib.nastar_chan_stats_f16(None, z_.data_ptr(), None, None, sums.data_ptr(), None, npix, C, int(split), st), "stats")
     assert torch.allclose(sums[:, 0].cpu(), zs.sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
     assert torch.allclose(sums[:, 1].cpu(), (zs * zs).sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
     mask = (ms.cpu().float().view(1, -1, 1, 1) * zs.float() + mt.cpu().float().view(1, -1, 1, 1)) > 0
-    _native.check(lib.nastar_chan_stats_f16(da_.data_ptr(), z_.data_ptr(), ms.data_ptr(), mt.data_ptr(), sums.data_ptr(), npix, C,
-                                            int(split), st), "stats")
+    amax = torch.full((1,), -1.0, device=dev)
+    _native.check(lib.nastar_chan_stats_f16(da_.data_ptr(), z_.data_ptr(), ms.data_ptr(), mt.data_ptr(), sums.data_ptr(), amax.data_ptr(),
+                                            npix, C, int(split), st), "stats")
     dy = das * mask
+    assert float(amax) == float(dy.abs().max().float())
     assert torch.allclose(sums[:, 0].cpu(), dy.sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
     assert torch.allclose(sums[:, 1].cpu(), (dy * zs).sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
     out = torch.empty_like(z_)
@@ -111,6 +120,30 @@ def test_chan_stats_and_affine(split):
         if relu:
             ref = ref.clamp_min(0)
         assert float((got - ref).abs().max()) <= (2e-6 if split else 2e-3) * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_device_weight_pack_matches_the_torch_pack(split):
+    """nastar_pack_conv_weight_f16 (forward and input-gradient forms) against the torch-op pack of neural_astar/encoder_train.py"""
+    from neural_astar import encoder_train as ET
+    dev = _dev()
+    L = ET._Lib(dev)
+    g = torch.Generator().manual_seed(4)
+    for (co, ci) in ((64, 32), (1, 256), (32, 2), (96, 40)):
+        w = (torch.randn((co, ci, 3, 3), generator=g) * 0.03).to(dev)
+        b = torch.randn(co, generator=g).to(dev)
+        for tf in (False, True):
+            wl = w.transpose(0, 1).flip(2, 3).contiguous() if tf else w
+            ref_pack, ref_unscale = ET.pack_flat_weight(wl, split)
+            wpack, scale, shift = L.pack(w, tf, split, None if tf else b)
+            torch.cuda.synchronize()
+            assert torch.equal(wpack.view(ref_pack.shape), ref_pack), (co, ci, tf)
+            cout_l = ci if tf else co
+            assert torch.equal(scale, ref_unscale.float().expand_as(scale))
+            exp_shift = torch.zeros_like(shift)
+            if not tf:
+                exp_shift[:cout_l] = b
+            assert torch.equal(shift, exp_shift)
 
 
 def _shipped_cnn_planner():
