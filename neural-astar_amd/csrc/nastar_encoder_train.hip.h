@@ -155,6 +155,8 @@ __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t*
     }
 }
 
+__global__ void nastar_absmax_kernel(const float* __restrict__ d, long long n, unsigned int* __restrict__ amax_bits);
+
 // ---- small host-replacing kernels: everything a training step needs between the big launches runs on the device, in ONE launch each,
 // so that a step is ~100 launches instead of ~600 tiny framework ops (at the reference's batch of 100 maps the step is launch-bound) ------
 
@@ -179,36 +181,29 @@ __device__ __forceinline__ float pow2_scale(float amax, float target, int lo, in
     return ldexpf(1.f, e);
 }
 
-// Weight pack for nastar_conv3x3_f16 from torch's [co][ci][3][3] fp32 weight, ONE workgroup pass for the maximum + a grid pass for
-// the pack.  transpose_flip: the input-gradient form W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (logical cout = ci, cin = co).
-// scal[0] = 2^-s (to fold into the conv's epilogue scale), scal[1] = 2^s.
-__global__ __launch_bounds__(256) void nastar_pack_amax_kernel(const float* __restrict__ w, int n, int split, float* __restrict__ scal,
-                                                               float* __restrict__ scale_out, const float* __restrict__ bias,
-                                                               float* __restrict__ shift_out, int cout_l, int cout_p)
-{
-    __shared__ float red[4];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
-    m = block_max_256(m, red);
-    const float sc = split ? pow2_scale(m, 16384.f, 0, 24) : 1.f;
-    if (threadIdx.x == 0) {
-        scal[0] = 1.f / sc;
-        scal[1] = sc;
-    }
-    for (int c = threadIdx.x; c < cout_p; c += 256) {
-        scale_out[c] = 1.f / sc;
-        shift_out[c] = (bias && c < cout_l) ? bias[c] : 0.f;
-    }
-}
-
+// Weight pack for nastar_conv3x3_f16 from torch's [co][ci][3][3] fp32 weight: a grid pass for max|w| (nastar_absmax_kernel, float bits in
+// scal[2]) + a grid pass for the pack.  transpose_flip: the input-gradient form W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (logical
+// cout = ci, cin = co).  scal[0] = 2^-s (folded into the conv's epilogue scale), scal[1] = 2^s; block 0 also fills scale_out / shift_out.
 __global__ __launch_bounds__(256) void nastar_pack_weight_kernel(const float* __restrict__ w, int co, int ci, int transpose_flip, int split,
-                                                                 const float* __restrict__ scal, uint16_t* __restrict__ wpack)
+                                                                 float* __restrict__ scal, uint16_t* __restrict__ wpack,
+                                                                 float* __restrict__ scale_out, const float* __restrict__ bias,
+                                                                 float* __restrict__ shift_out)
 {
     const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
     const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
     const int cinv = split ? 3 * cin_p : cin_p;
     const int total = 9 * cinv * cout_p;  // elements of [tap][cinv/8][cout_p][8]
-    const float sc = scal[1];
+    const float sc = split ? pow2_scale(scal[2], 16384.f, 0, 24) : 1.f;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            scal[0] = 1.f / sc;
+            scal[1] = sc;
+        }
+        for (int c = threadIdx.x; c < cout_p; c += 256) {
+            scale_out[c] = 1.f / sc;
+            shift_out[c] = (bias && c < cout_l) ? bias[c] : 0.f;
+        }
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int e = i & 7;
         int r = i >> 3;

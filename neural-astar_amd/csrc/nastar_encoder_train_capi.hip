@@ -13,7 +13,7 @@ static int wgrad_nsplit(int nchunk, int co, int ci)
 {
     const int cob = co % 64 == 0 ? 2 : 1, cib = ci % 64 == 0 ? 2 : 1;
     const int tiles = (co / (32 * cob)) * (ci / (32 * cib));
-    int nsplit = 512 / tiles;                      // ~2 workgroups per CU in flight
+    int nsplit = 256 / tiles;                      // one 6..12-wave workgroup per CU
     if (nsplit > nchunk / 4) nsplit = nchunk / 4;  // ... but at least 4 chunks of 64 pixels per workgroup
     if (nsplit < 1) nsplit = 1;
     return nsplit;
@@ -95,8 +95,8 @@ int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms,
     if (e == hipSuccess && amax_out) e = hipMemsetAsync(amax_out, 0, sizeof(float), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(sums)");
     const long long per = 256 / (C / 8);
-    long long grid = (npix + per * 64 - 1) / (per * 64);  // ~64 pixels per pixel lane
-    if (grid > 2048) grid = 2048;
+    long long grid = (npix + per * 16 - 1) / (per * 16);  // >= 16 pixels per pixel lane, at most 512 workgroups of double atomics
+    if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     unsigned int* ab = reinterpret_cast<unsigned int*>(amax_out);
     if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, ab, npix, C);
@@ -132,11 +132,16 @@ int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_fl
     const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
     const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(nastar_pack_amax_kernel, dim3(1), dim3(256), 0, s, w, co * ci * 9, split, scal_out, scale_out, bias, shift_out, cout_l, cout_p);
+    hipError_t e = hipMemsetAsync(scal_out + 2, 0, sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    const int n = co * ci * 9;
+    if (split)
+        hipLaunchKernelGGL(nastar_absmax_kernel, dim3((unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256)), dim3(256), 0, s, w, (long long)n,
+                           reinterpret_cast<unsigned int*>(scal_out + 2));
     const int total = 9 * (split ? 3 : 1) * cin_p * cout_p;
     hipLaunchKernelGGL(nastar_pack_weight_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, w,
-                       co, ci, transpose_flip, split, scal_out, wpack);
-    hipError_t e = hipGetLastError();
+                       co, ci, transpose_flip, split, scal_out, wpack, scale_out, bias, shift_out);
+    e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }

@@ -67,7 +67,7 @@ class _Lib:
         cout_l, cin_l = (ci, co) if transpose_flip else (co, ci)
         cin_p, cout_p = _pad32(cin_l), _pad32(cout_l)
         wpack = torch.empty((9 * (3 if split else 1) * cin_p * cout_p,), dtype=torch.int16, device=self.dev)
-        scale, shift, scal = self.f32(cout_p), self.f32(cout_p), self.f32(2)
+        scale, shift, scal = self.f32(cout_p), self.f32(cout_p), self.f32(3)
         wc = w.detach()
         wc = wc if wc.is_contiguous() and wc.dtype == torch.float32 else wc.float().contiguous()
         bc = None

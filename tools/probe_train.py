@@ -30,11 +30,12 @@ def step_ms(na, m, s, g, R, reps=5):
 def main():
     dev = torch.device("cuda:0")
     res = {}
-    for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [100, 1024, 4096]):
+    backends = sys.argv[2].split(",") if len(sys.argv) > 2 else ["hip_f16x3", "hip_f16", "torch"]
+    for B in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [100, 1024, 4096]):
         pr = syn.maze_maps(B, 32, seed=3)
         m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
         R = torch.randn((B, 1, 32, 32), device=dev) / (B * 1024)
-        for backend in ("hip_f16x3", "hip_f16", "torch"):
+        for backend in backends:
             na = T._shipped_cnn_planner().to(dev).train()
             na.encoder_backend = backend
             try:
