@@ -438,6 +438,39 @@ def neural_astar_unet_ms(pr, dev, precision, reps=5):
                                          + ") / wall time of the whole encoder incl. pooling and input assembly launches"}}
 
 
+def encoder_train_step_ms(pr, dev):
+    """Extra (training): forward + backward of the CNN encoder alone (loss = sum(cost * R)) through the MI355X training
+    kernels (neural_astar/encoder_train.py: fp16-MFMA convolutions, input and weight gradients, batch-statistics BatchNorm), at the
+    reference's training batch (100 maps) and at the bench batch.  The fp32 torch.nn encoder on the same box: 4.07 / 132.8 ms per
+    100 / 4096 maps (profiles/r02/encoder_train_step_ms.json; not re-timed here, MIOpen's autotuning takes minutes)."""
+    from neural_astar.planner import NeuralAstar
+    out = {}
+    for B in (100, 4096):
+        m, s, g = (torch.from_numpy(x[:B]).to(dev) for x in pr)
+        R = torch.randn((B, 1, H, W), device=dev) / (B * H * W)
+        for backend in ("hip_f16x3", "hip_f16"):
+            torch.manual_seed(0)
+            na = NeuralAstar(encoder_arch="CNN").to(dev).train()
+            na.encoder_backend = backend
+
+            def one():
+                for p in na.parameters():
+                    p.grad = None
+                (na.encode(m, s, g) * R).sum().backward()
+            one()
+            torch.cuda.synchronize(dev)
+            reps = 10 if B == 100 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            torch.cuda.synchronize(dev)
+            out[f"batch_{B}_{backend}_ms"] = (time.perf_counter() - t0) / reps * 1e3
+            del na
+    out["torch_fp32_ms_same_box"] = {"batch_100": 4.07, "batch_4096": 132.75, "source": "profiles/r02/encoder_train_step_ms.json"}
+    out["unit"] = "ms per encoder forward+backward (wall clock), random-init CNN depth 4, 32x32 maps"
+    return out
+
+
 def kernel_launch_ms(run, steps, dev):
     """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
     (torch's current stream), one event pair per launch."""
@@ -751,6 +784,7 @@ def main():
                              ("neural_astar_cnn_hip_f16x3", lambda: neural_astar_f16x3_ms(pr, dev)),
                              ("neural_astar_unet_hip_f16", lambda: neural_astar_unet_ms(pr, dev, "f16")),
                              ("neural_astar_unet_hip_f16x3", lambda: neural_astar_unet_ms(pr, dev, "f16x3")),
+                             ("encoder_train_step", lambda: encoder_train_step_ms(pr, dev)),
                              ("train_fwd_bwd_ms_per_4096_maps_Tmax025", lambda: training_step_ms(pr, dev)),
                              ("data_path_32x32", lambda: data_path_ms(dev)),
                              ("train_l1_step_Tmax025", lambda: {"batch_100": l1_training_step_ms(pr, dev, 100),

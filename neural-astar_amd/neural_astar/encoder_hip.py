@@ -309,6 +309,41 @@ def unet_layer_plan(model: nn.Module):
     return steps
 
 
+def sequential_layer_plan(seq: nn.Module):
+    """Launch plan (same step format as :func:`unet_layer_plan`) of a plain ``nn.Sequential`` of Conv2d / BatchNorm2d / ReLU /
+    MaxPool2d blocks whose last convolution (+ BatchNorm, no ReLU) has one output channel: the reference's ``CNN`` at any depth
+    (encoder.py:60-78) and any other stack of that shape."""
+    mods = list(seq)
+    steps, x, div, n, i = [], "x0", 1, 0, 0
+    last_conv = max(k for k, m in enumerate(mods) if isinstance(m, nn.Conv2d))
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.MaxPool2d):
+            steps.append(("pool", f"p{n}", x, None, div))
+            x, div = f"p{n}", div * 2
+            i += 1
+        elif isinstance(m, nn.Conv2d):
+            if m.kernel_size != (3, 3) or m.padding != (1, 1) or m.stride != (1, 1):
+                raise NotImplementedError("3x3 convolutions with padding 1 only")
+            j = i + 1
+            bn = mods[j] if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d) else None
+            j += bn is not None
+            relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+            j += relu
+            n += 1
+            if i == last_conv:
+                if m.out_channels != 1 or relu or div != 1:
+                    raise NotImplementedError("the last block must be a 1-channel conv (+ BatchNorm) at the input resolution")
+                steps.append(("conv", "cost", x, None, m, bn, CONV_FINAL, div))
+            else:
+                steps.append(("conv", f"e{n}", x, None, m, bn, CONV_RELU if relu else 0, div))
+            x = f"e{n}"
+            i = j
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return steps
+
+
 class HipUnetEncoder:
     """Eval-mode ``planner.encoder.Unet`` (from-scratch VggUnet definition; reference planner/encoder.py:37-57) on the MFMA through
     the layer-level C ABI ``nastar_conv3x3_f16`` / ``nastar_maxpool2x2_f16`` / ``nastar_encoder_prep_f16``.
@@ -317,12 +352,19 @@ class HipUnetEncoder:
     within ~1e-5 of the fp32 torch module).  Inference only; upsampling, skip concatenation, BatchNorm, ReLU, bias, sigmoid * const are
     all fused into the convolution launches (26 + 4 pooling launches per forward at depth 4)."""
 
-    def __init__(self, unet: nn.Module, precision: str = "f16"):
+    def _plan(self):
+        return unet_layer_plan(self.unet.model)
+
+    def _check(self, unet):
         from .planner.encoder import VggUnet
-        if precision not in ("f16", "f16x3"):
-            raise ValueError(precision)
         if not isinstance(unet.model, VggUnet):
             raise NotImplementedError("HipUnetEncoder implements this package's VggUnet definition of Unet(vgg16_bn)")
+        self.size_multiple = 1 << unet.model.depth
+
+    def __init__(self, unet: nn.Module, precision: str = "f16"):
+        if precision not in ("f16", "f16x3"):
+            raise ValueError(precision)
+        self._check(unet)
         self.unet = unet
         self.precision = precision
         self.split = precision == "f16x3"
@@ -336,7 +378,7 @@ class HipUnetEncoder:
         if key == self._key:
             return
         self.steps = []
-        for st in unet_layer_plan(self.unet.model):
+        for st in self._plan():
             if st[0] == "conv":
                 _, dst, src, skip, conv, bn, flags, div = st
                 # split form: hidden activations travel multiplied by 16 (their lo terms stay out of the fp16 subnormal range)
@@ -353,7 +395,7 @@ class HipUnetEncoder:
     def flops(self, H: int, W: int) -> float:
         """useful multiply-add FLOPs of the conv layers per image (real channel counts)"""
         total = 0.0
-        for st in unet_layer_plan(self.unet.model):
+        for st in self._plan():
             if st[0] == "conv":
                 conv, div = st[4], st[7]
                 total += 2.0 * 9 * conv.in_channels * conv.out_channels * (H // div) * (W // div)
@@ -374,9 +416,8 @@ class HipUnetEncoder:
         lib = _native.load()
         m = map_designs[:, 0].contiguous()
         B, H, W = m.shape
-        depth = self.unet.model.depth
-        if H % (1 << depth) or W % (1 << depth) or W > 94:
-            raise NotImplementedError(f"H, W must be multiples of {1 << depth} and W <= 94")
+        if H % self.size_multiple or W % self.size_multiple or W > 94:
+            raise NotImplementedError(f"H, W must be multiples of {self.size_multiple} and W <= 94")
         dev = m.device
         s = start_maps[:, 0].contiguous() if plus else None
         g = goal_maps[:, 0].contiguous() if plus else None
@@ -420,3 +461,18 @@ class HipUnetEncoder:
                     _native.check(rc, f"nastar_conv3x3_f16({dst})")
                     chans[dst] = cout_p
         return cost.unsqueeze(1)
+
+
+class HipFlatCnnEncoder(HipUnetEncoder):
+    """Eval-mode ``planner.encoder.CNN`` of ANY depth on maps of ANY size (W <= 94) through the same generic fp16 / f16x3 MFMA
+    convolution: what ``NeuralAstar.encode`` uses when the fixed-shape kernels of ``HipCnnEncoder`` (depth 4, H and W multiples of
+    32 / 16) do not apply -- e.g. 20x45 or 24x40 maps, ``encoder_depth=3``."""
+
+    def _plan(self):
+        return sequential_layer_plan(self.unet.model)
+
+    def _check(self, cnn):
+        sequential_layer_plan(cnn.model)  # raises on anything but conv3x3 / BatchNorm / ReLU / MaxPool stacks ending in 1 channel
+        if any(isinstance(m, nn.MaxPool2d) for m in cnn.model):
+            raise NotImplementedError("pooling stacks change the output resolution: use HipCnnDownSizeEncoder")
+        self.size_multiple = 1

@@ -78,9 +78,12 @@ class NeuralAstar(VanillaAstar):
             print("WARNING: learn_obstacles has been set to True")
         self.g_ratio = g_ratio
         self.use_differentiable_astar = use_differentiable_astar
-        # "torch" (default, fp32, differentiable), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder: eval mode,
-        # no gradients; csrc/nastar_encoder.hip.h), "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the
-        # matrix work, cost maps within 1e-5 of the fp32 encoder).  Not part of the reference's constructor signature.
+        # "torch" (default, fp32 torch.nn), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder,
+        # csrc/nastar_encoder.hip.h), "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the matrix work, cost
+        # maps within 1e-5 of the fp32 encoder).  With a hip_* backend: eval mode under no_grad = the inference kernels (CNN of any
+        # depth / size, CNNDownSize, Unet); training mode with autograd on = the training kernels for the depth-4 CNN
+        # (neural_astar/encoder_train.py: forward, input and weight gradients, batch-statistics BatchNorm); every other combination
+        # (eval mode with gradients, other encoders in training) stays on torch.nn.  Not part of the reference's constructor signature.
         self.encoder_backend = "torch"
         self._hip_encoder = None
 
@@ -106,10 +109,10 @@ class NeuralAstar(VanillaAstar):
             # Unet(vgg16_bn): generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h); "hip_f16x3" = split operands, fp32-grade
             precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipUnetEncoder
-            if not isinstance(self._hip_encoder, HipUnetEncoder) or self._hip_encoder.precision != precision:
+            if type(self._hip_encoder) is not HipUnetEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
-        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled()
+        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
                 and _is_depth4_cnn(self.encoder) and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]):
             # TRAINING: convolutions, batch-statistics BatchNorm, ReLU and all their gradients on the MI355X kernels
@@ -128,6 +131,15 @@ class NeuralAstar(VanillaAstar):
             if getattr(self._hip_encoder, "precision", None) != precision:
                 from ..encoder_hip import HipCnnEncoder
                 self._hip_encoder = HipCnnEncoder(self.encoder, precision)
+            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
+        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+                and type(self.encoder) is encoder.CNN and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
+                and map_designs.shape[-1] <= 94 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
+            # any other depth / map size: the generic fp16 MFMA convolution ("hip_f16x3" = split operands, otherwise plain fp16)
+            precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
+            from ..encoder_hip import HipFlatCnnEncoder
+            if type(self._hip_encoder) is not HipFlatCnnEncoder or self._hip_encoder.precision != precision:
+                self._hip_encoder = HipFlatCnnEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         inputs = map_designs
         if "+" in self.encoder_input:

@@ -248,8 +248,9 @@ def test_f16x3_split_and_virtual_channel_packing():
 
 
 def test_hip_encoder_backends_fall_back_to_torch_when_gradients_are_needed():
-    """The MFMA encoders are inference kernels: in training mode, or with autograd recording, `encode` silently stays on the
-    differentiable torch encoder whatever `encoder_backend` says (so a training loop can leave the flag set)."""
+    """The eval-mode MFMA encoders are inference kernels: with autograd recording in eval mode, or in training mode under no_grad
+    (batch statistics without a backward), `encode` stays on the torch encoder whatever `encoder_backend` says.  (Training mode WITH
+    autograd on a device goes to the HIP training kernels: tests/test_encoder_train_gpu.py.)"""
     import torch
     from neural_astar.planner import NeuralAstar
     torch.manual_seed(0)

@@ -208,3 +208,31 @@ def test_unet_encoder_matches_torch(precision, tol_truth, tol_torch):
         g2[:, 0, 14, 40] = 1
         t2 = _truth64(planner.encoder, m2, s2, g2)
         assert float((planner.encode(m2, s2, g2).cpu() - t2).abs().max()) <= tol_truth
+
+
+@pytest.mark.parametrize("depth,H,W,enc_in,precision,tol", [(3, 20, 45, "m+", "f16x3", 1e-5), (2, 24, 40, "m", "f16x3", 1e-5),
+                                                             (4, 20, 45, "m+", "f16", 2e-2), (4, 12, 12, "m+", "bf16", 2e-2)])
+def test_cnn_of_any_depth_and_size_takes_the_generic_kernel(depth, H, W, enc_in, precision, tol):
+    """CNN encoders the fixed-shape kernels do not cover (depth != 4, H / W not multiples of 32 or 16) run on the generic fp16 MFMA
+    convolution instead of falling back to torch.nn (reference encoder.py:60-78 at any encoder_depth)."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    torch.manual_seed(depth * 100 + H)
+    na = NeuralAstar(encoder_input=enc_in, encoder_arch="CNN", encoder_depth=depth, const=2.5).to(dev)
+    with torch.no_grad():
+        for mod in na.encoder.model:
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+    na.eval()
+    pr = syn.random_obstacle_maps(9, H, W, 0.2, seed=H + W)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        ref = na.encode(m, s, g)
+        na.encoder_backend = "hip_" + precision
+        got = na.encode(m, s, g)
+        assert type(na._hip_encoder).__name__ == "HipFlatCnnEncoder"
+        assert float((got - ref).abs().max()) <= tol * 2.5
+        out = na(m, s, g)
+        assert out.paths.shape == (9, 1, H, W) and int((na.astar.last_status != 0).sum()) == 0
