@@ -15,7 +15,7 @@
 //   * a chunk = RC whole image rows (RC * W = 64 pixels: 4 MFMA k-steps of 16 pixels): dz rows pixel-major in LDS, the activation rows
 //     with a one-pixel ZERO frame around them ((RC+2) x (W+2) slots, rows outside the image zero): a tap is a constant LDS offset,
 //     conv2d's zero padding costs nothing in the loop, and every staging / fragment address is a per-thread constant computed once;
-//   * pixel rows in LDS are padded by 64 bytes (row stride = 64 mod 256) so that the 4 pixels x 64 bytes a 32-lane pass of the
+//   * pixel rows in LDS are padded to a stride of 64 or 192 (mod 256) bytes so that the 4 pixels x 64 bytes a 32-lane pass of the
 //     transpose read touches fall into 4 different bank quarters;
 //   * kSplit ("f16x3"): operands are [hi | lo] fp16 pairs; per tap dz_hi*a_hi + dz_lo*a_hi + dz_hi*a_lo (fp32 accumulation);
 //   * no atomics: every workgroup stores its partial tile to part[split][tap][ci][co]; nastar_wgrad_reduce_kernel sums the splits in
@@ -39,6 +39,7 @@ struct WgradArgs {
     int nsplit;          // pixel splits: gridDim.x = nsplit * (CO/(32 COB)) * (CI/(32 CIB))
 };
 
+constexpr int wg_row_bytes(int r) { return r % 128 == 0 ? r + 64 : r; }
 constexpr int WG_MAX_SLOTS = 198;  // (RC+2)*(W+2) for W = 64; 136 for W = 32
 
 typedef __fp16 nastar_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
 {
     constexpr int NTHR = 192 * COB * CIB;
     constexpr int M = kSplit ? 2 : 1;
-    constexpr int RDZ = COB * 64 * M + 64;  // bytes per pixel row of the dz tile (32 channels = 64 B per block and precision half) + pad
-    constexpr int RA = CIB * 64 * M + 64;
+    // bytes per pixel row of the tiles (32 channels = 64 B per block and precision half), padded to 64 or 192 (mod 256): the 4 pixel
+    // rows a 32-lane pass of the transpose read touches then fall into 4 different bank quarters
+    constexpr int RDZ = wg_row_bytes(COB * 64 * M);
+    constexpr int RA = wg_row_bytes(CIB * 64 * M);
     constexpr int CPZ = M * COB * 4, CPA = M * CIB * 4;            // 16-byte chunks per pixel
     constexpr int NZ = (64 * CPZ + NTHR - 1) / NTHR;               // staged chunks per thread
     constexpr int NA = (WG_MAX_SLOTS * CPA + NTHR - 1) / NTHR;

@@ -25,7 +25,7 @@ static int launch_wgrad(WgradArgs g, hipStream_t s)
     auto kern = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit>;
     constexpr int M = kSplit ? 2 : 1;
     const int RC = 64 / g.W;
-    const size_t lds = (size_t)64 * (COB * 64 * M + 64) + (size_t)(RC + 2) * (g.W + 2) * (CIB * 64 * M + 64);
+    const size_t lds = (size_t)64 * wg_row_bytes(COB * 64 * M) + (size_t)(RC + 2) * (g.W + 2) * wg_row_bytes(CIB * 64 * M);
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
     const int tiles = (g.CO / (32 * COB)) * (g.CI / (32 * CIB));

@@ -111,3 +111,47 @@ def test_warcraft_data_parallel_training_smoke_two_processes(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_warcraft_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read()[:1] for r in range(2)] == ["1", "1"]
+
+
+def _maze_cnn_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import distributed as D
+    from neural_astar.utils import synthetic as syn
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the box's single GPU: gloo, not RCCL
+    torch.manual_seed(1 + rank)
+    planner = NeuralAstar(encoder_arch="CNN", Tmax=0.25).to(dev)  # scripts/config/train.yaml: CNN depth 4, Tmax 0.25
+    planner.encoder_backend = "hip_f16x3"                         # encoder forward + backward on the MI355X training kernels
+    tr = D.DataParallelTrainer(planner, lr=1e-3, coupling="none")
+    pr = syn.maze_maps(24, 32, seed=20 + rank)                    # every rank has its own rows
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    # a stand-in optimal trajectory: VanillaAstar's path (what the dataset's opt_trajs are for unit-cost mazes)
+    from neural_astar.planner import VanillaAstar
+    with torch.no_grad():
+        traj = VanillaAstar().to(dev).eval()(m, s, g).paths.float()
+    before = torch.cat([p.detach().reshape(-1) for p in planner.parameters()]).clone()
+    losses = [float(tr.train_step(m, s, g, traj)) for _ in range(4)]
+    flat = torch.cat([p.detach().reshape(-1) for p in planner.parameters()])
+    other = [torch.empty_like(flat.cpu()) for _ in range(world)]
+    dist.all_gather(other, flat.cpu())
+    ok = bool(torch.equal(other[0], other[1])) and all(np.isfinite(losses)) and losses[0] > 0
+    ok = ok and float((flat - before).abs().max()) > 0  # the encoder moved
+    ok = ok and type(planner.encoder.model[0]).__name__ == "Conv2d" and planner.encoder.model[1].num_batches_tracked.item() == 4
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0 " + repr(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_maze_cnn_data_parallel_training_on_the_hip_encoder_kernels(tmp_path):
+    """The reference's maze training configuration (CNN depth 4, Tmax 0.25) for 4 steps on 2 processes with the encoder's forward AND
+    backward on the MI355X training kernels (encoder_backend = "hip_f16x3"), the HIP search + replay backward in between, gradients
+    averaged by one flat all-reduce: finite losses, parameters move, ranks stay in lockstep, BatchNorm counters advance."""
+    import torch.multiprocessing as mp
+    mp.spawn(_maze_cnn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read()[:1] for r in range(2)] == ["1", "1"]
