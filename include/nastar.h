@@ -231,7 +231,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
  *          [W_hi | W_hi | W_lo] with NASTAR_CONV_SPLIT;   scale/shift fp32 [cout] (folded eval-mode BatchNorm / bias)
  *   out  [B, H, W, cout] fp16 (x2 when split), or with NASTAR_CONV_FINAL out_f32 [B,H,W] = sigmoid(y[..., 0]) * final_mul (cout == 32,
  *        channel 0 real: reference encoder.py:32-34)
- *   c1, c2 multiples of 32, cout a multiple of 32, W <= 94, B*H*W*max(fp16 per pixel) < 2^34 (32 GiB per tensor).
+ *   c1, c2 multiples of 32, cout a multiple of 32, W <= 126, B*H*W*max(fp16 per pixel) < 2^34 (32 GiB per tensor).
  */
 #define NASTAR_CONV_RELU 1
 #define NASTAR_CONV_FINAL 2
@@ -257,7 +257,8 @@ int nastar_encoder_prep_f16(const float* map, const float* start, const float* g
  *   padding) on the fp16 MFMA with gfx950's LDS transpose reads (csrc/nastar_conv_wgrad.hip.h).  dz [B,H,W,co], a [B,H,W,ci] with co, ci the
  *   PADDED channel counts (multiples of 32); dw fp32 [co_real][ci_real][3][3] = torch's weight layout, cropped.  grad_scale_dev: device
  *   float holding the power-of-two gradient scale to divide out, or NULL.  Deterministic (per-workgroup partial sums in `workspace`,
- *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  W must divide 64 (2..64), H % (64/W) == 0.
+ *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  2 <= W <= 96; a chunk is R whole image rows (R*W <= 96 pixels, 64 for
+ *   the power-of-two widths) and H must be a multiple of R (workspace_bytes == 0 flags an unsupported shape).
  * nastar_chan_stats_f16: per-channel sums over all pixels in double: sums[c] = (sum v, sum v^2), or with u != NULL
  *   (sum u*m, sum u*m*v), m = [ms[c]*v + mt[c] > 0] (the ReLU mask).  sums double [C][2], zeroed inside the call; amax_out
  *   (optional device float): max |u*m| over the tensor (feeds the power-of-two gradient re-scaling).
@@ -293,6 +294,9 @@ int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta
 int nastar_bn_coef_bwd(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
                        long long npix, float* gscale, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C, void* stream);
 int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dzb, float* gscale, float* amax_scratch, void* stream);
+/* 2x2 max-pool backward (CNNDownSize blocks, reference encoder.py:91-95 under autograd): r [B,H,W,C] the pool's input, dp [B,H/2,W/2,C]
+ * the gradient w.r.t. its output -> dr [B,H,W,C]: dp at each window's FIRST maximum (torch's tie rule), 0 elsewhere. */
+int nastar_maxpool2x2_bwd_f16(const uint16_t* r, const uint16_t* dp, uint16_t* dr, int B, int H, int W, int C, int split, void* stream);
 
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */

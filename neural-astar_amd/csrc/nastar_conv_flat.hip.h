@@ -38,8 +38,8 @@ constexpr int FC_TP = 256;       // flat pixels per workgroup
 constexpr int FC_KS = 32;        // channels per LDS slice (two MFMA k-steps)
 constexpr int FC_PIXB = 64;      // bytes per pixel slot in LDS
 constexpr int FC_THREADS = 256;
-constexpr int FC_MAXW = 94;      // widest image row the staging registers cover (tile slots = 256 + 2W + 2 <= 7*64)
-constexpr int FC_NTQ = 7;        // 16-byte pixel chunks staged per thread and slice
+constexpr int FC_MAXW = 126;     // widest image row the staging registers cover (tile slots = 256 + 2W + 2 <= 8*64)
+constexpr int FC_NTQ = 8;        // 16-byte pixel chunks staged per thread and slice
 
 struct FlatConvArgs {
     const uint16_t* in;    // [B, H(/2), W(/2), C1 (x2 when split)] fp16

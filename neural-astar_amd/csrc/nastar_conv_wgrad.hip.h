@@ -12,16 +12,17 @@
 //   * a workgroup owns a (COB x 32) x (CIB x 32) channel tile of dW for all 9 taps and a strided set of pixel chunks; it runs
 //     3 x COB x CIB wavefronts: wavefront (wco, wci, wdy) holds the 3 accumulators (dx = -1, 0, 1) of its 32 x 32 block and tap row
 //     dy: 48 accumulator registers, which leaves room to PREFETCH the next chunk into registers while the matrix pipe works;
-//   * a chunk = RC whole image rows (RC * W = 64 pixels: 4 MFMA k-steps of 16 pixels): dz rows pixel-major in LDS, the activation rows
-//     with a one-pixel ZERO frame around them ((RC+2) x (W+2) slots, rows outside the image zero): a tap is a constant LDS offset,
-//     conv2d's zero padding costs nothing in the loop, and every staging / fragment address is a per-thread constant computed once;
+//   * a chunk = R whole image rows (NP = R * W <= 96 pixels = up to 6 MFMA k-steps of 16 pixels; 64 pixels for the power-of-two map
+//     widths, 96 / 72 / 90 for 96-, 12-, 45-wide maps; the dz rows of a partial last k-step are zero): dz rows pixel-major in LDS, the
+//     activation rows with a one-pixel ZERO frame around them ((R+2) x (W+2) slots, rows outside the image zero): a tap is a constant LDS
+//     offset, conv2d's zero padding costs nothing in the loop, and every staging / fragment address is a per-thread constant computed once;
 //   * pixel rows in LDS are padded to a stride of 64 or 192 (mod 256) bytes so that the 4 pixels x 64 bytes a 32-lane pass of the
 //     transpose read touches fall into 4 different bank quarters;
 //   * kSplit ("f16x3"): operands are [hi | lo] fp16 pairs; per tap dz_hi*a_hi + dz_lo*a_hi + dz_hi*a_lo (fp32 accumulation);
 //   * no atomics: every workgroup stores its partial tile to part[split][tap][ci][co]; nastar_wgrad_reduce_kernel sums the splits in
 //     a fixed order (bitwise reproducible), applies out_scale (undoes the power-of-two gradient scale read from device memory) and
 //     writes torch's [co][ci][3][3] layout cropped to the real channel counts.
-// Shapes: W in {2,4,...,64} dividing 64, H a multiple of RC = 64 / W; CO, CI multiples of 32 (zero padded).
+// Shapes: 2 <= W <= 96, H a multiple of the chunk's row count R (nastar_wgrad_chunk_rows); CO, CI multiples of 32 (zero padded).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,12 +36,25 @@ struct WgradArgs {
     const uint16_t* a;   // [P][CI (x2)] fp16 NHWC (the layer's input activations)
     float* part;         // [nsplit][9][CI][CO] fp32 partial sums
     int B, H, W, CO, CI;
-    int nchunk;          // B*H*W / 64
+    int R, NP, KS;       // chunk: R image rows = NP pixels = KS k-steps of 16 pixels (KS*16 >= NP)
+    int nchunk;          // B*H / R
     int nsplit;          // pixel splits: gridDim.x = nsplit * (CO/(32 COB)) * (CI/(32 CIB))
 };
 
 constexpr int wg_row_bytes(int r) { return r % 128 == 0 ? r + 64 : r; }
-constexpr int WG_MAX_SLOTS = 198;  // (RC+2)*(W+2) for W = 64; 136 for W = 32
+constexpr int WG_MAX_SLOTS = 200;       // (R+2)*(W+2) for W <= 64: 198 for W = 64, 200 for W = 48 / 2, 136 for W = 32
+constexpr int WG_MAX_SLOTS_WIDE = 294;  // 64 < W <= 96: 3 x 98
+constexpr int WG_MAX_PIX = 96, WG_MAX_KS = 6;
+
+// rows per chunk for an H x W map, 0 = unsupported: 64-pixel chunks where W divides 64, otherwise the most rows with R*W <= 96
+inline int nastar_wgrad_chunk_rows(int H, int W)
+{
+    if (W < 2 || W > WG_MAX_PIX || H <= 0) return 0;
+    if (64 % W == 0 && H % (64 / W) == 0) return 64 / W;
+    for (int r = WG_MAX_PIX / W; r >= 1; --r)
+        if (H % r == 0) return r;
+    return 0;
+}
 
 typedef __fp16 nastar_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -55,7 +69,7 @@ __device__ __forceinline__ bf16x8 wg_tr_read2(uint32_t addr0, uint32_t addr1)
     return u.v;
 }
 
-template <int COB, int CIB, bool kSplit>
+template <int COB, int CIB, bool kSplit, bool kWide>
 __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(const WgradArgs g)
 {
     constexpr int NTHR = 192 * COB * CIB;
@@ -65,12 +79,13 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
     constexpr int RDZ = wg_row_bytes(COB * 64 * M);
     constexpr int RA = wg_row_bytes(CIB * 64 * M);
     constexpr int CPZ = M * COB * 4, CPA = M * CIB * 4;            // 16-byte chunks per pixel
-    constexpr int NZ = (64 * CPZ + NTHR - 1) / NTHR;               // staged chunks per thread
-    constexpr int NA = (WG_MAX_SLOTS * CPA + NTHR - 1) / NTHR;
+    constexpr int NZ = (WG_MAX_PIX * CPZ + NTHR - 1) / NTHR;       // staged chunks per thread
+    constexpr int NA = ((kWide ? WG_MAX_SLOTS_WIDE : WG_MAX_SLOTS) * CPA + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int W = g.W, RC = 64 / W, PW = W + 2;
-    unsigned char* dzt = smem;                    // [64][RDZ]
-    // activation tile [(RC+2)*(W+2)][RA] follows at smem + 64 * RDZ
+    const int W = g.W, RC = g.R, PW = W + 2, NP = g.NP, KS = g.KS;
+    const int ZROWS = KS * 16;                    // pixel rows of the dz tile (rows >= NP stay zero)
+    unsigned char* dzt = smem;                    // [ZROWS][RDZ]
+    // activation tile [(RC+2)*(W+2)][RA] follows at smem + ZROWS * RDZ
     const int nslot_a = (RC + 2) * PW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,7 +106,7 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         const int q = tid + i * NTHR;
         const int pix = q / CPZ, c = q - pix * CPZ;
         const int half = c / (COB * 4), cc = c - half * (COB * 4);
-        const bool ok = q < 64 * CPZ;
+        const bool ok = q < NP * CPZ;
         zsrc[i] = ok ? pix * sdz + half * g.CO + co0 + cc * 8 : -1;
         zdst[i] = pix * RDZ + half * (COB * 64) + cc * 16;
     }
@@ -105,25 +120,30 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         const bool inx = sc >= 1 && sc <= W;
         // relative to the chunk's first pixel (row y0, column 0): (sr - 1) rows up/down, column sc - 1
         asrc[i] = ((sr - 1) * W + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
-        adst[i] = ok ? 64 * RDZ + slot * RA + half * (CIB * 64) + cc * 16 : -1;
+        adst[i] = ok ? ZROWS * RDZ + slot * RA + half * (CIB * 64) + cc * 16 : -1;
         arow[i] = (ok && inx) ? sr - 1 : -(1 << 28);  // image row offset of the slot; hugely negative = always zero (frame column / unused)
     }
 
     // ---- per-lane fragment addresses (constants): k-step ks, read half tt: pixel = 16 ks + 8 kh + 4 tt + (r16 >> 2) ----
     const int r16 = lane & 15, grp = (lane >> 4) & 1, kh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;  // LDS byte address of the dynamic region
-    uint32_t adz[4][2], aa[4][2];
+    // dz side: linear in (ks, tt): adz0 + (16 ks + 4 tt) * RDZ;  activation side: one address per (ks, tt) (rows wrap at W)
+    const int chan = 16 * grp + 4 * (r16 & 3);
+    const uint32_t adz0 = lds0 + (8 * kh + (r16 >> 2)) * RDZ + wco * 64 + chan * 2;
+    uint32_t aa[WG_MAX_KS][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < WG_MAX_KS; ++ks)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int pix = 16 * ks + 8 * kh + 4 * tt + (r16 >> 2);
-            const int chan = 16 * grp + 4 * (r16 & 3);
-            adz[ks][tt] = lds0 + pix * RDZ + wco * 64 + chan * 2;
-            const int row = pix / W, col = pix - row * W;
+            const int pc = pix < NP ? pix : NP - 1;  // pixels of a partial last k-step: their dz rows are zero, any in-range address does
+            const int row = pc / W, col = pc - row * W;
             // tap row dy = wdy - 1 is folded in here; the three dx taps are +-RA around it
-            aa[ks][tt] = lds0 + 64 * RDZ + ((row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2;
+            aa[ks][tt] = lds0 + ZROWS * RDZ + ((row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2;
         }
+    // zero rows [NP, ZROWS) of the dz tile once (never staged)
+    for (int q = tid; q < (ZROWS - NP) * (RDZ / 16); q += NTHR)
+        *reinterpret_cast<uint4*>(dzt + NP * RDZ + q * 16) = make_uint4(0u, 0u, 0u, 0u);
 
     f32x16 acc[3];
 #pragma unroll
@@ -165,10 +185,12 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         __syncthreads();
         if (ch + g.nsplit < g.nchunk) load_chunk(ch + g.nsplit);  // in flight during the MFMAs below
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 zh = wg_tr_read2(adz[ks][0], adz[ks][1]);
+        for (int ks = 0; ks < WG_MAX_KS; ++ks) {
+            if (ks >= KS) break;
+            const uint32_t z0 = adz0 + 16 * ks * RDZ, z1 = z0 + 4 * RDZ;
+            const bf16x8 zh = wg_tr_read2(z0, z1);
             bf16x8 zl = zh;
-            if constexpr (kSplit) zl = wg_tr_read2(adz[ks][0] + COB * 64, adz[ks][1] + COB * 64);
+            if constexpr (kSplit) zl = wg_tr_read2(z0 + COB * 64, z1 + COB * 64);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int toff = (dx - 1) * RA;

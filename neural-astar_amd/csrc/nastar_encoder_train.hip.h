@@ -155,6 +155,55 @@ __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t*
     }
 }
 
+// 2x2 max-pool backward (CNNDownSize blocks, reference encoder.py:91-95 under autograd): r [B,H,W,C] = the pool's input (post-ReLU
+// activations), dp [B,H/2,W/2,C] the gradient w.r.t. its output; dr[pixel] = dp[window] where the pixel is the window's FIRST maximum
+// (torch's tie rule), 0 elsewhere.  Split form: values are hi + lo, gradients are moved as (hi, lo) pairs.
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_maxpool2x2_bwd_kernel(const uint16_t* __restrict__ r, const uint16_t* __restrict__ dp,
+                                                                    uint16_t* __restrict__ dr, int B, int H, int W, int C)
+{
+    const int Ho = H >> 1, Wo = W >> 1, CG = C >> 3;
+    const int stride = kSplit ? 2 * C : C;
+    const long long total = (long long)B * Ho * Wo * CG;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % CG);
+        long long t = i / CG;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float v[4][8];
+        size_t pin[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pin[k] = ((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+            load8<kSplit>(r, pin[k], stride, C, c8, v[k]);
+        }
+        const size_t po = ((size_t)b * Ho + yo) * Wo + xo;
+        const nastar_f16x8 ghi = *reinterpret_cast<const nastar_f16x8*>(dp + po * stride + c8 * 8);
+        nastar_f16x8 glo = ghi;
+        if constexpr (kSplit) glo = *reinterpret_cast<const nastar_f16x8*>(dp + po * stride + C + c8 * 8);
+        int best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            best[e] = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > v[best[e]][e]) best[e] = k;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nastar_f16x8 ohi, olo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ohi[e] = best[e] == k ? ghi[e] : (_Float16)0.f;
+                olo[e] = best[e] == k ? glo[e] : (_Float16)0.f;
+            }
+            *reinterpret_cast<nastar_f16x8*>(dr + pin[k] * stride + c8 * 8) = ohi;
+            if constexpr (kSplit) *reinterpret_cast<nastar_f16x8*>(dr + pin[k] * stride + C + c8 * 8) = olo;
+        }
+    }
+}
+
 __global__ void nastar_absmax_kernel(const float* __restrict__ d, long long n, unsigned int* __restrict__ amax_bits);
 
 // ---- small host-replacing kernels: everything a training step needs between the big launches runs on the device, in ONE launch each,

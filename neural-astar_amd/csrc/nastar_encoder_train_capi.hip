@@ -22,10 +22,11 @@ static int wgrad_nsplit(int nchunk, int co, int ci)
 template <int COB, int CIB, bool kSplit>
 static int launch_wgrad(WgradArgs g, hipStream_t s)
 {
-    auto kern = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit>;
+    void (*kern)(const WgradArgs) = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit, false>;
+    if (g.W > 64) kern = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit, true>;
     constexpr int M = kSplit ? 2 : 1;
-    const int RC = 64 / g.W;
-    const size_t lds = (size_t)64 * wg_row_bytes(COB * 64 * M) + (size_t)(RC + 2) * (g.W + 2) * wg_row_bytes(CIB * 64 * M);
+    const size_t lds = (size_t)g.KS * 16 * wg_row_bytes(COB * 64 * M) + (size_t)(g.R + 2) * (g.W + 2) * wg_row_bytes(CIB * 64 * M);
+    if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
     const int tiles = (g.CO / (32 * COB)) * (g.CI / (32 * CIB));
@@ -44,7 +45,9 @@ extern "C" {
 size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci)
 {
     if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0 || co % 32 || ci % 32) return 0;
-    const int nchunk = (int)(((long long)B * H * W) / 64);
+    const int R = nastar_wgrad_chunk_rows(H, W);
+    if (R == 0) return 0;
+    const int nchunk = (int)(((long long)B * H) / R);
     return (size_t)wgrad_nsplit(nchunk, co, ci) * 9 * ci * co * sizeof(float);
 }
 
@@ -54,13 +57,15 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
 {
     if (!dz || !a || !dw || !workspace) return NASTAR_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0 || co_real <= 0 || ci_real <= 0 || co_real > co || ci_real > ci) return NASTAR_ERR_BAD_SHAPE;
-    if (co % 32 || ci % 32 || W < 2 || W > 64 || 64 % W || H % (64 / W)) return NASTAR_ERR_UNSUPPORTED;
+    const int R = nastar_wgrad_chunk_rows(H, W);
+    if (co % 32 || ci % 32 || R == 0) return NASTAR_ERR_UNSUPPORTED;
     if (!aligned16(dz) || !aligned16(a) || !aligned16(workspace)) return NASTAR_ERR_BAD_SHAPE;
     if (workspace_bytes < nastar_conv3x3_wgrad_workspace_bytes(B, H, W, co, ci)) return NASTAR_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     WgradArgs g;
     g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.W = W; g.CO = co; g.CI = ci;
-    g.nchunk = (int)(((long long)B * H * W) / 64);
+    g.R = R; g.NP = R * W; g.KS = (g.NP + 15) / 16;
+    g.nchunk = (int)(((long long)B * H) / R);
     g.nsplit = wgrad_nsplit(g.nchunk, co, ci);
     const bool co2 = co % 64 == 0, ci2 = ci % 64 == 0;
     int rc;
@@ -185,6 +190,21 @@ int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dz
     if (split) hipLaunchKernelGGL(nastar_grad_seed_kernel<true>, dim3(g2), dim3(256), 0, s, d, npix, amax_scratch, gscale, dzb);
     else hipLaunchKernelGGL(nastar_grad_seed_kernel<false>, dim3(g2), dim3(256), 0, s, d, npix, amax_scratch, gscale, dzb);
     e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_maxpool2x2_bwd_f16(const uint16_t* r, const uint16_t* dp, uint16_t* dr, int B, int H, int W, int C, int split, void* stream)
+{
+    if (!r || !dp || !dr) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((H | W) & 1 || C % 8) return NASTAR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (split) hipLaunchKernelGGL(nastar_maxpool2x2_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, r, dp, dr, B, H, W, C);
+    else hipLaunchKernelGGL(nastar_maxpool2x2_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, r, dp, dr, B, H, W, C);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }

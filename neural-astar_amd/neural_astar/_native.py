@@ -70,6 +70,7 @@ EXPORTED_SYMBOLS = (
     "nastar_bn_coef_fwd",
     "nastar_bn_coef_bwd",
     "nastar_grad_seed_f16",
+    "nastar_maxpool2x2_bwd_f16",
 )
 
 
@@ -168,6 +169,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_bn_coef_fwd.argtypes = [vp, vp, vp, cd, ctypes.c_longlong, cd, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_bwd.restype = ci
     lib.nastar_bn_coef_bwd.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_maxpool2x2_bwd_f16.restype = ci
+    lib.nastar_maxpool2x2_bwd_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.nastar_grad_seed_f16.restype = ci
     lib.nastar_grad_seed_f16.argtypes = [vp, ctypes.c_longlong, ci, vp, vp, vp, vp]
     lib.nastar_debug_occupancy.restype = ci

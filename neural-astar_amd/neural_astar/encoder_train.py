@@ -111,40 +111,57 @@ class _Lib:
         return dw
 
 
-def supported_shape(H: int, W: int) -> bool:
-    """nastar_conv3x3_wgrad_f16 works on chunks of 64 pixels = whole image rows"""
-    return 2 <= W <= 64 and 64 % W == 0 and H % (64 // W) == 0
+def chunk_rows(H: int, W: int) -> int:
+    """rows per weight-gradient chunk (csrc/nastar_conv_wgrad.hip.h: nastar_wgrad_chunk_rows); 0 = unsupported shape"""
+    if W < 2 or W > 96 or H <= 0:
+        return 0
+    if 64 % W == 0 and H % (64 // W) == 0:
+        return 64 // W
+    for r in range(96 // W, 0, -1):
+        if H % r == 0:
+            return r
+    return 0
+
+
+def supported_shape(H: int, W: int, depth: int = 4, pool: bool = False) -> bool:
+    """every resolution the stack visits must suit the weight-gradient kernel (whole image rows per <= 96-pixel chunk) and the
+    generic convolution (W <= 126); pooling stacks halve the resolution after every hidden block"""
+    for l in range(depth + 1):
+        h, w = (H >> l, W >> l) if pool else (H, W)
+        if pool and l < depth and ((h | w) & 1):
+            return False
+        if chunk_rows(h, w) == 0 or w > 126:
+            return False
+    return True
 
 
 class _CnnTrunk(torch.autograd.Function):
-    """(map, start+goal inputs, conv / BatchNorm parameters of the 4 hidden blocks, last conv) -> z5 [B,1,H,W] fp32 (raw output of the
-    last convolution, bias included).  ``cfg``: dict(split, plus, eps[4], bns[4] for the running statistics)."""
+    """(assembled input x0, conv / BatchNorm parameters of the D hidden blocks, last conv) -> z [B,1,h,w] fp32 (raw output of the
+    last convolution, bias included).  ``cfg``: dict(split, depth D, pool, shape (B, H, W), eps[D], bns[D] for the running
+    statistics).  Hidden block: conv3x3 -> BatchNorm (batch statistics) -> ReLU [-> 2x2 max-pool]."""
 
     @staticmethod
-    def forward(ctx, cfg, m, s, g, *params):
-        split = cfg["split"]
-        dev = m.device
-        B, H, W = m.shape
-        npix = B * H * W
+    def forward(ctx, cfg, x0, *params):
+        split, D, pool = cfg["split"], cfg["depth"], cfg["pool"]
+        dev = x0.device
+        B, H, W = cfg["shape"]
         L = _Lib(dev)
         mult = 2 if split else 1
         sflag = CONV_SPLIT if split else 0
-        ws = list(params[0:20:4])           # conv weights of blocks 1..5
-        bs = list(params[1:20:4])           # conv biases
-        gammas = list(params[2:16:4])       # BatchNorm weights of blocks 1..4
-        betas = list(params[3:16:4])
+        ws = list(params[0:4 * D + 1:4])             # conv weights of blocks 1..D+1
+        bs = list(params[1:4 * D + 2:4])             # conv biases
+        gammas = list(params[2:4 * D:4])             # BatchNorm weights of the hidden blocks
+        betas = list(params[3:4 * D:4])
         with torch.cuda.device(dev):
-            x0 = torch.empty((npix * 32 * mult,), dtype=torch.int16, device=dev)
-            rc = L.lib.nastar_encoder_prep_f16(m.data_ptr(), s.data_ptr() if cfg["plus"] else None, g.data_ptr() if cfg["plus"] else None,
-                                               int(cfg["plus"]), npix, 32, int(split), x0.data_ptr(), L.stream)
-            _native.check(rc, "nastar_encoder_prep_f16")
-            acts, zs, coef = [x0], [], []
-            for l in range(4):
-                w = ws[l]
-                cout, cin_p = w.shape[0], _pad32(w.shape[1])
-                wpack, scale, shift = L.pack(w, False, split, bs[l])
+            acts, zs, rs, coef = [x0], [], [], []
+            h, w = H, W
+            for l in range(D):
+                wt = ws[l]
+                cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
+                npix = B * h * w
+                wpack, scale, shift = L.pack(wt, False, split, bs[l])
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
-                L.conv(acts[-1], wpack, scale, shift, B, H, W, cin_p, cout, sflag, out=z)
+                L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
                 sums = L.stats(None, z, None, None, npix, cout, split)
                 k2, k3 = L.f32(cout), L.f32(cout)
                 mean = torch.empty((cout,), dtype=torch.float64, device=dev)
@@ -160,37 +177,45 @@ class _CnnTrunk(torch.autograd.Function):
                                               bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                               k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
                 _native.check(rc, "nastar_bn_coef_fwd")
-                a = torch.empty_like(z)
-                L.affine(None, z, None, k2, k3, None, None, a, npix, cout, True, split)
+                r = torch.empty_like(z)
+                L.affine(None, z, None, k2, k3, None, None, r, npix, cout, True, split)
                 zs.append(z)
-                acts.append(a)
                 coef.append((mean, invstd, k2, k3))
-            w5 = ws[4]
-            wpack5, scale5, shift5 = L.pack(w5, False, split, bs[4])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
-            z5 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-            L.conv(acts[-1], wpack5, scale5, shift5, B, H, W, w5.shape[1], 32, sflag | CONV_FINAL | CONV_RAW, out_f32=z5)
+                if pool:
+                    a = torch.empty((B * (h // 2) * (w // 2) * cout * mult,), dtype=torch.int16, device=dev)
+                    rc = L.lib.nastar_maxpool2x2_f16(r.data_ptr(), a.data_ptr(), B, h, w, cout, int(split), L.stream)
+                    _native.check(rc, "nastar_maxpool2x2_f16")
+                    rs.append(r)  # the pool's input: its backward needs the arg-max
+                    acts.append(a)
+                    h, w = h // 2, w // 2
+                else:
+                    acts.append(r)
+            wl = ws[D]
+            wpackl, scalel, shiftl = L.pack(wl, False, split, bs[D])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+            zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+            L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
         ctx.cfg = cfg
-        ctx.shape = (B, H, W)
-        ctx.acts, ctx.zs, ctx.coef = acts, zs, coef
+        ctx.acts, ctx.zs, ctx.rs, ctx.coef = acts, zs, rs, coef
         ctx.save_for_backward(*params)
-        return z5.unsqueeze(1)
+        return zl.unsqueeze(1)
 
     @staticmethod
-    def backward(ctx, dz5):
+    def backward(ctx, dzl):
         cfg = ctx.cfg
-        split = cfg["split"]
+        split, D, pool = cfg["split"], cfg["depth"], cfg["pool"]
         params = ctx.saved_tensors
-        ws = list(params[0:20:4])
-        gammas = list(params[2:16:4])
-        B, H, W = ctx.shape
-        npix = B * H * W
-        dev = dz5.device
+        ws = list(params[0:4 * D + 1:4])
+        gammas = list(params[2:4 * D:4])
+        B, H, W = cfg["shape"]
+        dev = dzl.device
         L = _Lib(dev)
         mult = 2 if split else 1
         sflag = CONV_SPLIT if split else 0
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         with torch.cuda.device(dev):
-            d = dz5.reshape(npix)
+            h, w = (H >> D, W >> D) if pool else (H, W)   # resolution of the last convolution
+            npix = B * h * w
+            d = dzl.reshape(npix)
             d = d if d.is_contiguous() and d.dtype == torch.float32 else d.float().contiguous()
             # gradients travel multiplied by a power of two S (device scalar `gscale`, re-centred per block): scaled values peak near
             # 2^10, so fp16 neither overflows nor loses the small terms; S is divided out inside the weight-gradient / coefficient kernels
@@ -199,22 +224,29 @@ class _CnnTrunk(torch.autograd.Function):
             rc = L.lib.nastar_grad_seed_f16(d.data_ptr(), npix, int(split), dzb.data_ptr(), gscale.data_ptr(), amax.data_ptr(), L.stream)
             _native.check(rc, "nastar_grad_seed_f16")
             cur_co = 32  # padded channel count of the current dz
-            for l in range(4, -1, -1):
-                w = ws[l]
-                cout, cin = w.shape[:2]
+            for l in range(D, -1, -1):
+                wt = ws[l]
+                cout, cin = wt.shape[:2]
                 cin_p = _pad32(cin)
-                grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, H, W, cur_co, cin_p, cout, cin, split, gscale)
+                grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, h, w, cur_co, cin_p, cout, cin, split, gscale)
                 grads[4 * l + 1] = torch.zeros_like(params[4 * l + 1])             # conv bias in front of a BatchNorm: exactly 0
                 if l == 0:
                     break
                 # input gradient: the same convolution with W^T flipped (cin <-> cout; cout 1 of the last block padded to 32 inputs)
-                wpack, scale, shift = L.pack(w, True, split)
+                wpack, scale, shift = L.pack(wt, True, split)
                 da = torch.empty((npix * cin_p * mult,), dtype=torch.int16, device=dev)
-                L.conv(dzb, wpack, scale, shift, B, H, W, cur_co, cin_p, sflag, out=da)
-                # ReLU mask + BatchNorm backward of block l (its output is a_l = acts[l], pre-activation zs[l-1])
+                L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
+                C = cin_p
+                if pool:  # da is the gradient w.r.t. the pooled activations: route it to each window's arg-max at the finer resolution
+                    h, w = h * 2, w * 2
+                    npix = B * h * w
+                    dr = torch.empty((npix * C * mult,), dtype=torch.int16, device=dev)
+                    rc = L.lib.nastar_maxpool2x2_bwd_f16(ctx.rs[l - 1].data_ptr(), da.data_ptr(), dr.data_ptr(), B, h, w, C, int(split), L.stream)
+                    _native.check(rc, "nastar_maxpool2x2_bwd_f16")
+                    da = dr
+                # ReLU mask + BatchNorm backward of hidden block l (pre-activation zs[l-1])
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
-                C = cin_p
                 sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)         # (sum dy, sum dy z) * S, max|dy| * S
                 dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                 rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
@@ -226,41 +258,76 @@ class _CnnTrunk(torch.autograd.Function):
                 dzb = torch.empty_like(da)
                 L.affine(da, z, c1, c2, c3, k2f, k3f, dzb, npix, C, False, split)
                 cur_co = C
-        return (None, None, None, None) + tuple(grads)
+        return (None, None) + tuple(grads)
+
+
+def _assemble_input(map_designs, start_maps, goal_maps, plus, split, L) -> torch.Tensor:
+    """x0 [B,H,W,32 (x2)] fp16 NHWC of NeuralAstar.encode's input (reference astar.py:171-177)"""
+    B, C, H, W = map_designs.shape
+    dev = map_designs.device
+    mult = 2 if split else 1
+    if C == 1 and (not plus or start_maps.shape[-2:] == map_designs.shape[-2:]):
+        m = map_designs[:, 0].contiguous()
+        s = start_maps[:, 0].contiguous() if plus else m
+        g = goal_maps[:, 0].contiguous() if plus else m
+        x0 = torch.empty((B * H * W * 32 * mult,), dtype=torch.int16, device=dev)
+        rc = L.lib.nastar_encoder_prep_f16(m.data_ptr(), s.data_ptr() if plus else None, g.data_ptr() if plus else None, int(plus),
+                                           B * H * W, 32, int(split), x0.data_ptr(), L.stream)
+        _native.check(rc, "nastar_encoder_prep_f16")
+        return x0
+    # multi-channel images (WarCraft: RGB + nearest-upsampled start + goal): a handful of tensor ops on the small input
+    x = map_designs
+    if plus:
+        sg = start_maps + goal_maps
+        if sg.shape[-2:] != x.shape[-2:]:
+            sg = nn.functional.interpolate(sg, size=x.shape[-2:], mode="nearest")
+        x = torch.cat((x, sg), dim=1)
+    x = x.permute(0, 2, 3, 1).float()
+    xp = torch.zeros((B, H, W, 32), dtype=torch.float32, device=dev)
+    xp[..., :x.shape[-1]] = x
+    hi = xp.to(torch.float16)
+    if split:
+        hi = torch.cat((hi, (xp - hi.float()).to(torch.float16)), dim=-1)
+    return hi.contiguous().view(torch.int16).reshape(-1)
 
 
 def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
                       precision: str = "f16x3") -> torch.Tensor:
-    """``cnn(cat(map, start + goal))`` for a ``planner.encoder.CNN`` of depth 4 in TRAINING mode (batch-statistics BatchNorm, running
-    statistics updated), differentiable w.r.t. every encoder parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
+    """``cnn(cat(map, start + goal))`` for a ``planner.encoder.CNN`` / ``CNNDownSize`` in TRAINING mode (batch-statistics BatchNorm,
+    running statistics updated), differentiable w.r.t. every encoder parameter, on the MI355X kernels.  Returns the cost map
+    [B,1,h,w] fp32 (h, w = H, W >> depth for the pooling stack)."""
     layers = list(cnn.model)
     convs = [m for m in layers if isinstance(m, nn.Conv2d)]
     bns = [m for m in layers if isinstance(m, nn.BatchNorm2d)]
-    if [c.out_channels for c in convs] != [32, 64, 128, 256, 1] or len(bns) != 5:
-        raise NotImplementedError("cnn_train_forward implements the reference's depth-4 CNN (.. -> 32 -> 64 -> 128 -> 256 -> 1)")
+    pool = any(isinstance(m, nn.MaxPool2d) for m in layers)
+    D = len(convs) - 1
+    if (D < 1 or len(bns) != D + 1 or convs[-1].out_channels != 1 or any(c.out_channels % 32 for c in convs[:-1])
+            or any(c.kernel_size != (3, 3) or c.padding != (1, 1) for c in convs) or convs[0].in_channels > 32):
+        raise NotImplementedError("conv3x3 -> BatchNorm -> ReLU [-> max-pool] blocks with channel counts that are multiples of 32, "
+                                  "closed by a 1-channel conv3x3 + BatchNorm")
     B, _, H, W = map_designs.shape
-    if not supported_shape(H, W):
-        raise NotImplementedError("W must divide 64 and H must be a multiple of 64 / W")
+    if not supported_shape(H, W, D, pool):
+        raise NotImplementedError("map size not supported by the training kernels (see encoder_train.supported_shape)")
     params = []
-    for l in range(5):
+    for l in range(D + 1):
         params += [convs[l].weight, convs[l].bias, bns[l].weight, bns[l].bias]
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")
-    cfg = {"split": precision == "f16x3", "plus": bool(plus), "eps": [bn.eps for bn in bns[:4]], "bns": bns[:4]}
-    m = map_designs[:, 0].contiguous()
-    s = start_maps[:, 0].contiguous() if plus else m
-    g = goal_maps[:, 0].contiguous() if plus else m
-    z5 = _CnnTrunk.apply(cfg, m, s, g, *params[:18])
-    # last block's 1-channel BatchNorm (batch statistics) + sigmoid * const as plain tensor ops on [B,1,H,W]: torch's autograd serves
-    # bn5.weight / bias and const (MIOpen's spatial BatchNorm kernels are slow on a single channel)
-    bn5 = bns[4]
-    var, mean = torch.var_mean(z5, unbiased=False)
-    y = (z5 - mean) * torch.rsqrt(var + bn5.eps) * bn5.weight + bn5.bias
-    if bn5.track_running_stats and bn5.running_mean is not None:
+    split = precision == "f16x3"
+    cfg = {"split": split, "depth": D, "pool": pool, "shape": (B, H, W), "eps": [bn.eps for bn in bns[:D]], "bns": bns[:D]}
+    with torch.cuda.device(map_designs.device):
+        x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
+    zl = _CnnTrunk.apply(cfg, x0, *params[:4 * D + 2])
+    # last block's 1-channel BatchNorm (batch statistics) + sigmoid * const as plain tensor ops on [B,1,h,w]: torch's autograd serves
+    # its weight / bias and const (MIOpen's spatial BatchNorm kernels are slow on a single channel)
+    bnl = bns[D]
+    var, mean = torch.var_mean(zl, unbiased=False)
+    y = (zl - mean) * torch.rsqrt(var + bnl.eps) * bnl.weight + bnl.bias
+    if bnl.track_running_stats and bnl.running_mean is not None:
         with torch.no_grad():
-            n = z5.numel()
-            mom = bn5.momentum if bn5.momentum is not None else 1.0 / float(int(bn5.num_batches_tracked) + 1)
-            bn5.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
-            bn5.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
-            bn5.num_batches_tracked += 1
+            n = zl.numel()
+            mom = bnl.momentum if bnl.momentum is not None else 1.0 / float(int(bnl.num_batches_tracked) + 1)
+            bnl.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
+            bnl.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
+            bnl.num_batches_tracked += 1
     return torch.sigmoid(y) * cnn.const

@@ -105,7 +105,7 @@ class NeuralAstar(VanillaAstar):
                 and isinstance(self.encoder, encoder.Unet) and isinstance(self.encoder.model, encoder.VggUnet)
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % (1 << self.encoder.model.depth) == 0
-                and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0 and map_designs.shape[-1] <= 94):
+                and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0 and map_designs.shape[-1] <= 126):
             # Unet(vgg16_bn): generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h); "hip_f16x3" = split operands, fp32-grade
             precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipUnetEncoder
@@ -113,13 +113,18 @@ class NeuralAstar(VanillaAstar):
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
-                and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
-                and _is_depth4_cnn(self.encoder) and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]):
-            # TRAINING: convolutions, batch-statistics BatchNorm, ReLU and all their gradients on the MI355X kernels
-            # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade)
+                and isinstance(self.encoder, encoder.CNN)):
+            # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
+            # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade).
+            # CNN (any depth) and CNNDownSize (WarCraft); shapes the kernels do not take stay on torch.nn.
             from ..encoder_train import cnn_train_forward, supported_shape
-            if supported_shape(map_designs.shape[-2], map_designs.shape[-1]):
-                return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
+            convs = [m for m in self.encoder.model if isinstance(m, nn.Conv2d)]
+            pool = isinstance(self.encoder, encoder.CNNDownSize)
+            plus = "+" in self.encoder_input
+            if (supported_shape(map_designs.shape[-2], map_designs.shape[-1], len(convs) - 1, pool)
+                    and map_designs.shape[1] + int(plus) == convs[0].in_channels
+                    and (pool or map_designs.shape[-2:] == start_maps.shape[-2:])):
+                return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus,
                                          "f16" if self.encoder_backend == "hip_f16" else "f16x3")
         tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
         if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
@@ -134,7 +139,7 @@ class NeuralAstar(VanillaAstar):
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and type(self.encoder) is encoder.CNN and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
-                and map_designs.shape[-1] <= 94 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
+                and map_designs.shape[-1] <= 126 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
             # any other depth / map size: the generic fp16 MFMA convolution ("hip_f16x3" = split operands, otherwise plain fp16)
             precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipFlatCnnEncoder

@@ -7,7 +7,7 @@ logic is checked on the CPU (against torch's conv2d) before the kernel ever runs
 """
 import numpy as np
 
-FC_TP, FC_KS, FC_PIXB, FC_THREADS, FC_NTQ = 256, 32, 64, 256, 7
+FC_TP, FC_KS, FC_PIXB, FC_THREADS, FC_NTQ = 256, 32, 64, 256, 8
 
 
 def slot_off(slot, c):

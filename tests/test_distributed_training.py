@@ -77,6 +77,7 @@ def _warcraft_worker(rank, world, port, tmp):
     torch.manual_seed(1 + rank)
     planner = NeuralAstar(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3, const=10.0, Tmax=0.25,
                           learn_obstacles=True).to(dev)  # scripts/train_warcraft.py:30-37 + config/train_warcraft.yaml
+    planner.encoder_backend = "hip_f16x3"  # training: conv / BatchNorm / ReLU / max-pool forward + backward on the MI355X kernels
     tr = D.DataParallelTrainer(planner, lr=1e-3, coupling="none")
     g = torch.Generator().manual_seed(7 + rank)  # every rank has its own rows
     B = 16
@@ -95,6 +96,7 @@ def _warcraft_worker(rank, world, port, tmp):
     # inference afterwards through the f32-MFMA CNNDownSize encoder agrees with the torch encoder of the trained weights
     planner.eval()
     with torch.no_grad():
+        planner.encoder_backend = "torch"
         ref = planner.encode(img, s, gl)
         planner.encoder_backend = "hip_f16x3"
         got = planner.encode(img, s, gl)

@@ -71,7 +71,9 @@ CASES = [
     (5, 8, 8, 64, 64, 128, True, True, False),      # decoder block: upsample + concat
     (5, 8, 8, 32, 64, 64, True, True, True),
     (3, 16, 12, 64, 0, 32, True, True, False),      # upsample only (last decoder block), non-square
-    (2, 6, 94, 32, 0, 32, False, False, False),     # widest supported row
+    (2, 6, 126, 32, 0, 32, False, False, False),    # widest supported row
+    (6, 48, 48, 64, 0, 32, False, False, True),     # 32-channel workgroups, split operands, two slices per segment
+    (6, 96, 96, 32, 0, 32, True, False, True),
     (1, 40, 56, 96, 0, 64, True, False, True),
     (40, 2, 2, 512, 512, 256, True, True, False),   # deepest decoder block: 1024 input channels
 ]
