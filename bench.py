@@ -466,7 +466,32 @@ def encoder_train_step_ms(pr, dev):
             torch.cuda.synchronize(dev)
             out[f"batch_{B}_{backend}_ms"] = (time.perf_counter() - t0) / reps * 1e3
             del na
-    out["torch_fp32_ms_same_box"] = {"batch_100": 4.07, "batch_4096": 132.75, "source": "profiles/r02/encoder_train_step_ms.json"}
+    # BASELINE config 5's encoder: CNNDownSize, rgb+, depth 3, 96x96 RGB -> 12x12, the reference's batch of 100 (train_warcraft.yaml)
+    img = torch.rand((100, 3, 96, 96), device=dev)
+    s12 = torch.zeros((100, 1, 12, 12), device=dev)
+    g12 = torch.zeros((100, 1, 12, 12), device=dev)
+    s12[:, 0, 0, 0] = 1
+    g12[:, 0, 11, 11] = 1
+    R12 = torch.randn((100, 1, 12, 12), device=dev) / 14400
+    for backend in ("hip_f16x3", "hip_f16"):
+        torch.manual_seed(0)
+        na = NeuralAstar(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3, const=10.0).to(dev).train()
+        na.encoder_backend = backend
+
+        def one_w():
+            for p in na.parameters():
+                p.grad = None
+            (na.encode(img, s12, g12) * R12).sum().backward()
+        one_w()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            one_w()
+        torch.cuda.synchronize(dev)
+        out[f"warcraft_batch_100_{backend}_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+        del na
+    out["torch_fp32_ms_same_box"] = {"batch_100": 4.07, "batch_4096": 132.75, "warcraft_batch_100": 3.13,
+                                     "source": "profiles/r02/encoder_train_step_ms.json, encoder_train_step_warcraft_b100_ms.json"}
     out["unit"] = "ms per encoder forward+backward (wall clock), random-init CNN depth 4, 32x32 maps"
     return out
 
