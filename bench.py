@@ -602,6 +602,31 @@ def cpu_baseline_reference(pr, gpu_hist, gpu_paths):
             "gpu_matches_reference_on_sample": j["ok"]}
 
 
+def reference_on_this_gpu(pr, gpu_hist, gpu_paths, dev):
+    """Extra: the REAL reference DifferentiableAstar.forward (the staged torch-only module, oracle/_ref/) run through PyTorch-ROCm on
+    the SAME MI355X -- what a user of the reference gets on this hardware without this package (~45 ATen launches + one device->host
+    sync per loop iteration).  One warm-up call on 256 maps, then the whole bench batch once; masks compared with the HIP kernel's."""
+    import importlib.util
+    if not os.path.exists(REF_STAGED):
+        return {"available": False, "note": "oracle/_ref/differentiable_astar.py not staged (built outside the authoring container)"}
+    spec = importlib.util.spec_from_file_location("ref_differentiable_astar_gpu", REF_STAGED)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    planner = ref.DifferentiableAstar(g_ratio=G_RATIO, Tmax=1.0).to(dev).eval()
+    m, s_, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        planner(m[:256], s_[:256], g[:256], m[:256])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = planner(m, s_, g, m)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(out.histories[:, 0].cpu().numpy(), gpu_hist) and np.array_equal(out.paths[:, 0].cpu().numpy(), gpu_paths))
+    return {"available": True, "value": m.shape[0] / dt, "unit": "maps/s", "seconds_per_batch": dt, "batch": int(m.shape[0]),
+            "torch": torch.__version__, "masks_equal_to_hip_kernel": ok,
+            "note": "reference differentiable_astar.py on the same GPU via PyTorch-ROCm, eval mode, no_grad"}
+
+
 def cpu_baseline(pr, gpu_hist, gpu_paths):
     port = cpu_baseline_port(pr, gpu_hist, gpu_paths)
     if os.path.exists(REF_STAGED):
@@ -771,6 +796,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pr, hist, paths)
             _log("through_module")
             out["through_module"] = through_module_ms(pr, dev)
+            _log("reference on this gpu")
+            try:
+                out["reference_torch_on_this_gpu"] = reference_on_this_gpu(pr, hist, paths, dev)
+            except Exception as e:  # noqa: BLE001 - reported, never fatal for the headline
+                out["reference_torch_on_this_gpu"] = {"available": False, "note": f"{type(e).__name__}: {e}"}
         if n_gpus == 1 and not args.no_secondary:
             # secondary workloads on the same GPU (not the headline): short searches and the 64x64 shard of config 4
             sec = []
