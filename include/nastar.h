@@ -278,7 +278,8 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
  * step is launch-bound, so nothing between the big kernels is left to framework ops):
  * nastar_pack_conv_weight_f16: torch conv weight w fp32 [co][ci][3][3] -> the wpack of nastar_conv3x3_f16 (channels padded to 32;
  *   transpose_flip = the input-gradient form W'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]; split = [W_hi | W_hi | W_lo] of w * 2^s with
- *   2^s bringing max|w| to ~2^14), scale_out[cout_p] = 2^-s, shift_out[cout_p] = bias (or 0), scal_out[3] = (2^-s, 2^s, max|w|).
+ *   2^s bringing max|w| to ~2^14), scale_out[cout_p] = 2^-s, shift_out[cout_p] = bias (or 0), scal_out[3] = (2^-s, 2^s, max|w|);
+ *   reuse_max != 0: scal_out[2] already holds max|w| (a previous pack of the same weight), the reduction pass is skipped.
  * nastar_bn_coef_fwd: batch sums [C][2] (nastar_chan_stats_f16) -> k2 = gamma*invstd, k3 = beta - mean*k2, mean / invstd (double [C]),
  *   running_mean / running_var updated like nn.BatchNorm2d in training mode (may be NULL).
  * nastar_bn_coef_bwd: backward sums + amax|dy| + forward mean / invstd -> dgamma, dbeta (already divided by the gradient scale
@@ -287,7 +288,7 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
  *   1024 / max|d|)) written to gscale[0]; amax_scratch: one device float.
  */
 int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
-                                float* scale_out, float* shift_out, float* scal_out, void* stream);
+                                float* scale_out, float* shift_out, float* scal_out, int reuse_max, void* stream);
 int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta, double eps, long long npix, double momentum,
                        float* running_mean, float* running_var, float* k2, float* k3, double* mean_out, double* invstd_out, int C,
                        void* stream);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
                                                                 double* __restrict__ sums, unsigned int* __restrict__ amax_bits,
                                                                 long long npix, int C)
 {
-    __shared__ double red[256][2];
+    __shared__ double red[256][16];
     const int stride = kSplit ? 2 * C : C;
     const int CG = C >> 3;                 // 8-channel groups (C/8 <= 256 and divides 256: C in {8, 16, 32, 64, ... 2048})
     const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
@@ -95,22 +95,19 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
         if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
     }
-    // reduce over the pixel lanes of the workgroup (fixed order), then one atomic pair per channel and workgroup
+    // reduce over the pixel lanes of the workgroup (fixed order): all 16 partial sums of a thread go to LDS at once, then thread
+    // (c8, e) adds the NPL pixel lanes of "its" channel; one atomic pair per channel and workgroup
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        __syncthreads();
-        red[threadIdx.x][0] = s0[e];
-        red[threadIdx.x][1] = s1[e];
-        __syncthreads();
-        if (pl == 0) {
-            double a0 = 0.0, a1 = 0.0;
-            for (int k = 0; k < NPL; ++k) {
-                a0 += red[k * CG + c8][0];
-                a1 += red[k * CG + c8][1];
-            }
-            unsafeAtomicAdd(&sums[(size_t)(c8 * 8 + e) * 2 + 0], a0);
-            unsafeAtomicAdd(&sums[(size_t)(c8 * 8 + e) * 2 + 1], a1);
-        }
+        red[threadIdx.x][2 * e] = s0[e];
+        red[threadIdx.x][2 * e + 1] = s1[e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < CG * 16; o += 256) {  // o = c8 * 16 + (2 e + which)
+        const int oc8 = o >> 4, w = o & 15;
+        double acc = 0.0;
+        for (int k = 0; k < NPL; ++k) acc += red[k * CG + oc8][w];
+        unsafeAtomicAdd(&sums[(size_t)(oc8 * 8 + (w >> 1)) * 2 + (w & 1)], acc);
     }
 }
 

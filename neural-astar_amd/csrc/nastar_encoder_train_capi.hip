@@ -130,17 +130,20 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
 }
 
 int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
-                                float* scale_out, float* shift_out, float* scal_out, void* stream)
+                                float* scale_out, float* shift_out, float* scal_out, int reuse_max, void* stream)
 {
     if (!w || !wpack || !scale_out || !shift_out || !scal_out) return NASTAR_ERR_NULL;
     if (co <= 0 || ci <= 0) return NASTAR_ERR_BAD_SHAPE;
     const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
     const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(scal_out + 2, 0, sizeof(float), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    hipError_t e = hipSuccess;
     const int n = co * ci * 9;
-    if (split)
+    if (split && !reuse_max) {  // reuse_max: scal_out[2] already holds max|w| (the forward pack of the same weight computed it)
+        e = hipMemsetAsync(scal_out + 2, 0, sizeof(float), s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    }
+    if (split && !reuse_max)
         hipLaunchKernelGGL(nastar_absmax_kernel, dim3((unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256)), dim3(256), 0, s, w, (long long)n,
                            reinterpret_cast<unsigned int*>(scal_out + 2));
     const int total = 9 * (split ? 3 : 1) * cin_p * cout_p;

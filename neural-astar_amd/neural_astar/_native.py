@@ -164,7 +164,7 @@ def load() -> ctypes.CDLL:
     lib.nastar_chan_affine_f16.restype = ci
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_pack_conv_weight_f16.restype = ci
-    lib.nastar_pack_conv_weight_f16.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.nastar_pack_conv_weight_f16.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_fwd.restype = ci
     lib.nastar_bn_coef_fwd.argtypes = [vp, vp, vp, cd, ctypes.c_longlong, cd, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_bwd.restype = ci

@@ -61,13 +61,16 @@ class _Lib:
     def f32(self, n):
         return torch.empty((n,), dtype=torch.float32, device=self.dev)
 
-    def pack(self, w, transpose_flip, split, bias=None):
-        """device-side weight pack: (wpack, scale[cout_p], shift[cout_p])"""
+    def pack(self, w, transpose_flip, split, bias=None, scal=None):
+        """device-side weight pack: (wpack, scale[cout_p], shift[cout_p], scal); ``scal``: the scalars of an earlier pack of the same
+        weight (its max|w| is reused instead of reduced again)"""
         co, ci = w.shape[:2]
         cout_l, cin_l = (ci, co) if transpose_flip else (co, ci)
         cin_p, cout_p = _pad32(cin_l), _pad32(cout_l)
         wpack = torch.empty((9 * (3 if split else 1) * cin_p * cout_p,), dtype=torch.int16, device=self.dev)
-        scale, shift, scal = self.f32(cout_p), self.f32(cout_p), self.f32(3)
+        scale, shift = self.f32(cout_p), self.f32(cout_p)
+        reuse = scal is not None
+        scal = scal if reuse else self.f32(3)
         wc = w.detach()
         wc = wc if wc.is_contiguous() and wc.dtype == torch.float32 else wc.float().contiguous()
         bc = None
@@ -76,9 +79,9 @@ class _Lib:
             bc = bc if bc.is_contiguous() and bc.dtype == torch.float32 else bc.float().contiguous()
         rc = self.lib.nastar_pack_conv_weight_f16(wc.data_ptr(), co, ci, int(transpose_flip), int(split),
                                                   bc.data_ptr() if bc is not None else None, wpack.data_ptr(), scale.data_ptr(),
-                                                  shift.data_ptr(), scal.data_ptr(), self.stream)
+                                                  shift.data_ptr(), scal.data_ptr(), int(reuse), self.stream)
         _native.check(rc, "nastar_pack_conv_weight_f16")
-        return wpack, scale, shift
+        return wpack, scale, shift, scal
 
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None):
         rc = self.lib.nastar_conv3x3_f16(src.data_ptr(), None, wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(),
@@ -153,13 +156,14 @@ class _CnnTrunk(torch.autograd.Function):
         gammas = list(params[2:4 * D:4])             # BatchNorm weights of the hidden blocks
         betas = list(params[3:4 * D:4])
         with torch.cuda.device(dev):
-            acts, zs, rs, coef = [x0], [], [], []
+            acts, zs, rs, coef, scals = [x0], [], [], [], []
             h, w = H, W
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
                 npix = B * h * w
-                wpack, scale, shift = L.pack(wt, False, split, bs[l])
+                wpack, scale, shift, scal = L.pack(wt, False, split, bs[l])
+                scals.append(scal)
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
                 L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
                 sums = L.stats(None, z, None, None, npix, cout, split)
@@ -191,11 +195,12 @@ class _CnnTrunk(torch.autograd.Function):
                 else:
                     acts.append(r)
             wl = ws[D]
-            wpackl, scalel, shiftl = L.pack(wl, False, split, bs[D])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+            wpackl, scalel, shiftl, scal = L.pack(wl, False, split, bs[D])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+            scals.append(scal)
             zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
             L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
         ctx.cfg = cfg
-        ctx.acts, ctx.zs, ctx.rs, ctx.coef = acts, zs, rs, coef
+        ctx.acts, ctx.zs, ctx.rs, ctx.coef, ctx.scals = acts, zs, rs, coef, scals
         ctx.save_for_backward(*params)
         return zl.unsqueeze(1)
 
@@ -233,7 +238,7 @@ class _CnnTrunk(torch.autograd.Function):
                 if l == 0:
                     break
                 # input gradient: the same convolution with W^T flipped (cin <-> cout; cout 1 of the last block padded to 32 inputs)
-                wpack, scale, shift = L.pack(wt, True, split)
+                wpack, scale, shift, _ = L.pack(wt, True, split, scal=ctx.scals[l])
                 da = torch.empty((npix * cin_p * mult,), dtype=torch.int16, device=dev)
                 L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
                 C = cin_p

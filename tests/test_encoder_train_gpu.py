@@ -141,7 +141,10 @@ def test_device_weight_pack_matches_the_torch_pack(split):
         for tf in (False, True):
             wl = w.transpose(0, 1).flip(2, 3).contiguous() if tf else w
             ref_pack, ref_unscale = ET.pack_flat_weight(wl, split)
-            wpack, scale, shift = L.pack(w, tf, split, None if tf else b)
+            wpack, scale, shift, scal = L.pack(w, tf, split, None if tf else b)
+            if tf:  # the input-gradient pack re-using the forward pack's maximum is the same pack
+                wp2 = L.pack(w, True, split, None, scal=L.pack(w, False, split, b)[3])[0]
+                assert torch.equal(wp2, wpack)
             torch.cuda.synchronize()
             assert torch.equal(wpack.view(ref_pack.shape), ref_pack), (co, ci, tf)
             cout_l = ci if tf else co
