@@ -266,6 +266,29 @@ class _CnnTrunk(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _structure(cnn: nn.Module):
+    """(convs, bns, pool, depth) of a conv3x3 -> BatchNorm -> ReLU [-> max-pool] stack closed by a 1-channel conv3x3 + BatchNorm, or None
+    if the module is anything else (channel counts must be 32, 64, ... powers of two times 32: the streaming kernels' lane layout)"""
+    layers = list(cnn.model)
+    convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+    bns = [m for m in layers if isinstance(m, nn.BatchNorm2d)]
+    pool = any(isinstance(m, nn.MaxPool2d) for m in layers)
+    D = len(convs) - 1
+    ok_c = lambda c: c >= 32 and c <= 2048 and (c & (c - 1)) == 0  # noqa: E731
+    if (D < 1 or len(bns) != D + 1 or convs[-1].out_channels != 1 or not all(ok_c(c.out_channels) for c in convs[:-1])
+            or any(c.kernel_size != (3, 3) or c.padding != (1, 1) or c.stride != (1, 1) or c.bias is None for c in convs)
+            or convs[0].in_channels > 32
+            or any(not isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.MaxPool2d)) for m in layers)):
+        return None
+    return convs, bns, pool, D
+
+
+def supported(cnn: nn.Module, H: int, W: int) -> bool:
+    """can ``cnn_train_forward`` run this encoder on H x W inputs?  (``NeuralAstar.encode`` asks before leaving torch.nn)"""
+    st = _structure(cnn)
+    return st is not None and supported_shape(H, W, st[3], st[2])
+
+
 def _assemble_input(map_designs, start_maps, goal_maps, plus, split, L) -> torch.Tensor:
     """x0 [B,H,W,32 (x2)] fp16 NHWC of NeuralAstar.encode's input (reference astar.py:171-177)"""
     B, C, H, W = map_designs.shape
@@ -301,15 +324,11 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     """``cnn(cat(map, start + goal))`` for a ``planner.encoder.CNN`` / ``CNNDownSize`` in TRAINING mode (batch-statistics BatchNorm,
     running statistics updated), differentiable w.r.t. every encoder parameter, on the MI355X kernels.  Returns the cost map
     [B,1,h,w] fp32 (h, w = H, W >> depth for the pooling stack)."""
-    layers = list(cnn.model)
-    convs = [m for m in layers if isinstance(m, nn.Conv2d)]
-    bns = [m for m in layers if isinstance(m, nn.BatchNorm2d)]
-    pool = any(isinstance(m, nn.MaxPool2d) for m in layers)
-    D = len(convs) - 1
-    if (D < 1 or len(bns) != D + 1 or convs[-1].out_channels != 1 or any(c.out_channels % 32 for c in convs[:-1])
-            or any(c.kernel_size != (3, 3) or c.padding != (1, 1) for c in convs) or convs[0].in_channels > 32):
-        raise NotImplementedError("conv3x3 -> BatchNorm -> ReLU [-> max-pool] blocks with channel counts that are multiples of 32, "
-                                  "closed by a 1-channel conv3x3 + BatchNorm")
+    st = _structure(cnn)
+    if st is None:
+        raise NotImplementedError("conv3x3 -> BatchNorm -> ReLU [-> max-pool] blocks with 32 * 2^k channels, closed by a 1-channel "
+                                  "conv3x3 + BatchNorm")
+    convs, bns, pool, D = st
     B, _, H, W = map_designs.shape
     if not supported_shape(H, W, D, pool):
         raise NotImplementedError("map size not supported by the training kernels (see encoder_train.supported_shape)")

@@ -117,11 +117,11 @@ class NeuralAstar(VanillaAstar):
             # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
             # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade).
             # CNN (any depth) and CNNDownSize (WarCraft); shapes the kernels do not take stay on torch.nn.
-            from ..encoder_train import cnn_train_forward, supported_shape
+            from ..encoder_train import cnn_train_forward, supported
             convs = [m for m in self.encoder.model if isinstance(m, nn.Conv2d)]
             pool = isinstance(self.encoder, encoder.CNNDownSize)
             plus = "+" in self.encoder_input
-            if (supported_shape(map_designs.shape[-2], map_designs.shape[-1], len(convs) - 1, pool)
+            if (supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
                     and map_designs.shape[1] + int(plus) == convs[0].in_channels
                     and (pool or map_designs.shape[-2:] == start_maps.shape[-2:])):
                 return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus,

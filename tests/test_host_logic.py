@@ -295,3 +295,22 @@ def test_unet_vgg16_bn_encoder_constructs_and_runs_without_smp():
     na.train()
     na.encoder(x).sum().backward()
     assert all(p.grad is not None for p in na.encoder.model.decoder.parameters())
+
+
+def test_encoder_training_support_checks_are_host_logic():
+    """neural_astar/encoder_train.py decides on the host which encoders / map sizes the training kernels take (everything else stays on
+    torch.nn): stack structure, channel counts, weight-gradient chunking (csrc/nastar_conv_wgrad.hip.h: nastar_wgrad_chunk_rows)."""
+    import torch.nn as nn
+    from neural_astar import encoder_train as ET
+    from neural_astar.planner.encoder import CNN, CNNDownSize
+    # chunk = R whole rows, R*W <= 96 pixels; 64-pixel chunks where W divides 64
+    assert [ET.chunk_rows(h, w) for (h, w) in ((32, 32), (64, 64), (16, 16), (8, 8), (96, 96), (48, 48), (24, 24), (12, 12), (20, 45), (7, 5))] \
+        == [2, 1, 4, 8, 1, 2, 4, 6, 2, 7]
+    assert ET.chunk_rows(10, 97) == 0 and ET.chunk_rows(5, 1) == 0
+    assert ET.supported(CNN(2, 4, None), 32, 32) and ET.supported(CNN(1, 2, None), 20, 45)
+    assert ET.supported(CNNDownSize(4, 3, 10.0), 96, 96)            # WarCraft: 96 -> 48 -> 24 -> 12
+    assert not ET.supported(CNNDownSize(4, 3, 10.0), 100, 100)      # 25 x 25 cannot be pooled again
+    assert not ET.supported(CNN(2, 4, None), 8, 130)                # wider than the generic convolution's rows
+    odd = CNN(2, 2, None)
+    odd.model[0] = nn.Conv2d(2, 48, 3, padding=1)                   # 48 channels: not 32 * 2^k
+    assert not ET.supported(odd, 32, 32)
