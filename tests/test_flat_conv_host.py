@@ -119,3 +119,42 @@ def test_unet_launch_plan_and_packing():
     assert float(((hi + lo)[:, :conv.in_channels, :conv.out_channels] * 2.0 ** -s_exp - ref).abs().max()) <= 2.0 ** -22 * float(ref.abs().max())
     sc_plain = E.pack_flat_conv(conv, convs[1][5], False)[1]
     assert torch.allclose(sc * 2.0 ** s_exp, sc_plain, rtol=1e-6)
+
+
+WG_CASES = [
+    # B, H, W, co, ci, split
+    (2, 8, 8, 32, 32, False),     # one 64-pixel chunk per image
+    (2, 4, 16, 64, 32, True),     # split operands, two output blocks
+    (1, 6, 12, 32, 64, True),     # 12-wide rows: 6 rows = 72 pixels, a partial fifth k-step
+    (1, 4, 45, 32, 32, False),    # 2 x 45 = 90 pixels
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "B%d_%dx%d_co%d_ci%d_s%d" % tuple(int(v) for v in c))
+def test_wgrad_emulation_matches_torch_autograd(case):
+    """the weight-gradient kernel's addressing (chunks, framed LDS tiles, measured ds_read_b64_tr_b16 semantics, MFMA layout, partial
+    sums) reproduced on the CPU must give conv2d's weight gradient"""
+    import wgrad_emulator as wemu
+    B, H, W, co, ci, split = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    a = torch.randn((B, ci, H, W), generator=g)
+    dz = torch.randn((B, co, H, W), generator=g)
+    co_r, ci_r = co - 1, ci - 2
+    got = wemu.run(nhwc_f16(dz, split), nhwc_f16(a, split), B, H, W, co, ci, co_r, ci_r, split, nsplit=3, out_scale=0.5)
+
+    def seen(t):
+        hi = t.to(torch.float16).float()
+        return (hi + (t - hi).to(torch.float16).float()) if split else hi
+    w = torch.zeros((co, ci, 3, 3), dtype=torch.float64, requires_grad=True)
+    nn.functional.conv2d(seen(a).double(), w, None, padding=1).backward(seen(dz).double())
+    ref = 0.5 * w.grad[:co_r, :ci_r]
+    if split:  # the kernel drops the lo * lo product (2^-22 relative)
+        assert float((torch.from_numpy(got).double() - ref).abs().max() / ref.abs().max()) <= 1e-6
+    else:
+        assert np.allclose(got, ref.numpy(), rtol=0, atol=1e-6 * float(ref.abs().max()))
+    assert wemu.chunk_rows(H, W) == E_chunk_rows(H, W)
+
+
+def E_chunk_rows(H, W):
+    from neural_astar import encoder_train as ET
+    return ET.chunk_rows(H, W)
