@@ -258,7 +258,8 @@ int nastar_encoder_prep_f16(const float* map, const float* start, const float* g
  *   PADDED channel counts (multiples of 32); dw fp32 [co_real][ci_real][3][3] = torch's weight layout, cropped.  grad_scale_dev: device
  *   float holding the power-of-two gradient scale to divide out, or NULL.  Deterministic (per-workgroup partial sums in `workspace`,
  *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  2 <= W <= 96; a chunk is R whole image rows (R*W <= 96 pixels, 64 for
- *   the power-of-two widths) and H must be a multiple of R (workspace_bytes == 0 flags an unsupported shape).
+ *   the power-of-two widths) and H must be a multiple of R (workspace_bytes == 0 flags an unsupported shape); images of <= 48 pixels
+ *   (the 4x4 / 2x2 levels of a U-Net) are taken several per chunk, each with its own zero frame.
  * nastar_chan_stats_f16: per-channel sums over all pixels in double: sums[c] = (sum v, sum v^2), or with u != NULL
  *   (sum u*m, sum u*m*v), m = [ms[c]*v + mt[c] > 0] (the ReLU mask).  sums double [C][2], zeroed inside the call; amax_out
  *   (optional device float): max |u*m| over the tensor (feeds the power-of-two gradient re-scaling).
@@ -298,6 +299,18 @@ int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dz
 /* 2x2 max-pool backward (CNNDownSize blocks, reference encoder.py:91-95 under autograd): r [B,H,W,C] the pool's input, dp [B,H/2,W/2,C]
  * the gradient w.r.t. its output -> dr [B,H,W,C]: dp at each window's FIRST maximum (torch's tie rule), 0 elsewhere. */
 int nastar_maxpool2x2_bwd_f16(const uint16_t* r, const uint16_t* dp, uint16_t* dr, int B, int H, int W, int C, int split, void* stream);
+/*
+ * U-Net decoder plumbing under autograd (reference encoder.py:37-57: nearest x2 upsampling + skip concatenation in front of a conv):
+ * nastar_upcat_f16: out [B,H,W,c1+c2] = cat(x [B,H/2,W/2,c1] read at (y/2, x/2), skip [B,H,W,c2]) -- materialised for the weight gradient
+ *   (the convolution itself gathers, NASTAR_CONV_UPSAMPLE);   nastar_upcat_bwd_f16: dx [B,H/2,W/2,c1] = 2x2 block sums of dcat[..., :c1],
+ *   dskip [B,H,W,c2] = dcat[..., c1:].
+ * nastar_grad_add_f16: two gradients of one tensor carried with different power-of-two scales (device floats):
+ *   out = a * (So/Sa) + b * (So/Sb), *scale_out = So = min(Sa, Sb)   (a skip feature collects a decoder and an encoder gradient).
+ */
+int nastar_upcat_f16(const uint16_t* x, const uint16_t* skip, uint16_t* out, int B, int H, int W, int c1, int c2, int split, void* stream);
+int nastar_upcat_bwd_f16(const uint16_t* dcat, uint16_t* dx, uint16_t* dskip, int B, int H, int W, int c1, int c2, int split, void* stream);
+int nastar_grad_add_f16(const uint16_t* a, const float* scale_a, const uint16_t* b, const float* scale_b, uint16_t* out, float* scale_out,
+                        long long npix, int C, int split, void* stream);
 
 /* Resident forward workgroups (= maps) per CU the runtime reports for an HxW map, and the LDS bytes one map takes
  * (diagnostics for DESIGN.md / bench.py; returns -1 on error, 0 if the size is unsupported). */

@@ -12,6 +12,7 @@
 //   * a workgroup owns a (COB x 32) x (CIB x 32) channel tile of dW for all 9 taps and a strided set of pixel chunks; it runs
 //     3 x COB x CIB wavefronts: wavefront (wco, wci, wdy) holds the 3 accumulators (dx = -1, 0, 1) of its 32 x 32 block and tap row
 //     dy: 48 accumulator registers, which leaves room to PREFETCH the next chunk into registers while the matrix pipe works;
+//   * tiny images (H*W <= 48: the deep levels of a U-Net) are taken G at a time, each with its own zero frame; otherwise
 //   * a chunk = R whole image rows (NP = R * W <= 96 pixels = up to 6 MFMA k-steps of 16 pixels; 64 pixels for the power-of-two map
 //     widths, 96 / 72 / 90 for 96-, 12-, 45-wide maps; the dz rows of a partial last k-step are zero): dz rows pixel-major in LDS, the
 //     activation rows with a one-pixel ZERO frame around them ((R+2) x (W+2) slots, rows outside the image zero): a tap is a constant LDS
@@ -36,8 +37,8 @@ struct WgradArgs {
     const uint16_t* a;   // [P][CI (x2)] fp16 NHWC (the layer's input activations)
     float* part;         // [nsplit][9][CI][CO] fp32 partial sums
     int B, H, W, CO, CI;
-    int R, NP, KS;       // chunk: R image rows = NP pixels = KS k-steps of 16 pixels (KS*16 >= NP)
-    int nchunk;          // B*H / R
+    int R, G, NP, KS;    // chunk: G blocks of R image rows (G > 1: whole tiny images, R == H) = NP pixels = KS k-steps of 16 (KS*16 >= NP)
+    int nchunk;          // B*H / R  (G == 1)  or  ceil(B / G)
     int nsplit;          // pixel splits: gridDim.x = nsplit * (CO/(32 COB)) * (CI/(32 CIB))
 };
 
@@ -54,6 +55,16 @@ inline int nastar_wgrad_chunk_rows(int H, int W)
     for (int r = WG_MAX_PIX / W; r >= 1; --r)
         if (H % r == 0) return r;
     return 0;
+}
+// images per chunk: tiny images (H*W <= 48: the 4x4 and 2x2 levels of a U-Net) are taken several at a time, each with its own zero
+// frame in LDS, as many as fit 96 pixels and the 200 frame slots; 1 for everything else (then a chunk is R rows of ONE image)
+inline int nastar_wgrad_chunk_images(int H, int W)
+{
+    if (H * W > 48 || nastar_wgrad_chunk_rows(H, W) < H) return 1;
+    int g = WG_MAX_PIX / (H * W);
+    const int by_slots = WG_MAX_SLOTS / ((H + 2) * (W + 2));
+    if (g > by_slots) g = by_slots;
+    return g < 1 ? 1 : g;
 }
 
 typedef __fp16 nastar_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -83,10 +94,11 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
     constexpr int NA = ((kWide ? WG_MAX_SLOTS_WIDE : WG_MAX_SLOTS) * CPA + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, RC = g.R, PW = W + 2, NP = g.NP, KS = g.KS;
+    const int BP = RC * W, BS = (RC + 2) * PW;    // pixels / frame slots per block (one block per image when G > 1)
     const int ZROWS = KS * 16;                    // pixel rows of the dz tile (rows >= NP stay zero)
     unsigned char* dzt = smem;                    // [ZROWS][RDZ]
-    // activation tile [(RC+2)*(W+2)][RA] follows at smem + ZROWS * RDZ
-    const int nslot_a = (RC + 2) * PW;
+    // activation tile [G * (RC+2)*(W+2)][RA] follows at smem + ZROWS * RDZ
+    const int nslot_a = g.G * BS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wdy = wave % 3, wco = (wave / 3) % COB, wci = wave / (3 * COB);
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
     const int sdz = M * g.CO, sa = M * g.CI;      // fp16 elements per pixel in HBM
 
     // ---- staging plan (constants per thread): global element offset relative to the chunk's first pixel, LDS byte offset ----
-    int zsrc[NZ], zdst[NZ], asrc[NA], adst[NA], arow[NA];
+    int zsrc[NZ], zdst[NZ], zblk[NZ], asrc[NA], adst[NA], arow[NA], ablk[NA];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const int q = tid + i * NTHR;
@@ -109,17 +121,20 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         const bool ok = q < NP * CPZ;
         zsrc[i] = ok ? pix * sdz + half * g.CO + co0 + cc * 8 : -1;
         zdst[i] = pix * RDZ + half * (COB * 64) + cc * 16;
+        zblk[i] = pix / BP;  // which image of the chunk (0 when G == 1)
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int q = tid + i * NTHR;
         const int slot = q / CPA, c = q - slot * CPA;
         const int half = c / (CIB * 4), cc = c - half * (CIB * 4);
-        const int sr = slot / PW, sc = slot - sr * PW;
+        const int gi = slot / BS, sb = slot - gi * BS;
+        const int sr = sb / PW, sc = sb - sr * PW;
         const bool ok = q < nslot_a * CPA;
         const bool inx = sc >= 1 && sc <= W;
-        // relative to the chunk's first pixel (row y0, column 0): (sr - 1) rows up/down, column sc - 1
-        asrc[i] = ((sr - 1) * W + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
+        // relative to the chunk's first pixel (row y0, column 0): block gi, (sr - 1) rows up/down, column sc - 1
+        asrc[i] = (gi * BP + (sr - 1) * W + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
+        ablk[i] = gi;
         adst[i] = ok ? ZROWS * RDZ + slot * RA + half * (CIB * 64) + cc * 16 : -1;
         arow[i] = (ok && inx) ? sr - 1 : -(1 << 28);  // image row offset of the slot; hugely negative = always zero (frame column / unused)
     }
@@ -137,9 +152,10 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         for (int tt = 0; tt < 2; ++tt) {
             const int pix = 16 * ks + 8 * kh + 4 * tt + (r16 >> 2);
             const int pc = pix < NP ? pix : NP - 1;  // pixels of a partial last k-step: their dz rows are zero, any in-range address does
-            const int row = pc / W, col = pc - row * W;
+            const int gi = pc / BP, pb = pc - gi * BP;
+            const int row = pb / W, col = pb - row * W;
             // tap row dy = wdy - 1 is folded in here; the three dx taps are +-RA around it
-            aa[ks][tt] = lds0 + ZROWS * RDZ + ((row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2;
+            aa[ks][tt] = lds0 + ZROWS * RDZ + (gi * BS + (row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2;
         }
     // zero rows [NP, ZROWS) of the dz tile once (never staged)
     for (int q = tid; q < (ZROWS - NP) * (RDZ / 16); q += NTHR)
@@ -154,19 +170,22 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
     const int rows_per_img = g.H / RC;  // chunks per image
     uint4 zq[NZ], aq[NA];
     auto load_chunk = [&](int ch) {
-        const int b = ch / rows_per_img, y0 = (ch - b * rows_per_img) * RC;
+        // G == 1: rows [y0, y0 + R) of image b;  G > 1: whole images [b, b + G), the last chunk possibly fewer (gcount)
+        const int b = g.G > 1 ? ch * g.G : ch / rows_per_img;
+        const int y0 = g.G > 1 ? 0 : (ch - b * rows_per_img) * RC;
+        const int gcount = g.G > 1 ? (g.B - b < g.G ? g.B - b : g.G) : 1;
         const size_t p0 = ((size_t)b * g.H + y0) * W;
         const uint16_t* zb = g.dz + p0 * sdz;
         const uint16_t* ab = g.a + (ptrdiff_t)p0 * sa;
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             zq[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (zsrc[i] >= 0) zq[i] = *reinterpret_cast<const uint4*>(zb + zsrc[i]);
+            if (zsrc[i] >= 0 && zblk[i] < gcount) zq[i] = *reinterpret_cast<const uint4*>(zb + zsrc[i]);
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             aq[i] = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)(y0 + arow[i]) < (unsigned)g.H) aq[i] = *reinterpret_cast<const uint4*>(ab + asrc[i]);
+            if ((unsigned)(y0 + arow[i]) < (unsigned)g.H && ablk[i] < gcount) aq[i] = *reinterpret_cast<const uint4*>(ab + asrc[i]);
         }
     };
     auto store_chunk = [&]() {

@@ -201,6 +201,93 @@ __global__ __launch_bounds__(256) void nastar_maxpool2x2_bwd_kernel(const uint16
     }
 }
 
+// ---- U-Net decoder plumbing under autograd (reference encoder.py:37-57: nearest x2 upsampling + skip concatenation) -------------------
+// forward: cat[b,y,x] = (x[b,y/2,x/2,:C1], skip[b,y,x,:C2]) materialised once for the weight gradient (the convolution itself gathers)
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_upcat_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ skip,
+                                                           uint16_t* __restrict__ out, int B, int H, int W, int C1, int C2)
+{
+    const int C = C1 + C2, CG = C >> 3, h = H >> 1, w = W >> 1;
+    const int so = kSplit ? 2 * C : C, sx = kSplit ? 2 * C1 : C1, ss = kSplit ? 2 * C2 : C2;
+    const long long total = (long long)B * H * W * CG * (kSplit ? 2 : 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % CG);
+        long long t = i / CG;
+        const int half = kSplit ? (int)(t & 1) : 0;
+        if (kSplit) t >>= 1;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int b = (int)(t / H);
+        const size_t po = ((size_t)b * H + yy) * W + xx;
+        uint4 v;
+        if (c8 * 8 < C1) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * h + (yy >> 1)) * w + (xx >> 1)) * sx + half * C1 + c8 * 8);
+        else v = *reinterpret_cast<const uint4*>(skip + po * ss + half * C2 + (c8 * 8 - C1));
+        *reinterpret_cast<uint4*>(out + po * so + half * C + c8 * 8) = v;
+    }
+}
+
+// backward: d_x[b,y,x,:] = sum over the 2x2 block of d_cat[..., :C1] (nearest-upsampling backward), d_skip = d_cat[..., C1:]
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_upcat_bwd_kernel(const uint16_t* __restrict__ dcat, uint16_t* __restrict__ dx,
+                                                               uint16_t* __restrict__ dskip, int B, int H, int W, int C1, int C2)
+{
+    const int C = C1 + C2, h = H >> 1, w = W >> 1;
+    const int so = kSplit ? 2 * C : C, sx = kSplit ? 2 * C1 : C1, ss = kSplit ? 2 * C2 : C2;
+    const int G1 = C1 >> 3, G2 = C2 >> 3;
+    const long long n1 = (long long)B * h * w * G1, n2 = (long long)B * H * W * G2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int c8 = (int)(i % G1);
+            long long t = i / G1;
+            const int xo = (int)(t % w); t /= w;
+            const int yo = (int)(t % h);
+            const int b = (int)(t / h);
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
+                load8<kSplit>(dcat, ((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1), so, C, c8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+            store8<kSplit>(dx, ((size_t)b * h + yo) * w + xo, sx, C1, c8, acc);
+        } else {
+            const long long j = i - n1;
+            const int c8 = (int)(j % G2);
+            const size_t p = (size_t)(j / G2);
+            *reinterpret_cast<uint4*>(dskip + p * ss + c8 * 8) = *reinterpret_cast<const uint4*>(dcat + p * so + C1 + c8 * 8);
+            if constexpr (kSplit)
+                *reinterpret_cast<uint4*>(dskip + p * ss + C2 + c8 * 8) = *reinterpret_cast<const uint4*>(dcat + p * so + C + C1 + c8 * 8);
+        }
+    }
+}
+
+// two gradients of the same tensor that travelled with different power-of-two scales: out = a * (So/Sa) + b * (So/Sb), So = min(Sa, Sb)
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_grad_add_kernel(const uint16_t* __restrict__ a, const float* __restrict__ sa_dev,
+                                                              const uint16_t* __restrict__ b, const float* __restrict__ sb_dev,
+                                                              uint16_t* __restrict__ out, float* __restrict__ so_dev, long long npix, int C)
+{
+    const float Sa = sa_dev[0], Sb = sb_dev[0];
+    const float So = fminf(Sa, Sb);
+    const float fa = So / Sa, fb = So / Sb;
+    const int stride = kSplit ? 2 * C : C, CG = C >> 3;
+    const long long total = npix * CG;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % CG);
+        const size_t p = (size_t)(i / CG);
+        float x[8], y[8];
+        load8<kSplit>(a, p, stride, C, c8, x);
+        load8<kSplit>(b, p, stride, C, c8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = x[e] * fa + y[e] * fb;
+        store8<kSplit>(out, p, stride, C, c8, x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) so_dev[0] = So;
+}
+
 __global__ void nastar_absmax_kernel(const float* __restrict__ d, long long n, unsigned int* __restrict__ amax_bits);
 
 // ---- small host-replacing kernels: everything a training step needs between the big launches runs on the device, in ONE launch each,

@@ -25,7 +25,7 @@ static int launch_wgrad(WgradArgs g, hipStream_t s)
     void (*kern)(const WgradArgs) = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit, false>;
     if (g.W > 64) kern = &nastar_conv3x3_wgrad_kernel<COB, CIB, kSplit, true>;
     constexpr int M = kSplit ? 2 : 1;
-    const size_t lds = (size_t)g.KS * 16 * wg_row_bytes(COB * 64 * M) + (size_t)(g.R + 2) * (g.W + 2) * wg_row_bytes(CIB * 64 * M);
+    const size_t lds = (size_t)g.KS * 16 * wg_row_bytes(COB * 64 * M) + (size_t)g.G * (g.R + 2) * (g.W + 2) * wg_row_bytes(CIB * 64 * M);
     if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
@@ -47,7 +47,8 @@ size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci)
     if (B <= 0 || H <= 0 || W <= 0 || co <= 0 || ci <= 0 || co % 32 || ci % 32) return 0;
     const int R = nastar_wgrad_chunk_rows(H, W);
     if (R == 0) return 0;
-    const int nchunk = (int)(((long long)B * H) / R);
+    const int G = nastar_wgrad_chunk_images(H, W);
+    const int nchunk = G > 1 ? (B + G - 1) / G : (int)(((long long)B * H) / R);
     return (size_t)wgrad_nsplit(nchunk, co, ci) * 9 * ci * co * sizeof(float);
 }
 
@@ -64,8 +65,9 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     WgradArgs g;
     g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.W = W; g.CO = co; g.CI = ci;
-    g.R = R; g.NP = R * W; g.KS = (g.NP + 15) / 16;
-    g.nchunk = (int)(((long long)B * H) / R);
+    g.G = nastar_wgrad_chunk_images(H, W);
+    g.R = R; g.NP = g.G * R * W; g.KS = (g.NP + 15) / 16;
+    g.nchunk = g.G > 1 ? (B + g.G - 1) / g.G : (int)(((long long)B * H) / R);
     g.nsplit = wgrad_nsplit(g.nchunk, co, ci);
     const bool co2 = co % 64 == 0, ci2 = ci % 64 == 0;
     int rc;
@@ -207,6 +209,55 @@ int nastar_maxpool2x2_bwd_f16(const uint16_t* r, const uint16_t* dp, uint16_t* d
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (split) hipLaunchKernelGGL(nastar_maxpool2x2_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, r, dp, dr, B, H, W, C);
     else hipLaunchKernelGGL(nastar_maxpool2x2_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, r, dp, dr, B, H, W, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+static unsigned stream_grid(long long total)
+{
+    const long long g = (total + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+int nastar_upcat_f16(const uint16_t* x, const uint16_t* skip, uint16_t* out, int B, int H, int W, int c1, int c2, int split, void* stream)
+{
+    if (!x || !out || (c2 > 0 && !skip)) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || c1 <= 0 || c2 < 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((H | W) & 1 || c1 % 8 || c2 % 8) return NASTAR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * H * W * ((c1 + c2) / 8) * (split ? 2 : 1);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (split) hipLaunchKernelGGL(nastar_upcat_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, s, x, skip, out, B, H, W, c1, c2);
+    else hipLaunchKernelGGL(nastar_upcat_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, s, x, skip, out, B, H, W, c1, c2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_upcat_bwd_f16(const uint16_t* dcat, uint16_t* dx, uint16_t* dskip, int B, int H, int W, int c1, int c2, int split, void* stream)
+{
+    if (!dcat || !dx || (c2 > 0 && !dskip)) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || c1 <= 0 || c2 < 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((H | W) & 1 || c1 % 8 || c2 % 8) return NASTAR_ERR_UNSUPPORTED;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (c1 / 8) + (long long)B * H * W * (c2 / 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (split) hipLaunchKernelGGL(nastar_upcat_bwd_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, s, dcat, dx, dskip, B, H, W, c1, c2);
+    else hipLaunchKernelGGL(nastar_upcat_bwd_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, s, dcat, dx, dskip, B, H, W, c1, c2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_grad_add_f16(const uint16_t* a, const float* scale_a, const uint16_t* b, const float* scale_b, uint16_t* out, float* scale_out,
+                        long long npix, int C, int split, void* stream)
+{
+    if (!a || !b || !out || !scale_a || !scale_b || !scale_out) return NASTAR_ERR_NULL;
+    if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8) return NASTAR_ERR_UNSUPPORTED;
+    const long long total = npix * (C / 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (split) hipLaunchKernelGGL(nastar_grad_add_kernel<true>, dim3(stream_grid(total)), dim3(256), 0, s, a, scale_a, b, scale_b, out, scale_out, npix, C);
+    else hipLaunchKernelGGL(nastar_grad_add_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, s, a, scale_a, b, scale_b, out, scale_out, npix, C);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;

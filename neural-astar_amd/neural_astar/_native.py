@@ -71,6 +71,9 @@ EXPORTED_SYMBOLS = (
     "nastar_bn_coef_bwd",
     "nastar_grad_seed_f16",
     "nastar_maxpool2x2_bwd_f16",
+    "nastar_upcat_f16",
+    "nastar_upcat_bwd_f16",
+    "nastar_grad_add_f16",
 )
 
 
@@ -169,6 +172,12 @@ def load() -> ctypes.CDLL:
     lib.nastar_bn_coef_fwd.argtypes = [vp, vp, vp, cd, ctypes.c_longlong, cd, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_bwd.restype = ci
     lib.nastar_bn_coef_bwd.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_upcat_f16.restype = ci
+    lib.nastar_upcat_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.nastar_upcat_bwd_f16.restype = ci
+    lib.nastar_upcat_bwd_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.nastar_grad_add_f16.restype = ci
+    lib.nastar_grad_add_f16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
     lib.nastar_maxpool2x2_bwd_f16.restype = ci
     lib.nastar_maxpool2x2_bwd_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     lib.nastar_grad_seed_f16.restype = ci

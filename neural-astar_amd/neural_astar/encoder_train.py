@@ -83,11 +83,14 @@ class _Lib:
         _native.check(rc, "nastar_pack_conv_weight_f16")
         return wpack, scale, shift, scal
 
-    def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None):
-        rc = self.lib.nastar_conv3x3_f16(src.data_ptr(), None, wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                         out.data_ptr() if out is not None else None,
-                                         out_f32.data_ptr() if out_f32 is not None else None, B, H, W, cin, 0, cout, flags, 1.0, self.stream)
+    def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None, src2=None, c2=0):
+        rc = self.lib.nastar_conv3x3_f16(src.data_ptr(), src2.data_ptr() if src2 is not None else None, wpack.data_ptr(),
+                                         scale.data_ptr(), shift.data_ptr(), out.data_ptr() if out is not None else None,
+                                         out_f32.data_ptr() if out_f32 is not None else None, B, H, W, cin, c2, cout, flags, 1.0, self.stream)
         _native.check(rc, "nastar_conv3x3_f16")
+
+    def i16(self, n):
+        return torch.empty((n,), dtype=torch.int16, device=self.dev)
 
     def stats(self, u, v, ms, mt, npix, C, split, amax=None):
         sums = torch.empty((C, 2), dtype=torch.float64, device=self.dev)
@@ -355,3 +358,221 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
             bnl.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
             bnl.num_batches_tracked += 1
     return torch.sigmoid(y) * cnn.const
+
+
+# ---- U-Net (vgg16_bn) training: the same kernels over the launch plan of encoder_hip.unet_layer_plan ------------------------------------
+class _UnetTrunk(torch.autograd.Function):
+    """(assembled input x0, parameters in plan order) -> raw head output [B,1,H,W] fp32 of a ``planner.encoder.VggUnet`` in training mode.
+    ``cfg``: dict(split, shape, plan) where plan = list of dict steps (kind conv / pool, names, channel counts, flags, div, parameter
+    slots).  Gradients of tensors with several consumers (skip features) are summed with ``nastar_grad_add_f16``: every gradient tensor
+    carries its own power-of-two scale."""
+
+    @staticmethod
+    def forward(ctx, cfg, x0, *params):
+        from .encoder_hip import CONV_UPSAMPLE
+        split = cfg["split"]
+        B, H, W = cfg["shape"]
+        dev = x0.device
+        L = _Lib(dev)
+        mult = 2 if split else 1
+        sflag = CONV_SPLIT if split else 0
+        acts = {"x0": (x0, 32)}
+        saved = []
+        out = None
+        with torch.cuda.device(dev):
+            for st in cfg["plan"]:
+                h, w = H // st["div"], W // st["div"]
+                if st["kind"] == "pool":
+                    src, C = acts[st["src"]]
+                    hi, wi = H // st["div_in"], W // st["div_in"]
+                    a = L.i16(B * (hi // 2) * (wi // 2) * C * mult)
+                    _native.check(L.lib.nastar_maxpool2x2_f16(src.data_ptr(), a.data_ptr(), B, hi, wi, C, int(split), L.stream), "nastar_maxpool2x2_f16")
+                    acts[st["dst"]] = (a, C)
+                    saved.append(None)
+                    if cfg.get("debug") is not None:  # dev / test probe: what this pool saw (its arg-max decisions)
+                        cfg["debug"]["fwd:" + st["dst"]] = (src, (B, hi, wi, C))
+                    continue
+                wt = params[st["w"]]
+                bias = params[st["b"]] if st["b"] is not None else None
+                src, c1 = acts[st["src"]]
+                src2, c2 = acts[st["skip"]] if st["skip"] is not None else (None, 0)
+                ups = CONV_UPSAMPLE if st["ups"] else 0
+                npix = B * h * w
+                wpack, scale, shift, scal = L.pack(wt, False, split, bias)
+                if st["final"]:
+                    out = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+                    L.conv(src, wpack, scale, shift, B, h, w, c1, 32, sflag | CONV_FINAL | CONV_RAW, out_f32=out)
+                    saved.append({"scal": scal})
+                    continue
+                cout = wt.shape[0]
+                z = L.i16(npix * cout * mult)
+                L.conv(src, wpack, scale, shift, B, h, w, c1, cout, sflag | ups, out=z, src2=src2, c2=c2)
+                sums = L.stats(None, z, None, None, npix, cout, split)
+                k2, k3 = L.f32(cout), L.f32(cout)
+                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
+                bn = st["bn"]
+                track = bn.track_running_stats and bn.running_mean is not None
+                mom = 0.0
+                if track:
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+                    bn.num_batches_tracked += 1
+                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
+                                              float(bn.eps), npix, float(mom), bn.running_mean.data_ptr() if track else None,
+                                              bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
+                _native.check(rc, "nastar_bn_coef_fwd")
+                a = L.i16(npix * cout * mult)
+                L.affine(None, z, None, k2, k3, None, None, a, npix, cout, True, split)
+                acts[st["dst"]] = (a, cout)
+                saved.append({"z": z, "coef": (mean, invstd, k2, k3), "scal": scal})
+                if cfg.get("debug") is not None:  # ... and the ReLU mask of this block: [k2 z + k3 > 0]
+                    cfg["debug"]["fwd:" + st["dst"]] = (z, k2, k3, (B, h, w, cout))
+        ctx.cfg, ctx.acts, ctx.saved = cfg, acts, saved
+        ctx.save_for_backward(*params)
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, dz):
+        cfg = ctx.cfg
+        split = cfg["split"]
+        B, H, W = cfg["shape"]
+        params = ctx.saved_tensors
+        acts, saved = ctx.acts, ctx.saved
+        dev = dz.device
+        L = _Lib(dev)
+        mult = 2 if split else 1
+        sflag = CONV_SPLIT if split else 0
+        grads_p: List[Optional[torch.Tensor]] = [None] * len(params)
+        grads = {}  # activation name -> (gradient buffer, device scale)
+
+        def accumulate(name, buf, S, npix, C):
+            if name not in grads:
+                grads[name] = (buf, S)
+                return
+            b0, S0 = grads[name]
+            out, So = torch.empty_like(buf), L.f32(1)
+            rc = L.lib.nastar_grad_add_f16(b0.data_ptr(), S0.data_ptr(), buf.data_ptr(), S.data_ptr(), out.data_ptr(), So.data_ptr(), npix, C,
+                                           int(split), L.stream)
+            _native.check(rc, "nastar_grad_add_f16")
+            grads[name] = (out, So)
+
+        with torch.cuda.device(dev):
+            amax = L.f32(1)
+            for idx in range(len(cfg["plan"]) - 1, -1, -1):
+                st, sv = cfg["plan"][idx], saved[idx]
+                h, w = H // st["div"], W // st["div"]
+                npix = B * h * w
+                if st["kind"] == "pool":
+                    g, S = grads.pop(st["dst"])
+                    src, C = acts[st["src"]]
+                    hi, wi = H // st["div_in"], W // st["div_in"]
+                    dr = L.i16(B * hi * wi * C * mult)
+                    _native.check(L.lib.nastar_maxpool2x2_bwd_f16(src.data_ptr(), g.data_ptr(), dr.data_ptr(), B, hi, wi, C, int(split), L.stream),
+                                  "nastar_maxpool2x2_bwd_f16")
+                    accumulate(st["src"], dr, S, B * hi * wi, C)
+                    continue
+                wt = params[st["w"]]
+                cout, cin = wt.shape[:2]
+                src, c1 = acts[st["src"]]
+                src2, c2 = acts[st["skip"]] if st["skip"] is not None else (None, 0)
+                if st["final"]:
+                    d = dz.reshape(npix)
+                    d = d if d.is_contiguous() and d.dtype == torch.float32 else d.float().contiguous()
+                    S = L.f32(1)
+                    dzb = L.i16(npix * 32 * mult)
+                    _native.check(L.lib.nastar_grad_seed_f16(d.data_ptr(), npix, int(split), dzb.data_ptr(), S.data_ptr(), amax.data_ptr(), L.stream),
+                                  "nastar_grad_seed_f16")
+                    cur_co = 32
+                    if st["b"] is not None:
+                        grads_p[st["b"]] = d.sum().reshape(1)  # no BatchNorm behind the head: its bias has a real gradient
+                else:
+                    g, S_in = grads.pop(st["dst"])
+                    if cfg.get("debug") is not None:  # dev probe: the gradient w.r.t. this block's output, as it arrives
+                        cfg["debug"][st["dst"]] = (g.clone(), S_in.clone(), (B, h, w, cout))
+                    S = S_in.clone()  # the BatchNorm backward re-centres the scale in place
+                    z = sv["z"]
+                    mean, invstd, k2f, k3f = sv["coef"]
+                    sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
+                    dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
+                    rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                  params[st["g"]].detach().data_ptr(), npix, S.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                  c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout, L.stream)
+                    _native.check(rc, "nastar_bn_coef_bwd")
+                    grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta
+                    if cfg.get("debug") is not None:
+                        cfg["debug"][st["dst"] + ":bn"] = (z, k2f, k3f, dbeta.clone(), dgamma.clone(), sums.clone(), S_in.clone())
+                    dzb = L.i16(npix * cout * mult)
+                    L.affine(g, z, c1v, c2v, c3v, k2f, k3f, dzb, npix, cout, False, split)
+                    cur_co = cout
+                    if st["b"] is not None:
+                        grads_p[st["b"]] = torch.zeros_like(params[st["b"]])  # conv bias in front of a BatchNorm: exactly 0
+                # the convolution's input as ONE tensor (the decoder's upsample + concat is materialised for the weight gradient)
+                cin_p = c1 + c2
+                if st["ups"]:
+                    a_in = L.i16(npix * cin_p * mult)
+                    _native.check(L.lib.nastar_upcat_f16(src.data_ptr(), src2.data_ptr() if src2 is not None else None, a_in.data_ptr(), B, h, w,
+                                                         c1, c2, int(split), L.stream), "nastar_upcat_f16")
+                else:
+                    a_in = src
+                grads_p[st["w"]] = L.wgrad(dzb, a_in, B, h, w, cur_co, cin_p, cout, cin, split, S)
+                if st["src"] == "x0":
+                    continue
+                wpack, scale, shift, _ = L.pack(wt, True, split, scal=sv["scal"])
+                da = L.i16(npix * cin_p * mult)
+                L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
+                if st["ups"]:
+                    dx = L.i16(B * (h // 2) * (w // 2) * c1 * mult)
+                    dsk = L.i16(npix * c2 * mult) if c2 else None
+                    _native.check(L.lib.nastar_upcat_bwd_f16(da.data_ptr(), dx.data_ptr(), dsk.data_ptr() if dsk is not None else None, B, h, w,
+                                                             c1, c2, int(split), L.stream), "nastar_upcat_bwd_f16")
+                    accumulate(st["src"], dx, S, B * (h // 2) * (w // 2), c1)
+                    if c2:
+                        accumulate(st["skip"], dsk, S, npix, c2)
+                else:
+                    accumulate(st["src"], da, S, npix, cin_p)
+        return (None, None) + tuple(grads_p)
+
+
+def unet_supported(unet: nn.Module, H: int, W: int) -> bool:
+    from .planner.encoder import VggUnet
+    model = getattr(unet, "model", None)
+    if not isinstance(model, VggUnet):
+        return False
+    depth = model.depth
+    if H % (1 << depth) or W % (1 << depth) or W > 126:
+        return False
+    return all(chunk_rows(H >> l, W >> l) > 0 and (W >> l) >= 2 for l in range(depth + 1))
+
+
+def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
+                       precision: str = "f16x3") -> torch.Tensor:
+    """``unet(cat(map, start + goal))`` for this package's ``VggUnet`` definition of the reference's Unet(vgg16_bn) (encoder.py:37-57)
+    in TRAINING mode, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
+    from .encoder_hip import CONV_FINAL as _F, CONV_UPSAMPLE as _U, unet_layer_plan
+    B, _, H, W = map_designs.shape
+    if not unet_supported(unet, H, W):
+        raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (W <= 126)")
+    params, plan = [], []
+
+    def slot(t):
+        if t is None:
+            return None
+        params.append(t)
+        return len(params) - 1
+    for st in unet_layer_plan(unet.model):
+        if st[0] == "pool":
+            plan.append({"kind": "pool", "dst": st[1], "src": st[2], "div_in": st[4], "div": st[4] * 2})
+            continue
+        _, dst, src, skip, conv, bn, flags, div = st
+        plan.append({"kind": "conv", "dst": dst, "src": src, "skip": skip, "div": div, "ups": bool(flags & _U), "final": bool(flags & _F),
+                     "bn": bn, "w": slot(conv.weight), "b": slot(conv.bias), "g": slot(bn.weight if bn is not None else None),
+                     "be": slot(bn.bias if bn is not None else None)})
+    if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+        raise NotImplementedError("fp32 contiguous parameters expected")
+    split = precision == "f16x3"
+    cfg = {"split": split, "shape": (B, H, W), "plan": plan, "debug": getattr(unet, "_nastar_debug", None)}
+    with torch.cuda.device(map_designs.device):
+        x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
+    z = _UnetTrunk.apply(cfg, x0, *params)
+    return torch.sigmoid(z) * unet.const

@@ -113,6 +113,13 @@ class NeuralAstar(VanillaAstar):
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
+                and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
+                and map_designs.shape[-2:] == start_maps.shape[-2:]):
+            from ..encoder_train import unet_supported, unet_train_forward
+            if unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1]):
+                return unet_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
+                                          "f16" if self.encoder_backend == "hip_f16" else "f16x3")
+        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.CNN)):
             # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
             # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade).

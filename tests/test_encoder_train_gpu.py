@@ -50,6 +50,8 @@ WG_CASES = [
     (7, 24, 24, 128, 64, True),    # four rows per chunk
     (9, 12, 12, 32, 128, True),    # six rows = 72 pixels: a partial fifth k-step
     (4, 20, 45, 64, 64, True),     # 2 x 45 = 90 pixels
+    (37, 4, 4, 64, 128, True),     # tiny images (U-Net 4x4 level): five per chunk, the last chunk partial
+    (50, 2, 2, 128, 64, False),    # twelve 2x2 images per chunk
 ]
 
 
@@ -332,3 +334,171 @@ def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H
     for (name, b), (_, c) in zip(na.encoder.named_buffers(), ref.encoder.named_buffers()):
         if b.dtype.is_floating_point:
             assert _rel(b, c) <= 1e-5, name
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_unet_decoder_plumbing_kernels(split):
+    """nastar_upcat_f16 / nastar_upcat_bwd_f16 (nearest x2 upsampling + skip concatenation and its backward) and nastar_grad_add_f16
+    (two gradients with different power-of-two scales) against torch"""
+    from neural_astar import _native
+    lib = _native.load()
+    dev = _dev()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(21)
+    B, H, W, C1, C2 = 3, 8, 12, 64, 32
+    x = torch.randn((B, C1, H // 2, W // 2), generator=g)
+    sk = torch.randn((B, C2, H, W), generator=g)
+    x_, sk_ = _nhwc(x, split).to(dev), _nhwc(sk, split).to(dev)
+    M = 2 if split else 1
+    cat = torch.empty((B, H, W, (C1 + C2) * M), dtype=torch.float16, device=dev)
+    _native.check(lib.nastar_upcat_f16(x_.data_ptr(), sk_.data_ptr(), cat.data_ptr(), B, H, W, C1, C2, int(split), st), "upcat")
+    ref = torch.cat((nn.functional.interpolate(_seen(x, split), scale_factor=2, mode="nearest"), _seen(sk, split)), dim=1)
+    o = cat.float().cpu()
+    C = C1 + C2
+    got = (o[..., :C] + (o[..., C:] if split else 0)).permute(0, 3, 1, 2)
+    assert torch.equal(got, ref)
+    # backward
+    d = torch.randn((B, C, H, W), generator=g)
+    d_ = _nhwc(d, split).to(dev)
+    dx = torch.empty((B, H // 2, W // 2, C1 * M), dtype=torch.float16, device=dev)
+    dsk = torch.empty((B, H, W, C2 * M), dtype=torch.float16, device=dev)
+    _native.check(lib.nastar_upcat_bwd_f16(d_.data_ptr(), dx.data_ptr(), dsk.data_ptr(), B, H, W, C1, C2, int(split), st), "upcat bwd")
+    ds = _seen(d, split)
+    ox, os_ = dx.float().cpu(), dsk.float().cpu()
+    gx = (ox[..., :C1] + (ox[..., C1:] if split else 0)).permute(0, 3, 1, 2)
+    gs = (os_[..., :C2] + (os_[..., C2:] if split else 0)).permute(0, 3, 1, 2)
+    assert torch.equal(gs, ds[:, C1:])
+    refx = nn.functional.avg_pool2d(ds[:, :C1].double(), 2) * 4
+    assert float((gx.double() - refx).abs().max()) <= (2e-6 if split else 4e-3) * float(refx.abs().max())
+    # scaled accumulate
+    a = torch.randn((B, C2, H, W), generator=g) * 300
+    b = torch.randn((B, C2, H, W), generator=g) * 20
+    a_, b_ = _nhwc(a, split).to(dev), _nhwc(b, split).to(dev)
+    Sa, Sb, So = torch.tensor([1024.0], device=dev), torch.tensor([64.0], device=dev), torch.zeros(1, device=dev)
+    out = torch.empty_like(a_)
+    _native.check(lib.nastar_grad_add_f16(a_.data_ptr(), Sa.data_ptr(), b_.data_ptr(), Sb.data_ptr(), out.data_ptr(), So.data_ptr(), B * H * W, C2,
+                                          int(split), st), "grad add")
+    assert float(So) == 64.0
+    oo = out.float().cpu()
+    got = (oo[..., :C2] + (oo[..., C2:] if split else 0)).permute(0, 3, 1, 2)
+    ref = _seen(a, split).double() / 16 + _seen(b, split).double()
+    assert float((got.double() - ref).abs().max()) <= (2e-6 if split else 2e-3) * float(ref.abs().max())
+
+
+class _ForcedReLU(nn.Module):
+    """ReLU with a prescribed mask: the float64 reference takes the HIP path's discrete decisions, so that the comparison sees only
+    arithmetic (a ReLU mask or pooling arg-max decided the other way moves a whole gradient element: not a rounding error)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask
+
+
+class _ForcedPool(nn.MaxPool2d):  # still an nn.MaxPool2d: VggUnet splits its stages at the pools
+    def __init__(self, onehot):
+        super().__init__(kernel_size=2, stride=2)
+        self.onehot = onehot  # [B,C,H/2,W/2,4] one-hot of the window element the HIP path took
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        win = x.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+        return (win * self.onehot).sum(-1)
+
+
+def _unsplit(buf, shape):
+    B, h, w, C = shape
+    o = buf.view(torch.float16).float().reshape(B, h, w, 2 * C).cpu().double()
+    return (o[..., :C] + o[..., C:]).permute(0, 3, 1, 2)
+
+
+def test_unet_trains_on_the_hip_kernels():
+    """Unet(vgg16_bn) (this package's VggUnet definition; reference encoder.py:37-57) in training mode: 23 conv + batch-statistics BatchNorm +
+    ReLU blocks, four max-pools, four upsample + concat decoder blocks and the head -- forward and every parameter gradient on the MI355X
+    kernels against the torch module in float64.
+
+    A 26-layer network takes ~2.5 million discrete decisions per batch here (ReLU masks, pooling arg-maxes); fp32-grade arithmetic leaves
+    ~1e-5 on the normalised pre-activations, so a handful of them legitimately fall the other way than in float64, and each moves a whole
+    gradient element (1/55 of a BatchNorm-bias gradient summed over 3072 pixels).  The parity statement is therefore made twice:
+    (1) against the plain float64 module: cost map within 2e-5, every gradient within 3e-2;
+    (2) against the float64 module FORCED to the HIP path's own decisions (same masks, same arg-maxes): every gradient within 2e-4."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    from neural_astar import encoder_hip as E
+    import test_unet_gpu as TU
+    dev = _dev()
+    B = 3
+    pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=4)
+    m, s, g = (torch.from_numpy(x) for x in pr)
+    base = NeuralAstar(encoder_arch="Unet", encoder_depth=4)
+    base.encoder = TU._calibrated_unet(seed=3)
+    for mod in base.encoder.modules():
+        if isinstance(mod, nn.ReLU):
+            mod.inplace = False
+    na = copy.deepcopy(base).to(dev).train()
+    R = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(9)) / (B * 1024)
+    dbg = {}
+    na.encoder._nastar_debug = dbg
+    na.encoder_backend = "hip_f16x3"
+    cost = na.encode(m.to(dev), s.to(dev), g.to(dev))
+    assert cost.grad_fn is not None
+    (cost * R.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+
+    def compare(ref):
+        cost_ref = ref.encode(m.double(), s.double(), g.double())
+        (cost_ref * R.double()).sum().backward()
+        err_cost = float((cost.detach().cpu().double() - cost_ref.detach()).abs().max())
+        worst = {}
+        for (name, p), (_, q) in zip(na.encoder.named_parameters(), ref.encoder.named_parameters()):
+            assert p.grad is not None, name
+            if name.endswith("bias") and float(p.grad.abs().max()) == 0 and float(q.grad.abs().max()) <= 1e-9 * float(R.abs().max()):
+                continue  # conv biases in front of a BatchNorm
+            worst[name] = _rel(p.grad, q.grad)
+        return err_cost, worst
+
+    # (1) the plain float64 module
+    ref = copy.deepcopy(base).double().train()
+    err_cost, worst = compare(ref)
+    print("GRADERR unet plain", "cost", err_cost, "n", len(worst), "max", max(worst.values()))
+    assert err_cost <= 2e-5 and len(worst) >= 24 + 2 * 23 and max(worst.values()) <= 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    for (name, b), (_, c) in zip(na.encoder.named_buffers(), ref.encoder.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert _rel(b, c) <= 2e-5, name
+        else:
+            assert int(b) == int(c), name
+    # (2) the float64 module with the HIP path's decisions forced onto its ReLUs and max-pools
+    forced = copy.deepcopy(base).double().train()
+    model = forced.encoder.model
+    plan = E.unet_layer_plan(model)
+    conv_name = {id(st[4]): st[1] for st in plan if st[0] == "conv"}
+    n_relu = 0
+    for seq in [mod for mod in model.modules() if isinstance(mod, nn.Sequential)]:
+        ch = list(seq)
+        for i, c in enumerate(ch):
+            if isinstance(c, nn.Conv2d) and id(c) in conv_name and "fwd:" + conv_name[id(c)] in dbg:
+                for j in range(i + 1, min(i + 3, len(ch))):
+                    if isinstance(ch[j], nn.ReLU):
+                        z, k2, k3, shape = dbg["fwd:" + conv_name[id(c)]]
+                        zz = _unsplit(z, shape)
+                        mask = (k2.cpu().float().view(1, -1, 1, 1) * zz.float() + k3.cpu().float().view(1, -1, 1, 1)) > 0  # the kernels' fp32 test
+                        seq[j] = _ForcedReLU(mask.double())
+                        n_relu += 1
+    feats = model.encoder.features
+    pools = [st for st in plan if st[0] == "pool"]
+    pi = 0
+    for i, mod in enumerate(feats):
+        if isinstance(mod, nn.MaxPool2d) and pi < len(pools):
+            src, shape = dbg["fwd:" + pools[pi][1]]
+            x = _unsplit(src, shape)
+            Bn, C, H, W = x.shape
+            win = x.reshape(Bn, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, C, H // 2, W // 2, 4)
+            feats[i] = _ForcedPool(nn.functional.one_hot(win.argmax(dim=-1), 4).double())  # argmax: first maximum, the kernel's rule
+            pi += 1
+    assert n_relu == 23 and pi == 4
+    err_cost2, worst2 = compare(forced)
+    w3 = sorted(worst2.items(), key=lambda kv: -kv[1])[:4]
+    print("GRADERR unet forced-decisions", "cost", err_cost2, "worst", " ".join(f"{k}={v:.1e}" for k, v in w3))
+    assert max(worst2.values()) <= 2e-4, w3

@@ -127,6 +127,8 @@ WG_CASES = [
     (2, 4, 16, 64, 32, True),     # split operands, two output blocks
     (1, 6, 12, 32, 64, True),     # 12-wide rows: 6 rows = 72 pixels, a partial fifth k-step
     (1, 4, 45, 32, 32, False),    # 2 x 45 = 90 pixels
+    (7, 4, 4, 32, 32, True),      # tiny images, five per chunk (the last chunk holds two)
+    (13, 2, 2, 32, 64, False),    # twelve 2x2 images per chunk + one
 ]
 
 

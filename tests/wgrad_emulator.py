@@ -21,6 +21,12 @@ def chunk_rows(H, W):
     return 0
 
 
+def chunk_images(H, W):
+    if H * W > 48 or chunk_rows(H, W) < H:
+        return 1
+    return max(1, min(WG_MAX_PIX // (H * W), 200 // ((H + 2) * (W + 2))))
+
+
 def row_bytes(r):
     return r + 64 if r % 128 == 0 else r
 
@@ -44,14 +50,16 @@ def run(dz, a, B, H, W, CO, CI, co_real, ci_real, split, nsplit=3, out_scale=1.0
     NTHR = 192 * COB * CIB
     R = chunk_rows(H, W)
     assert R > 0
-    NP, PW = R * W, W + 2
+    G = chunk_images(H, W)
+    NP, PW = G * R * W, W + 2
+    BP, BS = R * W, (R + 2) * (W + 2)
     KS = (NP + 15) // 16
     ZROWS = KS * 16
     RDZ, RA = row_bytes(COB * 64 * M), row_bytes(CIB * 64 * M)
     CPZ, CPA = M * COB * 4, M * CIB * 4
-    nslot_a = (R + 2) * PW
+    nslot_a = G * BS
     sdz, sa = M * CO, M * CI
-    nchunk = B * H // R
+    nchunk = (B + G - 1) // G if G > 1 else B * H // R
     nsplit = max(1, min(nsplit, nchunk))
     rows_per_img = H // R
     ntco, ntci = CO // (32 * COB), CI // (32 * CIB)
@@ -67,7 +75,11 @@ def run(dz, a, B, H, W, CO, CI, co_real, ci_real, split, nsplit=3, out_scale=1.0
         co0, ci0 = tco * 32 * COB, tci * 32 * CIB
         acc = np.zeros((3 * COB * CIB, 3, 32, 32), np.float64)  # [wave][dx][row = co][col = ci]
         for ch in range(split_id, nchunk, nsplit):
-            b, y0 = ch // rows_per_img, (ch % rows_per_img) * R
+            if G > 1:
+                b, y0 = ch * G, 0
+                gcount = min(G, B - b)
+            else:
+                b, y0, gcount = ch // rows_per_img, (ch % rows_per_img) * R, 1
             p0 = (b * H + y0) * W
             lds = np.full(lds_bytes // 2, 777.0, np.float16)
             lds[NP * RDZ // 2: ZROWS * RDZ // 2] = 0  # rows [NP, ZROWS) of the dz tile are zeroed once
@@ -76,15 +88,16 @@ def run(dz, a, B, H, W, CO, CI, co_real, ci_real, split, nsplit=3, out_scale=1.0
                 half, cc = c // (COB * 4), c % (COB * 4)
                 src = (p0 + pix) * sdz + half * CO + co0 + cc * 8
                 dst = (pix * RDZ + half * (COB * 64) + cc * 16) // 2
-                lds[dst:dst + 8] = dz[src:src + 8]
+                lds[dst:dst + 8] = dz[src:src + 8] if pix // BP < gcount else 0
             for q in range(nslot_a * CPA):            # framed activation rows
                 slot, c = q // CPA, q % CPA
                 half, cc = c // (CIB * 4), c % (CIB * 4)
-                sr, sc = slot // PW, slot % PW
+                gi, sb = slot // BS, slot % BS
+                sr, sc = sb // PW, sb % PW
                 dst = (ZROWS * RDZ + slot * RA + half * (CIB * 64) + cc * 16) // 2
                 y = y0 + sr - 1
-                if 1 <= sc <= W and 0 <= y < H:
-                    src = (p0 + (sr - 1) * W + (sc - 1)) * sa + half * CI + ci0 + cc * 8
+                if 1 <= sc <= W and 0 <= y < H and gi < gcount:
+                    src = (p0 + gi * BP + (sr - 1) * W + (sc - 1)) * sa + half * CI + ci0 + cc * 8
                     lds[dst:dst + 8] = a[src:src + 8]
                 else:
                     lds[dst:dst + 8] = 0
@@ -103,8 +116,9 @@ def run(dz, a, B, H, W, CO, CI, co_real, ci_real, split, nsplit=3, out_scale=1.0
                     for tt in range(2):
                         pix = 16 * ks + 8 * kh + 4 * tt + (r16 >> 2)
                         pc = np.minimum(pix, NP - 1)
-                        row, col = pc // W, pc % W
-                        aa.append(ZROWS * RDZ + ((row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2)
+                        gi, pb = pc // BP, pc % BP
+                        row, col = pb // W, pb % W
+                        aa.append(ZROWS * RDZ + (gi * BS + (row + 1 + (wdy - 1)) * PW + col + 1) * RA + wci * 64 + chan * 2)
                     for dx in range(3):
                         toff = (dx - 1) * RA
                         xh = frag(aa[0] + toff, aa[1] + toff)
