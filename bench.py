@@ -490,8 +490,29 @@ def encoder_train_step_ms(pr, dev):
         torch.cuda.synchronize(dev)
         out[f"warcraft_batch_100_{backend}_ms"] = (time.perf_counter() - t0) / 10 * 1e3
         del na
-    out["torch_fp32_ms_same_box"] = {"batch_100": 4.07, "batch_4096": 132.75, "warcraft_batch_100": 3.13,
-                                     "source": "profiles/r02/encoder_train_step_ms.json, encoder_train_step_warcraft_b100_ms.json"}
+    # Unet(vgg16_bn) (BASELINE config 3's encoder), 100 maps: ~330 launches per step, launch-bound at this batch
+    m, s, g = (torch.from_numpy(x[:100]).to(dev) for x in pr)
+    R = torch.randn((100, 1, H, W), device=dev) / (100 * H * W)
+    for backend in ("hip_f16x3", "hip_f16"):
+        torch.manual_seed(0)
+        na = NeuralAstar(encoder_arch="Unet", encoder_depth=4).to(dev).train()
+        na.encoder_backend = backend
+
+        def one_u():
+            for p in na.parameters():
+                p.grad = None
+            (na.encode(m, s, g) * R).sum().backward()
+        one_u()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            one_u()
+        torch.cuda.synchronize(dev)
+        out[f"unet_batch_100_{backend}_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        del na
+    out["torch_fp32_ms_same_box"] = {"batch_100": 4.07, "batch_4096": 132.75, "warcraft_batch_100": 3.13, "unet_batch_100": 6.65,
+                                     "source": "profiles/r02/encoder_train_step_ms.json, encoder_train_step_warcraft_b100_ms.json, "
+                                               "encoder_train_step_unet_b100_ms.json"}
     out["unit"] = "ms per encoder forward+backward (wall clock), random-init CNN depth 4, 32x32 maps"
     return out
 
