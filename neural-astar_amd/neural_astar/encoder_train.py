@@ -545,14 +545,11 @@ def unet_supported(unet: nn.Module, H: int, W: int) -> bool:
     return all(chunk_rows(H >> l, W >> l) > 0 and (W >> l) >= 2 for l in range(depth + 1))
 
 
-def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
-                       precision: str = "f16x3") -> torch.Tensor:
-    """``unet(cat(map, start + goal))`` for this package's ``VggUnet`` definition of the reference's Unet(vgg16_bn) (encoder.py:37-57)
-    in TRAINING mode, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
+def unet_training_plan(model: nn.Module):
+    """(plan, params): the launch plan of encoder_hip.unet_layer_plan as dict steps for ``_UnetTrunk`` -- kind, buffer names, resolution
+    divisors, flags, the BatchNorm module (running statistics) and the SLOTS of the step's parameters in the flat ``params`` list
+    (conv weight, conv bias or None, BatchNorm weight / bias or None for the head).  Pure host logic."""
     from .encoder_hip import CONV_FINAL as _F, CONV_UPSAMPLE as _U, unet_layer_plan
-    B, _, H, W = map_designs.shape
-    if not unet_supported(unet, H, W):
-        raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (W <= 126)")
     params, plan = [], []
 
     def slot(t):
@@ -560,7 +557,7 @@ def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: t
             return None
         params.append(t)
         return len(params) - 1
-    for st in unet_layer_plan(unet.model):
+    for st in unet_layer_plan(model):
         if st[0] == "pool":
             plan.append({"kind": "pool", "dst": st[1], "src": st[2], "div_in": st[4], "div": st[4] * 2})
             continue
@@ -568,6 +565,17 @@ def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: t
         plan.append({"kind": "conv", "dst": dst, "src": src, "skip": skip, "div": div, "ups": bool(flags & _U), "final": bool(flags & _F),
                      "bn": bn, "w": slot(conv.weight), "b": slot(conv.bias), "g": slot(bn.weight if bn is not None else None),
                      "be": slot(bn.bias if bn is not None else None)})
+    return plan, params
+
+
+def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
+                       precision: str = "f16x3") -> torch.Tensor:
+    """``unet(cat(map, start + goal))`` for this package's ``VggUnet`` definition of the reference's Unet(vgg16_bn) (encoder.py:37-57)
+    in TRAINING mode, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
+    B, _, H, W = map_designs.shape
+    if not unet_supported(unet, H, W):
+        raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (W <= 126)")
+    plan, params = unet_training_plan(unet.model)
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")
     split = precision == "f16x3"

@@ -314,3 +314,28 @@ def test_encoder_training_support_checks_are_host_logic():
     odd = CNN(2, 2, None)
     odd.model[0] = nn.Conv2d(2, 48, 3, padding=1)                   # 48 channels: not 32 * 2^k
     assert not ET.supported(odd, 32, 32)
+
+
+def test_unet_training_plan_is_consistent_host_logic():
+    """neural_astar/encoder_train.unet_training_plan: every parameter of the VggUnet gets exactly one slot, every buffer is produced before
+    it is consumed, gradients of multiply-consumed tensors (the skip features) are what _UnetTrunk accumulates"""
+    import torch
+    from neural_astar import encoder_train as ET
+    from neural_astar.planner.encoder import Unet
+    torch.manual_seed(0)
+    u = Unet(2, 4, None)
+    plan, params = ET.unet_training_plan(u.model)
+    assert len(params) == len(list(u.model.parameters())) and {id(p) for p in params} == {id(p) for p in u.model.parameters()}
+    convs = [s for s in plan if s["kind"] == "conv"]
+    assert len(convs) == 24 and sum(s["final"] for s in convs) == 1 and convs[-1]["final"] and convs[-1]["g"] is None
+    assert [s["b"] is None for s in convs].count(True) == 10         # the centre block + the 8 decoder-block convs have no bias
+    have, consumers = {"x0"}, {}
+    for s in plan:
+        assert s["src"] in have and (s.get("skip") is None or s["skip"] in have)
+        for n in (s["src"], s.get("skip")):
+            if n is not None:
+                consumers[n] = consumers.get(n, 0) + 1
+        have.add(s["dst"])
+    multi = sorted(n for n, c in consumers.items() if c > 1)
+    assert multi == ["e10", "e4", "e7"]                                # the three skip features: decoder block + next encoder stage
+    assert ET.unet_supported(u, 32, 32) and ET.unet_supported(u, 64, 96) and not ET.unet_supported(u, 16, 16) and not ET.unet_supported(u, 36, 32)
