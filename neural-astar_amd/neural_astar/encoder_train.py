@@ -188,6 +188,8 @@ class _CnnTrunk(torch.autograd.Function):
                 L.affine(None, z, None, k2, k3, None, None, r, npix, cout, True, split)
                 zs.append(z)
                 coef.append((mean, invstd, k2, k3))
+                if cfg.get("debug") is not None:  # test probe: this block's ReLU mask is [k2 z + k3 > 0], its pool sees r
+                    cfg["debug"][f"fwd:{l}"] = (z, k2, k3, r, (B, h, w, cout))
                 if pool:
                     a = torch.empty((B * (h // 2) * (w // 2) * cout * mult,), dtype=torch.int16, device=dev)
                     rc = L.lib.nastar_maxpool2x2_f16(r.data_ptr(), a.data_ptr(), B, h, w, cout, int(split), L.stream)
@@ -341,7 +343,8 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")
     split = precision == "f16x3"
-    cfg = {"split": split, "depth": D, "pool": pool, "shape": (B, H, W), "eps": [bn.eps for bn in bns[:D]], "bns": bns[:D]}
+    cfg = {"split": split, "depth": D, "pool": pool, "shape": (B, H, W), "eps": [bn.eps for bn in bns[:D]], "bns": bns[:D],
+           "debug": getattr(cnn, "_nastar_debug", None)}
     with torch.cuda.device(map_designs.device):
         x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
     zl = _CnnTrunk.apply(cfg, x0, *params[:4 * D + 2])

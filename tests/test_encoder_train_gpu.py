@@ -314,6 +314,8 @@ def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H
         hk.remove()
     (cost_ref * R.double()).sum().backward()
     na.encoder_backend = "hip_f16x3"
+    dbg = {}
+    na.encoder._nastar_debug = dbg
     cost = na.encode(img.to(dev), s.to(dev), gl.to(dev))
     assert cost.grad_fn is not None
     (cost * R.to(dev)).sum().backward()
@@ -331,6 +333,29 @@ def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H
     assert len(worst) >= 2 * depth + 2 and max(worst.values()) <= (1e-4 if clear else 3e-2), (margins, worst)
     if seed == 1000:
         assert clear, margins  # this seed was chosen for its clear decisions: the strict bound must have been the one applied
+    if not clear or max(worst.values()) > 1e-4:
+        # the same function under the HIP path's own discrete decisions (ReLU masks, pooling arg-maxes), differentiated in float64: 1e-4
+        forced = copy.deepcopy(ref)
+        for p_ in forced.parameters():
+            p_.grad = None
+        mods = list(forced.encoder.model)
+        blk = 0
+        for i, mod in enumerate(mods):
+            if isinstance(mod, nn.ReLU):
+                z, k2, k3, r, shape = dbg[f"fwd:{blk}"]
+                mask = (k2.cpu().float().view(1, -1, 1, 1) * _unsplit(z, shape).float() + k3.cpu().float().view(1, -1, 1, 1)) > 0
+                forced.encoder.model[i] = _ForcedReLU(mask.double())
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.MaxPool2d):
+                    x = _unsplit(r, shape)
+                    Bn, Cn, Hn, Wn = x.shape
+                    win = x.reshape(Bn, Cn, Hn // 2, 2, Wn // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, Cn, Hn // 2, Wn // 2, 4)
+                    forced.encoder.model[i + 1] = _ForcedPool(nn.functional.one_hot(win.argmax(dim=-1), 4).double())
+                blk += 1
+        (forced.encode(img.double(), s.double(), gl.double()) * R.double()).sum().backward()
+        worst2 = {name: _rel(p.grad, q.grad) for (name, p), (_, q) in zip(na.encoder.named_parameters(), forced.encoder.named_parameters())
+                  if not (name.endswith("bias") and "model." in name and float(p.grad.abs().max()) == 0)}
+        print("GRADERR forced-decisions", " ".join(f"{k}={v:.1e}" for k, v in worst2.items()))
+        assert max(worst2.values()) <= 1e-4, worst2
     for (name, b), (_, c) in zip(na.encoder.named_buffers(), ref.encoder.named_buffers()):
         if b.dtype.is_floating_point:
             assert _rel(b, c) <= 1e-5, name
