@@ -248,8 +248,17 @@ __global__ __launch_bounds__(256) void nastar_wgrad_reduce_kernel(const float* _
     const int ci = r % CI;
     const int tap = r / CI;
     if (co >= co_real || ci >= ci_real) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * total + i];
+    // fixed summation order (bitwise reproducible); four independent partial sums keep four loads in flight
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+        s0 += part[(size_t)k * total + i];
+        s1 += part[(size_t)(k + 1) * total + i];
+        s2 += part[(size_t)(k + 2) * total + i];
+        s3 += part[(size_t)(k + 3) * total + i];
+    }
+    for (; k < nsplit; ++k) s0 += part[(size_t)k * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
     const float sc = grad_scale_dev ? out_scale / *grad_scale_dev : out_scale;
     dw[((size_t)co * ci_real + ci) * 9 + tap] = s * sc;
 }

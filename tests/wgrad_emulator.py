@@ -135,5 +135,5 @@ def run(dz, a, B, H, W, CO, CI, co_real, ci_real, split, nsplit=3, out_scale=1.0
                 tap = wdy * 3 + dx
                 # D[row = co][col = ci] -> part[split][tap][ci][co]
                 part[split_id, tap, ci0 + wci * 32: ci0 + wci * 32 + 32, co0 + wco * 32: co0 + wco * 32 + 32] = acc[wave, dx].T
-    s = part.sum(axis=0) * out_scale                 # [tap][ci][co]
+    s = part.sum(axis=0) * out_scale                 # [tap][ci][co] (the kernel sums the splits in a fixed 4-way interleaved order)
     return s.transpose(2, 1, 0)[:co_real, :ci_real].reshape(co_real, ci_real, 3, 3).astype(np.float32)
