@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 100 /* 0.1.0 */
+#define NASTAR_VERSION 200 /* 0.2.0: replay backward, generic MFMA convolution, encoder training kernels */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0

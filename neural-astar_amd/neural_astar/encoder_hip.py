@@ -1,4 +1,6 @@
-"""MFMA inference paths of the reference's ``CNN`` encoder (``csrc/nastar_encoder.hip.h``): bf16 (fast) and f16x3 (fp32-grade).
+"""MFMA inference paths of the reference's encoders: ``CNN`` on the fixed-shape kernels (``csrc/nastar_encoder.hip.h``: bf16, fp16,
+f16x3 = fp32-grade), ``CNNDownSize`` on the f32-input MFMA, ``Unet`` and CNNs of any depth / map size on the generic convolution
+(``csrc/nastar_conv_flat.hip.h``).  Training lives in ``encoder_train.py``.
 
 ``HipCnnEncoder`` wraps a ``planner.encoder.CNN`` module (depth 4: 2 -> 32 -> 64 -> 128 -> 256 -> 1): it folds the eval-mode
 BatchNorm and the conv bias into per-channel scale/shift, packs the weights in the kernel's ``[tap][cin/8][cout][8]`` bf16

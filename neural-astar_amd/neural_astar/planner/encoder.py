@@ -1,8 +1,10 @@
 """Cost-map encoders (reference ``planner/encoder.py``).
 
-NOT part of the hot path (SURVEY.md section 8f "next #1"): plain torch.nn modules whose only job here is to keep
-``NeuralAstar`` constructible and checkpoint-compatible (state-dict keys ``encoder.model.<n>.*`` of the shipped
-``mazes_032_moore_c8`` checkpoint load strictly).  The convolutions run on whatever MIOpen/hipBLASLt give.
+Plain torch.nn modules that keep ``NeuralAstar`` constructible and checkpoint-compatible (state-dict keys
+``encoder.model.<n>.*`` of the shipped ``mazes_032_moore_c8`` checkpoint load strictly) and hold the parameters.  With the
+default ``encoder_backend = "torch"`` their convolutions run on MIOpen; with a ``hip_*`` backend ``NeuralAstar.encode`` runs the
+same parameters through this package's MFMA kernels instead (``encoder_hip.py`` for inference, ``encoder_train.py`` for
+training: SURVEY.md section 8f "next #1").
 """
 from __future__ import annotations
 
