@@ -142,7 +142,7 @@ class VggUnet(nn.Module):
 class Unet(EncoderBase):
     """U-Net with a vgg16_bn backbone (reference encoder.py:37-57).  Uses ``segmentation_models_pytorch`` when it is installed
     (the reference's own dependency); otherwise the from-scratch :class:`VggUnet` of the same structure (parity unpinned).
-    torch.nn convolutions (MIOpen) -- no MFMA kernels of this package yet."""
+    The ``VggUnet`` form has MFMA inference and training paths (``encoder_hip.HipUnetEncoder``, ``encoder_train.unet_train_forward``)."""
 
     DECODER_CHANNELS = [256, 128, 64, 32, 16]
 
