@@ -69,24 +69,36 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
             ft[e] = mt[c8 * 8 + e];
         }
     }
-    for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += (long long)gridDim.x * NPL) {
-        float x[8];
+    // two pixels per iteration: their loads are independent (2-4 sixteen-byte loads in flight per thread)
+    const long long step = (long long)gridDim.x * NPL;
+    for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += 2 * step) {
+        const bool two = p + step < npix;
+        const size_t p2 = (size_t)(two ? p + step : p);
+        float x[8], y[8];
         load8<kSplit>(v, (size_t)p, stride, C, c8, x);
+        load8<kSplit>(v, p2, stride, C, c8, y);
         if (u) {
-            float d[8];
+            float d[8], f[8];
             load8<kSplit>(u, (size_t)p, stride, C, c8, d);
+            load8<kSplit>(u, p2, stride, C, c8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float dy = (fs[e] * x[e] + ft[e] > 0.f) ? d[e] : 0.f;
-                amax = fmaxf(amax, fabsf(dy));
+                const float fy = (two && fs[e] * y[e] + ft[e] > 0.f) ? f[e] : 0.f;
+                amax = fmaxf(amax, fmaxf(fabsf(dy), fabsf(fy)));
                 s0[e] += (double)dy;
                 s1[e] += (double)dy * (double)x[e];
+                s0[e] += (double)fy;
+                s1[e] += (double)fy * (double)y[e];
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                const float yy = two ? y[e] : 0.f;
                 s0[e] += (double)x[e];
                 s1[e] += (double)x[e] * (double)x[e];
+                s0[e] += (double)yy;
+                s1[e] += (double)yy * (double)yy;
             }
         }
     }
