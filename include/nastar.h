@@ -241,6 +241,11 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
 int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* wpack, const float* scale, const float* shift,
                        uint16_t* out, float* out_f32, int B, int H, int W, int c1, int c2, int cout, int flags, float final_mul,
                        void* stream);
+/* The same layer for 32x32 images on the CNN encoder's persistent whole-image kernel (csrc/nastar_encoder.hip.h: ~1.4x the generic
+ * kernel's rate): (cin, cout) in {(32,64), (64,128), (128,256), (256,128), (128,64)}, flags: NASTAR_CONV_RELU | NASTAR_CONV_SPLIT;
+ * same tensor / weight-pack layouts as nastar_conv3x3_f16.  The training path uses it for its forward and input-gradient convolutions. */
+int nastar_conv3x3_img32_f16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out, int B,
+                             int cin, int cout, int flags, void* stream);
 /* 2x2 max-pool of an NHWC fp16 tensor [B,H,W,C] -> [B,H/2,W/2,C] (split: [hi | lo] pairs, the pair with the larger hi + lo wins) */
 int nastar_maxpool2x2_f16(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, int split, void* stream);
 /* input assembly of NeuralAstar.encode (reference astar.py:171-177): (map, start + goal, 0, ...) as cp-channel NHWC fp16

@@ -439,6 +439,58 @@ int nastar_encoder_cnn_downsize_forward(const float* image, const float* start, 
 
 }  // extern "C"
 
+// ---- the persistent whole-image kernel of the CNN encoder as a stand-alone layer for 32x32 maps (training forward / input gradient) ----
+namespace nastar {
+
+template <int CIN, int COUT, bool kRelu, bool kSplit>
+static int launch_img32_layer(const ConvArgs& ca, hipStream_t stream)
+{
+    void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<CIN, COUT, kRelu, false, 0, false, true, kSplit>;
+    int rc = ensure_lds(kern, I32_LDS_BYTES);
+    if (rc) return rc;
+    int n_cu = 0;
+    if ((rc = conv_cu_count(&n_cu))) return rc;
+    const long long items = (long long)ca.B * (COUT / I32_NT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(items < n_cu ? items : n_cu)), dim3(512), I32_LDS_BYTES, stream, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+template <int CIN, int COUT>
+static int launch_img32_pick(const ConvArgs& ca, bool relu, bool split, hipStream_t s)
+{
+    if (split) return relu ? launch_img32_layer<CIN, COUT, true, true>(ca, s) : launch_img32_layer<CIN, COUT, false, true>(ca, s);
+    return relu ? launch_img32_layer<CIN, COUT, true, false>(ca, s) : launch_img32_layer<CIN, COUT, false, false>(ca, s);
+}
+
+}  // namespace nastar
+
+extern "C" {
+
+int nastar_conv3x3_img32_f16(const uint16_t* in, const uint16_t* wpack, const float* scale, const float* shift, uint16_t* out, int B,
+                             int cin, int cout, int flags, void* stream)
+{
+    if (!in || !wpack || !scale || !shift || !out) return NASTAR_ERR_NULL;
+    if (B <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (!aligned16(in) || !aligned16(wpack) || !aligned16(out)) return NASTAR_ERR_BAD_SHAPE;
+    const bool relu = flags & NASTAR_CONV_RELU, split = flags & NASTAR_CONV_SPLIT;
+    if (flags & ~(NASTAR_CONV_RELU | NASTAR_CONV_SPLIT)) return NASTAR_ERR_UNSUPPORTED;
+    ConvArgs ca;
+    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.wfin = nullptr;
+    ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr; ca.final_mul = 1.0f;
+    ca.B = B; ca.H = 32; ca.W = 32;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (cin == 32 && cout == 64) return launch_img32_pick<32, 64>(ca, relu, split, s);
+    if (cin == 64 && cout == 128) return launch_img32_pick<64, 128>(ca, relu, split, s);
+    if (cin == 128 && cout == 256) return launch_img32_pick<128, 256>(ca, relu, split, s);
+    if (cin == 256 && cout == 128) return launch_img32_pick<256, 128>(ca, relu, split, s);
+    if (cin == 128 && cout == 64) return launch_img32_pick<128, 64>(ca, relu, split, s);
+    return NASTAR_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"
+
 // ---- generic fp16 / f16x3 building blocks (nastar_conv_flat.hip.h): any image size, any channel count -------------------------------
 namespace nastar {
 

@@ -60,6 +60,7 @@ EXPORTED_SYMBOLS = (
     "nastar_encoder_downsize_workspace_bytes",
     "nastar_encoder_cnn_downsize_forward",
     "nastar_conv3x3_f16",
+    "nastar_conv3x3_img32_f16",
     "nastar_maxpool2x2_f16",
     "nastar_encoder_prep_f16",
     "nastar_conv3x3_wgrad_workspace_bytes",
@@ -154,6 +155,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_conv3x3_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.nastar_conv3x3_f16.restype = ci
     lib.nastar_conv3x3_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    lib.nastar_conv3x3_img32_f16.restype = ci
+    lib.nastar_conv3x3_img32_f16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.nastar_maxpool2x2_f16.restype = ci
     lib.nastar_maxpool2x2_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
     lib.nastar_encoder_prep_f16.restype = ci

@@ -83,7 +83,17 @@ class _Lib:
         _native.check(rc, "nastar_pack_conv_weight_f16")
         return wpack, scale, shift, scal
 
+    IMG32 = {(32, 64), (64, 128), (128, 256), (256, 128), (128, 64)}
+
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None, src2=None, c2=0):
+        if (H == 32 and W == 32 and (cin, cout) in self.IMG32 and src2 is None and out is not None
+                and not (flags & ~(CONV_RELU | CONV_SPLIT)) and B >= 256):
+            # large batches of 32x32 maps: the CNN encoder's persistent whole-image kernel (same layouts, ~1.4x the generic kernel;
+            # below ~256 maps its one-workgroup-per-CU grid has nothing to amortise)
+            rc = self.lib.nastar_conv3x3_img32_f16(src.data_ptr(), wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), B,
+                                                   cin, cout, flags, self.stream)
+            _native.check(rc, "nastar_conv3x3_img32_f16")
+            return
         rc = self.lib.nastar_conv3x3_f16(src.data_ptr(), src2.data_ptr() if src2 is not None else None, wpack.data_ptr(),
                                          scale.data_ptr(), shift.data_ptr(), out.data_ptr() if out is not None else None,
                                          out_f32.data_ptr() if out_f32 is not None else None, B, H, W, cin, c2, cout, flags, 1.0, self.stream)

@@ -241,3 +241,44 @@ def test_cnn_of_any_depth_and_size_takes_the_generic_kernel(depth, H, W, enc_in,
         assert float((got - ref).abs().max()) <= tol * 2.5
         out = na(m, s, g)
         assert out.paths.shape == (9, 1, H, W) and int((na.astar.last_status != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (128, 256), (256, 128), (128, 64)])
+@pytest.mark.parametrize("split", [False, True])
+def test_img32_layer_agrees_with_the_generic_convolution(cin, cout, split):
+    """nastar_conv3x3_img32_f16 (the CNN encoder's persistent 32x32 kernel as a stand-alone layer, incl. the input-gradient shapes
+    256 -> 128 and 128 -> 64 and the raw no-ReLU epilogue the training path uses) against nastar_conv3x3_f16 on the same operands, and
+    against torch for one of them"""
+    from neural_astar import _native, encoder_hip as E
+    lib = _native.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout + int(split))
+    B = 41
+    x = torch.randn((B, cin, 32, 32), generator=g)
+    conv = nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    wpack, scale, shift, _, _ = E.pack_flat_conv(conv, None, split)
+    xin = _nhwc(x, split).to(dev)
+    wpack, scale, shift = wpack.to(dev), scale.to(dev), shift.to(dev)
+    M = 2 if split else 1
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for relu in (False, True):
+        flags = (E.CONV_RELU if relu else 0) | (E.CONV_SPLIT if split else 0)
+        o1 = torch.full((B, 32, 32, cout * M), 3.0, dtype=torch.float16, device=dev)
+        o2 = torch.full((B, 32, 32, cout * M), 5.0, dtype=torch.float16, device=dev)
+        _native.check(lib.nastar_conv3x3_img32_f16(xin.data_ptr(), wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(), o1.data_ptr(), B, cin,
+                                                   cout, flags, st), "img32")
+        _native.check(lib.nastar_conv3x3_f16(xin.data_ptr(), None, wpack.data_ptr(), scale.data_ptr(), shift.data_ptr(), o2.data_ptr(), None, B,
+                                             32, 32, cin, 0, cout, flags, 1.0, st), "flat")
+        torch.cuda.synchronize()
+        a, b = o1.float(), o2.float()
+        va = a[..., :cout] + (a[..., cout:] if split else 0)
+        vb = b[..., :cout] + (b[..., cout:] if split else 0)
+        tol = (2e-6 if split else 1e-3) * float(vb.abs().max())  # accumulation order only (plain: one fp16 ulp of the output)
+        assert float((va - vb).abs().max()) <= tol, (relu, float((va - vb).abs().max()))
+    ref = nn.functional.conv2d(_seen(x, split).double(), (conv.weight.detach() if split else _seen(conv.weight.detach(), False)).double(),
+                               conv.bias.detach().double(), padding=1).clamp_min(0)
+    got = va.permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) <= (1e-5 if split else 1.5e-3) * float(ref.abs().max())
