@@ -22,7 +22,6 @@ where torch's autograd returns ~1e-10 of rounding noise.
 """
 from __future__ import annotations
 
-import ctypes
 from typing import List, Optional
 
 import torch

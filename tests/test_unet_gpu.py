@@ -7,9 +7,6 @@ Tolerances: plain fp16 operands -- the kernel must agree with a float64 conv2d o
 U-Net: the truth is the torch module evaluated in float64 on the CPU (the fp32 torch module itself is only ~1e-5 away from it after
 26 layers, MIOpen's fp32 algorithms more); f16x3 must be within 1e-5 absolute of that truth on the (0,1) cost map (north-star float
 tolerance) and no further from the fp32 torch module than 4e-5; plain fp16 within 3e-2."""
-import ctypes
-
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn

@@ -5,7 +5,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.nn as nn
 
