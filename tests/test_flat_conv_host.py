@@ -42,6 +42,8 @@ CASES = [
     (2, 4, 4, 32, 0, 32, False, True, False, False),
     (5, 8, 8, 32, 0, 32, True, False, False, False),
     (1, 4, 4, 32, 32, 32, True, False, True, True),
+    (1, 3, 5, 64, 0, 64, True, False, False, False),   # two slices, odd sizes
+    (2, 2, 2, 64, 0, 128, False, False, False, True),  # 2x2 images, two 64-channel blocks, split: six virtual slices
 ]
 
 
