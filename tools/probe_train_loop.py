@@ -21,12 +21,22 @@ from neural_astar.utils import synthetic as syn  # noqa: E402
 from neural_astar.utils.training import fused_l1_step  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+WARCRAFT = len(sys.argv) > 2 and sys.argv[2] == "warcraft"   # BASELINE config 5: CNNDownSize, 96x96 RGB -> 12x12, learn_obstacles
 dev = torch.device("cuda:0")
-pr = syn.maze_maps(B, 32, seed=7)
-m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
-with torch.no_grad():
-    traj = VanillaAstar().to(dev).eval()(m, s, g).paths.float()
-res = {"batch": B}
+if WARCRAFT:
+    m = torch.rand((B, 3, 96, 96), device=dev)
+    s = torch.zeros((B, 1, 12, 12), device=dev)
+    g = torch.zeros((B, 1, 12, 12), device=dev)
+    s[:, 0, 0, 0] = 1
+    g[:, 0, 11, 11] = 1
+    traj = torch.zeros((B, 1, 12, 12), device=dev)
+    traj[:, 0, torch.arange(12), torch.arange(12)] = 1
+else:
+    pr = syn.maze_maps(B, 32, seed=7)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        traj = VanillaAstar().to(dev).eval()(m, s, g).paths.float()
+res = {"batch": B, "config": "warcraft (train_warcraft.yaml)" if WARCRAFT else "maze (train.yaml)"}
 
 
 def timed(step, reps):
@@ -41,7 +51,11 @@ def timed(step, reps):
 
 for name in ("hip_all_f16x3", "hip_all_f16", "hip_search", "reference"):
     torch.manual_seed(0)
-    na = NeuralAstar(encoder_arch="CNN", Tmax=0.25).to(dev).train()
+    if WARCRAFT:
+        na = NeuralAstar(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3, const=10.0, Tmax=0.25,
+                         learn_obstacles=True).to(dev).train()
+    else:
+        na = NeuralAstar(encoder_arch="CNN", Tmax=0.25).to(dev).train()
     opt = torch.optim.RMSprop(na.parameters(), 1e-3)
     if name == "reference":
         spec = importlib.util.spec_from_file_location("ref_da", os.path.join(ROOT, "oracle", "_ref", "differentiable_astar.py"))
@@ -54,7 +68,7 @@ for name in ("hip_all_f16x3", "hip_all_f16", "hip_search", "reference"):
         def step():
             opt.zero_grad(set_to_none=True)
             cost = na.encode(m, s, g)
-            out = astar(cost, s, g, m)
+            out = astar(cost, s, g, torch.ones_like(s) if WARCRAFT else m)
             nn.L1Loss()(out.histories, traj).backward()
             opt.step()
         reps = 2
@@ -70,4 +84,4 @@ for name in ("hip_all_f16x3", "hip_all_f16", "hip_search", "reference"):
     res[name + "_ms_per_step"] = timed(step, reps)
     print(name, res[name + "_ms_per_step"], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "probe_train_loop.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "probe_train_loop_warcraft.json" if WARCRAFT else "probe_train_loop.json"), "w"), indent=1)
