@@ -683,6 +683,206 @@ def through_module_ms(pr, dev, reps=30):
     return out
 
 
+# ---- --mode train: BASELINE config 5 (and the maze configuration of scripts/train.py) as a driver-runnable training bench ---------------
+TRAIN_CONFIGS = {
+    # constructor arguments = the reference's scripts (scripts/train.py:33-39 + config/train.yaml, scripts/train_warcraft.py:33-40 +
+    # config/train_warcraft.yaml); batch_size 100 per step in both
+    "maze": dict(kw=dict(encoder_input="m+", encoder_arch="CNN", encoder_depth=4, Tmax=0.25), chans=[2, 32, 64, 128, 256, 1], pool=False, hw=(32, 32)),
+    "warcraft": dict(kw=dict(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3, const=10.0, learn_obstacles=True, Tmax=0.25),
+                     chans=[4, 32, 64, 128, 1], pool=True, hw=(96, 96)),
+}
+
+
+def train_batch(config, B, seed, dev):
+    """synthetic training batch in the reference loaders' layout (utils/data.py): (map_designs, start_maps, goal_maps, opt_trajs)"""
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    if config == "warcraft":
+        g_ = torch.Generator().manual_seed(seed)
+        tiles = torch.rand((B, 3, 12, 12), generator=g_)
+        img = (tiles.repeat_interleave(8, 2).repeat_interleave(8, 3) + 0.08 * torch.randn((B, 3, 96, 96), generator=g_)).clamp_(0, 1).to(dev)
+        s = torch.zeros((B, 1, 12, 12), device=dev)
+        gl = torch.zeros((B, 1, 12, 12), device=dev)
+        s[:, 0, 0, 0] = 1
+        gl[:, 0, -1, -1] = 1
+        true_cost = (0.1 + 0.9 * torch.rand((B, 1, 12, 12), generator=g_)).to(dev)
+        with torch.no_grad():  # the label of a WarCraft sample is the shortest path under hidden per-tile costs
+            traj = VanillaAstar().to(dev).eval().astar(true_cost, s, gl, torch.ones_like(s)).paths.float()
+        return img, s, gl, traj
+    pr = syn.maze_maps(B, 32, seed=seed)
+    m, s, gl = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        traj = VanillaAstar().to(dev).eval()(m, s, gl).paths.float()
+    return m, s, gl, traj
+
+
+def train_flops_per_map(config):
+    """useful convolution FLOPs of one training step per map: forward + input gradient (not for the first layer) + weight gradient"""
+    c = TRAIN_CONFIGS[config]
+    h, w = c["hw"]
+    fwd, total = 0.0, 0.0
+    for l, (ci, co) in enumerate(zip(c["chans"][:-1], c["chans"][1:])):
+        f = 2.0 * 9 * h * w * ci * co
+        fwd += f
+        total += f * (2 if l == 0 else 3)
+        if c["pool"] and l < len(c["chans"]) - 2:
+            h, w = h // 2, w // 2
+    return fwd, total
+
+
+def train_cpu_baseline(config, B, budget_s=25.0):
+    """The reference training step on the host cores: the reference's OWN DifferentiableAstar (staged oracle/_ref module, ~45 ATen ops
+    per search iteration under autograd) behind this package's torch.nn encoder (tests/test_reference_modules_cpu.py pins it to the
+    reference's encoder classes: identical cost maps and gradients), nn.L1Loss, RMSprop -- utils/training.py:55-61 as the reference
+    runs it on a CPU.  A bounded sample: `B` maps, as many steps as fit the budget (at least 1)."""
+    import importlib.util
+    from neural_astar.planner import NeuralAstar
+    path = os.path.join(ROOT, "oracle", "_ref", "differentiable_astar.py")
+    if not os.path.exists(path):
+        return {"available": False, "note": "oracle/_ref not staged (run __graft_entry__.build() where /root/reference exists)"}
+    spec = importlib.util.spec_from_file_location("ref_da_train", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cores = min(32, os.cpu_count() or 1)  # small per-iteration tensors: more threads only add fork/join overhead (as in cpu_baseline)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    na = NeuralAstar(**TRAIN_CONFIGS[config]["kw"]).train()
+    astar = ref.DifferentiableAstar(g_ratio=0.5, Tmax=0.25).train()
+    opt = torch.optim.RMSprop(na.parameters(), 1e-3)
+    g_ = torch.Generator().manual_seed(5)
+    if config == "warcraft":
+        m = torch.rand((B, 3, 96, 96), generator=g_)
+        s = torch.zeros((B, 1, 12, 12)); gl = torch.zeros((B, 1, 12, 12))
+        s[:, 0, 0, 0] = 1; gl[:, 0, -1, -1] = 1
+        traj = torch.zeros((B, 1, 12, 12)); traj[:, 0, torch.arange(12), torch.arange(12)] = 1
+        passable = torch.ones_like(s)
+    else:
+        from neural_astar.utils import synthetic as syn
+        pr = syn.maze_maps(B, 32, seed=9)
+        m, s, gl = (torch.from_numpy(x) for x in pr)
+        traj = (torch.rand(m.shape, generator=g_) < 0.1).float() * m
+        passable = m
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = astar(na.encode(m, s, gl), s, gl, passable)
+        torch.nn.L1Loss()(out.histories, traj).backward()
+        opt.step()
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 20):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "maps/s", "cores": cores, "kind": "reference",
+            "sample": f"{n} training step(s) of {B} maps after 1 warm-up: the reference's DifferentiableAstar under autograd (staged module) + "
+                      f"torch.nn encoder + L1Loss + RMSprop on {cores} host threads", "ms_per_step": dt * 1e3}
+
+
+def train_main(args, real_stdout):
+    """`bench.py --mode train --config maze|warcraft [--gpus N]`: the reference's training step (planner forward, L1 loss on histories,
+    straight-through backward, RMSprop) with encoder AND search on the MI355X kernels; N > 1 = DataParallelTrainer over RCCL (each
+    rank its own `--batch-per-gpu` maps: weak scaling; BatchNorm statistics of the global batch, one flat gradient all-reduce)."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import distributed as D
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1 or args.force_collate:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = max(world, 1)
+    B = args.batch_per_gpu
+    cfg = TRAIN_CONFIGS[args.config]
+    torch.manual_seed(1234)
+    planner = NeuralAstar(**cfg["kw"]).to(dev)
+    planner.encoder_backend = args.encoder_backend
+    multi = dist.is_initialized() and (world > 1 or args.force_collate)  # --force-collate: the RCCL path in a 1-rank group
+    sync_bn = multi and args.encoder_backend.startswith("hip")
+    trainer = D.DataParallelTrainer(planner, lr=1e-3, coupling="global" if multi else "local", sync_bn=sync_bn,
+                                    force_collectives=args.force_collate)
+    batches = [train_batch(args.config, B, 1234 + 17 * rank + 1000 * k, dev) for k in range(4)]  # a few distinct batches in rotation
+    _log(f"train mode: {args.config}, {B} maps/GPU, encoder_backend={args.encoder_backend}, world={world}, sync_bn={sync_bn}")
+
+    def run(n):
+        last = None
+        for i in range(n):
+            last = trainer.train_step(*batches[i % len(batches)])
+        return last
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    loss = run(args.steps)
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        fwd_f, step_f = train_flops_per_map(args.config)
+        ms = dt / args.steps * 1e3
+        split = args.encoder_backend == "hip_f16x3"
+        out = {
+            "metric": f"map-instances/s (NeuralAstar TRAINING step, {args.config} configuration, Tmax 0.25, batch {B}/GPU)",
+            "value": n_gpus * B * args.steps / dt, "unit": "maps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"hip_f16x3": "f16x3 (split fp16 operands, fp32 accumulation: fp32-grade)", "hip_f16": "f16 (fp32 accumulation)",
+                      "torch": "f32"}[args.encoder_backend] + " encoder, f32 search",
+            "data": "synthetic",
+            "config": {"workload": f"train/{args.config}: NeuralAstar({', '.join(f'{k}={v}' for k, v in cfg['kw'].items())}), {B} maps/GPU per step, "
+                                   f"encoder forward+backward on {'the MI355X training kernels' if args.encoder_backend.startswith('hip') else 'torch.nn (MIOpen)'}, "
+                                   "HIP search forward + replay backward, fused L1 loss, RMSprop(lr 1e-3); random-init weights",
+                       "batch_per_gpu": B, "global_batch": B * n_gpus, "encoder_backend": args.encoder_backend,
+                       "parallelism": (f"dp{n_gpus}: flat fp32 gradient all-reduce (RCCL) + all-reduced BatchNorm sums (sync_bn={sync_bn}), "
+                                       "coupling=global") if multi else "single"},
+            "steps_per_s": args.steps / dt, "final_loss": float(loss),
+            "roofline": {"bound": "mfma", "achieved": B * step_f / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": B * step_f / (ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                         "kernel": "WHOLE STEP, not one kernel: useful convolution FLOPs (forward + input gradient + weight gradient, "
+                                   "no split-operand products counted) / wall time of the step; at 100 maps the step is launch-bound",
+                         "useful_flops_per_map": step_f, "forward_flops_per_map": fwd_f,
+                         "matrix_products_issued_x": 3 if split else 1},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            _log("train: same step with the torch.nn encoder on this GPU")
+            try:
+                torch.manual_seed(1234)
+                p2 = NeuralAstar(**cfg["kw"]).to(dev)
+                t2 = D.DataParallelTrainer(p2, lr=1e-3, coupling="local")
+                for i in range(3):
+                    t2.train_step(*batches[i % len(batches)])
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(max(5, args.steps // 4)):
+                    t2.train_step(*batches[i % len(batches)])
+                torch.cuda.synchronize(dev)
+                out["torch_encoder_on_this_gpu"] = {"ms_per_step": (time.perf_counter() - t0) / max(5, args.steps // 4) * 1e3,
+                                                    "note": "HIP search kernels + torch.nn (MIOpen fp32) encoder"}
+            except Exception as e:  # noqa: BLE001
+                out["torch_encoder_on_this_gpu"] = {"available": False, "note": f"{type(e).__name__}: {e}"}
+            _log("train: cpu baseline")
+            try:
+                out["cpu_baseline"] = train_cpu_baseline(args.config, min(B, 100))
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"available": False, "note": f"{type(e).__name__}: {e}"}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--ref-worker":
         _reference_worker(sys.argv[2])
@@ -707,6 +907,12 @@ def main():
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
     ap.add_argument("--force-collate", action="store_true",
                     help="dev: run the N>1 collation path (pack kernel + all-gather) in a 1-rank RCCL group")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward = the headline (BASELINE config 2 / 4); train = one full NeuralAstar training step per bench step "
+                         "(BASELINE config 5 with --config warcraft)")
+    ap.add_argument("--config", default="warcraft", choices=sorted(TRAIN_CONFIGS), help="--mode train: which reference training configuration")
+    ap.add_argument("--batch-per-gpu", type=int, default=100, help="--mode train: maps per rank and step (the reference's batch_size is 100)")
+    ap.add_argument("--encoder-backend", default="hip_f16x3", choices=["hip_f16x3", "hip_f16", "torch"], help="--mode train")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -716,6 +922,10 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env, stdout=real_stdout))
+    if args.mode == "train":
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
+        train_main(args, real_stdout)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != max(args.gpus, 1) and rank == 0:

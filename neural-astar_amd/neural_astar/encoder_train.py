@@ -33,6 +33,75 @@ from .encoder_hip import CONV_FINAL, CONV_RELU, CONV_SPLIT, _pad32, pack_conv_we
 CONV_RAW = 16  # include/nastar.h
 
 
+class SyncBatchNorm:
+    """Process-wide switch for data-parallel training (set by ``utils.distributed.DataParallelTrainer(sync_bn=True)``).
+
+    The reference's step runs on ONE device, so its BatchNorm layers (encoder.py:60-97, training mode) normalise with the statistics
+    of the WHOLE batch and their backward couples all rows of it.  With the batch sharded over ranks the per-channel sums that the
+    statistics kernels produce -- ``(sum z, sum z^2)`` forward, ``(sum dy, sum dy z)`` backward, [C][2] doubles -- are all-reduced
+    before the coefficient kernels turn them into scale / shift (forward) and the closed-form backward coefficients: one tiny
+    collective per BatchNorm layer and direction, after which a sharded step is the single-device step on the concatenated batch
+    (parameters AND running statistics; equal shard sizes assumed, as everywhere in ``neural_astar.parallel``)."""
+    enabled = False
+    group = None
+    force = False  # dev / bench: run the collectives even in a 1-rank group (RCCL smoke on a single GPU)
+
+    @classmethod
+    def world(cls) -> int:
+        import torch.distributed as dist
+        if not cls.enabled or not dist.is_available() or not dist.is_initialized():
+            return 1
+        return dist.get_world_size(cls.group)
+
+    @classmethod
+    def active(cls) -> bool:
+        return cls.world() > 1 or (cls.force and cls.world() == 1 and cls.enabled and torch.distributed.is_initialized())
+
+
+def _sync_sums(sums: torch.Tensor, scale: Optional[torch.Tensor] = None) -> int:
+    """all-reduce (SUM) per-channel double sums over the ranks when SyncBatchNorm is on; returns the world size (1 = untouched).
+    ``scale``: device scalar S the sums are multiplied by on THIS rank (the fp16 gradient scale differs per rank): they travel
+    unscaled and come back in this rank's scale (S is a power of two: exact)."""
+    world = SyncBatchNorm.world()
+    if not SyncBatchNorm.active():
+        return 1
+    import torch.distributed as dist
+    if scale is not None:
+        sums.div_(scale.double())
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=SyncBatchNorm.group)
+    if scale is not None:
+        sums.mul_(scale.double())
+    return world
+
+
+class _SyncBatchNorm1(torch.autograd.Function):
+    """the last block's 1-channel BatchNorm with GLOBAL batch statistics: y = (z - mean) * invstd (affine applied by the caller)"""
+
+    @staticmethod
+    def forward(ctx, z, eps):
+        import torch.distributed as dist
+        zd = z.double()
+        st = torch.stack((zd.sum(), (zd * zd).sum()))
+        dist.all_reduce(st, group=SyncBatchNorm.group)
+        n = z.numel() * SyncBatchNorm.world()
+        mean = st[0] / n
+        var = (st[1] / n - mean * mean).clamp_min(0.0)
+        invstd = torch.rsqrt(var + eps)
+        xhat = ((zd - mean) * invstd).float()
+        ctx.save_for_backward(xhat, invstd.float())
+        ctx.n = n
+        return xhat, mean.float(), var.float()
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        import torch.distributed as dist
+        xhat, invstd = ctx.saved_tensors
+        st = torch.stack((dy.double().sum(), (dy.double() * xhat.double()).sum()))
+        dist.all_reduce(st, group=SyncBatchNorm.group)
+        m1, m2 = (st[0] / ctx.n).float(), (st[1] / ctx.n).float()
+        return invstd * (dy - m1 - xhat * m2), None
+
+
 def pack_flat_weight(w: torch.Tensor, split: bool):  # torch-op reference of nastar_pack_conv_weight_f16 (tests compare the two)
     """[cout, cin, 3, 3] fp32 -> (wpack, unscale): channels zero padded to multiples of 32, the kernel's ``[9][cin_v/8][cout][8]`` fp16
     order; split form: weights times 2^s (max|w| -> ~2^14, keeps the lo terms normal fp16 numbers), ``unscale`` = 2^-s as a DEVICE
@@ -179,6 +248,7 @@ class _CnnTrunk(torch.autograd.Function):
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
                 L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
                 sums = L.stats(None, z, None, None, npix, cout, split)
+                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
                 k2, k3 = L.f32(cout), L.f32(cout)
                 mean = torch.empty((cout,), dtype=torch.float64, device=dev)
                 invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
@@ -189,7 +259,7 @@ class _CnnTrunk(torch.autograd.Function):
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     bn.num_batches_tracked += 1
                 gam, bet = gammas[l].detach(), betas[l].detach()
-                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix, float(mom),
+                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix_bn, float(mom),
                                               bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                               k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
                 _native.check(rc, "nastar_bn_coef_fwd")
@@ -267,11 +337,15 @@ class _CnnTrunk(torch.autograd.Function):
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
                 sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)         # (sum dy, sum dy z) * S, max|dy| * S
+                world = _sync_sums(sums, gscale)
                 dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                 rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                              gammas[l - 1].detach().data_ptr(), npix, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                              gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                               c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
                 _native.check(rc, "nastar_bn_coef_bwd")
+                if world > 1:  # the kernel formed dgamma / dbeta from the GLOBAL sums; the flat gradient all-reduce AVERAGES over ranks
+                    dgamma /= world
+                    dbeta /= world
                 grads[4 * (l - 1) + 2] = dgamma
                 grads[4 * (l - 1) + 3] = dbeta
                 dzb = torch.empty_like(da)
@@ -360,11 +434,15 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     # last block's 1-channel BatchNorm (batch statistics) + sigmoid * const as plain tensor ops on [B,1,h,w]: torch's autograd serves
     # its weight / bias and const (MIOpen's spatial BatchNorm kernels are slow on a single channel)
     bnl = bns[D]
-    var, mean = torch.var_mean(zl, unbiased=False)
-    y = (zl - mean) * torch.rsqrt(var + bnl.eps) * bnl.weight + bnl.bias
+    n = zl.numel() * SyncBatchNorm.world()
+    if SyncBatchNorm.active():
+        xhat, mean, var = _SyncBatchNorm1.apply(zl, bnl.eps)
+        y = xhat * bnl.weight + bnl.bias
+    else:
+        var, mean = torch.var_mean(zl, unbiased=False)
+        y = (zl - mean) * torch.rsqrt(var + bnl.eps) * bnl.weight + bnl.bias
     if bnl.track_running_stats and bnl.running_mean is not None:
         with torch.no_grad():
-            n = zl.numel()
             mom = bnl.momentum if bnl.momentum is not None else 1.0 / float(int(bnl.num_batches_tracked) + 1)
             bnl.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
             bnl.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
@@ -420,6 +498,7 @@ class _UnetTrunk(torch.autograd.Function):
                 z = L.i16(npix * cout * mult)
                 L.conv(src, wpack, scale, shift, B, h, w, c1, cout, sflag | ups, out=z, src2=src2, c2=c2)
                 sums = L.stats(None, z, None, None, npix, cout, split)
+                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
                 k2, k3 = L.f32(cout), L.f32(cout)
                 mean = torch.empty((cout,), dtype=torch.float64, device=dev)
                 invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
@@ -430,7 +509,7 @@ class _UnetTrunk(torch.autograd.Function):
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     bn.num_batches_tracked += 1
                 rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
-                                              float(bn.eps), npix, float(mom), bn.running_mean.data_ptr() if track else None,
+                                              float(bn.eps), npix_bn, float(mom), bn.running_mean.data_ptr() if track else None,
                                               bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
                                               mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
                 _native.check(rc, "nastar_bn_coef_fwd")
@@ -506,11 +585,15 @@ class _UnetTrunk(torch.autograd.Function):
                     z = sv["z"]
                     mean, invstd, k2f, k3f = sv["coef"]
                     sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
+                    world = _sync_sums(sums, S)
                     dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
                     rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                  params[st["g"]].detach().data_ptr(), npix, S.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                  params[st["g"]].detach().data_ptr(), npix * world, S.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                   c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout, L.stream)
                     _native.check(rc, "nastar_bn_coef_bwd")
+                    if world > 1:  # formed from the GLOBAL sums; the flat gradient all-reduce averages over ranks
+                        dgamma /= world
+                        dbeta /= world
                     grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta
                     if cfg.get("debug") is not None:
                         cfg["debug"][st["dst"] + ":bn"] = (z, k2f, k3f, dbeta.clone(), dgamma.clone(), sums.clone(), S_in.clone())

@@ -27,7 +27,7 @@ import torch.distributed as dist
 from .. import ops
 from .training import fused_l1_step
 
-__all__ = ["init_distributed", "broadcast_parameters", "allreduce_gradients", "DataParallelTrainer"]
+__all__ = ["init_distributed", "broadcast_parameters", "allreduce_gradients", "DataParallelTrainer"]  # + encoder_train.SyncBatchNorm
 
 
 def init_distributed(backend: Optional[str] = None) -> torch.device:
@@ -87,35 +87,119 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group: Optional[di
         o += p.numel()
 
 
+class _FlatGradBucket:
+    """ONE persistent flat fp32 buffer holding every parameter gradient: after ``backward()`` the gradients are gathered into it with
+    one fused multi-tensor copy, all-reduced in place (average) and handed to the optimiser as views of the buffer -- no per-step
+    ``torch.cat`` and no copy back."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+
+    def reduce(self, group=None, async_op: bool = False):
+        """returns a ``finish()`` callable; with ``async_op`` the collective runs on the backend's own stream (RCCL) until then"""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        world = dist.get_world_size(group)
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+        def finish():
+            if work is not None and async_op:
+                work.wait()
+            self.flat.div_(world)
+            for v, p in zip(self.views, self.params):
+                p.grad = v
+        return finish
+
+
 class DataParallelTrainer:
     """The reference's training step (utils/training.py:55-61: planner forward, L1 loss on histories, RMSprop) data-parallel
     over the process group: each rank runs ``fused_l1_step`` on ITS rows, gradients are averaged with one flat all-reduce.
 
     ``coupling``: "none" (default) = shard-size independent gradients; "global" = the reference's batch-coupled terms over the
-    GLOBAL batch (one extra scalar all-reduce per step); "local" = coupled within each rank's shard."""
+    GLOBAL batch (one extra scalar all-reduce per step); "local" = coupled within each rank's shard.
+
+    ``sync_bn``: BatchNorm with the statistics of the GLOBAL batch, forward and backward (``encoder_train.SyncBatchNorm``: the
+    per-channel double sums of the statistics kernels are all-reduced before the coefficient kernels) -- what the reference's
+    single-device step computes; a sharded step then equals the step on the concatenated batch, running statistics included, and
+    the ranks' buffers cannot drift.  Needs a ``hip_*`` encoder backend (the training kernels own the statistics); with the
+    torch.nn encoder use ``torch.nn.SyncBatchNorm.convert_sync_batchnorm``.  Without ``sync_bn`` every rank normalises with its own
+    rows and keeps its own running statistics: call ``sync_buffers()`` before evaluation / checkpointing (rank-averaged, like the
+    gradients), as ``train_step`` does every ``buffer_sync_every`` steps."""
 
     def __init__(self, planner: torch.nn.Module, lr: float = 1e-3, group: Optional[dist.ProcessGroup] = None,
-                 coupling: str = "none"):
+                 coupling: str = "none", sync_bn: bool = False, buffer_sync_every: int = 0, force_collectives: bool = False):
         self.planner = planner
         self.group = group
         self.optimizer = torch.optim.RMSprop(planner.parameters(), lr)  # reference training.py:52-53
         if coupling not in ("none", "global", "local"):
             raise ValueError(coupling)
         self.coupling = coupling
+        self.sync_bn = bool(sync_bn)
+        if self.sync_bn and not str(getattr(planner, "encoder_backend", "torch")).startswith("hip"):
+            raise ValueError("sync_bn=True needs planner.encoder_backend = 'hip_f16x3' / 'hip_f16' (the BatchNorm statistics are "
+                             "all-reduced inside the HIP training path); for the torch.nn encoder convert it with "
+                             "torch.nn.SyncBatchNorm.convert_sync_batchnorm instead")
+        self.buffer_sync_every = int(buffer_sync_every)
+        self.force_collectives = bool(force_collectives)  # dev / bench: run every collective even in a 1-rank group (RCCL smoke)
+        self.steps = 0
+        self._bucket = None
         broadcast_parameters(planner, 0, group)
+
+    def _distributed(self) -> bool:
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force_collectives)
+
+    def sync_buffers(self) -> None:
+        """Average the floating-point buffers (BatchNorm running statistics) over the ranks: one flat all-reduce.  A no-op in effect
+        under ``sync_bn`` (the ranks already hold identical statistics)."""
+        if not self._distributed():
+            return
+        bufs = [b for b in self.planner.buffers() if b.is_floating_point()]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat /= dist.get_world_size(self.group)
+        o = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flat[o:o + b.numel()].reshape(b.shape))
+                o += b.numel()
 
     def train_step(self, map_designs, start_maps, goal_maps, opt_trajs) -> torch.Tensor:
         from .. import parallel
+        from ..encoder_train import SyncBatchNorm
         self.planner.train()
         prev = ops.BatchCoupling.mode
+        prev_sync = (SyncBatchNorm.enabled, SyncBatchNorm.group, SyncBatchNorm.force)
         ops.BatchCoupling.mode = {"none": "none", "local": "batch",
                                   "global": parallel.global_t_batch(self.group) if dist.is_initialized() else "batch"}[self.coupling]
+        SyncBatchNorm.enabled, SyncBatchNorm.group, SyncBatchNorm.force = self.sync_bn and self._distributed(), self.group, self.force_collectives
         try:
             self.optimizer.zero_grad(set_to_none=True)
             loss, _ = fused_l1_step(self.planner, map_designs, start_maps, goal_maps, opt_trajs)
             loss.backward()
         finally:
             ops.BatchCoupling.mode = prev
-        allreduce_gradients(self.planner.parameters(), self.group)
+            SyncBatchNorm.enabled, SyncBatchNorm.group, SyncBatchNorm.force = prev_sync
+        if self._distributed():
+            if self._bucket is None:
+                self._bucket = _FlatGradBucket(self.planner.parameters())
+            # the optimiser needs the averaged gradients right away and the whole encoder backward is ONE autograd node, so there is
+            # no later compute to hide this collective behind: issue, wait (stream-side, no host sync), step
+            self._bucket.reduce(self.group, async_op=True)()
         self.optimizer.step()
+        self.steps += 1
+        if self.buffer_sync_every and not self.sync_bn and self.steps % self.buffer_sync_every == 0:
+            self.sync_buffers()
         return loss.detach()

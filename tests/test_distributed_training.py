@@ -157,3 +157,122 @@ def test_maze_cnn_data_parallel_training_on_the_hip_encoder_kernels(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_maze_cnn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read()[:1] for r in range(2)] == ["1", "1"]
+
+
+def _sync_bn_setup(dev):
+    """16 mazes + the shipped-checkpoint CNN planner (tests/golden/ckpt_mazes032_cnn.npz), identical in every process"""
+    sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT, os.path.join(ROOT, "tests")]
+    from neural_astar.planner import NeuralAstar, VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_mazes032_cnn.npz"))
+    planner = NeuralAstar(encoder_arch="CNN", Tmax=0.25)
+    planner.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=True)
+    planner = planner.to(dev)
+    planner.encoder_backend = "hip_f16x3"
+    pr = syn.maze_maps(16, 32, seed=91)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    with torch.no_grad():
+        traj = VanillaAstar().to(dev).eval()(m, s, g).paths.float()
+    return planner, (m, s, g, traj)
+
+
+def _state(planner):
+    return {"p/" + k: v.detach().cpu().clone() for k, v in planner.named_parameters()} | \
+           {"b/" + k: v.detach().cpu().clone() for k, v in planner.named_buffers()}
+
+
+def _sync_bn_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    planner, batch = _sync_bn_setup(dev)
+    from neural_astar.utils import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the box's single GPU: gloo, not RCCL
+    tr = D.DataParallelTrainer(planner, lr=1e-3, coupling="global", sync_bn=True)
+    tr.optimizer = torch.optim.SGD(planner.parameters(), lr=1.0)  # see the test's docstring
+    rows = slice(rank * 8, rank * 8 + 8)
+    losses = [float(tr.train_step(*(x[rows] for x in batch))) for _ in range(2)]
+    grads = {k: p.grad.detach().cpu().clone() for k, p in planner.named_parameters() if p.grad is not None}
+    torch.save({"state": _state(planner), "losses": losses, "grads": grads}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_two_rank_step_equals_the_single_device_step(tmp_path):
+    """the reference's step runs on ONE device, so BatchNorm sees the whole batch (encoder.py:60-78 in training mode,
+    utils/training.py:55-61).  Two ranks with 8 maps each, sync_bn=True (all-reduced per-channel sums, forward and backward) and
+    coupling="global", must reproduce the single-process step on the 16-map batch: parameters, gradients and running statistics.
+    Two steps, so the second one starts from the first one's updated weights and running statistics.  The optimiser is plain SGD in both
+    runs: RMSprop's first update is lr * g / (sqrt(0.01 g^2) + eps) ~ 10 lr sign(g), which turns fp32-grade rounding noise on
+    near-zero gradient elements into +-0.01 parameter differences -- a property of the reference's optimiser, not of the sharding."""
+    import torch.multiprocessing as mp
+    dev = torch.device("cuda:0")
+    planner, batch = _sync_bn_setup(dev)
+    from neural_astar.utils import distributed as D
+    tr = D.DataParallelTrainer(planner, lr=1e-3, coupling="local")  # no process group: plain single-device training
+    tr.optimizer = torch.optim.SGD(planner.parameters(), lr=1.0)
+    ref_losses = [float(tr.train_step(*batch)) for _ in range(2)]
+    ref_grads = {k: p.grad.detach().cpu().clone() for k, p in planner.named_parameters() if p.grad is not None}
+    ref = _state(planner)
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    for k in ref:  # the ranks end identical, buffers included (nothing drifts)
+        assert torch.equal(got[0]["state"][k], got[1]["state"][k]), k
+    # mean over 16 maps = average of the two ranks' means over 8 (and the histories, hence the per-rank losses, must be the reference's)
+    for i in range(2):
+        assert abs(0.5 * (got[0]["losses"][i] + got[1]["losses"][i]) - ref_losses[i]) <= 1e-6, (i, got[0]["losses"], got[1]["losses"], ref_losses)
+    worst = 0.0
+    for k, v in ref_grads.items():
+        scale = float(v.abs().max())
+        if scale == 0.0:
+            assert float(got[0]["grads"][k].abs().max()) == 0.0, k
+            continue
+        worst = max(worst, float((got[0]["grads"][k] - v).abs().max()) / scale)
+    assert worst <= 5e-5, worst  # two f16x3 runs with different fp16 gradient scales / summation orders (each ~1e-5 from float64)
+    for k, v in ref.items():
+        if not v.dtype.is_floating_point:
+            assert int(got[0]["state"][k]) == int(v), k
+            continue
+        assert float((got[0]["state"][k] - v).abs().max()) <= 1e-6 * max(1.0, float(v.abs().max())), k
+
+
+def _flat_bucket_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
+    from neural_astar.utils import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2))
+    x = torch.arange(12, dtype=torch.float32).reshape(2, 6) * (rank + 1)
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    if rank == 1:
+        net[1].bias.grad = None
+        local[3] = torch.zeros_like(local[3])
+    bucket = D._FlatGradBucket(net.parameters())
+    ok = True
+    for step in range(2):  # the second round starts from gradients that ARE views of the bucket
+        bucket.reduce(async_op=bool(step))()
+        both = [torch.empty_like(bucket.flat) for _ in range(world)]
+        dist.all_gather(both, bucket.flat)
+        ok = ok and torch.equal(both[0], both[1])
+        ok = ok and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(net.parameters(), bucket.views))
+        if step == 0:
+            mine = torch.cat([g.reshape(-1) for g in local])
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            ok = ok and torch.allclose(bucket.flat, 0.5 * (gathered[0] + gathered[1]), atol=1e-6)
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_persistent_flat_gradient_bucket_world_size_2_gloo(tmp_path):
+    """DataParallelTrainer's bucket: gradients gathered with one multi-tensor copy, averaged in place, handed back as views."""
+    import torch.multiprocessing as mp
+    mp.spawn(_flat_bucket_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
