@@ -239,7 +239,11 @@ def training_step_ms(pr, dev, reps=10):
         h, _, it, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
         torch.ops.nastar.astar_backward(gh, cost, s, g, m, G_RATIO, mi, it, tb)
     out = {}
-    for name, once in (("replay_ms", replay), ("round1_reselect_ms", reselect)):
+    from neural_astar import _native
+    variants = [("replay_ms", replay)]
+    if _native.load().nastar_has_dev_kernels():  # `make DEV=1` builds only
+        variants.append(("round1_reselect_ms", reselect))
+    for name, once in variants:
         for _ in range(2):
             once()
         torch.cuda.synchronize(dev)

@@ -54,9 +54,15 @@ extern "C" {
 #define NASTAR_FLAG_FORCE_LDS 1 /* forward: round-1 LDS layout (17 B/cell, one map per wavefront); A/B measurements only */
 #define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
 #define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
+#define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
 #define NASTAR_FLAG_DUO 4        /* forward: two maps per wavefront (nastar_search_duo.hip.h), a measured non-improvement */
 
 int nastar_version(void);
+
+/* 1 when the library was built with `make DEV=1`: the superseded / negative-result kernels behind NASTAR_FLAG_FORCE_LDS, _FORCE_REG, _DUO and
+ * the round-1 nastar_backward / nastar_backward_l1 are present.  0 (the product build): those flags and entry points return
+ * NASTAR_ERR_UNSUPPORTED; use nastar_backward_replay / nastar_backward_l1_replay. */
+int nastar_has_dev_kernels(void);
 
 /* Human-readable description of the last NASTAR_ERR_HIP on this thread ("" if none). */
 const char* nastar_last_error(void);

@@ -6,13 +6,21 @@
 #include <stdio.h>
 #include <string.h>
 
+#ifndef NASTAR_DEV_KERNELS
+#define NASTAR_DEV_KERNELS 0  // make DEV=1: also build the superseded / negative-result kernels kept for A/B measurements
+#endif
 #include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
+#if NASTAR_DEV_KERNELS
 #include "nastar_search_reg.hip.h"
+#endif
 #include "nastar_search_global.hip.h"
 #include "nastar_search_compact.hip.h"
+#if NASTAR_DEV_KERNELS
 #include "nastar_search_duo.hip.h"
+#endif
 #include "nastar_search_asm.hip.h"
+#include "nastar_search_asm3.hip.h"
 #include "nastar_backward_replay.hip.h"
 #include "nastar_backward_replay_asm.hip.h"
 
@@ -34,6 +42,7 @@ struct FwdArgs {
     MapDims d;
 };
 
+#if NASTAR_DEV_KERNELS  // round-1 17 B/cell kernel: A/B measurements only (make DEV=1)
 // ---- forward: DifferentiableAstar.forward (differentiable_astar.py:150-267), one wavefront per map ------
 // LOGH > 0 (together with LOGW > 0): the map is exactly (1<<LOGH) x (1<<LOGW), so every size, loop bound and LDS array
 // offset is a compile-time constant (immediate ds offsets, fully unrolled load/store loops).
@@ -103,6 +112,8 @@ __global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, con
     }
 }
 
+#endif  // NASTAR_DEV_KERNELS
+
 // ---- forward, compact LDS state (nastar_search_compact.hip.h): the default for every map that fits LDS ------------------
 struct FwdCArgs {
     const float* cost;
@@ -117,6 +128,7 @@ struct FwdCArgs {
     uint8_t* packed;
     int max_iters;
     int B;
+    int flags;
     CompactDims d;
 };
 
@@ -145,7 +157,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
 
     int start_idx, goal_idx;
     constexpr int kLoadIter = (kVec4 && LOGH > 0 && LOGW > 0 && LOGH + LOGW >= 8) ? (1 << (LOGH + LOGW - 8)) : 0;
-    compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
+    bool any_signed = true;
+    // round-3 instruction stream (raw-bit keys): every cost >= +0 and 0 <= g_ratio <= 1 so that every priority is >= +0
+    compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx,
+                                       ABL == -1 ? &any_signed : nullptr);
+    const bool asm3 = ABL == -1 && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
     const int gi = goal_idx < 0 ? 0 : goal_idx;
     const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
     const int goal_c = gi - goal_r * d.W;
@@ -157,12 +173,13 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (start_idx < 0 || goal_idx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
     } else {
-        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
+        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, asm3);
         int s = 0;
         if constexpr (ABL == -1) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
-            s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW,
-                                                    kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr);
+            int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
+            if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
         } else
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     }
 }
 
+#if NASTAR_DEV_KERNELS  // measured non-improvements kept for the record (make DEV=1): two maps per wavefront, register-resident state
 // ---- forward, two maps per wavefront (nastar_search_duo.hip.h): the default wherever two compact states fit one CU's LDS ----
 // a.d.CPL / a.d.NCp count chunk minima per 32-lane half here.
 template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog>
@@ -333,6 +351,9 @@ __global__ __launch_bounds__(64) void nastar_forward_reg_kernel(const FwdArgs a,
     }
 }
 
+#endif  // NASTAR_DEV_KERNELS
+
+#if NASTAR_DEV_KERNELS  // round-1 backward (repeats the selection, full softmax per step): superseded by the replay kernels; make DEV=1
 struct BwdArgs {
     const float* grad_hist;  // upstream dL/dhistories, or nullptr: L1 loss fused (below)
     const float* l1_hist;    // fused L1 (training.py:58): dL/dhistories = l1_scale * *l1_up * sign(histories - opt_trajs)
@@ -544,6 +565,8 @@ __global__ __launch_bounds__(64) void nastar_backward_small_kernel(const BwdArgs
     for (int c = 0; c < NCH; ++c) a.grad_cost[off + c * CHUNK + lane] = acc[c];
 }
 
+#endif  // NASTAR_DEV_KERNELS
+
 // ---- get_heuristic standalone (parity/debug) ------------------------------------------------------------
 __global__ __launch_bounds__(64) void nastar_heuristic_kernel(const float* goal, float* out, int H, int W, uint32_t magicW)
 {
@@ -633,7 +656,7 @@ static bool needs_global_state(int H, int W)
 }
 
 // round-1 layout (17 B/cell, 64-cell chunks): kept behind NASTAR_FLAG_FORCE_LDS for A/B measurements
-static bool fits_legacy_lds(int H, int W)
+__attribute__((unused)) static bool fits_legacy_lds(int H, int W)
 {
     const long long HW = (long long)H * W;
     if (HW > 65535) return false;
@@ -641,7 +664,7 @@ static bool fits_legacy_lds(int H, int W)
     return map_lds_bytes((int)(nchunks * 64), (int)(((nchunks + 63) / 64) * 64)) <= kMaxLdsBytes;
 }
 
-static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
+__attribute__((unused)) static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
 {
     if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
     if (H > 65535 || W > 65535 || (long long)H * W > 65535) return NASTAR_ERR_UNSUPPORTED;
@@ -659,7 +682,7 @@ static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims
 }
 
 // largest number of 64-cell slots the (clipped) 3x3 neighbourhood of any cell spans, for the register-resident kernel
-static int reg_max_slot_steps(int H, int W)
+__attribute__((unused)) static int reg_max_slot_steps(int H, int W)
 {
     int best = 1;
     for (int r = 0; r < H; ++r)
@@ -690,6 +713,15 @@ using namespace nastar;
 extern "C" {
 
 int nastar_version(void) { return NASTAR_VERSION; }
+
+int nastar_has_dev_kernels(void)
+{
+#if NASTAR_DEV_KERNELS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char* nastar_last_error(void) { return g_last_error; }
 
@@ -730,7 +762,12 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         return NASTAR_OK;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#if NASTAR_DEV_KERNELS
     const bool legacy = (flags & (NASTAR_FLAG_FORCE_LDS | NASTAR_FLAG_FORCE_REG)) && B > 0 && H > 0 && W > 0 && fits_legacy_lds(H, W);
+#else
+    if (flags & (NASTAR_FLAG_FORCE_LDS | NASTAR_FLAG_FORCE_REG | NASTAR_FLAG_DUO)) return NASTAR_ERR_UNSUPPORTED;  // make DEV=1
+    const bool legacy = false;
+#endif
     if (!legacy) {
         FwdCArgs c;
         int rc = make_cdims(B, H, W, max_iters, g_ratio, c.d);
@@ -741,6 +778,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.hist = histories_out; c.paths = reinterpret_cast<long long*>(paths_out);
         c.sel_log = sel_log_out; c.iters = iters_out; c.status = status_out; c.max_iters = max_iters;
         c.packed = nullptr;
+        c.flags = flags;
         const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                           aligned16(histories_out) && aligned16(paths_out);
         if (packed_out && vec4 && (c.d.HW % 8 == 0)) {  // fused emission of the bit-packed masks
@@ -752,6 +790,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const bool lg = sel_log_out != nullptr;
         void (*kern)(const FwdCArgs, const float) = nullptr;
         c.B = B;
+#if NASTAR_DEV_KERNELS
         // two maps per wavefront (opt-in, NASTAR_FLAG_DUO): measured no faster in bulk and slower per step than one map per
         // wavefront, kept for the record
         const int dcpl = (c.d.nchunks + 31) / 32;
@@ -773,8 +812,10 @@ static int forward_impl(const float* cost, const float* start, const float* goal
 #undef NASTAR_DPICK
             return launch(kern, (B + 1) / 2, dlds, s, c, rcp);
         }
+#endif
 #define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
     kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
+#if NASTAR_DEV_KERNELS
         static const int ablate = getenv("NASTAR_ABLATE") ? atoi(getenv("NASTAR_ABLATE")) : 0;  // dev timing probe only
         if (ablate && vec4 && fast && H == 32 && W == 32 && !lg) {
             switch (ablate) {
@@ -786,6 +827,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             }
             return launch(kern, B, lds, s, c, rcp);
         }
+#endif
         const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
         if (use_asm && vec4 && fast && H == 32 && W == 32)
             kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, -1>;
@@ -804,6 +846,9 @@ static int forward_impl(const float* cost, const float* start, const float* goal
 #undef NASTAR_CPICK
         return launch(kern, B, lds, s, c, rcp);
     }
+#if !NASTAR_DEV_KERNELS
+    return NASTAR_ERR_UNSUPPORTED;
+#else
     FwdArgs a;
     int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
     if (rc) return rc;
@@ -862,6 +907,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         else kern = lg ? &nastar_forward_kernel<false, true, 0, false, true> : &nastar_forward_kernel<false, true, 0, false, false>;
         return launch(kern, B, lds, s, a, rcp);
     }
+#endif  // NASTAR_DEV_KERNELS
 }
 
 int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
@@ -887,6 +933,7 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);  // shapes the fused path skips
 }
 
+#if NASTAR_DEV_KERNELS
 static int backward_impl(BwdArgs& a, const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
                          int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
                          float* grad_cost_out, void* stream)
@@ -916,6 +963,7 @@ static int backward_impl(BwdArgs& a, const float* cost, const float* start, cons
     if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
     return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
 }
+#endif  // NASTAR_DEV_KERNELS
 
 int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
                     const float* passable, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
@@ -923,22 +971,34 @@ int nastar_backward(const float* grad_histories, const float* cost, const float*
                     int flags, void* stream)
 {
     (void)workspace; (void)workspace_bytes; (void)flags;
+#if !NASTAR_DEV_KERNELS
+    (void)grad_histories; (void)cost; (void)start; (void)goal; (void)passable; (void)B; (void)H; (void)W; (void)g_ratio; (void)max_iters;
+    (void)iters; (void)t_batch_dev; (void)grad_cost_out; (void)stream;
+    return NASTAR_ERR_UNSUPPORTED;  // round-1 kernel: development builds only (make DEV=1); use nastar_backward_replay
+#else
     if (!grad_histories) return NASTAR_ERR_NULL;
     BwdArgs a;
     a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
     return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
+#endif
 }
 
 int nastar_backward_l1(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
                        const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
                        int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream)
 {
+#if !NASTAR_DEV_KERNELS
+    (void)histories; (void)opt_trajs; (void)grad_loss_dev; (void)cost; (void)start; (void)goal; (void)passable; (void)B; (void)H; (void)W;
+    (void)g_ratio; (void)max_iters; (void)iters; (void)t_batch_dev; (void)grad_cost_out; (void)stream;
+    return NASTAR_ERR_UNSUPPORTED;  // round-1 kernel: development builds only (make DEV=1); use nastar_backward_l1_replay
+#else
     if (!histories || !opt_trajs) return NASTAR_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
     BwdArgs a;
     a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
     a.l1_scale = (float)(1.0 / ((double)B * H * W));
     return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
+#endif
 }
 
 // ---- backward by replay of the forward's selection log (nastar_backward_replay.hip.h) ------------------------------------

@@ -1,0 +1,134 @@
+// nastar_search_asm3.hip.h -- round-3 form of the hand-scheduled selection/expansion loop (nastar_search_asm.hip.h is round 2's):
+// 74 instructions per step instead of 92 (42 VALU instead of ~57), same LDS layout, same semantics, for maps whose costs are all
+// >= +0 (every encoder of the reference ends in sigmoid * const, VanillaAstar passes 0/1 maps; the kernel checks while loading and
+// takes the round-2 stream otherwise).
+//
+// Why instruction count: the launch of the 4096-map batch lasts (longest chain) x (step latency), and profiles/r02 put the step at
+// max(650 cycles lone-wave latency, 4 x VALU count x active waves of the SIMD): with all 16 maps of a CU resident, a SIMD's four
+// waves are VALU-issue bound (4 x 60 x 4 = 960 cycles per step) for the first ~100-200 steps of every chain, and the rand32 launch
+// IS its longest chain at lone-wave latency.  Length-aware placement was simulated first (tools/sim_placement.py): it needs a chain
+// length predictor, and Chebyshev start-goal distance correlates 0.13 with the step count on mazes -- useless; fewer VALU
+// instructions per step help every chain with no predictor.  What went:
+//   * coordinates first: r_l = r* + dr, c_l = (c* & colmask) + dcol give the in-map test (max(r_l, c_l) < W, unsigned), the cell
+//     index (v_lshl_add) AND the heuristic's inputs, instead of deriving (r, c) back from the cell index;
+//   * h0 on integers: |dr|, |dc| by v_sad_u32, Chebyshev = v_max_u32 (== fl(fl(dr+dc) - min(dr,dc)) exactly), dr^2 + dc^2 by
+//     v_mul_u32_u24 / v_mad_u32_u24 (exact, like the fp32 sum of two small squares), two converts: 10 instead of 15 instructions;
+//   * s* is closed (g = -inf) BEFORE the lanes read their cells, so the chunk lane that holds s* sees a closed cell by itself (no
+//     lane compare / select), and lane 8's own cell IS s*, so its chunk-entry offset needs no scalar detour;
+//   * "open" for the chunk re-insertion is ONE v_cmpx_class_f32 with a per-lane class mask (finite classes on chunk lanes, nothing
+//     elsewhere); the neighbours' "g[n] > g2" runs under EXEC = in-map neighbour lanes, so no value-to-beat select;
+//   * keys are the raw bits of q = fl(f / fl32(sqrt(W))): q >= +0 when all costs are, and non-negative floats order like their bits.
+// Hazard rules as in nastar_search_asm.hip.h.
+#pragma once
+#include "nastar_search_asm.hip.h"
+
+namespace nastar {
+
+#define NASTAR_ASM3_EXPAND \
+        "s_add_u32 %[it], %[it], 1\n\t" \
+        "s_lshr_b32 s43, s42, %[LOGW]\n\t" /* r* */ \
+        "s_and_b32 s44, s42, %[WM1]\n\t" /* c* */ \
+        "v_add_u32 v32, s43, %[dr]\n\t" /* r_l */ \
+        "v_and_b32 v33, s44, %[cmask]\n\t" /* chunk lanes: first column of the chunk of s*; others: c* */ \
+        "v_add_u32 v33, v33, %[dcc]\n\t" /* c_l */ \
+        "v_mov_b32 v24, s42\n\t" \
+        "v_max_u32 v23, v32, v33\n\t" \
+        "v_lshl_add_u32 v46, v32, %[LOGW], v33\n\t" /* this lane's cell (garbage outside the map) */ \
+        "v_cmp_gt_u32 vcc, %[W], v23\n\t" /* inside the map (conv2d zero padding, :77-93); true for lane 8 and the chunk lanes */ \
+        "v_lshlrev_b32 v27, 3, v24\n\t" \
+        "ds_read_b64 v[28:29], v27\n\t" /* g[s*], cost[s*] */ \
+        "s_and_b64 s[54:55], vcc, %[mnb]\n\t" /* in-map neighbour lanes */ \
+        "v_cndmask_b32 v46, v24, v46, vcc\n\t" /* il: s* itself for out-of-map neighbours */ \
+        "v_lshlrev_b32 v26, 3, v46\n\t" \
+        "v_lshrrev_b32 v50, 4, v46\n\t" \
+        "v_lshlrev_b32 v50, 3, v50\n\t" /* byte offset of cmin[chunk of il] */ \
+ /* lane 8 (il == s*) closes s* (:222-225) and empties its chunk's entry BEFORE the lanes read their cells */ \
+        "s_mov_b64 exec, 0x100\n\t" \
+        "ds_write_b32 v27, %[vminf]\n\t" \
+        "ds_write_b64 v50, v[48:49] offset:%[CMIN]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "ds_read_b64 v[30:31], v26\n\t" /* g[il], cost[il] */ \
+ /* h0 = get_heuristic at (r_l, c_l) (:26-52) on integers, in the shadow of the LDS round trip */ \
+        "v_sad_u32 v35, v32, %[gr], 0\n\t" /* |dr| */ \
+        "v_sad_u32 v36, v33, %[gc], 0\n\t" /* |dc| */ \
+        "v_max_u32 v37, v35, v36\n\t" /* == fl(fl(|dr| + |dc|) - min(|dr|, |dc|)) */ \
+        "v_mul_u32_u24 v34, v35, v35\n\t" \
+        "v_mad_u32_u24 v34, v36, v36, v34\n\t" \
+        "v_cvt_f32_u32 v34, v34\n\t" \
+        "v_sqrt_f32 v34, v34\n\t" \
+        "v_cvt_f32_u32 v37, v37\n\t" /* independent: the wait state between the transcendental and its use */ \
+        "v_mul_f32 v34, 0x3a83126f, v34\n\t" /* fl32(0.001) * euclid */ \
+        "v_add_f32 v34, v37, v34\n\t" /* h0 */ \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_add_f32 v34, v34, v31\n\t" /* :191-192 h = h0 + cost */ \
+        "v_add_f32 v40, v28, v29\n\t" /* :234 g2 = g[s*] + cost[s*] */ \
+        "v_mul_f32 v34, %[comg], v34\n\t" /* :206 (1-g_ratio)*h */ \
+        "v_cndmask_b32_e64 v41, v30, v40, %[mnb]\n\t" /* neighbour lanes key g2, chunk lanes their own g */ \
+        "v_mul_f32 v41, %[cgr], v41\n\t" \
+        "v_add_f32 v41, v41, v34\n\t" /* :206 f */ \
+        "v_mul_f32 v42, %[crcp], v41\n\t" /* :207 f / sqrt(W), correctly rounded (tools/fastdiv_check.c) */ \
+        "v_fma_f32 v43, -v42, %[csq], v41\n\t" \
+        "v_fma_f32 v47, v43, %[crcp], v42\n\t" /* q >= +0: its bits are the order-preserving key; [v46:v47] = (cell, key) */ \
+ /* the chunk's open cells (finite g; s* reads -inf) re-enter its minimum through the same 64-bit atomic the neighbours use */ \
+        "v_cmpx_class_f32 vcc, v30, %[cls]\n\t" \
+        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" \
+        "s_mov_b64 exec, s[54:55]\n\t" \
+        "v_cmpx_gt_f32 vcc, v30, v40\n\t" /* :229,:235 g[n] > g2 on in-map neighbour lanes */ \
+        "ds_write_b32 v26, v40\n\t" /* :238 g[n] = g2 */ \
+        "ds_write_b8 v46, %[pcode] offset:%[PDIR]\n\t" /* :246-249 parent = s* */ \
+        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 (key, n) enters its chunk's minimum */ \
+        "s_mov_b64 exec, -1\n\t"
+
+#define NASTAR_ASM3_OPERANDS \
+        : [it] "+s"(it), [sel] "=s"(sel) \
+        : [l8] "v"(v_l8), [dr] "v"(v_dr), [cmask] "v"(v_cmask), [dcc] "v"(v_dcc), [pcode] "v"(v_pcode), [cls] "v"(v_cls), \
+          [vminf] "v"(v_minf), [goal] "s"(goal_idx), [gr] "s"(goal_r), [gc] "s"(goal_c), \
+          [maxit] "s"(max_iters), [cgr] "s"(d.gr), [comg] "s"(d.omg), [csq] "s"(d.sqrtW), [crcp] "s"(rcp_sqrtW), \
+          [mnb] "s"(m_nb), [logp] "s"(logp), \
+          [CMIN] "i"(L::CMIN), [CMIN16] "i"(L::CMIN + 16), [PDIR] "i"(L::PDIR), [LOGW] "i"(LOGW), [WM1] "i"(L::W - 1), [W] "i"(L::W) \
+        : "memory", "vcc", "scc", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
+          "v34", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v46", "v47", "v48", "v49", "v50", "s40", "s41", "s42", \
+          "s43", "s44", "s54", "s55", "s53", "v53", "v54", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "s48", "s49", \
+          "s50", "s51"
+
+// Same contract as compact_search_loop_asm; precondition: every cost >= +0, g_ratio in [0, 1] (keys are raw float bits).
+template <int LOGW, bool kLog>
+__device__ __forceinline__ int compact_search_loop_asm3(const CompactDims& d, int lane, int goal_idx, int goal_r, int goal_c,
+                                                        int max_iters, int& iters, float rcp_sqrtW, int* log_row)
+{
+    using L = AsmLayout<LOGW>;
+    static_assert((L::CPL == 1 || L::CPL == 4) && L::HW >= 256, "1 or 4 chunk minima per lane, chunks inside one map row");
+    int dr, dc;
+    neighbour_delta(lane & 7, dr, dc);
+    const bool is_nb = lane < 8, is_chk = (lane & 48) == 16;
+    const int v_dr = is_nb ? dr : 0;
+    const int v_dcc = is_nb ? dc : (is_chk ? (lane & 15) : 0);
+    const uint32_t v_cmask = is_chk ? 0xFFFFFFF0u : 0xFFFFFFFFu;
+    const uint32_t v_cls = is_chk ? 0x1F8u : 0u;  // v_cmp_class: -normal | -denormal | -0 | +0 | +denormal | +normal = finite = open
+    const uint32_t v_pcode = P_PASS | (uint32_t)(lane & 7);
+    const uint32_t v_l8 = (uint32_t)lane * 8u * L::CPL;
+    const float v_minf = NASTAR_NEG_INF;
+    const unsigned long long m_nb = 0xFFull;
+    int it = __builtin_amdgcn_readfirstlane(iters);
+    goal_idx = __builtin_amdgcn_readfirstlane(goal_idx);
+    goal_r = __builtin_amdgcn_readfirstlane(goal_r);
+    goal_c = __builtin_amdgcn_readfirstlane(goal_c);
+    max_iters = __builtin_amdgcn_readfirstlane(max_iters);
+    int sel;
+    unsigned long long logp = reinterpret_cast<unsigned long long>(log_row);
+#define NASTAR_ASM3_BODY(N, LOGPART) \
+    NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N NASTAR_ASM_LOOPTOP NASTAR_ASM_LOCALMIN_##N NASTAR_ASM_SELECT LOGPART NASTAR_ASM3_EXPAND \
+        NASTAR_ASM_READ_##N NASTAR_ASM_LOOPEND
+    if constexpr (L::CPL == 1) {
+        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(1, NASTAR_ASM_LOG) NASTAR_ASM3_OPERANDS);
+        else asm volatile(NASTAR_ASM3_BODY(1, ) NASTAR_ASM3_OPERANDS);
+    } else {
+        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(4, NASTAR_ASM_LOG) NASTAR_ASM3_OPERANDS);
+        else asm volatile(NASTAR_ASM3_BODY(4, ) NASTAR_ASM3_OPERANDS);
+    }
+#undef NASTAR_ASM3_BODY
+    iters = it;
+    return sel;
+}
+
+}  // namespace nastar

@@ -93,12 +93,15 @@ __device__ __forceinline__ float heuristic0_fast(int r, int c, int goal_r, int g
 
 // ITER > 0: the map has exactly ITER * 256 cells (compile-time size): the loads of up to 4 iterations (16 x 16 B per lane) are all
 // issued before the first is consumed, so a map costs ~one HBM latency to load instead of one per iteration.
+// any_signed (optional): set when some cost is < 0 or NaN (wave-uniform) -- the round-3 instruction stream keys on raw float bits
 template <bool kVec4, int ITER = 0>
 __device__ __forceinline__ void compact_load_map(const CompactDims& d, const CompactLds& l, const float* __restrict__ cost,
                                                  const float* __restrict__ start, const float* __restrict__ goal,
-                                                 const float* __restrict__ passable, int lane, int& start_idx, int& goal_idx)
+                                                 const float* __restrict__ passable, int lane, int& start_idx, int& goal_idx,
+                                                 bool* any_signed = nullptr)
 {
     int sidx = -1, gidx = -1;
+    bool sgn = false;
     if constexpr (kVec4) {
         const float4* s4 = reinterpret_cast<const float4*>(start);
         const float4* g4 = reinterpret_cast<const float4*>(goal);
@@ -114,6 +117,7 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
             if (gv.y != 0.f) gidx = i + 1;
             if (gv.z != 0.f) gidx = i + 2;
             if (gv.w != 0.f) gidx = i + 3;
+            sgn |= !(cv.x >= 0.f) | !(cv.y >= 0.f) | !(cv.z >= 0.f) | !(cv.w >= 0.f);
             float4 lo, hi;
             lo.x = pv.x != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
             lo.y = cv.x;
@@ -155,6 +159,7 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
             if (start[i] != 0.f) sidx = i;
             if (goal[i] != 0.f) gidx = i;
             const float pv = passable[i];
+            sgn |= !(cost[i] >= 0.f);
             l.gc[i] = make_float2(pv != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF, cost[i]);
             l.pdir[i] = (uint8_t)(PARENT_UNSET | (pv != 0.f ? P_PASS : 0u));
         }
@@ -163,19 +168,21 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
     for (int c = lane; c < d.NCp; c += 64) l.cmin[c] = ~0ull;
     start_idx = wave_max_i32(sidx);
     goal_idx = wave_max_i32(gidx);
+    if (any_signed != nullptr) *any_signed = __ballot(sgn) != 0ull;
     wave_sync();
 }
 
-// open list = {start} (:187), g[start] = 0 (:193)
+// open list = {start} (:187), g[start] = 0 (:193).  raw_key: the key is the bit pattern of q itself (nastar_search_asm3.hip.h, q >= +0)
 template <bool kFastDiv>
 __device__ __forceinline__ void compact_open_start(const CompactDims& d, const CompactLds& l, int lane, int sidx, int goal_r,
-                                                   int goal_c, float rcp_sqrtW)
+                                                   int goal_c, float rcp_sqrtW, bool raw_key = false)
 {
     if (lane == 0) {
         const int r = (int)div_magic((uint32_t)sidx, d.magicW);
         const int c = sidx - r * d.W;
         const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + l.gc[sidx].y);  // :191-192 h = h0 + cost ; :206
-        const uint32_t k0 = compact_key<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
+        uint32_t k0 = compact_key<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
+        if (raw_key) k0 = __float_as_uint(ord_to_f32(k0));
         l.gc[sidx].x = 0.0f;
         l.cmin[sidx >> CCL] = cmin_entry(k0, (uint32_t)sidx);
         l.pdir[sidx] = (uint8_t)(PARENT_UNSET | P_PASS);  // the start is expanded even if it sits on an obstacle (:187)

@@ -35,6 +35,7 @@ _ERR_NAMES = {
 # every symbol include/nastar.h declares -- tests check the library exports all of them
 EXPORTED_SYMBOLS = (
     "nastar_version",
+    "nastar_has_dev_kernels",
     "nastar_last_error",
     "nastar_workspace_bytes",
     "nastar_forward",
@@ -104,6 +105,8 @@ def load() -> ctypes.CDLL:
     vp, ci, cd, cz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
     lib.nastar_version.restype = ci
     lib.nastar_version.argtypes = []
+    lib.nastar_has_dev_kernels.restype = ci
+    lib.nastar_has_dev_kernels.argtypes = []
     lib.nastar_last_error.restype = ctypes.c_char_p
     lib.nastar_last_error.argtypes = []
     lib.nastar_workspace_bytes.restype = cz

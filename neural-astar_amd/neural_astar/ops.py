@@ -156,7 +156,11 @@ def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
     if sel_log.numel() > 0 and BACKWARD_MODE != "reselect":  # the forward logged its selections: replay them
         grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
                                                            ctx.g_ratio, ctx.max_iters, iters, t_batch)
-    else:  # round-1 kernels: repeat the selection and sweep the open list every step (LDS-resident maps only)
+    else:  # round-1 kernels: repeat the selection and sweep the open list every step (LDS-resident maps only; `make DEV=1` builds)
+        if not _native.load().nastar_has_dev_kernels():
+            raise RuntimeError("backward needs the forward's selection log: call astar_forward(..., want_log=True) "
+                               "(DifferentiableAstar.forward does whenever cost_maps.requires_grad); the log-free round-1 backward "
+                               "kernels are only in development builds (make -C neural-astar_amd/csrc DEV=1)")
         grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
                                                     ctx.max_iters, iters, t_batch)
     return grad_cost, None, None, None, None, None, None
