@@ -92,6 +92,8 @@ namespace nastar {
           "s50", "s51"
 
 // Same contract as compact_search_loop_asm; precondition: every cost >= +0, g_ratio in [0, 1] (keys are raw float bits).
+// Tried on top (measured, dropped): running the expansion's LDS reads under EXEC = lanes 0-8 and 16-31 only: 173.0 vs 169.5 us (maze32),
+// 83.8 vs 79.7 (rand32) -- the extra s_mov on the lone-wave path costs more than the LDS passes it saves.
 template <int LOGW, bool kLog>
 __device__ __forceinline__ int compact_search_loop_asm3(const CompactDims& d, int lane, int goal_idx, int goal_r, int goal_c,
                                                         int max_iters, int& iters, float rcp_sqrtW, int* log_row)

@@ -137,6 +137,8 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
         if constexpr (ITER > 0) {
             constexpr int G = ITER < 4 ? ITER : 4;
             static_assert(ITER % G == 0, "groups of up to 4 iterations");
+            // VanillaAstar hands ONE tensor over as cost map and obstacle map (astar.py:93-94): read it once (wave-uniform test)
+            const bool same_cp = passable == cost;
             for (int base = 0; base < ITER; base += G) {
                 float4 sv[G], gv[G], cv[G], pv[G];
 #pragma unroll
@@ -145,7 +147,13 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
                     sv[k] = s4[q];
                     gv[k] = g4[q];
                     cv[k] = c4[q];
-                    pv[k] = p4[q];
+                }
+                if (same_cp) {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) pv[k] = cv[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) pv[k] = p4[lane + (base + k) * 64];
                 }
 #pragma unroll
                 for (int k = 0; k < G; ++k) place(lane + (base + k) * 64, sv[k], gv[k], cv[k], pv[k]);

@@ -637,6 +637,12 @@ def unet_supported(unet: nn.Module, H: int, W: int) -> bool:
     depth = model.depth
     if H % (1 << depth) or W % (1 << depth) or W > 126:
         return False
+    # every convolution but the 1-channel head must produce a multiple of 32 channels (the training kernels do not pad outputs; the
+    # inference path does): encoder_depth = 5 ends in a 16-channel decoder block and stays on torch.nn -- decided HERE, before any
+    # BatchNorm running statistic has been touched
+    convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
+    if not convs or any(c.out_channels % 32 for c in convs if c.out_channels != 1) or convs[0].in_channels > 32:
+        return False
     return all(chunk_rows(H >> l, W >> l) > 0 and (W >> l) >= 2 for l in range(depth + 1))
 
 

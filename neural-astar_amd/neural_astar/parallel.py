@@ -121,7 +121,7 @@ def _equal_shards(n_local: int, group: Optional[dist.ProcessGroup], device: torc
 
 def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = None,
                       async_op: bool = False, unpack: bool = True, order: Optional[torch.Tensor] = None,
-                      check_sizes: bool = True):
+                      check_sizes: Optional[bool] = None):
     """Collate the per-rank ``AstarOutput`` of equally sized shards with ONE all-gather (RCCL on GPUs).
 
     Returns ``AstarOutput`` of the full batch (rank-major row order, or the original order when ``order`` =
@@ -134,7 +134,10 @@ def all_gather_output(out: AstarOutput, group: Optional[dist.ProcessGroup] = Non
     ``intermediate_results`` list."""
     H, W = out.histories.shape[-2:]
     packed = pack_masks(out.histories.detach(), out.paths)
-    if check_sizes:
+    # the shard-size check is an extra all-reduce + a host sync: on by default for the blocking form only -- the async form exists to
+    # overlap the collective with the next batch's search and must not block on the host (pass check_sizes=True to force it; the
+    # decision must not depend on per-rank state, or a rank that skips the check would leave the others waiting in its all-reduce)
+    if check_sizes or (check_sizes is None and not async_op):
         _equal_shards(packed.shape[0], group, packed.device)
     world = dist.get_world_size(group)
     gathered = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.uint8, device=packed.device)

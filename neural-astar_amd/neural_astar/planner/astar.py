@@ -80,10 +80,11 @@ class NeuralAstar(VanillaAstar):
         self.use_differentiable_astar = use_differentiable_astar
         # "torch" (default, fp32 torch.nn), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder,
         # csrc/nastar_encoder.hip.h), "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the matrix work, cost
-        # maps within 1e-5 of the fp32 encoder).  With a hip_* backend: eval mode under no_grad = the inference kernels (CNN of any
-        # depth / size, CNNDownSize, Unet); training mode with autograd on = the training kernels for the depth-4 CNN
-        # (neural_astar/encoder_train.py: forward, input and weight gradients, batch-statistics BatchNorm); every other combination
-        # (eval mode with gradients, other encoders in training) stays on torch.nn.  Not part of the reference's constructor signature.
+        # maps within 1e-5 of the fp32 encoder -- the only hip_* mode that meets the reference's float tolerance).  With a hip_*
+        # backend: eval mode under no_grad = the inference kernels (CNN of any depth / size, CNNDownSize, Unet); training mode with
+        # autograd on = the training kernels of neural_astar/encoder_train.py (forward, input and weight gradients, batch-statistics
+        # BatchNorm, max-pool, upsample-concat) for CNN of any depth / map size, CNNDownSize and the VggUnet definition of Unet;
+        # shapes those kernels do not take, and eval mode with gradients, stay on torch.nn.  Not part of the reference's constructor.
         self.encoder_backend = "torch"
         self._hip_encoder = None
 
@@ -116,7 +117,9 @@ class NeuralAstar(VanillaAstar):
                 and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
                 and map_designs.shape[-2:] == start_maps.shape[-2:]):
             from ..encoder_train import unet_supported, unet_train_forward
-            if unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1]):
+            first = next(m for m in self.encoder.model.modules() if isinstance(m, nn.Conv2d))
+            if (unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
+                    and first.in_channels == 1 + int("+" in self.encoder_input)):
                 return unet_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
                                           "f16" if self.encoder_backend == "hip_f16" else "f16x3")
         if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
@@ -140,8 +143,8 @@ class NeuralAstar(VanillaAstar):
                 and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
                 and _is_depth4_cnn(self.encoder)):
             precision = self.encoder_backend[4:]
-            if getattr(self._hip_encoder, "precision", None) != precision:
-                from ..encoder_hip import HipCnnEncoder
+            from ..encoder_hip import HipCnnEncoder
+            if type(self._hip_encoder) is not HipCnnEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipCnnEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
         if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()

@@ -31,15 +31,42 @@ class UnsolvableMapError(RuntimeError):
     (SURVEY.md section 0.4); here the kernel reports a per-map status instead."""
 
 
+class _PendingStatus:
+    """status of an earlier call on its way to the host: a device-side any() + a non-blocking copy into pinned memory + an event"""
+
+    def __init__(self, status: torch.Tensor):
+        self.status = status
+        self.flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
+        self.flag.copy_((status != 0).any().reshape(1), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(status.device))
+
+    def raise_if_unsolvable(self) -> None:
+        self.event.synchronize()  # long past by the time the next call is issued
+        if bool(self.flag[0]):
+            _raise_unsolvable(self.status)
+
+
+def _raise_unsolvable(status: torch.Tensor) -> None:
+    bad = torch.nonzero(status != 0).flatten().tolist()
+    raise UnsolvableMapError(
+        f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map "
+        f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''})")
+
+
 class DifferentiableAstar(nn.Module):
-    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, check_solvable: bool = True):
+    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, check_solvable=True):
         """
         Args:
             g_ratio: weight of g(v) in f = g_ratio*g + (1-g_ratio)*h; 0 = best-first search (reference :129-135).
             Tmax: fraction of W*W search steps allowed in training mode (reference :135,:200-202).
-            check_solvable: synchronise once per call and raise ``UnsolvableMapError`` if any map's open list ran
-                empty (extension over the reference, which crashes).  Set False to stay fully asynchronous; the
-                per-map status is then available as ``self.last_status``.
+            check_solvable: what to do about maps whose open list ran empty (extension over the reference, which crashes with an
+                ``IndexError`` inside ``backtrack`` for the whole batch):
+                ``True`` / ``"deferred"`` (default) -- NO host synchronisation in ``forward()``: the per-map status travels to the
+                host asynchronously and ``UnsolvableMapError`` is raised by the NEXT ``forward()`` call or by
+                ``raise_if_unsolvable()`` (call it after the last batch); ``"sync"`` -- wait for the kernel and raise in the same
+                call (one device->host sync per call: +20 % on a 4096-map 32x32 batch); ``False`` -- never raise.
+                The per-map status of the latest call is always available as ``self.last_status``.
         """
         super().__init__()
         nf = torch.ones(1, 1, 3, 3)
@@ -52,6 +79,26 @@ class DifferentiableAstar(nn.Module):
         self.check_solvable = check_solvable
         self.last_status: Optional[torch.Tensor] = None
         self.last_iters: Optional[torch.Tensor] = None
+        self._pending: Optional[_PendingStatus] = None
+
+    def raise_if_unsolvable(self) -> None:
+        """Raise ``UnsolvableMapError`` if the most recent ``forward()`` call (deferred mode) met an unsolvable map."""
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            pending.raise_if_unsolvable()
+
+    def note_status(self, status: torch.Tensor, iters: torch.Tensor) -> None:
+        """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
+        step and the validation pair, which launch the search themselves)"""
+        self.last_status, self.last_iters = status, iters
+        mode = self.check_solvable
+        if not mode or torch.cuda.is_current_stream_capturing():  # nothing may synchronise inside a hipGraph capture
+            return
+        if mode == "sync":
+            if bool((status != 0).any()):
+                _raise_unsolvable(status)
+            return
+        self._pending = _PendingStatus(status)
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
                 obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
@@ -71,14 +118,11 @@ class DifferentiableAstar(nn.Module):
         # autograd will need it
         want_log = bool(store_intermediate_results) or (
             torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
+        if not torch.cuda.is_current_stream_capturing():
+            self.raise_if_unsolvable()  # deferred verdict on the previous call's maps
         hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
             cost, start, goal, passable, float(self.g_ratio), max_iters, want_log)
-        self.last_status, self.last_iters = status, iters
-        if self.check_solvable and bool((status != 0).any()):
-            bad = torch.nonzero(status != 0).flatten().tolist()
-            raise UnsolvableMapError(
-                f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map "
-                f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''})")
+        self.note_status(status, iters)
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:

@@ -122,13 +122,11 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
     else:
         cost_maps, obstacles = map_designs, map_designs
     astar = planner.astar
+    if not torch.cuda.is_current_stream_capturing():
+        astar.raise_if_unsolvable()  # deferred verdict on the previous step's maps
     W = cost_maps.shape[-1]
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)
     loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
                                                          opt_trajs[:, 0], astar.g_ratio, max_iters)
-    astar.last_status, astar.last_iters = status, iters
-    if astar.check_solvable and bool((status != 0).any()):  # same contract as DifferentiableAstar.forward (one sync per call)
-        from ..planner.differentiable_astar import UnsolvableMapError
-        bad = torch.nonzero(status != 0).flatten().tolist()
-        raise UnsolvableMapError(f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map (batch rows {bad[:16]})")
+    astar.note_status(status, iters)  # same contract as DifferentiableAstar.forward (deferred verdict by default: no host sync)
     return loss, AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), [])

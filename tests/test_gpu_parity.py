@@ -163,8 +163,23 @@ def test_unsolvable_and_degenerate_maps_report_status():
     assert iters[2] == 1 and hist[2].sum() == 1 and paths[2].sum() == 1
     from neural_astar.planner import VanillaAstar
     from neural_astar.planner.differentiable_astar import UnsolvableMapError
+    va = VanillaAstar().to(_dev())
+    va.astar.check_solvable = "sync"               # one host sync per call: raises in the same call
     with pytest.raises(UnsolvableMapError):
-        VanillaAstar().to(_dev())(_t(m), _t(s), _t(g))
+        va(_t(m), _t(s), _t(g))
+    va = VanillaAstar().to(_dev())                 # default = deferred: forward() itself never waits for the kernel ...
+    out = va(_t(m), _t(s), _t(g))
+    assert out.histories.shape == (3, 1, 16, 16) and va.astar.last_status.tolist() == [3, 0, 0]
+    with pytest.raises(UnsolvableMapError):        # ... the NEXT call (or raise_if_unsolvable()) delivers the verdict
+        va(_t(m[1:]), _t(s[1:]), _t(g[1:]))
+    va(_t(m[1:]), _t(s[1:]), _t(g[1:]))            # the solvable batch itself is fine
+    va.astar.raise_if_unsolvable()
+    va(_t(m), _t(s), _t(g))
+    with pytest.raises(UnsolvableMapError):
+        va.astar.raise_if_unsolvable()
+    va.astar.check_solvable = False
+    va(_t(m), _t(s), _t(g))
+    va.astar.raise_if_unsolvable()
     with pytest.raises(AssertionError):
         VanillaAstar().to(_dev())(_t(m[:, 0]), _t(s[:, 0]), _t(g[:, 0]))  # non-4-D input (reference :172-175)
 
@@ -521,7 +536,7 @@ def test_fused_l1_training_step_matches_autograd_through_l1loss(training):
     mi = ops.max_iters_for(32, 0.25, training)
     c1 = _t(syn.random_costs(64, 32, 32, seed=5))[:, 0].contiguous().requires_grad_(True)
     c2 = c1.detach().clone().requires_grad_(True)
-    hist, _, _, _, _ = torch.ops.nastar.astar_forward(c1, s, go, m, 0.5, mi, False)
+    hist, _, _, _, _ = torch.ops.nastar.astar_forward(c1, s, go, m, 0.5, mi, True)  # the selection log is the backward's tape
     loss_ref = torch.nn.L1Loss()(hist, traj)
     (3.0 * loss_ref).backward()
     loss, h2, p2, it2, st2 = ops.astar_l1_loss(c2, s, go, m, traj, 0.5, mi)
@@ -781,3 +796,33 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
                 assert (outs[0][3] == 0).all()
     finally:
         ops.FORWARD_FLAGS = prev
+
+
+def test_vanilla_astar_forward_is_hipgraph_capturable_and_has_no_host_sync():
+    """The default forward() (deferred solvability verdict) must not synchronise the host: captured into a hipGraph on a side stream
+    and replayed on fresh inputs it reproduces the eager outputs (reference astar.py:73-102 is one module call per batch)."""
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    pr = syn.maze_maps(256, 32, seed=41)
+    pr2 = syn.maze_maps(256, 32, seed=42)
+    m, s, g = (_t(x).clone() for x in pr)
+    va = VanillaAstar().to(dev).eval()
+    with torch.no_grad():
+        ref2 = va(*(_t(x) for x in pr2))
+        va.astar.raise_if_unsolvable()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up on the capture stream (library load, LDS attribute calls)
+                va(m, s, g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        va.astar.raise_if_unsolvable()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = va(m, s, g)
+        for dst, src in zip((m, s, g), pr2):
+            dst.copy_(_t(src))
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out.histories, ref2.histories) and torch.equal(out.paths, ref2.paths)

@@ -18,7 +18,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 SQ2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU"
-for V in 0 1; do
+for V in 0 16; do
   NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ --kernel-trace -d $OUT/sq_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq_f$V.log 2>&1
   NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ2 --kernel-trace -d $OUT/sq2_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq2_f$V.log 2>&1
 done
@@ -55,7 +55,7 @@ def counters(pat):
     return {k: {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items() if "nastar" in k}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c] = counters("$OUT/pmc_%s/**/*counter_collection.csv" % c)
-for V in ("0", "1"):
+for V in ("0", "16"):
     d = counters("$OUT/sq_f%s/**/*counter_collection.csv" % V)
     d2 = counters("$OUT/sq2_f%s/**/*counter_collection.csv" % V)
     for k in d2:
