@@ -209,13 +209,15 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         }
     }
     wave_sync();
-    if (goal_idx >= 0) compact_backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    compact_store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off,
-                                 a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
+    // histories depend on the closed list only: their stores are issued first and drain under the serial backtrack
+    compact_store_hist<kVec4>(d, l, lane, a.hist + off);
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
     }
+    if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
+    compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
+                                        a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
 }
 
 #if NASTAR_DEV_KERNELS  // measured non-improvements kept for the record (make DEV=1): two maps per wavefront, register-resident state

@@ -347,37 +347,79 @@ __device__ __forceinline__ int compact_parent_of(const CompactDims& d, int n, ui
     return n - (dr * d.W + dc);
 }
 
-// backtrack (differentiable_astar.py:96-125), see nastar_search.hip.h::backtrack for the equivalence argument
+// backtrack (differentiable_astar.py:96-125), see nastar_search.hip.h::backtrack for the equivalence argument.
+// The walk is a serial pointer chase by lane 0 on the launch's critical path (the longest search usually has a long path): one LDS
+// round trip per hop + the parent decode.  LOGW > 0 (W = 2^LOGW <= 64): the eight "cell - parent" offsets dr*W + dc sit as signed
+// bytes in one 64-bit constant, so the decode is shift / sign-extend / subtract instead of neighbour_delta's compare chain.
+template <int LOGW = 0>
 __device__ __forceinline__ void compact_backtrack(const CompactDims& d, const CompactLds& l, int lane, int start_idx, int goal_idx,
                                                   int cap)
 {
     if (lane == 0) {
+        auto parent_of = [&](int n, uint32_t code) -> int {
+            if constexpr (LOGW > 0 && LOGW <= 6) {
+                constexpr int W = 1 << LOGW;
+                constexpr unsigned long long LUT =
+                    ((unsigned long long)(uint8_t)(int8_t)(-W - 1)) | ((unsigned long long)(uint8_t)(int8_t)(-W) << 8) |
+                    ((unsigned long long)(uint8_t)(int8_t)(-W + 1) << 16) | ((unsigned long long)(uint8_t)(int8_t)(-1) << 24) |
+                    ((unsigned long long)(uint8_t)(int8_t)(1) << 32) | ((unsigned long long)(uint8_t)(int8_t)(W - 1) << 40) |
+                    ((unsigned long long)(uint8_t)(int8_t)(W) << 48) | ((unsigned long long)(uint8_t)(int8_t)(W + 1) << 56);
+                return n - (int)(int8_t)(LUT >> (code * 8u));
+            } else {
+                return compact_parent_of(d, n, code);
+            }
+        };
         uint32_t m = l.pdir[goal_idx];
         l.pdir[goal_idx] = (uint8_t)(m | P_PATH);
         uint32_t code = m & P_DIRMASK;
         if (code != PARENT_UNSET) {
-            int loc = compact_parent_of(d, goal_idx, code);
+            int loc = parent_of(goal_idx, code);
             for (int k = 0; k < cap; ++k) {
                 uint32_t ml = l.pdir[loc];
                 l.pdir[loc] = (uint8_t)(ml | P_PATH);
                 if (loc == start_idx) break;
                 uint32_t cd = ml & P_DIRMASK;
                 if (cd == PARENT_UNSET) break;  // cannot happen for an opened non-start node
-                loc = compact_parent_of(d, loc, cd);
+                loc = parent_of(loc, cd);
             }
         }
     }
     wave_sync();
 }
 
-// AstarOutput.histories (fp32 0/1), .paths (int64 0/1) and optionally the 2-bit-per-cell packed masks (see store_outputs)
+// AstarOutput.histories alone (fp32 0/1): depends on the closed list only, so it can be written BEFORE the serial backtrack -- the
+// stores drain while lane 0 walks the parent chain (compact_store_outputs<.., kHist = false> then writes the paths)
 template <bool kVec4>
+__device__ __forceinline__ void compact_store_hist(const CompactDims& d, const CompactLds& l, int lane, float* __restrict__ hist)
+{
+    if constexpr (kVec4) {
+        const int n4 = d.HW >> 2;
+        float4* h4 = reinterpret_cast<float4*>(hist);
+        for (int q = lane; q < n4; q += 64) {
+            const uint32_t m = *reinterpret_cast<const uint32_t*>(l.pdir + (q << 2));
+            const float4 lo = *reinterpret_cast<const float4*>(l.gc + (q << 2));
+            const float4 hi = *reinterpret_cast<const float4*>(l.gc + (q << 2) + 2);
+            float4 v;
+            v.x = ((m & P_PASS) && lo.x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.y = ((m & (P_PASS << 8)) && lo.z == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.z = ((m & (P_PASS << 16)) && hi.x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            v.w = ((m & (P_PASS << 24)) && hi.z == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            h4[q] = v;
+        }
+    } else {
+        for (int i = lane; i < d.HW; i += 64) hist[i] = ((l.pdir[i] & P_PASS) && l.gc[i].x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+    }
+}
+
+// AstarOutput.histories (fp32 0/1), .paths (int64 0/1) and optionally the 2-bit-per-cell packed masks (see store_outputs)
+template <bool kVec4, bool kHist = true>
 __device__ __forceinline__ void compact_store_outputs(const CompactDims& d, const CompactLds& l, int lane, float* __restrict__ hist,
                                                       long long* __restrict__ paths, uint8_t* __restrict__ packed = nullptr)
 {
     if constexpr (kVec4) {
         const int n4 = d.HW >> 2;
         float4* h4 = reinterpret_cast<float4*>(hist);
+        if (kHist || packed != nullptr)
         for (int q = lane; q < n4; q += 64) {
             const uint32_t m = *reinterpret_cast<const uint32_t*>(l.pdir + (q << 2));
             const float4 lo = *reinterpret_cast<const float4*>(l.gc + (q << 2));
@@ -391,7 +433,7 @@ __device__ __forceinline__ void compact_store_outputs(const CompactDims& d, cons
             v.y = c1 ? 1.0f : 0.0f;
             v.z = c2 ? 1.0f : 0.0f;
             v.w = c3 ? 1.0f : 0.0f;
-            h4[q] = v;
+            if (kHist) h4[q] = v;
             if (packed != nullptr) {  // wave-uniform
                 const uint32_t nh = (c0 ? 8u : 0u) | (c1 ? 4u : 0u) | (c2 ? 2u : 0u) | (c3 ? 1u : 0u);
                 const uint32_t np = ((m & P_PATH) ? 8u : 0u) | ((m & (P_PATH << 8)) ? 4u : 0u) |
@@ -417,7 +459,7 @@ __device__ __forceinline__ void compact_store_outputs(const CompactDims& d, cons
     } else {
         for (int i = lane; i < d.HW; i += 64) {
             const uint32_t m = l.pdir[i];
-            hist[i] = ((m & P_PASS) && l.gc[i].x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+            if (kHist) hist[i] = ((m & P_PASS) && l.gc[i].x == NASTAR_NEG_INF) ? 1.0f : 0.0f;
             paths[i] = (m & P_PATH) ? 1 : 0;
         }
     }
