@@ -24,8 +24,57 @@
 
 namespace nastar {
 
-#define NASTAR_ASM3_EXPAND \
+#define NASTAR_ASM3_SELECT \
+ /* ---- select: first cell of the minimal (key, index) chunk entry.  v21 arrives from LDS (no VALU->DPP hazard), so the three      \
+    quad permutations all read IT and only the combined quad minimum waits for the next stage: 4 instructions, no s_nop;       \
+    the step counter moves into one of the remaining wait states (the exits below undo it) */ \
+        "v_min_u32_dpp v22, v21, v21 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32_dpp v23, v21, v21 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32_dpp v22, v21, v22 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32 v22, v22, v23\n\t" \
         "s_add_u32 %[it], %[it], 1\n\t" \
+        "s_nop 0\n\t" \
+        "v_min_u32_dpp v22, v22, v22 row_half_mirror row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v22, v22, v22 row_mirror row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v22, v22, v22 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_min_u32_dpp v22, v22, v22 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+        "s_nop 0\n\t" \
+        "v_readlane_b32 s40, v22, 63\n\t" /* M = minimal key */ \
+        "s_cmp_eq_u32 s40, -1\n\t" \
+        "s_cbranch_scc1 .Lempty%=\n\t" /* open list empty */ \
+        "v_cmp_eq_u32 vcc, s40, v21\n\t" \
+        "s_ff1_i32_b64 s41, vcc\n\t" /* first lane (= first chunks) with the minimum */ \
+        "v_readlane_b32 s42, v20, s41\n\t" /* s* (its entry names the chunk's first minimal cell) */ \
+        "s_cmp_eq_u32 s42, %[goal]\n\t" \
+        "s_cbranch_scc1 .Lgoal%=\n\t"
+#define NASTAR_ASM3_LOG \
+        "s_lshl_b32 s53, %[it], 2\n\t"                    /* sel_log[iters] = s*; the counter already includes this step */ \
+        "s_sub_u32 s53, s53, 4\n\t"                                                                                        \
+        "v_mov_b32 v53, s53\n\t"                                                                                           \
+        "v_mov_b32 v54, s42\n\t"                                                                                           \
+        "s_mov_b64 exec, 1\n\t"                                                                                            \
+        "global_store_dword v53, v54, %[logp]\n\t"                                                                         \
+        "s_mov_b64 exec, -1\n\t"
+#define NASTAR_ASM3_LOOPEND \
+        "s_cmp_lt_u32 %[it], %[maxit]\n\t" \
+        "s_cbranch_scc1 .Lloop%=\n" \
+        ".Lbudget%=:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" /* the prefetched chunk minima must have landed before v20/v21 are released */ \
+        "s_mov_b32 %[sel], -2\n\t" \
+        "s_branch .Lend%=\n" \
+        ".Lempty%=:\n\t" \
+        "s_sub_u32 %[it], %[it], 1\n\t" /* the selection that found nothing was not a step */ \
+        "s_mov_b32 %[sel], -1\n\t" \
+        "s_branch .Lend%=\n" \
+        ".Lgoal%=:\n\t" \
+        "s_sub_u32 %[it], %[it], 1\n\t" /* the goal's own step is counted by the caller */ \
+        "s_mov_b32 %[sel], s42\n" \
+        ".Lend%=:\n\t"
+
+#define NASTAR_ASM3_EXPAND \
         "s_lshr_b32 s43, s42, %[LOGW]\n\t" /* r* */ \
         "s_and_b32 s44, s42, %[WM1]\n\t" /* c* */ \
         "v_add_u32 v32, s43, %[dr]\n\t" /* r_l */ \
@@ -119,13 +168,13 @@ __device__ __forceinline__ int compact_search_loop_asm3(const CompactDims& d, in
     int sel;
     unsigned long long logp = reinterpret_cast<unsigned long long>(log_row);
 #define NASTAR_ASM3_BODY(N, LOGPART) \
-    NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N NASTAR_ASM_LOOPTOP NASTAR_ASM_LOCALMIN_##N NASTAR_ASM_SELECT LOGPART NASTAR_ASM3_EXPAND \
-        NASTAR_ASM_READ_##N NASTAR_ASM_LOOPEND
+    NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N NASTAR_ASM_LOOPTOP NASTAR_ASM_LOCALMIN_##N NASTAR_ASM3_SELECT LOGPART NASTAR_ASM3_EXPAND \
+        NASTAR_ASM_READ_##N NASTAR_ASM3_LOOPEND
     if constexpr (L::CPL == 1) {
-        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(1, NASTAR_ASM_LOG) NASTAR_ASM3_OPERANDS);
+        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(1, NASTAR_ASM3_LOG) NASTAR_ASM3_OPERANDS);
         else asm volatile(NASTAR_ASM3_BODY(1, ) NASTAR_ASM3_OPERANDS);
     } else {
-        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(4, NASTAR_ASM_LOG) NASTAR_ASM3_OPERANDS);
+        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(4, NASTAR_ASM3_LOG) NASTAR_ASM3_OPERANDS);
         else asm volatile(NASTAR_ASM3_BODY(4, ) NASTAR_ASM3_OPERANDS);
     }
 #undef NASTAR_ASM3_BODY

@@ -144,6 +144,7 @@ def _setup_context(ctx, inputs, output):
     ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
     ctx.g_ratio = g_ratio
     ctx.max_iters = max_iters
+    ctx.set_materialize_grads(False)  # no zero-filled gradient tensors for paths / iters / status / sel_log (4 fill launches per step)
 
 
 def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
@@ -281,11 +282,14 @@ class _AstarL1Loss(torch.autograd.Function):
         ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(hist, paths, iters, status)
+        ctx.set_materialize_grads(False)  # otherwise autograd zero-fills a gradient for every unused output: 5 fill launches per step
         return loss.reshape(()), hist, paths, iters, status
 
     @staticmethod
     def backward(ctx, g_loss, g_hist, g_paths, g_iters, g_status):
         cost, start, goal, passable, opt_trajs, hist, iters, sel_log = ctx.saved_tensors
+        if g_loss is None:
+            return None, None, None, None, None, None, None
         if sel_log.numel() > 0:
             grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
                                                                   ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters))

@@ -2,11 +2,11 @@
 # Run on the GPU box (via gpurun): the evidence the bench line's roofline block is checked against.
 #   1. rocprofv3 kernel trace + stats of the exact default bench command (N=1)          -> kernel_stats
 #   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slot limit), kernel-trace only
-#   3. SQ counters of the shipped forward kernel and, for comparison, of the round-1 LDS layout (NASTAR_FORWARD_FLAGS=1)
+#   3. SQ counters of the shipped forward kernel and, for comparison, of the round-2 instruction stream (NASTAR_FORWARD_FLAGS=16)
 #   4. kernel stats of the fused training step (forward with selection log + replay backward), 4096 maps, Tmax = 0.25
-# Usage: tools/profile_round.sh r02   -> writes gpurun_out/profiles_<tag>/ (copy the summaries into profiles/<tag>/)
+# Usage: tools/profile_round.sh r03   -> writes gpurun_out/profiles_<tag>/ (copy the summaries into profiles/<tag>/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
