@@ -283,6 +283,12 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
                              size_t workspace_bytes, void* stream);
 int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
                           long long npix, int C, int split, void* stream);
+/* Two-stage form of nastar_chan_stats_f16 (what the training path uses): per-workgroup partial sums in the caller's workspace
+ * (nastar_chan_stats_workspace_bytes), added by a second launch in a fixed order: bitwise reproducible, no zero-fill launches, no fp64
+ * atomics, and as many workgroups as the batch allows. */
+size_t nastar_chan_stats_workspace_bytes(long long npix, int C);
+int nastar_chan_stats_f16_ws(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
+                             long long npix, int C, int split, void* workspace, size_t workspace_bytes, void* stream);
 int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1, const float* k2, const float* k3, const float* ms,
                            const float* mt, uint16_t* out, long long npix, int C, int relu, int split, void* stream);
 /*

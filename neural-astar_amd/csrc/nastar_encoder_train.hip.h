@@ -47,11 +47,15 @@ __device__ __forceinline__ void store8(uint16_t* base, size_t pix, int stride, i
 
 // sums[c][0], sums[c][1] (double, accumulated with atomics: the caller zeroes them); amax_bits (optional): max |u*m| as float bits.  u == nullptr: (sum v, sum v^2);
 // otherwise (sum u*m, sum u*m*v) with the ReLU mask m = [ms[c]*v + mt[c] > 0].  256 threads = (256 / (C/8)) pixel lanes x C/8 channel groups.
+// part != nullptr (two-stage, deterministic form): instead of the atomics every workgroup writes its partial sums to part[blockIdx.x][C][2]
+// and its partial maximum to amax_part[blockIdx.x]; nastar_chan_stats_finish_kernel adds them in a fixed order.  No zero-fill launches, no
+// contended fp64 atomics (512 workgroups x 512 addresses at 4096 maps), and any number of workgroups: small batches get enough of them.
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                 const float* __restrict__ ms, const float* __restrict__ mt,
                                                                 double* __restrict__ sums, unsigned int* __restrict__ amax_bits,
-                                                                long long npix, int C)
+                                                                long long npix, int C, double* __restrict__ part = nullptr,
+                                                                float* __restrict__ amax_part = nullptr)
 {
     __shared__ double red[256][16];
     const int stride = kSplit ? 2 * C : C;
@@ -102,10 +106,15 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
             }
         }
     }
-    if (amax_bits) {  // non-negative floats order like their bit patterns
+    __shared__ float wmax[4];
+    if (amax_bits || amax_part) {  // non-negative floats order like their bit patterns
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(amax));
+        if (amax_part) {
+            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        } else if ((threadIdx.x & 63) == 0) {
+            atomicMax(amax_bits, __float_as_uint(amax));
+        }
     }
     // reduce over the pixel lanes of the workgroup (fixed order): all 16 partial sums of a thread go to LDS at once, then thread
     // (c8, e) adds the NPL pixel lanes of "its" channel; one atomic pair per channel and workgroup
@@ -119,7 +128,36 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
         const int oc8 = o >> 4, w = o & 15;
         double acc = 0.0;
         for (int k = 0; k < NPL; ++k) acc += red[k * CG + oc8][w];
-        unsafeAtomicAdd(&sums[(size_t)(oc8 * 8 + (w >> 1)) * 2 + (w & 1)], acc);
+        const size_t o2 = (size_t)(oc8 * 8 + (w >> 1)) * 2 + (w & 1);
+        if (part) part[(size_t)blockIdx.x * (size_t)(2 * C) + o2] = acc;
+        else unsafeAtomicAdd(&sums[o2], acc);
+    }
+    if (amax_part && threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+
+// second stage of the two-stage statistics: sums[o] = sum over workgroups of part[b][o], 32 lanes per output in a fixed order
+// (bitwise reproducible); workgroup 0 also reduces the partial maxima.  grid = ceil(2C / 8), 256 threads.
+__global__ __launch_bounds__(256) void nastar_chan_stats_finish_kernel(const double* __restrict__ part, const float* __restrict__ amax_part,
+                                                                       int nblk, int C2, double* __restrict__ sums, float* __restrict__ amax_out)
+{
+    const int o = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    double acc = 0.0;
+    if (o < C2)
+        for (int b = l; b < nblk; b += 32) acc += part[(size_t)b * (size_t)C2 + o];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);
+    if (o < C2 && l == 0) sums[o] = acc;
+    if (amax_out && blockIdx.x == 0) {
+        __shared__ float red[256];
+        float m = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += 256) m = fmaxf(m, amax_part[b]);
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) amax_out[0] = red[0];
     }
 }
 

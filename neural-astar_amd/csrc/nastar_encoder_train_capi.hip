@@ -113,6 +113,43 @@ int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms,
     return NASTAR_OK;
 }
 
+// two-stage form: partial sums per workgroup in the caller's workspace, then a fixed-order finishing kernel (no memsets, no atomics)
+static long long chan_stats_grid(long long npix, int C)
+{
+    const long long per = 256 / (C / 8);
+    long long grid = (npix + per * 4 - 1) / (per * 4);  // >= 4 pixels (two iterations) per pixel lane ...
+    if (grid > 1024) grid = 1024;                       // ... and at most 4 workgroups per CU
+    if (grid < 1) grid = 1;
+    return grid;
+}
+
+size_t nastar_chan_stats_workspace_bytes(long long npix, int C)
+{
+    if (npix <= 0 || C <= 0 || C % 8 || C > 2048 || 256 % (C / 8)) return 0;
+    const long long grid = chan_stats_grid(npix, C);
+    return (size_t)grid * (size_t)(2 * C) * sizeof(double) + (size_t)grid * sizeof(float);
+}
+
+int nastar_chan_stats_f16_ws(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
+                             long long npix, int C, int split, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!v || !sums || !workspace || (u && (!ms || !mt))) return NASTAR_ERR_NULL;
+    if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < nastar_chan_stats_workspace_bytes(npix, C)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long grid = chan_stats_grid(npix, C);
+    double* part = static_cast<double*>(workspace);
+    float* amax_part = reinterpret_cast<float*>(part + (size_t)grid * (size_t)(2 * C));
+    if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, nullptr, npix, C, part, amax_part);
+    else hipLaunchKernelGGL(nastar_chan_stats_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, u, v, ms, mt, sums, nullptr, npix, C, part, amax_part);
+    hipLaunchKernelGGL(nastar_chan_stats_finish_kernel, dim3((unsigned)((2 * C + 7) / 8)), dim3(256), 0, s, part, amax_part, (int)grid, 2 * C, sums,
+                       amax_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1, const float* k2, const float* k3, const float* ms,
                            const float* mt, uint16_t* out, long long npix, int C, int relu, int split, void* stream)
 {
@@ -120,7 +157,8 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
     if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
     if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
     const long long per = 256 / (C / 8);
-    long long grid = (npix + per * 16 - 1) / (per * 16);  // ~16 pixels per pixel lane
+    long long grid = (npix + per * 16 - 1) / (per * 16);  // ~16 pixels per pixel lane ...
+    if (grid < 1024) grid = (npix + per * 2 - 1) / (per * 2) < 1024 ? (npix + per * 2 - 1) / (per * 2) : 1024;  // ... but fill the chip at small batches
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -67,6 +67,8 @@ EXPORTED_SYMBOLS = (
     "nastar_conv3x3_wgrad_workspace_bytes",
     "nastar_conv3x3_wgrad_f16",
     "nastar_chan_stats_f16",
+    "nastar_chan_stats_workspace_bytes",
+    "nastar_chan_stats_f16_ws",
     "nastar_chan_affine_f16",
     "nastar_pack_conv_weight_f16",
     "nastar_bn_coef_fwd",
@@ -170,6 +172,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_conv3x3_wgrad_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
     lib.nastar_chan_stats_f16.restype = ci
     lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
+    lib.nastar_chan_stats_workspace_bytes.restype = cz
+    lib.nastar_chan_stats_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
+    lib.nastar_chan_stats_f16_ws.restype = ci
+    lib.nastar_chan_stats_f16_ws.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp, cz, vp]
     lib.nastar_chan_affine_f16.restype = ci
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_pack_conv_weight_f16.restype = ci

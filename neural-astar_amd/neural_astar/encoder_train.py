@@ -171,11 +171,15 @@ class _Lib:
         return torch.empty((n,), dtype=torch.int16, device=self.dev)
 
     def stats(self, u, v, ms, mt, npix, C, split, amax=None):
+        """per-channel double sums [C,2]: two-stage form (per-workgroup partials + a fixed-order finishing launch: deterministic)"""
         sums = torch.empty((C, 2), dtype=torch.float64, device=self.dev)
-        rc = self.lib.nastar_chan_stats_f16(u.data_ptr() if u is not None else None, v.data_ptr(),
-                                            ms.data_ptr() if ms is not None else None, mt.data_ptr() if mt is not None else None,
-                                            sums.data_ptr(), amax.data_ptr() if amax is not None else None, npix, C, int(split), self.stream)
-        _native.check(rc, "nastar_chan_stats_f16")
+        nbytes = int(self.lib.nastar_chan_stats_workspace_bytes(npix, C))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_chan_stats_f16_ws(u.data_ptr() if u is not None else None, v.data_ptr(),
+                                               ms.data_ptr() if ms is not None else None, mt.data_ptr() if mt is not None else None,
+                                               sums.data_ptr(), amax.data_ptr() if amax is not None else None, npix, C, int(split),
+                                               ws.data_ptr(), nbytes, self.stream)
+        _native.check(rc, "nastar_chan_stats_f16_ws")
         return sums
 
     def affine(self, u, v, k1, k2, k3, ms, mt, out, npix, C, relu, split):

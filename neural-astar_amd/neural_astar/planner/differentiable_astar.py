@@ -47,6 +47,11 @@ class _PendingStatus:
             _raise_unsolvable(self.status)
 
 
+def _capturing(t: torch.Tensor) -> bool:
+    """is a hipGraph capture underway on the stream this tensor's work goes to?  (CPU tensors: no -- the op itself rejects them)"""
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 def _raise_unsolvable(status: torch.Tensor) -> None:
     bad = torch.nonzero(status != 0).flatten().tolist()
     raise UnsolvableMapError(
@@ -92,7 +97,7 @@ class DifferentiableAstar(nn.Module):
         step and the validation pair, which launch the search themselves)"""
         self.last_status, self.last_iters = status, iters
         mode = self.check_solvable
-        if not mode or torch.cuda.is_current_stream_capturing():  # nothing may synchronise inside a hipGraph capture
+        if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
             return
         if mode == "sync":
             if bool((status != 0).any()):
@@ -118,7 +123,7 @@ class DifferentiableAstar(nn.Module):
         # autograd will need it
         want_log = bool(store_intermediate_results) or (
             torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
-        if not torch.cuda.is_current_stream_capturing():
+        if not _capturing(cost_maps):
             self.raise_if_unsolvable()  # deferred verdict on the previous call's maps
         hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
             cost, start, goal, passable, float(self.g_ratio), max_iters, want_log)

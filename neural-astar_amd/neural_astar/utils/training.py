@@ -122,7 +122,7 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
     else:
         cost_maps, obstacles = map_designs, map_designs
     astar = planner.astar
-    if not torch.cuda.is_current_stream_capturing():
+    if not (cost_maps.is_cuda and torch.cuda.is_current_stream_capturing()):
         astar.raise_if_unsolvable()  # deferred verdict on the previous step's maps
     W = cost_maps.shape[-1]
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)

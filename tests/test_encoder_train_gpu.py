@@ -114,6 +114,25 @@ def test_chan_stats_and_affine(split):
     assert float(amax) == float(dy.abs().max().float())
     assert torch.allclose(sums[:, 0].cpu(), dy.sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
     assert torch.allclose(sums[:, 1].cpu(), (dy * zs).sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
+    # two-stage form (what the training path launches): per-workgroup partials + a fixed-order finishing kernel -- same sums, no
+    # zero-filled outputs needed, bitwise reproducible
+    nb = int(lib.nastar_chan_stats_workspace_bytes(npix, C))
+    assert nb > 0
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    runs = []
+    for _ in range(2):
+        s2 = torch.full((C, 2), 7.0, dtype=torch.float64, device=dev)
+        a2 = torch.full((1,), -1.0, device=dev)
+        _native.check(lib.nastar_chan_stats_f16_ws(da_.data_ptr(), z_.data_ptr(), ms.data_ptr(), mt.data_ptr(), s2.data_ptr(), a2.data_ptr(),
+                                                   npix, C, int(split), ws.data_ptr(), nb, st), "stats_ws")
+        runs.append((s2.clone(), a2.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][1]) == float(amax)
+    assert torch.allclose(runs[0][0].cpu(), sums.cpu(), rtol=1e-13, atol=1e-10)
+    s3 = torch.full((C, 2), 7.0, dtype=torch.float64, device=dev)
+    _native.check(lib.nastar_chan_stats_f16_ws(None, z_.data_ptr(), None, None, s3.data_ptr(), None, npix, C, int(split), ws.data_ptr(), nb, st), "stats_ws")
+    assert torch.allclose(s3[:, 0].cpu(), zs.sum(dim=(0, 2, 3)), rtol=1e-12, atol=1e-9)
+    assert lib.nastar_chan_stats_f16_ws(None, z_.data_ptr(), None, None, s3.data_ptr(), None, npix, C, int(split), ws.data_ptr(), 8, st) == _native.NASTAR_ERR_WORKSPACE
     out = torch.empty_like(z_)
     v = lambda t: t.cpu().float().view(1, -1, 1, 1)  # noqa: E731
     for u, relu in ((None, True), (da_, False)):
