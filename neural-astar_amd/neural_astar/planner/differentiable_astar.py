@@ -41,8 +41,11 @@ class _PendingStatus:
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(status.device))
 
+    def done(self) -> bool:
+        return self.event.query()
+
     def raise_if_unsolvable(self) -> None:
-        self.event.synchronize()  # long past by the time the next call is issued
+        self.event.synchronize()
         if bool(self.flag[0]):
             _raise_unsolvable(self.status)
 
@@ -68,9 +71,11 @@ class DifferentiableAstar(nn.Module):
             check_solvable: what to do about maps whose open list ran empty (extension over the reference, which crashes with an
                 ``IndexError`` inside ``backtrack`` for the whole batch):
                 ``True`` / ``"deferred"`` (default) -- NO host synchronisation in ``forward()``: the per-map status travels to the
-                host asynchronously and ``UnsolvableMapError`` is raised by the NEXT ``forward()`` call or by
-                ``raise_if_unsolvable()`` (call it after the last batch); ``"sync"`` -- wait for the kernel and raise in the same
-                call (one device->host sync per call: +20 % on a 4096-map 32x32 batch); ``False`` -- never raise.
+                host asynchronously (a device-side any() + a copy into pinned memory + an event) and ``UnsolvableMapError`` is
+                raised by the first later ``forward()`` call that finds the verdict already on the host -- never waiting for it,
+                so the host keeps queueing launches ahead of the device -- or by ``raise_if_unsolvable()``, which waits (call it
+                after the last batch); ``"sync"`` -- wait for the kernel and raise in the same call (one device->host sync per
+                call: +25 % on a 4096-map 32x32 batch); ``False`` -- never raise.
                 The per-map status of the latest call is always available as ``self.last_status``.
         """
         super().__init__()
@@ -84,13 +89,14 @@ class DifferentiableAstar(nn.Module):
         self.check_solvable = check_solvable
         self.last_status: Optional[torch.Tensor] = None
         self.last_iters: Optional[torch.Tensor] = None
-        self._pending: Optional[_PendingStatus] = None
+        self._pending: List[_PendingStatus] = []
 
-    def raise_if_unsolvable(self) -> None:
-        """Raise ``UnsolvableMapError`` if the most recent ``forward()`` call (deferred mode) met an unsolvable map."""
-        pending, self._pending = self._pending, None
-        if pending is not None:
-            pending.raise_if_unsolvable()
+    def raise_if_unsolvable(self, wait: bool = True) -> None:
+        """Deliver the deferred verdicts: raise ``UnsolvableMapError`` if an earlier ``forward()`` call met an unsolvable map.
+        ``wait=True`` (explicit calls) waits for every outstanding launch; ``wait=False`` (what ``forward()`` does) only looks at
+        verdicts that have already reached the host."""
+        while self._pending and (wait or self._pending[0].done()):
+            self._pending.pop(0).raise_if_unsolvable()
 
     def note_status(self, status: torch.Tensor, iters: torch.Tensor) -> None:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
@@ -103,7 +109,9 @@ class DifferentiableAstar(nn.Module):
             if bool((status != 0).any()):
                 _raise_unsolvable(status)
             return
-        self._pending = _PendingStatus(status)
+        self._pending.append(_PendingStatus(status))
+        if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
+            self._pending.pop(0).raise_if_unsolvable()
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
                 obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
@@ -124,7 +132,7 @@ class DifferentiableAstar(nn.Module):
         want_log = bool(store_intermediate_results) or (
             torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
         if not _capturing(cost_maps):
-            self.raise_if_unsolvable()  # deferred verdict on the previous call's maps
+            self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
         hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
             cost, start, goal, passable, float(self.g_ratio), max_iters, want_log)
         self.note_status(status, iters)

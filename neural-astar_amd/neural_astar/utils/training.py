@@ -123,7 +123,7 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
         cost_maps, obstacles = map_designs, map_designs
     astar = planner.astar
     if not (cost_maps.is_cuda and torch.cuda.is_current_stream_capturing()):
-        astar.raise_if_unsolvable()  # deferred verdict on the previous step's maps
+        astar.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier steps that have reached the host
     W = cost_maps.shape[-1]
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)
     loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],

@@ -170,7 +170,8 @@ def test_unsolvable_and_degenerate_maps_report_status():
     va = VanillaAstar().to(_dev())                 # default = deferred: forward() itself never waits for the kernel ...
     out = va(_t(m), _t(s), _t(g))
     assert out.histories.shape == (3, 1, 16, 16) and va.astar.last_status.tolist() == [3, 0, 0]
-    with pytest.raises(UnsolvableMapError):        # ... the NEXT call (or raise_if_unsolvable()) delivers the verdict
+    torch.cuda.synchronize()                       # (the verdict has certainly reached the host now)
+    with pytest.raises(UnsolvableMapError):        # ... a LATER call (or raise_if_unsolvable()) delivers the verdict
         va(_t(m[1:]), _t(s[1:]), _t(g[1:]))
     va(_t(m[1:]), _t(s[1:]), _t(g[1:]))            # the solvable batch itself is fine
     va.astar.raise_if_unsolvable()
