@@ -203,6 +203,11 @@ def test_unet_encoder_matches_torch(precision, tol_truth, tol_torch):
               f"|torch fp32 (device) - truth| = {float((ref.cpu() - truth).abs().max()):.2e}")
         assert err_truth <= tol_truth, err_truth
         assert err_torch <= tol_torch, err_torch
+        if precision == "f16x3":
+            # the yardstick for a 26-layer stack is the float64 truth: torch's OWN fp32 module is ~7e-6 from it, so two fp32-grade
+            # implementations with different summation orders sit ~1e-5 from EACH OTHER however good they are; the split-operand
+            # path (22-bit operands) must stay within 2x of the fp32 module's own distance to the truth
+            assert err_truth <= 2.0 * float((ref.cpu() - truth).abs().max()) + 1e-6
         # the search consumes it (non-square maps as well: 16 x 48)
         out = planner(m, s, g)
         assert out.histories.shape == (24, 1, 32, 32) and float(out.paths.sum()) > 0
