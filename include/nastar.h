@@ -55,6 +55,7 @@ extern "C" {
 #define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
 #define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
 #define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
+#define NASTAR_FLAG_NO_DIVE 32   /* forward, 64x64 maps: the round-3 stream without its "dive" fast path (A/B) */
 #define NASTAR_FLAG_DUO 4        /* forward: two maps per wavefront (nastar_search_duo.hip.h), a measured non-improvement */
 
 int nastar_version(void);

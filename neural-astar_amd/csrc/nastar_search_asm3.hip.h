@@ -74,7 +74,7 @@ namespace nastar {
         "s_mov_b32 %[sel], s42\n" \
         ".Lend%=:\n\t"
 
-#define NASTAR_ASM3_EXPAND \
+#define NASTAR_ASM3_EXPAND_(INIT55, SET55) \
         "s_lshr_b32 s43, s42, %[LOGW]\n\t" /* r* */ \
         "s_and_b32 s44, s42, %[WM1]\n\t" /* c* */ \
         "v_add_u32 v32, s43, %[dr]\n\t" /* r_l */ \
@@ -97,6 +97,7 @@ namespace nastar {
         "ds_write_b64 v50, v[48:49] offset:%[CMIN]\n\t" \
         "s_mov_b64 exec, -1\n\t" \
         "ds_read_b64 v[30:31], v26\n\t" /* g[il], cost[il] */ \
+        INIT55 \
  /* h0 = get_heuristic at (r_l, c_l) (:26-52) on integers, in the shadow of the LDS round trip */ \
         "v_sad_u32 v35, v32, %[gr], 0\n\t" /* |dr| */ \
         "v_sad_u32 v36, v33, %[gc], 0\n\t" /* |dc| */ \
@@ -123,10 +124,63 @@ namespace nastar {
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" \
         "s_mov_b64 exec, s[54:55]\n\t" \
         "v_cmpx_gt_f32 vcc, v30, v40\n\t" /* :229,:235 g[n] > g2 on in-map neighbour lanes */ \
+        SET55 \
         "ds_write_b32 v26, v40\n\t" /* :238 g[n] = g2 */ \
         "ds_write_b8 v46, %[pcode] offset:%[PDIR]\n\t" /* :246-249 parent = s* */ \
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 (key, n) enters its chunk's minimum */ \
         "s_mov_b64 exec, -1\n\t"
+#define NASTAR_ASM3_EXPAND NASTAR_ASM3_EXPAND_(, )
+/* dive form: v55 = the key of every neighbour relaxed in this step, all ones elsewhere */
+#define NASTAR_ASM3_EXPAND_DIVE NASTAR_ASM3_EXPAND_("v_mov_b32 v55, -1\n\t", "v_mov_b32 v55, v47\n\t")
+
+// ---- the "dive" (64x64 instantiation only) ---------------------------------------------------------------------------------------
+// When the best neighbour relaxed in this step has a key STRICTLY below the key s* was selected with, it is the next selection: every
+// other open cell was >= (key of s*, s*) in the (key, index) order when s* won, and only the relaxed neighbours changed since.  The
+// step then continues with that neighbour without waiting for the chunk-minima read-back, the per-lane minimum of four entries and the
+// 64-lane reduction.  The test is a 3-stage minimum over lanes 0-7 (the neighbour lanes are in raster order = increasing cell index,
+// so the first lane holding the minimum is the reference's first-flat-index tie-break) + one scalar compare: ~12 instructions on every
+// step, ~35 fewer on a hit.  Hit rate on the longest searches of the bench batches (tools/sim_dive.py): 78 % on random-obstacle 64x64
+// maps (BASELINE config 4), 50-73 % on random 32x32, 26-28 % on mazes -- the 32x32 / 16x16 instantiations keep the plain loop (a net
+// loss at 27 %), the 64x64 one, whose selection phase is also the most expensive (four chunk minima per lane), dives.
+// Loop layout: both ways round cost exactly one taken branch (the dive's lookup code sits in front of the expansion and falls into it);
+// the chunk minima are still prefetched BEFORE the test (reading them only on the way into a full selection measured 2 % slower: -5.8 %
+// instead of -8.1 % against the plain loop on the rand64 batch).  Measured (4096 random-obstacle 64x64 maps, longest search 986 steps):
+// 308.6 -> 283.5 us per launch; the reference's 64x64 block fixture (1169 steps, few dives) pays 266 -> 282 ns per step.
+#define NASTAR_ASM3_DIVE_TEST \
+        "v_min_u32_dpp v56, v55, v55 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32_dpp v57, v55, v55 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32_dpp v56, v55, v56 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t" \
+        "v_min_u32 v56, v56, v57\n\t" \
+        "s_cmp_ge_u32 %[it], %[maxit]\n\t" /* the budget test doubles as the two wait states in front of the next DPP */ \
+        "s_cbranch_scc1 .Lbudget%=\n\t" \
+        "v_min_u32_dpp v56, v56, v56 row_half_mirror row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 0\n\t" \
+        "v_readfirstlane_b32 s56, v56\n\t" /* best key among the neighbours relaxed in this step (all ones: none) */ \
+        "s_cmp_lt_u32 s56, s40\n\t" \
+        "s_cbranch_scc1 .Ldive%=\n\t"
+#define NASTAR_ASM3_DIVE_LOOKUP \
+        ".Ldive%=:\n\t" \
+        "v_cmp_eq_u32 vcc, s56, v55\n\t" \
+        "s_ff1_i32_b64 s41, vcc\n\t" /* first neighbour lane with that key = smallest cell index among ties */ \
+        "v_readlane_b32 s42, v46, s41\n\t" /* the next s* */ \
+        "s_mov_b32 s40, s56\n\t" \
+        "s_add_u32 %[it], %[it], 1\n\t" \
+        "s_cmp_eq_u32 s42, %[goal]\n\t" \
+        "s_cbranch_scc1 .Lgoal%=\n" \
+        ".Lselected%=:\n\t"
+#define NASTAR_ASM3_EXITS \
+        ".Lbudget%=:\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" /* the prefetched chunk minima must have landed before their registers are released */ \
+        "s_mov_b32 %[sel], -2\n\t" \
+        "s_branch .Lend%=\n" \
+        ".Lempty%=:\n\t" \
+        "s_sub_u32 %[it], %[it], 1\n\t" \
+        "s_mov_b32 %[sel], -1\n\t" \
+        "s_branch .Lend%=\n" \
+        ".Lgoal%=:\n\t" \
+        "s_sub_u32 %[it], %[it], 1\n\t" \
+        "s_mov_b32 %[sel], s42\n" \
+        ".Lend%=:\n\t"
 
 #define NASTAR_ASM3_OPERANDS \
         : [it] "+s"(it), [sel] "=s"(sel) \
@@ -138,12 +192,12 @@ namespace nastar {
         : "memory", "vcc", "scc", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
           "v34", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v46", "v47", "v48", "v49", "v50", "s40", "s41", "s42", \
           "s43", "s44", "s54", "s55", "s53", "v53", "v54", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "s48", "s49", \
-          "s50", "s51"
+          "s50", "s51", "v55", "v56", "v57", "s56"
 
 // Same contract as compact_search_loop_asm; precondition: every cost >= +0, g_ratio in [0, 1] (keys are raw float bits).
 // Tried on top (measured, dropped): running the expansion's LDS reads under EXEC = lanes 0-8 and 16-31 only: 173.0 vs 169.5 us (maze32),
 // 83.8 vs 79.7 (rand32) -- the extra s_mov on the lone-wave path costs more than the LDS passes it saves.
-template <int LOGW, bool kLog>
+template <int LOGW, bool kLog, bool kDive = true>
 __device__ __forceinline__ int compact_search_loop_asm3(const CompactDims& d, int lane, int goal_idx, int goal_r, int goal_c,
                                                         int max_iters, int& iters, float rcp_sqrtW, int* log_row)
 {
@@ -170,13 +224,22 @@ __device__ __forceinline__ int compact_search_loop_asm3(const CompactDims& d, in
 #define NASTAR_ASM3_BODY(N, LOGPART) \
     NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N NASTAR_ASM_LOOPTOP NASTAR_ASM_LOCALMIN_##N NASTAR_ASM3_SELECT LOGPART NASTAR_ASM3_EXPAND \
         NASTAR_ASM_READ_##N NASTAR_ASM3_LOOPEND
+    /* entry -> select; [dive lookup ->] selected: log, expand, prefetch, budget + dive test -> dive | select -> selected */
+#define NASTAR_ASM3_BODY_DIVE(N, LOGPART) \
+    NASTAR_ASM_ENTRY NASTAR_ASM_READ_##N "s_branch .Lsel%=\n" NASTAR_ASM3_DIVE_LOOKUP LOGPART NASTAR_ASM3_EXPAND_DIVE NASTAR_ASM_READ_##N \
+        NASTAR_ASM3_DIVE_TEST ".Lsel%=:\n\t" "s_waitcnt lgkmcnt(0)\n\t" NASTAR_ASM_LOCALMIN_##N NASTAR_ASM3_SELECT \
+        "s_branch .Lselected%=\n" NASTAR_ASM3_EXITS
     if constexpr (L::CPL == 1) {
         if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(1, NASTAR_ASM3_LOG) NASTAR_ASM3_OPERANDS);
         else asm volatile(NASTAR_ASM3_BODY(1, ) NASTAR_ASM3_OPERANDS);
+    } else if constexpr (kDive) {
+        if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY_DIVE(4, NASTAR_ASM3_LOG) NASTAR_ASM3_OPERANDS);
+        else asm volatile(NASTAR_ASM3_BODY_DIVE(4, ) NASTAR_ASM3_OPERANDS);
     } else {
         if constexpr (kLog) asm volatile(NASTAR_ASM3_BODY(4, NASTAR_ASM3_LOG) NASTAR_ASM3_OPERANDS);
         else asm volatile(NASTAR_ASM3_BODY(4, ) NASTAR_ASM3_OPERANDS);
     }
+#undef NASTAR_ASM3_BODY_DIVE
 #undef NASTAR_ASM3_BODY
     iters = it;
     return sel;
