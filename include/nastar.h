@@ -284,6 +284,10 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
                              size_t workspace_bytes, void* stream);
 int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
                           long long npix, int C, int split, void* stream);
+/* max|w| of n fp32 tensors in ONE launch: table = device array [n][2] of (pointer, element count) as int64; scal [n][3] floats is zeroed
+ * and scal[t][2] receives max|w_t| -- the value nastar_pack_conv_weight_f16(..., reuse_max = 1) expects there. */
+int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* stream);
+
 /* Two-stage form of nastar_chan_stats_f16 (what the training path uses): per-workgroup partial sums in the caller's workspace
  * (nastar_chan_stats_workspace_bytes), added by a second launch in a fixed order: bitwise reproducible, no zero-fill launches, no fp64
  * atomics, and as many workgroups as the batch allows. */

@@ -194,6 +194,19 @@ int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_fl
     return NASTAR_OK;
 }
 
+int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* stream)
+{
+    if (!table || !scal) return NASTAR_ERR_NULL;
+    if (n <= 0 || n > 65535) return NASTAR_ERR_BAD_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(scal, 0, (size_t)n * 3 * sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    hipLaunchKernelGGL(nastar_absmax_multi_kernel, dim3(8, (unsigned)n), dim3(256), 0, s, table, scal);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta, double eps, long long npix, double momentum,
                        float* running_mean, float* running_var, float* k2, float* k3, double* mean_out, double* invstd_out, int C,
                        void* stream)

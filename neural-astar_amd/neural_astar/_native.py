@@ -68,6 +68,7 @@ EXPORTED_SYMBOLS = (
     "nastar_conv3x3_wgrad_f16",
     "nastar_chan_stats_f16",
     "nastar_chan_stats_workspace_bytes",
+    "nastar_absmax_multi_f32",
     "nastar_chan_stats_f16_ws",
     "nastar_chan_affine_f16",
     "nastar_pack_conv_weight_f16",
@@ -172,6 +173,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_conv3x3_wgrad_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
     lib.nastar_chan_stats_f16.restype = ci
     lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
+    lib.nastar_absmax_multi_f32.restype = ci
+    lib.nastar_absmax_multi_f32.argtypes = [vp, ci, vp, vp]
     lib.nastar_chan_stats_workspace_bytes.restype = cz
     lib.nastar_chan_stats_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
     lib.nastar_chan_stats_f16_ws.restype = ci

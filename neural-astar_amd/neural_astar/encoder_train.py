@@ -151,6 +151,26 @@ class _Lib:
         _native.check(rc, "nastar_pack_conv_weight_f16")
         return wpack, scale, shift, scal
 
+    _TABLES: dict = {}  # (device, data pointers, sizes) -> device table of nastar_absmax_multi_f32 (weights keep their storage across steps)
+
+    def weight_maxima(self, weights):
+        """max|w| of every convolution weight in ONE launch: float [n, 3] whose rows are the ``scal`` triples ``pack`` expects with
+        ``reuse`` (row[2] = max|w|).  Split operands only -- the plain fp16 pack needs no scale."""
+        ws = [w.detach() for w in weights]
+        if any(w.dtype != torch.float32 or not w.is_contiguous() for w in ws):
+            return None
+        key = (str(self.dev),) + tuple((w.data_ptr(), w.numel()) for w in ws)
+        table = self._TABLES.get(key)
+        if table is None:
+            if len(self._TABLES) > 64:
+                self._TABLES.clear()
+            table = torch.tensor([[w.data_ptr(), w.numel()] for w in ws], dtype=torch.int64).to(self.dev)
+            self._TABLES[key] = table
+        scal = torch.empty((len(ws), 3), dtype=torch.float32, device=self.dev)
+        rc = self.lib.nastar_absmax_multi_f32(table.data_ptr(), len(ws), scal.data_ptr(), self.stream)
+        _native.check(rc, "nastar_absmax_multi_f32")
+        return scal
+
     IMG32 = {(32, 64), (64, 128), (128, 256), (256, 128), (128, 64)}
 
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None, src2=None, c2=0):
@@ -243,11 +263,12 @@ class _CnnTrunk(torch.autograd.Function):
         with torch.cuda.device(dev):
             acts, zs, rs, coef, scals = [x0], [], [], [], []
             h, w = H, W
+            wmax = L.weight_maxima(ws) if split else None  # one launch for all D + 1 weight maxima
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
                 npix = B * h * w
-                wpack, scale, shift, scal = L.pack(wt, False, split, bs[l])
+                wpack, scale, shift, scal = L.pack(wt, False, split, bs[l], scal=wmax[l] if wmax is not None else None)
                 scals.append(scal)
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
                 L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
@@ -283,7 +304,7 @@ class _CnnTrunk(torch.autograd.Function):
                 else:
                     acts.append(r)
             wl = ws[D]
-            wpackl, scalel, shiftl, scal = L.pack(wl, False, split, bs[D])  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+            wpackl, scalel, shiftl, scal = L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None)  # cout 1 -> 32 (padded channels: zero weights, zero shift)
             scals.append(scal)
             zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
             L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
@@ -474,6 +495,9 @@ class _UnetTrunk(torch.autograd.Function):
         saved = []
         out = None
         with torch.cuda.device(dev):
+            conv_steps = [st for st in cfg["plan"] if st["kind"] != "pool"]
+            wmax = L.weight_maxima([params[st["w"]] for st in conv_steps]) if split else None  # one launch for all weight maxima
+            wrow = {id(st): k for k, st in enumerate(conv_steps)}
             for st in cfg["plan"]:
                 h, w = H // st["div"], W // st["div"]
                 if st["kind"] == "pool":
@@ -492,7 +516,7 @@ class _UnetTrunk(torch.autograd.Function):
                 src2, c2 = acts[st["skip"]] if st["skip"] is not None else (None, 0)
                 ups = CONV_UPSAMPLE if st["ups"] else 0
                 npix = B * h * w
-                wpack, scale, shift, scal = L.pack(wt, False, split, bias)
+                wpack, scale, shift, scal = L.pack(wt, False, split, bias, scal=wmax[wrow[id(st)]] if wmax is not None else None)
                 if st["final"]:
                     out = torch.empty((B, h, w), dtype=torch.float32, device=dev)
                     L.conv(src, wpack, scale, shift, B, h, w, c1, 32, sflag | CONV_FINAL | CONV_RAW, out_f32=out)
