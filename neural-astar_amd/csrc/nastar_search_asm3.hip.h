@@ -119,15 +119,16 @@ namespace nastar {
         "v_mul_f32 v42, %[crcp], v41\n\t" /* :207 f / sqrt(W), correctly rounded (tools/fastdiv_check.c) */ \
         "v_fma_f32 v43, -v42, %[csq], v41\n\t" \
         "v_fma_f32 v47, v43, %[crcp], v42\n\t" /* q >= +0: its bits are the order-preserving key; [v46:v47] = (cell, key) */ \
- /* the chunk's open cells (finite g; s* reads -inf) re-enter its minimum through the same 64-bit atomic the neighbours use */ \
-        "v_cmpx_class_f32 vcc, v30, %[cls]\n\t" \
-        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" \
+ /* the chunk's open cells (finite g; s* reads -inf) re-enter its minimum through the SAME 64-bit atomic instruction as the relaxed \
+    neighbours (EXEC = both lane sets): one LDS atomic per step instead of two -- with 16 waves per CU the LDS pipe is the shared resource */ \
+        "v_cmp_class_f32_e64 s[58:59], v30, %[cls]\n\t" /* chunk lanes whose cell is open */ \
         "s_mov_b64 exec, s[54:55]\n\t" \
         "v_cmpx_gt_f32 vcc, v30, v40\n\t" /* :229,:235 g[n] > g2 on in-map neighbour lanes */ \
         SET55 \
         "ds_write_b32 v26, v40\n\t" /* :238 g[n] = g2 */ \
         "ds_write_b8 v46, %[pcode] offset:%[PDIR]\n\t" /* :246-249 parent = s* */ \
-        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 (key, n) enters its chunk's minimum */ \
+        "s_or_b64 exec, exec, s[58:59]\n\t" \
+        "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 relaxed neighbours AND the chunk's open cells enter the chunk minima: ONE atomic */ \
         "s_mov_b64 exec, -1\n\t"
 #define NASTAR_ASM3_EXPAND NASTAR_ASM3_EXPAND_(, )
 /* dive form: v55 = the key of every neighbour relaxed in this step, all ones elsewhere */
@@ -192,7 +193,7 @@ namespace nastar {
         : "memory", "vcc", "scc", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
           "v34", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v46", "v47", "v48", "v49", "v50", "s40", "s41", "s42", \
           "s43", "s44", "s54", "s55", "s53", "v53", "v54", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "s48", "s49", \
-          "s50", "s51", "v55", "v56", "v57", "s56"
+          "s50", "s51", "v55", "v56", "v57", "s56", "s58", "s59"
 
 // Same contract as compact_search_loop_asm; precondition: every cost >= +0, g_ratio in [0, 1] (keys are raw float bits).
 // Tried on top (measured, dropped): running the expansion's LDS reads under EXEC = lanes 0-8 and 16-31 only: 173.0 vs 169.5 us (maze32),
