@@ -142,7 +142,8 @@ namespace nastar {
 // so the first lane holding the minimum is the reference's first-flat-index tie-break) + one scalar compare: ~12 instructions on every
 // step, ~35 fewer on a hit.  Hit rate on the longest searches of the bench batches (tools/sim_dive.py): 78 % on random-obstacle 64x64
 // maps (BASELINE config 4), 50-73 % on random 32x32, 26-28 % on mazes -- the 32x32 / 16x16 instantiations keep the plain loop (a net
-// loss at 27 %), the 64x64 one, whose selection phase is also the most expensive (four chunk minima per lane), dives.
+// loss at 27 %), the 64x64 one, whose selection phase is also the most expensive (four chunk minima per lane), dives.  Measured at 32x32
+// (same box, back to back): maze32 158.5 -> 174.5 us per launch, rand32 74.9 -> 76.2 us -- not shipped there.
 // Loop layout: both ways round cost exactly one taken branch (the dive's lookup code sits in front of the expansion and falls into it);
 // the chunk minima are still prefetched BEFORE the test (reading them only on the way into a full selection measured 2 % slower: -5.8 %
 // instead of -8.1 % against the plain loop on the rand64 batch).  Measured (4096 random-obstacle 64x64 maps, longest search 986 steps):
