@@ -31,15 +31,31 @@ class UnsolvableMapError(RuntimeError):
     (SURVEY.md section 0.4); here the kernel reports a per-map status instead."""
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
+
+
 class _PendingStatus:
-    """status of an earlier call on its way to the host: a device-side any() + a non-blocking copy into pinned memory + an event"""
+    """status of an earlier call on its way to the host: a device-side any() + a non-blocking copy into pinned memory + an event, all on
+    a SIDE stream that waits for the search launch -- the stream the caller keeps launching on never sees these three small ops"""
 
     def __init__(self, status: torch.Tensor):
         self.status = status
         self.flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
-        self.flag.copy_((status != 0).any().reshape(1), non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(status.device))
+        main = torch.cuda.current_stream(status.device)
+        side = _side_stream(status.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.flag.copy_((status != 0).any().reshape(1), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+        status.record_stream(side)
 
     def done(self) -> bool:
         return self.event.query()
