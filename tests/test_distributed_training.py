@@ -276,3 +276,51 @@ def test_persistent_flat_gradient_bucket_world_size_2_gloo(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_flat_bucket_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
+
+
+def _sync_bn_cpu_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_astar import encoder_train as ET
+    torch.manual_seed(3)
+    z_all = (torch.randn(8, 1, 6, 6) * 1.7 + 0.4).double().float()
+    w_all = torch.randn(8, 1, 6, 6)
+    rows = slice(rank * 4, rank * 4 + 4)
+    ok = True
+    # (1) the per-channel double sums of the statistics kernels: all-reduced, and un-scaled / re-scaled by THIS rank's gradient scale
+    ET.SyncBatchNorm.enabled, ET.SyncBatchNorm.group = True, None
+    sums = torch.tensor([[1.0 + rank, 2.0], [3.0, 4.0 * (rank + 1)]], dtype=torch.float64)
+    ok = ok and ET._sync_sums(sums) == 2 and torch.equal(sums, torch.tensor([[3.0, 4.0], [6.0, 12.0]], dtype=torch.float64))
+    scale = torch.tensor([2.0 ** (3 + rank)])  # ranks carry different power-of-two scales
+    true = torch.tensor([[0.5, 1.5]], dtype=torch.float64) * (rank + 1)
+    mine = true * scale.double()
+    ET._sync_sums(mine, scale)
+    ok = ok and torch.equal(mine, torch.tensor([[1.5, 4.5]], dtype=torch.float64) * scale.double())
+    # (2) the 1-channel last block with global statistics: forward values and dL/dz equal the single-process BatchNorm on all 8 rows
+    z = z_all[rows].clone().requires_grad_(True)
+    xhat, mean, var = ET._SyncBatchNorm1.apply(z, 1e-5)
+    (xhat * w_all[rows]).sum().backward()
+    zr = z_all.clone().requires_grad_(True)
+    var_r, mean_r = torch.var_mean(zr, unbiased=False)
+    xr = (zr - mean_r) * torch.rsqrt(var_r + 1e-5)
+    (xr * w_all).sum().backward()
+    ok = ok and torch.allclose(xhat, xr[rows].detach(), atol=1e-6) and abs(float(mean - mean_r)) < 1e-6 and abs(float(var - var_r)) < 1e-6
+    ok = ok and torch.allclose(z.grad, zr.grad[rows], atol=1e-5)
+    # switched off (or a 1-rank group without `force`): nothing is reduced
+    ET.SyncBatchNorm.enabled = False
+    s2 = torch.ones((2, 2), dtype=torch.float64)
+    ok = ok and ET._sync_sums(s2) == 1 and torch.equal(s2, torch.ones((2, 2), dtype=torch.float64)) and not ET.SyncBatchNorm.active()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_building_blocks_world_size_2_gloo(tmp_path):
+    """CPU coverage of the data-parallel BatchNorm path (the GPU test above needs the training kernels): the all-reduce of the
+    per-channel double sums incl. the per-rank power-of-two gradient scale, and the 1-channel last block with global statistics
+    (forward and backward) against torch's BatchNorm arithmetic on the concatenated batch."""
+    import torch.multiprocessing as mp
+    mp.spawn(_sync_bn_cpu_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
