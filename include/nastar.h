@@ -284,6 +284,26 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
                              size_t workspace_bytes, void* stream);
 int nastar_chan_stats_f16(const uint16_t* u, const uint16_t* v, const float* ms, const float* mt, double* sums, float* amax_out,
                           long long npix, int C, int split, void* stream);
+/* The closing block of the CNN / CNNDownSize encoders in TRAINING mode (reference encoder.py:60-97 last block + :32-34): 1-channel
+ * BatchNorm with batch statistics + sigmoid * const on z [n] fp32 (raw output of the last convolution), two launches each way:
+ *   nastar_bn1_fwd_partial          part[nastar_bn1_parts(n)][2] = per-workgroup (sum z, sum z^2) in double
+ *   nastar_bn1_sigmoid_fwd          cost = cmul * sigmoid(gamma (z - mean) invstd + beta); stat_out = (mean, invstd); running statistics
+ *                                   updated with `momentum` (unbiased variance) when running_mean != NULL
+ *   nastar_bn1_sigmoid_bwd_partial  part[..][3] = (sum dy, sum dy xhat, sum dcost s)
+ *   nastar_bn1_sigmoid_bwd          dz (closed-form BatchNorm backward), dgamma, dbeta, dconst (NULL when const is not a parameter)
+ * `part` / `nparts` / `n_total`: the kernel adds the partial rows itself in a fixed order; data-parallel training passes the all-reduced
+ * global sums as ONE row with n_total = the global element count (encoder_train.SyncBatchNorm).  cmul: device scalar or NULL (= 1). */
+int nastar_bn1_parts(long long n);
+int nastar_bn1_fwd_partial(const float* z, long long n, double* part, void* stream);
+int nastar_bn1_sigmoid_fwd(const float* z, long long n, const double* part, int nparts, double n_total, const float* gamma, const float* beta,
+                           double eps, const float* cmul, double momentum, float* running_mean, float* running_var, float* cost_out,
+                           double* stat_out, void* stream);
+int nastar_bn1_sigmoid_bwd_partial(const float* z, const float* dcost, long long n, const double* stat, const float* gamma, const float* beta,
+                                   const float* cmul, double* part, void* stream);
+int nastar_bn1_sigmoid_bwd(const float* z, const float* dcost, long long n, const double* stat, const float* gamma, const float* beta,
+                           const float* cmul, const double* part, int nparts, double n_total, float* dz_out, float* dgamma_out,
+                           float* dbeta_out, float* dconst_out, void* stream);
+
 /* max|w| of n fp32 tensors in ONE launch: table = device array [n][2] of (pointer, element count) as int64; scal [n][3] floats is zeroed
  * and scal[t][2] receives max|w_t| -- the value nastar_pack_conv_weight_f16(..., reuse_max = 1) expects there. */
 int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* stream);

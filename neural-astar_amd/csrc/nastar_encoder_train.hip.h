@@ -510,4 +510,129 @@ __global__ __launch_bounds__(256) void nastar_grad_seed_kernel(const float* __re
     }
 }
 
+
+// ---- the closing block of the CNN / CNNDownSize encoders: 1-channel BatchNorm (batch statistics) + sigmoid * const ---------------------
+// (reference encoder.py:60-97 last block + :32-34).  z [n] fp32 is the raw output of the last convolution; the plain-tensor form of this
+// block was ~35 framework launches per training step (var_mean, 7 elementwise passes, and autograd's ~25 for the backward).  Two launches
+// each way: per-workgroup double partial sums, then a kernel in which EVERY workgroup re-adds the (<= 256) partials in a fixed order and
+// applies.  Data-parallel training swaps the partials for the all-reduced global sums (nparts = 1, n_total = global element count).
+constexpr int BN1_MAX_PARTS = 256;
+
+__device__ __forceinline__ double bn1_block_sum(double v, double* red)  // 256 threads, fixed tree: bitwise reproducible
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// K = 2: part[b] = (sum z, sum z^2).   K = 3 (backward; stat = mean, invstd): with xhat = (z - mean) invstd, s = sigmoid(gamma xhat + beta),
+// dy = dcost * cmul * s (1 - s):  part[b] = (sum dy, sum dy xhat, sum dcost s).
+template <int K>
+__global__ __launch_bounds__(256) void nastar_bn1_partial_kernel(const float* __restrict__ z, const float* __restrict__ dcost, long long n,
+                                                                 const double* __restrict__ stat, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ cmul,
+                                                                 double* __restrict__ part)
+{
+    __shared__ double red[256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f, c = 1.f;
+    if constexpr (K == 3) {
+        mean = (float)stat[0];
+        invstd = (float)stat[1];
+        g = gamma[0];
+        b = beta[0];
+        c = cmul ? cmul[0] : 1.f;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = z[i];
+        if constexpr (K == 2) {
+            a0 += (double)x;
+            a1 += (double)x * (double)x;
+        } else {
+            const float xh = (x - mean) * invstd;
+            const float sg = 1.0f / (1.0f + __expf(-(g * xh + b)));
+            const float dc = dcost[i];
+            const float dy = dc * c * sg * (1.0f - sg);
+            a0 += (double)dy;
+            a1 += (double)dy * (double)xh;
+            a2 += (double)dc * (double)sg;
+        }
+    }
+    a0 = bn1_block_sum(a0, red);
+    a1 = bn1_block_sum(a1, red);
+    if constexpr (K == 3) a2 = bn1_block_sum(a2, red);
+    if (threadIdx.x == 0) {
+        part[(size_t)blockIdx.x * K] = a0;
+        part[(size_t)blockIdx.x * K + 1] = a1;
+        if constexpr (K == 3) part[(size_t)blockIdx.x * K + 2] = a2;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void bn1_total(const double* __restrict__ part, int nparts, double* red, double (&tot)[K])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) tot[k] = bn1_block_sum((int)threadIdx.x < nparts ? part[(size_t)threadIdx.x * K + k] : 0.0, red);
+}
+
+// cost = cmul * sigmoid(gamma (z - mean) invstd + beta); workgroup 0 stores (mean, invstd) for the backward and updates the running statistics
+__global__ __launch_bounds__(256) void nastar_bn1_sigmoid_fwd_kernel(const float* __restrict__ z, long long n, const double* __restrict__ part,
+                                                                     int nparts, double n_total, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, double eps, const float* __restrict__ cmul,
+                                                                     double momentum, float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, float* __restrict__ cost,
+                                                                     double* __restrict__ stat)
+{
+    __shared__ double red[256];
+    double tot[2];
+    bn1_total<2>(part, nparts, red, tot);
+    const double mean = tot[0] / n_total;
+    double var = tot[1] / n_total - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double invstd = 1.0 / sqrt(var + eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stat[0] = mean;
+        stat[1] = invstd;
+        if (running_mean) {
+            running_mean[0] = (float)((1.0 - momentum) * (double)running_mean[0] + momentum * mean);
+            running_var[0] = (float)((1.0 - momentum) * (double)running_var[0] + momentum * var * (n_total / (n_total > 1.0 ? n_total - 1.0 : 1.0)));
+        }
+    }
+    const float fm = (float)mean, fi = (float)invstd, g = gamma[0], b = beta[0], c = cmul ? cmul[0] : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        cost[i] = c / (1.0f + __expf(-(g * ((z[i] - fm) * fi) + b)));
+}
+
+// dz = gamma invstd (dy - sum dy / N - xhat sum dy xhat / N); workgroup 0 writes dgamma = sum dy xhat, dbeta = sum dy, dconst = sum dcost s
+__global__ __launch_bounds__(256) void nastar_bn1_sigmoid_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dcost, long long n,
+                                                                     const double* __restrict__ stat, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ cmul,
+                                                                     const double* __restrict__ part, int nparts, double n_total,
+                                                                     float* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float* __restrict__ dconst)
+{
+    __shared__ double red[256];
+    double tot[3];
+    bn1_total<3>(part, nparts, red, tot);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        dbeta[0] = (float)tot[0];
+        dgamma[0] = (float)tot[1];
+        if (dconst) dconst[0] = (float)tot[2];
+    }
+    const float mean = (float)stat[0], invstd = (float)stat[1], g = gamma[0], b = beta[0], c = cmul ? cmul[0] : 1.f;
+    const float m1 = (float)(tot[0] / n_total), m2 = (float)(tot[1] / n_total), k1 = g * invstd;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xh = (z[i] - mean) * invstd;
+        const float sg = 1.0f / (1.0f + __expf(-(g * xh + b)));
+        const float dy = dcost[i] * c * sg * (1.0f - sg);
+        dz[i] = k1 * (dy - m1 - xh * m2);
+    }
+}
+
 }  // namespace nastar

@@ -314,4 +314,66 @@ int nastar_grad_add_f16(const uint16_t* a, const float* scale_a, const uint16_t*
     return NASTAR_OK;
 }
 
+
+// ---- closing 1-channel BatchNorm + sigmoid * const block (nastar_encoder_train.hip.h) ---------------------------------------------------
+int nastar_bn1_parts(long long n)
+{
+    if (n <= 0) return 0;
+    long long g = (n + 2047) / 2048;
+    return (int)(g > BN1_MAX_PARTS ? BN1_MAX_PARTS : g);
+}
+
+int nastar_bn1_fwd_partial(const float* z, long long n, double* part, void* stream)
+{
+    if (!z || !part) return NASTAR_ERR_NULL;
+    if (n <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_bn1_partial_kernel<2>, dim3((unsigned)nastar_bn1_parts(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z,
+                       nullptr, n, nullptr, nullptr, nullptr, nullptr, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn1_sigmoid_fwd(const float* z, long long n, const double* part, int nparts, double n_total, const float* gamma, const float* beta,
+                           double eps, const float* cmul, double momentum, float* running_mean, float* running_var, float* cost_out,
+                           double* stat_out, void* stream)
+{
+    if (!z || !part || !gamma || !beta || !cost_out || !stat_out || (running_mean && !running_var)) return NASTAR_ERR_NULL;
+    if (n <= 0 || nparts <= 0 || nparts > BN1_MAX_PARTS || n_total < (double)n) return NASTAR_ERR_BAD_SHAPE;
+    long long g = (n + 1023) / 1024;
+    g = g > 2048 ? 2048 : g;
+    hipLaunchKernelGGL(nastar_bn1_sigmoid_fwd_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, n, part, nparts,
+                       n_total, gamma, beta, eps, cmul, momentum, running_mean, running_var, cost_out, stat_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn1_sigmoid_bwd_partial(const float* z, const float* dcost, long long n, const double* stat, const float* gamma, const float* beta,
+                                   const float* cmul, double* part, void* stream)
+{
+    if (!z || !dcost || !stat || !gamma || !beta || !part) return NASTAR_ERR_NULL;
+    if (n <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_bn1_partial_kernel<3>, dim3((unsigned)nastar_bn1_parts(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z,
+                       dcost, n, stat, gamma, beta, cmul, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn1_sigmoid_bwd(const float* z, const float* dcost, long long n, const double* stat, const float* gamma, const float* beta,
+                           const float* cmul, const double* part, int nparts, double n_total, float* dz_out, float* dgamma_out,
+                           float* dbeta_out, float* dconst_out, void* stream)
+{
+    if (!z || !dcost || !stat || !gamma || !beta || !part || !dz_out || !dgamma_out || !dbeta_out) return NASTAR_ERR_NULL;
+    if (n <= 0 || nparts <= 0 || nparts > BN1_MAX_PARTS || n_total < (double)n) return NASTAR_ERR_BAD_SHAPE;
+    long long g = (n + 1023) / 1024;
+    g = g > 2048 ? 2048 : g;
+    hipLaunchKernelGGL(nastar_bn1_sigmoid_bwd_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, dcost, n, stat,
+                       gamma, beta, cmul, part, nparts, n_total, dz_out, dgamma_out, dbeta_out, dconst_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 }  // extern "C"

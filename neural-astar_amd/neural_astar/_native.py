@@ -69,6 +69,11 @@ EXPORTED_SYMBOLS = (
     "nastar_chan_stats_f16",
     "nastar_chan_stats_workspace_bytes",
     "nastar_absmax_multi_f32",
+    "nastar_bn1_parts",
+    "nastar_bn1_fwd_partial",
+    "nastar_bn1_sigmoid_fwd",
+    "nastar_bn1_sigmoid_bwd_partial",
+    "nastar_bn1_sigmoid_bwd",
     "nastar_chan_stats_f16_ws",
     "nastar_chan_affine_f16",
     "nastar_pack_conv_weight_f16",
@@ -173,6 +178,17 @@ def load() -> ctypes.CDLL:
     lib.nastar_conv3x3_wgrad_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
     lib.nastar_chan_stats_f16.restype = ci
     lib.nastar_chan_stats_f16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp]
+    cll = ctypes.c_longlong
+    lib.nastar_bn1_parts.restype = ci
+    lib.nastar_bn1_parts.argtypes = [cll]
+    lib.nastar_bn1_fwd_partial.restype = ci
+    lib.nastar_bn1_fwd_partial.argtypes = [vp, cll, vp, vp]
+    lib.nastar_bn1_sigmoid_fwd.restype = ci
+    lib.nastar_bn1_sigmoid_fwd.argtypes = [vp, cll, vp, ci, cd, vp, vp, cd, vp, cd, vp, vp, vp, vp, vp]
+    lib.nastar_bn1_sigmoid_bwd_partial.restype = ci
+    lib.nastar_bn1_sigmoid_bwd_partial.argtypes = [vp, vp, cll, vp, vp, vp, vp, vp, vp]
+    lib.nastar_bn1_sigmoid_bwd.restype = ci
+    lib.nastar_bn1_sigmoid_bwd.argtypes = [vp, vp, cll, vp, vp, vp, vp, vp, ci, cd, vp, vp, vp, vp, vp]
     lib.nastar_absmax_multi_f32.restype = ci
     lib.nastar_absmax_multi_f32.argtypes = [vp, ci, vp, vp]
     lib.nastar_chan_stats_workspace_bytes.restype = cz

@@ -379,6 +379,84 @@ class _CnnTrunk(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+_CONSTS: dict = {}
+
+
+def _const_tensor(value: float, device: torch.device) -> torch.Tensor:
+    """a cached [1] fp32 device tensor for an encoder whose ``const`` is the plain float 1.0 (reference encoder.py:24-27)"""
+    key = (value, device.type, device.index)
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.full((1,), value, dtype=torch.float32, device=device)
+    return _CONSTS[key]
+
+
+class _LastBlock(torch.autograd.Function):
+    """cost = const * sigmoid(BatchNorm1(z)) for the closing 1-channel block (reference encoder.py:60-97 last block + :32-34), batch
+    statistics, on two launches each way (``nastar_bn1_*``) instead of ~35 framework launches.  Inputs: z [B,1,h,w] fp32 (raw output of
+    the last convolution), the BatchNorm's weight / bias ([1] each), ``const`` as a [1] tensor (parameter or plain).  Data-parallel
+    training (``SyncBatchNorm``): the partial sums are reduced to one row, all-reduced, and the kernels take the global sums."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, cmul, eps, momentum, running_mean, running_var):
+        dev = z.device
+        lib = _native.load()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        zc = z if z.is_contiguous() and z.dtype == torch.float32 else z.float().contiguous()
+        n = zc.numel()
+        nparts = int(lib.nastar_bn1_parts(n))
+        part = torch.empty((nparts, 2), dtype=torch.float64, device=dev)
+        cost = torch.empty_like(zc)
+        stat = torch.empty((2,), dtype=torch.float64, device=dev)
+        g, b, c = gamma.detach(), beta.detach(), cmul.detach()
+        with torch.cuda.device(dev):
+            _native.check(lib.nastar_bn1_fwd_partial(zc.data_ptr(), n, part.data_ptr(), st), "nastar_bn1_fwd_partial")
+            world = 1
+            if SyncBatchNorm.active():
+                part = part.sum(0, keepdim=True)
+                world = _sync_sums(part)
+                nparts = 1
+            _native.check(lib.nastar_bn1_sigmoid_fwd(zc.data_ptr(), n, part.data_ptr(), nparts, float(n * world), g.data_ptr(), b.data_ptr(),
+                                                     float(eps), c.data_ptr(), float(momentum),
+                                                     running_mean.data_ptr() if running_mean is not None else None,
+                                                     running_var.data_ptr() if running_var is not None else None, cost.data_ptr(),
+                                                     stat.data_ptr(), st), "nastar_bn1_sigmoid_fwd")
+        ctx.save_for_backward(zc, g, b, c, stat)
+        ctx.n_total = float(n * world)
+        ctx.world = world
+        ctx.set_materialize_grads(False)
+        return cost
+
+    @staticmethod
+    def backward(ctx, dcost):
+        if dcost is None:
+            return (None,) * 8
+        zc, g, b, c, stat = ctx.saved_tensors
+        dev = zc.device
+        lib = _native.load()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        d = dcost if dcost.is_contiguous() and dcost.dtype == torch.float32 else dcost.float().contiguous()
+        n = zc.numel()
+        nparts = int(lib.nastar_bn1_parts(n))
+        part = torch.empty((nparts, 3), dtype=torch.float64, device=dev)
+        dz = torch.empty_like(zc)
+        dgamma, dbeta, dconst = (torch.empty((1,), dtype=torch.float32, device=dev) for _ in range(3))
+        with torch.cuda.device(dev):
+            _native.check(lib.nastar_bn1_sigmoid_bwd_partial(zc.data_ptr(), d.data_ptr(), n, stat.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                                             c.data_ptr(), part.data_ptr(), st), "nastar_bn1_sigmoid_bwd_partial")
+            if ctx.world > 1 or SyncBatchNorm.active():
+                part = part.sum(0, keepdim=True)
+                _sync_sums(part)
+                nparts = 1
+            _native.check(lib.nastar_bn1_sigmoid_bwd(zc.data_ptr(), d.data_ptr(), n, stat.data_ptr(), g.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                                     part.data_ptr(), nparts, ctx.n_total, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                     dconst.data_ptr(), st), "nastar_bn1_sigmoid_bwd")
+        if ctx.world > 1:  # formed from the GLOBAL sums; the flat gradient all-reduce averages over ranks
+            dgamma /= ctx.world
+            dbeta /= ctx.world
+            dconst /= ctx.world
+        return dz, dgamma, dbeta, dconst, None, None, None, None
+
+
 def _structure(cnn: nn.Module):
     """(convs, bns, pool, depth) of a conv3x3 -> BatchNorm -> ReLU [-> max-pool] stack closed by a 1-channel conv3x3 + BatchNorm, or None
     if the module is anything else (channel counts must be 32, 64, ... powers of two times 32: the streaming kernels' lane layout)"""
@@ -456,23 +534,31 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     with torch.cuda.device(map_designs.device):
         x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
     zl = _CnnTrunk.apply(cfg, x0, *params[:4 * D + 2])
-    # last block's 1-channel BatchNorm (batch statistics) + sigmoid * const as plain tensor ops on [B,1,h,w]: torch's autograd serves
-    # its weight / bias and const (MIOpen's spatial BatchNorm kernels are slow on a single channel)
+    # last block: 1-channel BatchNorm (batch statistics) + sigmoid * const as ONE autograd node on two launches each way (the plain
+    # tensor form was ~35 framework launches per step; MIOpen's spatial BatchNorm kernels are slow on a single channel)
     bnl = bns[D]
-    n = zl.numel() * SyncBatchNorm.world()
-    if SyncBatchNorm.active():
-        xhat, mean, var = _SyncBatchNorm1.apply(zl, bnl.eps)
-        y = xhat * bnl.weight + bnl.bias
-    else:
-        var, mean = torch.var_mean(zl, unbiased=False)
-        y = (zl - mean) * torch.rsqrt(var + bnl.eps) * bnl.weight + bnl.bias
-    if bnl.track_running_stats and bnl.running_mean is not None:
-        with torch.no_grad():
-            mom = bnl.momentum if bnl.momentum is not None else 1.0 / float(int(bnl.num_batches_tracked) + 1)
-            bnl.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
-            bnl.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
-            bnl.num_batches_tracked += 1
-    return torch.sigmoid(y) * cnn.const
+    track = bnl.track_running_stats and bnl.running_mean is not None
+    mom = 0.0
+    if track:
+        mom = bnl.momentum if bnl.momentum is not None else 1.0 / float(int(bnl.num_batches_tracked) + 1)
+        bnl.num_batches_tracked += 1
+    const = cnn.const if isinstance(cnn.const, torch.Tensor) else _const_tensor(float(cnn.const), zl.device)
+    if bnl.weight is None or const.numel() != 1 or const.dtype != torch.float32:  # BatchNorm without affine / exotic const: tensor ops
+        if SyncBatchNorm.active():
+            y, mean, var = _SyncBatchNorm1.apply(zl, bnl.eps)
+        else:
+            var, mean = torch.var_mean(zl, unbiased=False)
+            y = (zl - mean) * torch.rsqrt(var + bnl.eps)
+        if bnl.weight is not None:
+            y = y * bnl.weight + bnl.bias
+        if track:
+            with torch.no_grad():
+                n = zl.numel() * SyncBatchNorm.world()
+                bnl.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
+                bnl.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)) * mom)
+        return torch.sigmoid(y) * cnn.const
+    return _LastBlock.apply(zl, bnl.weight, bnl.bias, const.reshape(1), bnl.eps, mom, bnl.running_mean if track else None,
+                            bnl.running_var if track else None)
 
 
 # ---- U-Net (vgg16_bn) training: the same kernels over the launch plan of encoder_hip.unet_layer_plan ------------------------------------

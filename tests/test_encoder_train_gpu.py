@@ -546,3 +546,38 @@ def test_unet_trains_on_the_hip_kernels():
     w3 = sorted(worst2.items(), key=lambda kv: -kv[1])[:4]
     print("GRADERR unet forced-decisions", "cost", err_cost2, "worst", " ".join(f"{k}={v:.1e}" for k, v in w3))
     assert max(worst2.values()) <= 2e-4, w3
+
+
+@pytest.mark.parametrize("n_maps,hw,const", [(3, 12, 10.0), (100, 32, None), (700, 32, 2.5)])
+def test_last_block_batchnorm_sigmoid_matches_torch_autograd(n_maps, hw, const):
+    """The closing 1-channel BatchNorm (batch statistics) + sigmoid * const block as two launches each way (nastar_bn1_*) against torch's
+    float64 autograd of encoder.py's last block + :32-34: cost, dz, dgamma, dbeta, dconst and the running-statistics update; one, a few
+    and the maximum number of partial rows; const as a parameter and as the plain 1.0."""
+    from neural_astar import encoder_train as ET
+    dev = _dev()
+    g = torch.Generator().manual_seed(n_maps)
+    z = (torch.randn((n_maps, 1, hw, hw), generator=g) * 1.3 + 0.2)
+    up = torch.randn((n_maps, 1, hw, hw), generator=g) / z.numel()
+    bn = nn.BatchNorm2d(1)
+    with torch.no_grad():
+        bn.weight.fill_(1.7); bn.bias.fill_(-0.3); bn.running_mean.fill_(0.4); bn.running_var.fill_(2.0)
+    cpar = nn.Parameter(torch.ones(1) * const) if const is not None else None
+    # truth: float64 torch modules
+    import copy
+    bn64 = copy.deepcopy(bn).double().train()
+    z64 = z.double().requires_grad_(True)
+    c64 = cpar.detach().double().requires_grad_(True) if cpar is not None else 1.0
+    cost64 = torch.sigmoid(bn64(z64)) * c64
+    (cost64 * up.double()).sum().backward()
+    # device
+    bnd = copy.deepcopy(bn).to(dev).train()
+    zd = z.to(dev).requires_grad_(True)
+    cd = nn.Parameter(cpar.detach().to(dev)) if cpar is not None else ET._const_tensor(1.0, dev)
+    cost = ET._LastBlock.apply(zd, bnd.weight, bnd.bias, cd.reshape(1), bnd.eps, bnd.momentum, bnd.running_mean, bnd.running_var)
+    (cost * up.to(dev)).sum().backward()
+    assert float((cost.detach().cpu().double() - cost64.detach()).abs().max()) <= 2e-6 * (const or 1.0)
+    assert _rel(zd.grad, z64.grad) <= 2e-5
+    assert _rel(bnd.weight.grad, bn64.weight.grad) <= 2e-5 and _rel(bnd.bias.grad, bn64.bias.grad) <= 2e-5
+    if cpar is not None:
+        assert _rel(cd.grad, c64.grad) <= 2e-5
+    assert _rel(bnd.running_mean, bn64.running_mean) <= 1e-6 and _rel(bnd.running_var, bn64.running_var) <= 1e-6
