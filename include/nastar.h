@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 200 /* 0.2.0: replay backward, generic MFMA convolution, encoder training kernels */
+#define NASTAR_VERSION 300 /* 0.3.0: round-3 search instruction stream, two-stage statistics, closing-block kernels, dev kernels behind DEV=1 */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0
