@@ -5,4 +5,4 @@ Only the hot path is re-implemented: ``neural_astar.planner.{VanillaAstar, Neura
 ``planner.encoder_backend = "hip_*"`` -- the cost-map encoders (CNN, CNNDownSize, Unet) run inference and training on MFMA kernels
 (see DESIGN.md).
 """
-__version__ = "0.2.0"
+__version__ = "0.3.0"
