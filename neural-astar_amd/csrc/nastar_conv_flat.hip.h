@@ -61,6 +61,10 @@ struct FlatConvArgs {
 
 __device__ __forceinline__ int fc_slot_off(int slot, int c) { return FC_PIXB + slot * FC_PIXB + (((c + (slot >> 2)) & 3) << 4); }
 
+// Tried in round 3 and dropped: NT = 128 (a 2 x 4 accumulator tile per wavefront: 6 fragment reads per 8 MFMAs instead of 4 per 4, 240 VGPRs +
+// 128 AGPRs, ONE workgroup per CU): 15-50 % SLOWER on every layer it applies to (U-Net, 4096 maps: 64->128 @16x16 0.230 -> 0.289 ms,
+// 256->256 @8x8 0.310 -> 0.408 ms, 512->512 @4x4 0.302 -> 0.314 ms): with a single workgroup per CU nothing covers the slice barriers and
+// the staging latency; the second resident workgroup is worth more than the saved fragment reads.
 template <int NT, bool kFinal, bool kSplit>
 __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(const FlatConvArgs a)
 {
