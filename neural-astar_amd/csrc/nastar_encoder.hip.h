@@ -89,6 +89,7 @@ struct ConvArgs {
     uint16_t* out;          // [B,H,W,COUT] bf16        (kFinal == false)
     float* out_f32;         // [B,H,W] fp32             (kFinal == true: sigmoid(acc*scale+shift) * mul)
     const uint16_t* wfin;   // fused last layer (img32 kernel, kFuse): its packed weights [9][COUT/8][32][8] ...
+    const uint16_t* wfin_lo;  // ... split precision (kFuse && kSplit): wfin = the fp16 hi halves, wfin_lo = the lo halves
     const float* fscale;    // ... and its folded BatchNorm scale / shift (1 channel)
     const float* fshift;
     // tap-major last-layer kernel only: channels per input pixel (0 = CIN) and multi-pass accumulation for the f16x3 form
@@ -298,7 +299,7 @@ constexpr int I32_TILE_BYTES = 34 * 34 * I32_PIX_B;               // 36992
 constexpr int I32_W_BYTES = 9 * 2 * I32_NT * 16;                  // 18432: [tap][khalf][n][8 bf16]
 constexpr int I32_BUF_BYTES = I32_TILE_BYTES + I32_W_BYTES;       // 55424
 constexpr int I32_P_BYTES = 1024 * 9 * 4;                         // fused last layer: per-pixel tap sums P[pixel][9] fp32
-constexpr int I32_OB_BYTES = I32_P_BYTES + 4096;                 // epilogue scratch: 8 transpose patches of 4 KB | P + last-layer fragments
+constexpr int I32_OB_BYTES = I32_P_BYTES + 8192;                 // epilogue scratch: 8 transpose patches of 4 KB | P + last-layer fragments (hi | lo)
 constexpr size_t I32_LDS_BYTES = 2 * (size_t)I32_BUF_BYTES + I32_OB_BYTES + 2 * 256 * 4;
 
 __device__ __forceinline__ int i32_tile_off(int ty, int tx, int c)
@@ -366,7 +367,6 @@ template <int CIN, int COUT, bool kRelu, bool kFuse = false, int kProbe = 0, boo
 __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArgs a)
 {
     static_assert(!(kFuse && kTiled), "the fused last layer needs the whole image in one workgroup");
-    static_assert(!(kFuse && kSplit), "split precision keeps the last layer a separate launch");
     static_assert(kF16 || !kSplit, "split precision is an fp16 form");
     constexpr int NS1 = CIN / I32_KS;                 // slices per precision block
     constexpr int NSLICE = (kSplit ? 3 : 1) * NS1;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         I32_DECODE(item, b, ty0, tx0, grp);
         const int n0 = grp * I32_NT;
         const int next = !kFuse ? item + (int)gridDim.x : (grp == NGRP - 1 ? item + ((int)gridDim.x - 1) * NGRP + 1 : item + 1);
-        uint4 wfq = make_uint4(0u, 0u, 0u, 0u);
+        uint4 wfq = make_uint4(0u, 0u, 0u, 0u), wfq_lo = make_uint4(0u, 0u, 0u, 0u);
         if constexpr (kFuse) {
             // last layer's weights for this channel group as MFMA A fragments: row = tap (lanes 0..8 of each half), k = the 8
             // channels this lane's accumulator registers 8j..8j+7 hold: n0 + 32 n + 16 j + 4 kh + {0..3} and the same + 8
@@ -489,6 +489,11 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                     const uint2 lo = *reinterpret_cast<const uint2*>(a.wfin + ((size_t)(tap * (COUT / 8) + (base >> 3)) * 32) * 8 + (base & 7));
                     const uint2 hi = *reinterpret_cast<const uint2*>(a.wfin + ((size_t)(tap * (COUT / 8) + ((base + 8) >> 3)) * 32) * 8 + (base & 7));
                     wfq = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    if constexpr (kSplit) {  // the fp16 lo halves of the same weights (x = hi + lo): third product of the split form
+                        const uint2 l2 = *reinterpret_cast<const uint2*>(a.wfin_lo + ((size_t)(tap * (COUT / 8) + (base >> 3)) * 32) * 8 + (base & 7));
+                        const uint2 h2 = *reinterpret_cast<const uint2*>(a.wfin_lo + ((size_t)(tap * (COUT / 8) + ((base + 8) >> 3)) * 32) * 8 + (base & 7));
+                        wfq_lo = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    }
                 }
             }
         }
@@ -506,7 +511,10 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
             else if (next < nitems) I32_LOAD_SLICE(next, 0);
             I32_SLICE_MFMAS(lds0 + (s & 1) * I32_BUF_BYTES);
             if constexpr (kFuse) {
-                if (s == 0 && tid < 256) *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;  // the previous item's epilogue copied its fragments before the hand-over barrier
+                if (s == 0 && tid < 256) {  // the previous item's epilogue copied its fragments before the hand-over barrier
+                    *reinterpret_cast<uint4*>(wf + tid * 16) = wfq;
+                    if constexpr (kSplit) *reinterpret_cast<uint4*>(wf + 4096 + tid * 16) = wfq_lo;
+                }
             }
             if (s + 1 < NSLICE) {
                 I32_STORE_SLICE(smem + ((s + 1) & 1) * I32_BUF_BYTES);  // last read in iteration s-1, before the previous barrier
@@ -520,12 +528,15 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
         // slice NSLICE-2, i.e. before that slice's barrier) and the barrier that publishes it is the last synchronisation of this
         // item.  The epilogue then runs unsynchronised: the SIMD's older wavefront finishes it first and starts the next item's
         // MFMAs while the younger one is still converting and storing -- half of the epilogue disappears behind the matrix pipe.
-        bf16x8 fa[I32_NB][2];
+        bf16x8 fa[I32_NB][2], fal[I32_NB][2];
         if constexpr (kFuse) {  // (read before the barrier: a fast wave rewrites wf at the end of the next item's first slice)
 #pragma unroll
             for (int n = 0; n < I32_NB; ++n)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fa[n][j] = *reinterpret_cast<const bf16x8*>(wf + ((n * 2 + j) * 64 + lane) * 16);
+                for (int j = 0; j < 2; ++j) {
+                    fa[n][j] = *reinterpret_cast<const bf16x8*>(wf + ((n * 2 + j) * 64 + lane) * 16);
+                    if constexpr (kSplit) fal[n][j] = *reinterpret_cast<const bf16x8*>(wf + 4096 + ((n * 2 + j) * 64 + lane) * 16);
+                }
         }
         if (next < nitems) {
             I32_STORE_SLICE(smem);
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                 for (int n = 0; n < I32_NB; ++n)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        uint32_t yw[4];
+                        uint32_t yw[4], yl[4];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int g = 2 * j + h, cl = n0 + n * 32 + 8 * g + 4 * kh;
@@ -562,11 +573,21 @@ __global__ __launch_bounds__(512) void nastar_conv3x3_img32_kernel(const ConvArg
                             if constexpr (kRelu) {
                                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
                             }
+                            if constexpr (kSplit) {  // the same (hi, lo) pair the unfused epilogue would have stored for the next layer
+                                v0 = f16_clamp(v0); v1 = f16_clamp(v1); v2 = f16_clamp(v2); v3 = f16_clamp(v3);
+                                yl[2 * h + 0] = pack_pair<kF16>(f16_residual(v0), f16_residual(v1));
+                                yl[2 * h + 1] = pack_pair<kF16>(f16_residual(v2), f16_residual(v3));
+                            }
                             yw[2 * h + 0] = pack_pair<kF16>(f16_sat<kF16>(v0), f16_sat<kF16>(v1));
                             yw[2 * h + 1] = pack_pair<kF16>(f16_sat<kF16>(v2), f16_sat<kF16>(v3));
                         }
                         const uint4 yq = make_uint4(yw[0], yw[1], yw[2], yw[3]);
                         pa = mfma16<kF16>(fa[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa);
+                        if constexpr (kSplit) {  // x_lo * W_hi + x_hi * W_lo: the two cross terms of the split product
+                            const uint4 ylq = make_uint4(yl[0], yl[1], yl[2], yl[3]);
+                            pa = mfma16<kF16>(fa[n][j], *reinterpret_cast<const bf16x8*>(&ylq), pa);
+                            pa = mfma16<kF16>(fal[n][j], *reinterpret_cast<const bf16x8*>(&yq), pa);
+                        }
                     }
                 // D row = tap = (reg & 3) + 8 (reg >> 2) + 4 kh: taps 0-3 / 8 in the lower half-wave, 4-7 in the upper
                 float* pp = P + ((wave * I32_RPW + m) * 32 + px) * 9 + 4 * kh;
@@ -955,41 +976,65 @@ __global__ __launch_bounds__(256) void nastar_conv_first_f32_kernel(const float*
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    uint16_t* __restrict__ out, int B, int H, int W)
 {
-    // weights / scale / shift are indexed with compile-time constants only: wave-uniform scalar loads, multiply-adds straight from SGPRs
+    // weights / scale / shift are indexed with compile-time constants only: wave-uniform scalar loads, multiply-adds straight from SGPRs.
+    // One thread computes one pixel (all 32 channels), but a pixel's 64 / 128 output bytes written by ONE lane make every store
+    // instruction touch 64 different lines with 16 bytes each (measured 222 us per 1024 maps for 146 MB of traffic).  The results
+    // therefore go through a wave-private LDS patch (144-byte pixel stride: conflict-free both ways) and leave as full-line stores:
+    // each store instruction writes 1 KB of consecutive bytes.
+    constexpr int OPB = kLo ? 128 : 64;          // output bytes per pixel
+    constexpr int LSTR = 144;                    // LDS bytes per pixel
+    __shared__ __attribute__((aligned(16))) unsigned char patch[4][64 * LSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* mine = patch[wave];
     const long long npix = (long long)B * H * W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        float in[CINR][9];
+    const long long nround = (npix + 255) / 256;
+    for (long long rd = blockIdx.x; rd < nround; rd += gridDim.x) {
+        const long long w0 = rd * 256 + wave * 64;  // first pixel of this wavefront
+        const long long i = w0 + lane;
+        if (i < npix) {
+            const int x = (int)(i % W), y = (int)((i / W) % H);
+            float in[CINR][9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const long long j = i + (long long)(t / 3 - 1) * W + (t % 3 - 1);
-            in[0][t] = ok ? map[j] : 0.f;
-            if constexpr (CINR == 2) in[1][t] = ok ? start[j] + goal[j] : 0.f;
-        }
-        uint32_t hi[16], lo[16];
-#pragma unroll
-        for (int c = 0; c < 32; c += 2) {
-            float v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float z = 0.f;
-#pragma unroll
-                for (int ci = 0; ci < CINR; ++ci)
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) z += w[((c + e) * CINR + ci) * 9 + t] * in[ci][t];  // [32][cin][3][3], the torch layout
-                v[e] = f16_clamp(fmaxf(z * scale[c + e] + shift[c + e], 0.f));
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                const long long j = i + (long long)(t / 3 - 1) * W + (t % 3 - 1);
+                in[0][t] = ok ? map[j] : 0.f;
+                if constexpr (CINR == 2) in[1][t] = ok ? start[j] + goal[j] : 0.f;
             }
-            hi[c >> 1] = pack_f16x2(v[0], v[1]);
-            lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));
-        }
-        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * (kLo ? 64 : 32));
+            uint32_t hi[16], lo[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dst[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
-            if constexpr (kLo) dst[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+            for (int c = 0; c < 32; c += 2) {
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float z = 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < CINR; ++ci)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) z += w[((c + e) * CINR + ci) * 9 + t] * in[ci][t];  // [32][cin][3][3], the torch layout
+                    v[e] = f16_clamp(fmaxf(z * scale[c + e] + shift[c + e], 0.f));
+                }
+                hi[c >> 1] = pack_f16x2(v[0], v[1]);
+                lo[c >> 1] = pack_f16x2(f16_residual(v[0]), f16_residual(v[1]));
+            }
+            uint4* dst = reinterpret_cast<uint4*>(mine + lane * LSTR);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dst[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+                if constexpr (kLo) dst[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+            }
         }
+        __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order: a compiler-level ordering point is enough
+        constexpr int CPP = OPB / 16;     // 16-byte chunks per pixel (4 or 8)
+        unsigned char* gout = reinterpret_cast<unsigned char*>(out) + (size_t)w0 * OPB;
+#pragma unroll
+        for (int r = 0; r < CPP; ++r) {
+            const int k = r * 64 + lane;  // chunk index inside the wavefront's 64-pixel block
+            const int p = k / CPP, c = k % CPP;
+            if (w0 + p < npix) *reinterpret_cast<uint4*>(gout + (size_t)k * 16) = *reinterpret_cast<const uint4*>(mine + p * LSTR + c * 16);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

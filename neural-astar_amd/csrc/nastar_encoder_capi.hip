@@ -82,10 +82,11 @@ static int launch_conv_stem32(const StemArgs& sa, hipStream_t stream, bool f16 =
 }
 
 // 128 -> 256 channels + the fused 256 -> 1 layer + sigmoid * const: writes the cost map, the 256-channel tensor never exists
-static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream, bool f16 = false)
+static int launch_conv_fused_final(const ConvArgs& ca, hipStream_t stream, bool f16 = false, bool split = false)
 {
     void (*kern)(const ConvArgs) = &nastar_conv3x3_img32_kernel<128, 256, true, true>;
     if (f16) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 0, false, true, false>;
+    if (split) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 0, false, true, true>;  // f16x3: the last layer's three split products chained in the epilogue
     if (enc_flags() & 512) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 2>;  // dev: every workgroup reads image 0 (L2 hits)
     if (enc_flags() & 256) kern = &nastar_conv3x3_img32_kernel<128, 256, true, true, 1>;  // dev: cycle totals into the (unused) output slab
     int rc = ensure_lds(kern, I32_LDS_BYTES);
@@ -193,7 +194,7 @@ static int encoder_fp16_impl(const float* map, const float* start, const float* 
                 if ((rc = launch_conv_stem32(sa, s, true))) return rc;
                 ConvArgs ca;
                 ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-                ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+                ca.wfin = nullptr; ca.wfin_lo = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
                 ca.in = a2; ca.out = a3; ca.wpack = w3; ca.scale = scale[2]; ca.shift = shift[2];
                 if ((rc = launch_conv_split<64, 128, false>(ca, s))) return rc;
                 ca.in = a3; ca.out = a4; ca.wpack = w4; ca.scale = scale[3]; ca.shift = shift[3];
@@ -210,12 +211,22 @@ static int encoder_fp16_impl(const float* map, const float* start, const float* 
                                shift[0], a1, nb, H, W);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+        ca.wfin = nullptr; ca.wfin_lo = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
         int rc;
         ca.in = a1; ca.out = a2; ca.wpack = w2; ca.scale = scale[1]; ca.shift = shift[1];
         if ((rc = launch_conv_split<32, 64, kSplit>(ca, s))) return rc;
         ca.in = a2; ca.out = a3; ca.wpack = w3; ca.scale = scale[2]; ca.shift = shift[2];
         if ((rc = launch_conv_split<64, 128, kSplit>(ca, s))) return rc;
+        if constexpr (kSplit) {
+            if (H == 32 && W == 32 && !(enc_flags() & 8)) {
+                // 32x32 maps: 128 -> 256 with the 1-channel last layer, its BatchNorm and sigmoid * const fused into the epilogue (as the
+                // bf16 / fp16 routes): the 1 KB-per-pixel split activation of the widest layer is never written, nor read three times
+                ca.in = a3; ca.out = a4; ca.wpack = w4; ca.scale = scale[3]; ca.shift = shift[3];
+                ca.wfin = wts[3]; ca.wfin_lo = wts[4]; ca.fscale = scale[4]; ca.fshift = shift[4]; ca.out_f32 = cost_out + off;
+                if ((rc = launch_conv_fused_final(ca, s, true, true))) return rc;
+                continue;
+            }
+        }
         ca.in = a3; ca.out = a4; ca.wpack = w4; ca.scale = scale[3]; ca.shift = shift[3];
         if ((rc = launch_conv_split<128, 256, kSplit>(ca, s))) return rc;
         ca.out = nullptr; ca.out_f32 = cost_out + off; ca.scale = scale[4]; ca.shift = shift[4]; ca.in_stride = 256 * M; ca.zacc = zacc;
@@ -287,7 +298,7 @@ int nastar_encoder_cnn_forward(const float* map, const float* start, const float
         const unsigned pg = (unsigned)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
         ConvArgs ca;
         ca.B = nb; ca.H = H; ca.W = W; ca.out_f32 = nullptr; ca.final_mul = final_mul;
-        ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+        ca.wfin = nullptr; ca.wfin_lo = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
         int rc;
         if (H == 32 && W == 32 && !(enc_flags() & 17)) {  // bit 4: keep input assembly and the first two layers separate launches
             StemArgs sa;
@@ -350,7 +361,7 @@ int nastar_conv3x3_bf16(const uint16_t* in, const uint16_t* wpack, const float* 
     if (B <= 0 || H % ENC_TH != 0 || W % ENC_TW != 0) return NASTAR_ERR_BAD_SHAPE;
     ConvArgs ca;
     ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.final_mul = 1.f;
-    ca.wfin = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
+    ca.wfin = nullptr; ca.wfin_lo = nullptr; ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr;
     ca.B = B; ca.H = H; ca.W = W;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (cin == 16 && cout == 32) return relu ? launch_conv<16, 32, 32, true, false>(ca, s) : launch_conv<16, 32, 32, false, false>(ca, s);
@@ -477,7 +488,7 @@ int nastar_conv3x3_img32_f16(const uint16_t* in, const uint16_t* wpack, const fl
     const bool relu = flags & NASTAR_CONV_RELU, split = flags & NASTAR_CONV_SPLIT;
     if (flags & ~(NASTAR_CONV_RELU | NASTAR_CONV_SPLIT)) return NASTAR_ERR_UNSUPPORTED;
     ConvArgs ca;
-    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.wfin = nullptr;
+    ca.in = in; ca.wpack = wpack; ca.scale = scale; ca.shift = shift; ca.out = out; ca.out_f32 = nullptr; ca.wfin = nullptr; ca.wfin_lo = nullptr;
     ca.fscale = nullptr; ca.fshift = nullptr; ca.in_stride = 0; ca.pass_flags = 0; ca.zacc = nullptr; ca.final_mul = 1.0f;
     ca.B = B; ca.H = 32; ca.W = 32;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
