@@ -224,43 +224,63 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     }
 
     // ---- epilogue: D layout col = lane&31 = pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = channel in the 32-block ----
+    if constexpr (kFinal) {
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int p = p0 + wave * 64 + pb * 32 + px;
-        if (p >= a.npix) continue;
-        if constexpr (kFinal) {
-            if (kh == 0 && nblk == 0) {
+        for (int pb = 0; pb < 2; ++pb) {
+            const int p = p0 + wave * 64 + pb * 32 + px;
+            if (p < a.npix && kh == 0 && nblk == 0) {
                 const float z = acc[pb][0][0] * ss[0] + ss[NT];
                 a.out_f32[p] = a.raw ? z : a.final_mul / (1.0f + __expf(-z));
             }
-        } else {
-            const size_t ob = (size_t)p * (kSplit ? 2 * a.COUT : a.COUT);
+        }
+    } else {
+        // A lane holds 4 consecutive channels of ITS pixel per register quad: stored directly, every store instruction would scatter 8
+        // bytes into 64 different lines.  The values go through a wave-private LDS patch instead (the staging area is free now; 16-byte
+        // chunk index XORed with the pixel pair: as in the 32x32 kernel) and leave as whole pixel rows: 64 / CPP pixels x NT channels
+        // = 1 KB of full 128- (or 64-) byte pieces per store instruction.
+        __syncthreads();  // every wave is done reading the last slice
+        constexpr int CPP = NT / 8;        // 16-byte chunks per pixel and precision half
+        constexpr int PPR = 64 / CPP;      // pixels per store round
+        unsigned char* ob = smem + FC_PIXB + wave * (32 * NT * 2);
+        const int ostride = kSplit ? 2 * a.COUT : a.COUT;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
+        for (int pb = 0; pb < 2; ++pb) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = n * 32 + 8 * g + 4 * kh;
-                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                    const float4 sh = *reinterpret_cast<const float4*>(ss + NT + cl);
-                    float v0 = acc[pb][n][4 * g + 0] * sc.x + sh.x;
-                    float v1 = acc[pb][n][4 * g + 1] * sc.y + sh.y;
-                    float v2 = acc[pb][n][4 * g + 2] * sc.z + sh.z;
-                    float v3 = acc[pb][n][4 * g + 3] * sc.w + sh.w;
-                    if (a.relu) {
-                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    }
-                    v0 = f16_clamp(v0); v1 = f16_clamp(v1); v2 = f16_clamp(v2); v3 = f16_clamp(v3);
-                    uint2 o;
-                    o.x = pack_f16x2(v0, v1);
-                    o.y = pack_f16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(a.out + ob + n0 + cl) = o;
-                    if constexpr (kSplit) {
-                        uint2 l;
-                        l.x = pack_f16x2(f16_residual(v0), f16_residual(v1));
-                        l.y = pack_f16x2(f16_residual(v2), f16_residual(v3));
-                        *reinterpret_cast<uint2*>(a.out + ob + a.COUT + n0 + cl) = l;
+            for (int part = 0; part < (kSplit ? 2 : 1); ++part) {  // the hi halves, then the lo halves (v - fp16(v))
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = n * 32 + 8 * g + 4 * kh;
+                        const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
+                        const float4 sh = *reinterpret_cast<const float4*>(ss + NT + cl);
+                        float v0 = acc[pb][n][4 * g + 0] * sc.x + sh.x;
+                        float v1 = acc[pb][n][4 * g + 1] * sc.y + sh.y;
+                        float v2 = acc[pb][n][4 * g + 2] * sc.z + sh.z;
+                        float v3 = acc[pb][n][4 * g + 3] * sc.w + sh.w;
+                        if (a.relu) {
+                            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                        }
+                        v0 = f16_clamp(v0); v1 = f16_clamp(v1); v2 = f16_clamp(v2); v3 = f16_clamp(v3);
+                        if (part == 1) {
+                            v0 = f16_residual(v0); v1 = f16_residual(v1); v2 = f16_residual(v2); v3 = f16_residual(v3);
+                        }
+                        uint2 o;
+                        o.x = pack_f16x2(v0, v1);
+                        o.y = pack_f16x2(v2, v3);
+                        const int chunk = n * 4 + g;
+                        *reinterpret_cast<uint2*>(ob + px * (NT * 2) + ((chunk ^ ((px >> 1) & (CPP - 1))) << 4) + kh * 8) = o;
                     }
                 }
+                __builtin_amdgcn_wave_barrier();  // a wavefront's LDS accesses execute in order: a compiler-level ordering point is enough
+#pragma unroll
+                for (int j = 0; j < 32 / PPR; ++j) {
+                    const int q = j * PPR + lane / CPP, chunk = lane % CPP;
+                    const uint4 v = *reinterpret_cast<const uint4*>(ob + q * (NT * 2) + ((chunk ^ ((q >> 1) & (CPP - 1))) << 4));
+                    const int p = p0 + wave * 64 + pb * 32 + q;
+                    if (p < a.npix) *reinterpret_cast<uint4*>(a.out + (size_t)p * ostride + part * a.COUT + n0 + chunk * 8) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }

@@ -145,31 +145,42 @@ def run(inp, inp2, wpack, scale, shift, B, H, W, C1, C2, COUT, relu, final, ups,
                                 a2 = wa[n].reshape(2, 32, 8)
                                 acc[wave, pb, n] += np.einsum("hre,hce->rc", a2, b2)
         sc, sh = scale[n0:n0 + NT].astype(np.float64), shift[n0:n0 + NT].astype(np.float64)
+        CPP, PPR = NT // 8, 64 // (NT // 8)  # 16-byte chunks per pixel and precision half; pixels per store round
         for wave in range(4):
             for pb in range(2):
-                for ln in range(64):
-                    p = p0 + wave * 64 + pb * 32 + (ln & 31)
-                    if p >= npix:
-                        continue
-                    khl = ln >> 5
-                    if final:
-                        if khl == 0 and nblk == 0:
+                if final:
+                    for ln in range(64):
+                        p = p0 + wave * 64 + pb * 32 + (ln & 31)
+                        if p < npix and (ln >> 5) == 0 and nblk == 0:
                             z = acc[wave, pb, 0, 0, ln & 31] * sc[0] + sh[0]
                             out32[p] = final_mul / (1.0 + np.exp(-z))
-                        continue
-                    ob = p * COUT * mult
-                    for n in range(NB):
-                        for g in range(4):
-                            cl = n * 32 + 8 * g + 4 * khl
-                            for e in range(4):
-                                reg = 4 * g + e
-                                row = (reg & 3) + 8 * (reg >> 2) + 4 * khl
-                                v = acc[wave, pb, n, row, ln & 31] * sc[cl + e] + sh[cl + e]
-                                if relu:
-                                    v = max(v, 0.0)
-                                v = np.float32(min(max(v, -65504.0), 65504.0))
-                                hi = np.float16(v)
-                                out[ob + n0 + cl + e] = hi
-                                if split:
-                                    out[ob + COUT + n0 + cl + e] = np.float16(v - np.float32(hi))
+                    continue
+                for part in range(mult):
+                    # the wave-private LDS patch of the kernel's epilogue: 32 pixels x NT fp16, 16-byte chunk index XORed with the pixel pair
+                    patch = np.full((32 * NT,), np.float16(777.0), np.float16)
+                    for ln in range(64):
+                        pxl, khl = ln & 31, ln >> 5
+                        for n in range(NB):
+                            for g in range(4):
+                                cl = n * 32 + 8 * g + 4 * khl
+                                chunk = n * 4 + g
+                                base = pxl * (NT * 2) + ((chunk ^ ((pxl >> 1) & (CPP - 1))) << 4) + khl * 8  # byte offset
+                                for e in range(4):
+                                    reg = 4 * g + e
+                                    row = (reg & 3) + 8 * (reg >> 2) + 4 * khl
+                                    v = acc[wave, pb, n, row, pxl] * sc[cl + e] + sh[cl + e]
+                                    if relu:
+                                        v = max(v, 0.0)
+                                    v = np.float32(min(max(v, -65504.0), 65504.0))
+                                    hi = np.float16(v)
+                                    patch[base // 2 + e] = hi if part == 0 else np.float16(v - np.float32(hi))
+                    assert not np.any(patch == np.float16(777.0)), "epilogue patch has a hole"
+                    for j in range(32 // PPR):
+                        for ln in range(64):
+                            q, chunk = j * PPR + ln // CPP, ln % CPP
+                            src = q * (NT * 2) + ((chunk ^ ((q >> 1) & (CPP - 1))) << 4)
+                            p = p0 + wave * 64 + pb * 32 + q
+                            if p < npix:
+                                dst = p * COUT * mult + part * COUT + n0 + chunk * 8
+                                out[dst:dst + 8] = patch[src // 2:src // 2 + 8]
     return out32 if final else out
