@@ -1140,8 +1140,8 @@ def main():
                                     "not the headline value, which times strictly serial launches on one stream"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             # strictly LAST and alone: 256 ATen threads on [B,32,32] maps starve the GPU launch thread of anything timed beside them
-            _log("cpu baseline in BASELINE.md's exact configuration (hard limit 75 s)")
-            out["cpu_baseline"]["spec_config"] = cpu_baseline_spec_collect(cpu_baseline_spec_start(pr, hist, paths), timeout_s=75.0)
+            _log("cpu baseline in BASELINE.md's exact configuration (hard limit 45 s)")
+            out["cpu_baseline"]["spec_config"] = cpu_baseline_spec_collect(cpu_baseline_spec_start(pr, hist, paths), timeout_s=45.0)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_collate:
