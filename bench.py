@@ -832,14 +832,17 @@ def train_main(args, real_stdout):
     from neural_astar.utils import distributed as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1 or args.force_collate:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = max(world, 1)
     B = args.batch_per_gpu
     cfg = TRAIN_CONFIGS[args.config]
@@ -889,7 +892,7 @@ def train_main(args, real_stdout):
                                    f"encoder forward+backward on {'the MI355X training kernels' if args.encoder_backend.startswith('hip') else 'torch.nn (MIOpen)'}, "
                                    "HIP search forward + replay backward, fused L1 loss, RMSprop(lr 1e-3); random-init weights",
                        "batch_per_gpu": B, "global_batch": B * n_gpus, "encoder_backend": args.encoder_backend,
-                       "parallelism": (f"dp{n_gpus}: flat fp32 gradient all-reduce (RCCL) + all-reduced BatchNorm sums (sync_bn={sync_bn}), "
+                       "parallelism": (f"dp{n_gpus}: flat fp32 gradient all-reduce ({'RCCL' if args.dist_backend == 'nccl' else args.dist_backend}) + all-reduced BatchNorm sums (sync_bn={sync_bn}), "
                                        "coupling=global") if multi else "single"},
             "steps_per_s": args.steps / dt, "final_loss": float(loss),
             "roofline": {"bound": "mfma", "achieved": B * step_f / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
@@ -958,6 +961,9 @@ def main():
     ap.add_argument("--config", default="warcraft", choices=sorted(TRAIN_CONFIGS), help="--mode train: which reference training configuration")
     ap.add_argument("--batch-per-gpu", type=int, default=100, help="--mode train: maps per rank and step (the reference's batch_size is 100)")
     ap.add_argument("--encoder-backend", default="hip_f16x3", choices=["hip_f16x3", "hip_f16", "torch"], help="--mode train")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="dev: gloo lets N ranks share ONE GPU (with --share-gpu) to exercise every world > 1 branch of this script on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="dev: every rank uses cuda:0 (only with --dist-backend gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -975,13 +981,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     if world != max(args.gpus, 1) and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or args.force_collate:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback in the product path)"
     dev = torch.device("cuda", local_rank)
@@ -1020,8 +1029,8 @@ def main():
             run.step()
             collate(None)()
             torch.cuda.synchronize(dev)
-            collate_note = ("bit-packed histories+paths emitted by the search launch itself, 1 RCCL all-gather per step "
-                            "(kept packed), overlapped with the next step's search")
+            collate_note = (f"bit-packed histories+paths emitted by the search launch itself, 1 all-gather per step over "
+                            f"{'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} (kept packed), overlapped with the next step's search")
         except Exception as e:  # reported, not hidden: the line then says the collective was not part of the step
             collate = None
             collate_note = f"FAILED ({type(e).__name__}: {e}); steps timed without the all-gather"
