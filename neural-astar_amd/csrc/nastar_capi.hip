@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         if constexpr (ABL == -1) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
             int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
-            if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
+            if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);

@@ -131,42 +131,48 @@ namespace nastar {
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 relaxed neighbours AND the chunk's open cells enter the chunk minima: ONE atomic */ \
         "s_mov_b64 exec, -1\n\t"
 #define NASTAR_ASM3_EXPAND NASTAR_ASM3_EXPAND_(, )
-/* dive form: v55 = the key of every neighbour relaxed in this step, all ones elsewhere */
-#define NASTAR_ASM3_EXPAND_DIVE NASTAR_ASM3_EXPAND_("v_mov_b32 v55, -1\n\t", "v_mov_b32 v55, v47\n\t")
+/* dive form: s[60:61] = the neighbours relaxed in this step whose key is STRICTLY below the key s* was selected with (one VALU
+   instruction under the EXEC mask the relaxation already runs with: the whole per-step price of the dive test) */
+#define NASTAR_ASM3_EXPAND_DIVE NASTAR_ASM3_EXPAND_(, "v_cmp_lt_u32_e64 s[60:61], v47, s40\n\t")
 
 // ---- the "dive" (64x64 instantiation only) ---------------------------------------------------------------------------------------
 // When the best neighbour relaxed in this step has a key STRICTLY below the key s* was selected with, it is the next selection: every
 // other open cell was >= (key of s*, s*) in the (key, index) order when s* won, and only the relaxed neighbours changed since.  The
 // step then continues with that neighbour without waiting for the chunk-minima read-back, the per-lane minimum of four entries and the
-// 64-lane reduction.  The test is a 3-stage minimum over lanes 0-7 (the neighbour lanes are in raster order = increasing cell index,
-// so the first lane holding the minimum is the reference's first-flat-index tie-break) + one scalar compare: ~12 instructions on every
-// step, ~35 fewer on a hit.  Hit rate on the longest searches of the bench batches (tools/sim_dive.py): 78 % on random-obstacle 64x64
-// maps (BASELINE config 4), 50-73 % on random 32x32, 26-28 % on mazes -- the 32x32 / 16x16 instantiations keep the plain loop (a net
-// loss at 27 %), the 64x64 one, whose selection phase is also the most expensive (four chunk minima per lane), dives.  Measured at 32x32
-// (same box, back to back): maze32 158.5 -> 174.5 us per launch, rand32 74.9 -> 76.2 us -- not shipped there.
+// 64-lane reduction.  The per-step test is ONE v_cmp (relaxed neighbours with a key below the previous minimum -> an SGPR pair) + one
+// scalar compare-and-branch; only a hit pays for the 3-stage minimum over lanes 0-7 that picks the best candidate (the neighbour lanes
+// are in raster order = increasing cell index, so the first lane holding the minimum is the reference's first-flat-index tie-break).
+// (A first version ran the 3-stage minimum on every step: ~12 instructions per step; it paid at 64x64 only.)
+// Hit rate on the longest searches of the bench batches (tools/sim_dive.py): 78 % on random-obstacle 64x64 maps (BASELINE config 4),
+// 50-73 % on random 32x32, 26-28 % on mazes.  Measured with the one-instruction test, same box, back to back (us per 4096-map launch,
+// with / without): rand64 275.2 / 298.9, rand32 75.0 / 77.3, maze32 162.4 / 161.2; the reference's 64x64 block fixture (1169 steps, few
+// dives) 263 ns per step either way.  The 64x64 instantiation, whose selection phase is the most expensive (four chunk minima per
+// lane), dives; the 32x32 / 16x16 ones keep the plain loop: at a maze's 27 % the dive buys nothing and the headline batch is mazes.
 // Loop layout: both ways round cost exactly one taken branch (the dive's lookup code sits in front of the expansion and falls into it);
-// the chunk minima are still prefetched BEFORE the test (reading them only on the way into a full selection measured 2 % slower: -5.8 %
-// instead of -8.1 % against the plain loop on the rand64 batch).  Measured (4096 random-obstacle 64x64 maps, longest search 986 steps):
-// 308.6 -> 283.5 us per launch; the reference's 64x64 block fixture (1169 steps, few dives) pays 266 -> 282 ns per step.
+// the chunk minima are still prefetched BEFORE the test (reading them only on the way into a full selection measured 2 % slower).
 #define NASTAR_ASM3_DIVE_TEST \
+        "s_cmp_ge_u32 %[it], %[maxit]\n\t" \
+        "s_cbranch_scc1 .Lbudget%=\n\t" \
+        "s_cmp_lg_u64 s[60:61], 0\n\t" /* did any relaxed neighbour beat the previous minimum? */ \
+        "s_cbranch_scc1 .Ldive%=\n\t"
+#define NASTAR_ASM3_DIVE_LOOKUP \
+        ".Ldive%=:\n\t" \
+        "v_cndmask_b32_e64 v55, v48, v47, s[60:61]\n\t" /* candidates keep their key, everyone else all ones (v48) */ \
+        "s_nop 1\n\t" \
         "v_min_u32_dpp v56, v55, v55 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
         "v_min_u32_dpp v57, v55, v55 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
         "v_min_u32_dpp v56, v55, v56 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t" \
         "v_min_u32 v56, v56, v57\n\t" \
-        "s_cmp_ge_u32 %[it], %[maxit]\n\t" /* the budget test doubles as the two wait states in front of the next DPP */ \
-        "s_cbranch_scc1 .Lbudget%=\n\t" \
+        "s_add_u32 %[it], %[it], 1\n\t" \
+        "s_nop 0\n\t" \
         "v_min_u32_dpp v56, v56, v56 row_half_mirror row_mask:0xf bank_mask:0xf\n\t" \
         "s_nop 0\n\t" \
-        "v_readfirstlane_b32 s56, v56\n\t" /* best key among the neighbours relaxed in this step (all ones: none) */ \
-        "s_cmp_lt_u32 s56, s40\n\t" \
-        "s_cbranch_scc1 .Ldive%=\n\t"
-#define NASTAR_ASM3_DIVE_LOOKUP \
-        ".Ldive%=:\n\t" \
+        "v_readfirstlane_b32 s56, v56\n\t" /* the best candidate key (lanes 0-7 all hold it) */ \
+        "s_mov_b32 s40, s56\n\t" /* = the key the next s* is selected with */ \
+        "s_nop 0\n\t" \
         "v_cmp_eq_u32 vcc, s56, v55\n\t" \
         "s_ff1_i32_b64 s41, vcc\n\t" /* first neighbour lane with that key = smallest cell index among ties */ \
         "v_readlane_b32 s42, v46, s41\n\t" /* the next s* */ \
-        "s_mov_b32 s40, s56\n\t" \
-        "s_add_u32 %[it], %[it], 1\n\t" \
         "s_cmp_eq_u32 s42, %[goal]\n\t" \
         "s_cbranch_scc1 .Lgoal%=\n" \
         ".Lselected%=:\n\t"
@@ -194,7 +200,7 @@ namespace nastar {
         : "memory", "vcc", "scc", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", \
           "v34", "v35", "v36", "v37", "v40", "v41", "v42", "v43", "v46", "v47", "v48", "v49", "v50", "s40", "s41", "s42", \
           "s43", "s44", "s54", "s55", "s53", "v53", "v54", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "s48", "s49", \
-          "s50", "s51", "v55", "v56", "v57", "s56", "s58", "s59"
+          "s50", "s51", "v55", "v56", "v57", "s56", "s58", "s59", "s60", "s61"
 
 // Same contract as compact_search_loop_asm; precondition: every cost >= +0, g_ratio in [0, 1] (keys are raw float bits).
 // Tried on top (measured, dropped): running the expansion's LDS reads under EXEC = lanes 0-8 and 16-31 only: 173.0 vs 169.5 us (maze32),
