@@ -827,3 +827,24 @@ def test_vanilla_astar_forward_is_hipgraph_capturable_and_has_no_host_sync():
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(out.histories, ref2.histories) and torch.equal(out.paths, ref2.paths)
+
+
+def test_search_on_the_high_priority_stream_of_the_collated_path():
+    """`parallel.search_stream()` (what bench.py's collated steps launch on): one cached high-priority stream per
+    device, and the search launched on it gives the default stream's outputs."""
+    from neural_astar import parallel
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    hp = parallel.search_stream(dev)
+    assert hp is parallel.search_stream(dev) and hp.priority == -1
+    pr = syn.maze_maps(512, 32, seed=77)
+    va = VanillaAstar().to(dev).eval()
+    with torch.no_grad():
+        ref = va(*(_t(x) for x in pr))
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(hp):
+            out = va(*(_t(x) for x in pr))
+        torch.cuda.current_stream(dev).wait_stream(hp)
+        va.astar.raise_if_unsolvable()
+    assert torch.equal(out.histories, ref.histories) and torch.equal(out.paths, ref.paths)
