@@ -21,6 +21,9 @@
 #endif
 #include "nastar_search_asm.hip.h"
 #include "nastar_search_asm3.hip.h"
+#if NASTAR_DEV_KERNELS
+#include "nastar_search_asm3_abl.hip.h"
+#endif
 #include "nastar_backward_replay.hip.h"
 #include "nastar_backward_replay_asm.hip.h"
 
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     bool any_signed = true;
     // round-3 instruction stream (raw-bit keys): every cost >= +0 and 0 <= g_ratio <= 1 so that every priority is >= +0
     compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx,
-                                       ABL == -1 ? &any_signed : nullptr);
-    const bool asm3 = ABL == -1 && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
+                                       (ABL == -1 || ABL >= 300) ? &any_signed : nullptr);
+    const bool asm3 = (ABL == -1 || ABL >= 300) && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
     const int gi = goal_idx < 0 ? 0 : goal_idx;
     const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
     const int goal_c = gi - goal_r * d.W;
@@ -182,6 +185,10 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+        } else if constexpr (ABL >= 300) {  // DEV timing probe of the round-3 stream (nastar_search_asm3_abl.hip.h): garbage results
+#if NASTAR_DEV_KERNELS
+            s = compact_search_loop_asm3_abl<LOGW, ABL - 300>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW);
+#endif
         } else
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             ++iters;
             compact_expand<LOGW, kFastDiv, CPL_T, ABL>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
         }
-        if ((ABL == -1) ? (s != -2) : (iters < a.max_iters)) {
+        if ((ABL == -1 || ABL >= 300) ? (s != -2) : (iters < a.max_iters)) {
             if (s < 0) {
                 status = NASTAR_ERR_UNSOLVABLE;
             } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
@@ -826,6 +833,9 @@ static int forward_impl(const float* cost, const float* start, const float* goal
 #define NASTAR_ABL(N) case N: kern = &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, N>; break;
                 NASTAR_ABL(128) NASTAR_ABL(129) NASTAR_ABL(130) NASTAR_ABL(132) NASTAR_ABL(136) NASTAR_ABL(144) NASTAR_ABL(160) NASTAR_ABL(192)
                 NASTAR_ABL(142) NASTAR_ABL(175) NASTAR_ABL(255)
+                NASTAR_ABL(300) NASTAR_ABL(301) NASTAR_ABL(302) NASTAR_ABL(303) NASTAR_ABL(304) NASTAR_ABL(305) NASTAR_ABL(306) NASTAR_ABL(307)
+                NASTAR_ABL(308) NASTAR_ABL(309) NASTAR_ABL(310) NASTAR_ABL(311) NASTAR_ABL(312) NASTAR_ABL(313) NASTAR_ABL(314) NASTAR_ABL(315)
+                NASTAR_ABL(316) NASTAR_ABL(317) NASTAR_ABL(318)
 #undef NASTAR_ABL
                 default: return NASTAR_ERR_UNSUPPORTED;
             }

@@ -74,7 +74,7 @@ namespace nastar {
         "s_mov_b32 %[sel], s42\n" \
         ".Lend%=:\n\t"
 
-#define NASTAR_ASM3_EXPAND_(INIT55, SET55) \
+#define NASTAR_ASM3_X_PREFIX \
         "s_lshr_b32 s43, s42, %[LOGW]\n\t" /* r* */ \
         "s_and_b32 s44, s42, %[WM1]\n\t" /* c* */ \
         "v_add_u32 v32, s43, %[dr]\n\t" /* r_l */ \
@@ -90,14 +90,16 @@ namespace nastar {
         "v_cndmask_b32 v46, v24, v46, vcc\n\t" /* il: s* itself for out-of-map neighbours */ \
         "v_lshlrev_b32 v26, 3, v46\n\t" \
         "v_lshrrev_b32 v50, 4, v46\n\t" \
-        "v_lshlrev_b32 v50, 3, v50\n\t" /* byte offset of cmin[chunk of il] */ \
+        "v_lshlrev_b32 v50, 3, v50\n\t" /* byte offset of cmin[chunk of il] */
+#define NASTAR_ASM3_X_CLOSE \
  /* lane 8 (il == s*) closes s* (:222-225) and empties its chunk's entry BEFORE the lanes read their cells */ \
         "s_mov_b64 exec, 0x100\n\t" \
         "ds_write_b32 v27, %[vminf]\n\t" \
         "ds_write_b64 v50, v[48:49] offset:%[CMIN]\n\t" \
-        "s_mov_b64 exec, -1\n\t" \
-        "ds_read_b64 v[30:31], v26\n\t" /* g[il], cost[il] */ \
-        INIT55 \
+        "s_mov_b64 exec, -1\n\t"
+#define NASTAR_ASM3_X_READCELL \
+        "ds_read_b64 v[30:31], v26\n\t" /* g[il], cost[il] */
+#define NASTAR_ASM3_X_HEUR \
  /* h0 = get_heuristic at (r_l, c_l) (:26-52) on integers, in the shadow of the LDS round trip */ \
         "v_sad_u32 v35, v32, %[gr], 0\n\t" /* |dr| */ \
         "v_sad_u32 v36, v33, %[gc], 0\n\t" /* |dc| */ \
@@ -108,8 +110,10 @@ namespace nastar {
         "v_sqrt_f32 v34, v34\n\t" \
         "v_cvt_f32_u32 v37, v37\n\t" /* independent: the wait state between the transcendental and its use */ \
         "v_mul_f32 v34, 0x3a83126f, v34\n\t" /* fl32(0.001) * euclid */ \
-        "v_add_f32 v34, v37, v34\n\t" /* h0 */ \
-        "s_waitcnt lgkmcnt(0)\n\t" \
+        "v_add_f32 v34, v37, v34\n\t" /* h0 */
+#define NASTAR_ASM3_X_WAIT \
+        "s_waitcnt lgkmcnt(0)\n\t"
+#define NASTAR_ASM3_X_KEY \
         "v_add_f32 v34, v34, v31\n\t" /* :191-192 h = h0 + cost */ \
         "v_add_f32 v40, v28, v29\n\t" /* :234 g2 = g[s*] + cost[s*] */ \
         "v_mul_f32 v34, %[comg], v34\n\t" /* :206 (1-g_ratio)*h */ \
@@ -118,7 +122,8 @@ namespace nastar {
         "v_add_f32 v41, v41, v34\n\t" /* :206 f */ \
         "v_mul_f32 v42, %[crcp], v41\n\t" /* :207 f / sqrt(W), correctly rounded (tools/fastdiv_check.c) */ \
         "v_fma_f32 v43, -v42, %[csq], v41\n\t" \
-        "v_fma_f32 v47, v43, %[crcp], v42\n\t" /* q >= +0: its bits are the order-preserving key; [v46:v47] = (cell, key) */ \
+        "v_fma_f32 v47, v43, %[crcp], v42\n\t" /* q >= +0: its bits are the order-preserving key; [v46:v47] = (cell, key) */
+#define NASTAR_ASM3_X_RELAX(SET55) \
  /* the chunk's open cells (finite g; s* reads -inf) re-enter its minimum through the SAME 64-bit atomic instruction as the relaxed \
     neighbours (EXEC = both lane sets): one LDS atomic per step instead of two -- with 16 waves per CU the LDS pipe is the shared resource */ \
         "v_cmp_class_f32_e64 s[58:59], v30, %[cls]\n\t" /* chunk lanes whose cell is open */ \
@@ -130,6 +135,10 @@ namespace nastar {
         "s_or_b64 exec, exec, s[58:59]\n\t" \
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 relaxed neighbours AND the chunk's open cells enter the chunk minima: ONE atomic */ \
         "s_mov_b64 exec, -1\n\t"
+/* the expansion = its sections in program order (split so that tools/probe_ablate3.py can time the step with one section removed) */
+#define NASTAR_ASM3_EXPAND_(INIT55, SET55) \
+    NASTAR_ASM3_X_PREFIX NASTAR_ASM3_X_CLOSE NASTAR_ASM3_X_READCELL INIT55 NASTAR_ASM3_X_HEUR NASTAR_ASM3_X_WAIT NASTAR_ASM3_X_KEY \
+        NASTAR_ASM3_X_RELAX(SET55)
 #define NASTAR_ASM3_EXPAND NASTAR_ASM3_EXPAND_(, )
 /* dive form: s[60:61] = the neighbours relaxed in this step whose key is STRICTLY below the key s* was selected with (one VALU
    instruction under the EXEC mask the relaxation already runs with: the whole per-step price of the dive test) */
@@ -189,6 +198,21 @@ namespace nastar {
         "s_sub_u32 %[it], %[it], 1\n\t" \
         "s_mov_b32 %[sel], s42\n" \
         ".Lend%=:\n\t"
+
+// ---- measured and dropped on top of this loop (round 3, profiles/r03/INDEX.md) -----------------------------------------------------
+// tools/probe_ablate3.py (`make DEV=1`, nastar_search_asm3_abl.hip.h; profiles/r03/ablate3_step_sections.txt) times the step with one
+// section removed at a time.  Lone wavefront, ns per step out of ~230: the four row-level reduction stages 22, the whole reduction 26,
+// compare + find-first of the pick 17, the address prefix 29, closing s* 15, the relaxation's three LDS instructions 32 (the atomic
+// alone 6), the read-back of the chunk minima 18 exposed, the cell read 7 exposed, one taken branch 10, the reduction's wait states 13,
+// the compares of the two exits 15.  A lone wavefront pays ~7 cycles per instruction wherever the instruction sits, so only REMOVING
+// instructions helps; three re-arrangements that keep the count were built, verified bit-identical on the 4096-map batches, and
+// measured against this loop (us per 4096-map launch, same box, same run; `er_*.json`, `v3b_*.json`):
+//   * "early reduction": the next minimum KEY from registers (old minima + the keys this step inserts) reduced while the atomic and the
+//     read-back are in flight, +3 VALU: maze32 161.5 vs 159.5, rand32 75.8 vs 75.9, lone wave 305 vs 295 ns per step;
+//   * exit tests moved behind the cell read (the LDS shadow) + two steps per loop trip: maze32 157.1 vs 157.2, rand32 74.2 vs 73.4;
+//   * the same + an all-VALU address prefix (no SALU hop after the v_readlane): 157.9 / 72.9; + the row stage as three independent row
+//     rotations instead of two dependent mirrors with wait states (+2 VALU): 162.3 / 73.4 -- slower on the full batch, where a SIMD's
+//     four wavefronts are VALU-issue bound during the first ~150 steps.
 
 #define NASTAR_ASM3_OPERANDS \
         : [it] "+s"(it), [sel] "=s"(sel) \
