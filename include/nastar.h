@@ -308,6 +308,15 @@ int nastar_bn1_sigmoid_bwd(const float* z, const float* dcost, long long n, cons
  * and scal[t][2] receives max|w_t| -- the value nastar_pack_conv_weight_f16(..., reuse_max = 1) expects there. */
 int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* stream);
 
+/* One-launch forms of the training step's small work (round 3: at the reference's batch of 100 a U-Net step was 437 launches).
+ * nastar_pack_conv_weights_multi_f16: every weight pack of a step at once.  table = device int64 [n][8]: {w, bias or 0, co, ci,
+ *   transpose_flip, offset of the pack in flat16 (fp16 elements), offset in flatf (floats; scale[cout_p] then shift[cout_p]), row of
+ *   scal}; scal [rows][3] as left by nastar_absmax_multi_f32 (same arithmetic as nastar_pack_conv_weight_f16 with reuse_max).
+ * nastar_rmsprop_multi_f32: torch.optim.RMSprop's plain step (no momentum / centering / weight decay) for n tensors: table = device
+ *   int64 [n][4]: {param, grad, square_avg, element count}. */
+int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int split, float* scal, uint16_t* flat16, float* flatf, void* stream);
+int nastar_rmsprop_multi_f32(const long long* table, int n, float lr, float alpha, float eps, void* stream);
+
 /* Two-stage form of nastar_chan_stats_f16 (what the training path uses): per-workgroup partial sums in the caller's workspace
  * (nastar_chan_stats_workspace_bytes), added by a second launch in a fixed order: bitwise reproducible, no zero-fill launches, no fp64
  * atomics, and as many workgroups as the batch allows. */
@@ -332,6 +341,11 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
  */
 int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
                                 float* scale_out, float* shift_out, float* scal_out, int reuse_max, void* stream);
+/* nastar_bn_coef_bwd with the gradient scale read from gscale_in and the re-centred one written to gscale_out (a scale shared by two
+ * branches of a U-Net is not overwritten: no copy launch per block) */
+int nastar_bn_coef_bwd_io(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
+                          long long npix, const float* gscale_in, float* gscale_out, float* dgamma, float* dbeta, float* c1, float* c2,
+                          float* c3, int C, void* stream);
 int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta, double eps, long long npix, double momentum,
                        float* running_mean, float* running_var, float* k2, float* k3, double* mean_out, double* invstd_out, int C,
                        void* stream);

@@ -50,6 +50,14 @@ __device__ __forceinline__ void store8(uint16_t* base, size_t pix, int stride, i
 // part != nullptr (two-stage, deterministic form): instead of the atomics every workgroup writes its partial sums to part[blockIdx.x][C][2]
 // and its partial maximum to amax_part[blockIdx.x]; nastar_chan_stats_finish_kernel adds them in a fixed order.  No zero-fill launches, no
 // contended fp64 atomics (512 workgroups x 512 addresses at 4096 maps), and any number of workgroups: small batches get enough of them.
+//
+// Tried in round 3 and dropped: ONE launch for statistics + finish + BatchNorm coefficients (the workgroups that arrive last, counted with
+// device atomics over two levels, add the partial rows and compute the coefficients).  With agent-scope fences every workgroup's
+// release / acquire wrote back and invalidated its XCD's L2 under the workgroups still streaming z (CNN step 2.0 -> 2.65 ms); with
+// fence-free agent-scope atomics for the few values that cross workgroups the tail's serial memory round trips cost more than the two
+// small launches they replaced (per BatchNorm pass at 100 maps: 27.7 / 38.2 us forward / backward against 31.9 / 32.5 in three launches;
+// U-Net 19.0 / 24.4 against 17.2 / 16.9; profiles/r03/census_one_launch_bn_rejected.txt): back-to-back launches in one stream have no gap
+// on this GPU, so merging launches only pays when it removes work.
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                 const float* __restrict__ ms, const float* __restrict__ mt,
@@ -407,6 +415,74 @@ __global__ __launch_bounds__(256) void nastar_pack_weight_kernel(const float* __
     }
 }
 
+// Every weight pack of a training step in ONE launch (the U-Net step had 47 of them, 12 us each): table row t = {w, bias or 0, co, ci,
+// transpose_flip, offset into flat16 (fp16 elements), offset into flatf (floats: scale[cout_p] then shift[cout_p]), row of `scal`}.
+// grid = (blocks per tensor, tensors); scal rows hold max|w| in [2] on entry (nastar_absmax_multi_f32) and get 2^-s, 2^s in [0], [1].
+__global__ __launch_bounds__(256) void nastar_pack_weight_multi_kernel(const long long* __restrict__ table, int split, float* __restrict__ scal_all,
+                                                                       uint16_t* __restrict__ flat16, float* __restrict__ flatf)
+{
+    const long long* row = table + 8 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    const float* bias = reinterpret_cast<const float*>(row[1]);
+    const int co = (int)row[2], ci = (int)row[3], transpose_flip = (int)row[4];
+    uint16_t* wpack = flat16 + row[5];
+    float* scale_out = flatf + row[6];
+    float* scal = scal_all + 3 * row[7];
+    const int cout_l = transpose_flip ? ci : co, cin_l = transpose_flip ? co : ci;
+    const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
+    float* shift_out = scale_out + cout_p;
+    const int cinv = split ? 3 * cin_p : cin_p;
+    const int total = 9 * cinv * cout_p;
+    const float sc = split ? pow2_scale(scal[2], 16384.f, 0, 24) : 1.f;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {  // the forward and the input-gradient pack of one weight write the same two values
+            scal[0] = 1.f / sc;
+            scal[1] = sc;
+        }
+        for (int c = threadIdx.x; c < cout_p; c += 256) {
+            scale_out[c] = 1.f / sc;
+            shift_out[c] = (bias && c < cout_l) ? bias[c] : 0.f;
+        }
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int e = i & 7;
+        int r = i >> 3;
+        const int n = r % cout_p; r /= cout_p;
+        const int cv8 = r % (cinv >> 3);
+        const int tap = r / (cinv >> 3);
+        const int v = cv8 * 8 + e;
+        const int seg = v / cin_p, c = v - seg * cin_p;
+        float x = 0.f;
+        if (n < cout_l && c < cin_l) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            x = transpose_flip ? w[((size_t)c * ci + n) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((size_t)n * ci + c) * 9 + tap];
+            x *= sc;
+        }
+        const _Float16 hi = (_Float16)x;
+        const _Float16 val = (seg == 2) ? (_Float16)(x - (float)hi) : hi;
+        wpack[i] = *reinterpret_cast<const uint16_t*>(&val);
+    }
+}
+
+// torch.optim.RMSprop's plain step (alpha, eps; no momentum, not centered, no weight decay: the reference's optimiser, utils/training.py:52-53)
+// for EVERY parameter in one launch: table row t = {param, grad, square_avg, element count}; grid = (blocks per tensor, tensors).
+//   square_avg = alpha * square_avg + (1 - alpha) * g * g;  param -= lr * g / (sqrt(square_avg) + eps)
+__global__ __launch_bounds__(256) void nastar_rmsprop_multi_kernel(const long long* __restrict__ table, float lr, float alpha, float eps)
+{
+    const long long* row = table + 4 * (size_t)blockIdx.y;
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* sq = reinterpret_cast<float*>(row[2]);
+    const long long n = row[3];
+    const float oma = 1.f - alpha;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float s2 = alpha * sq[i] + oma * gi * gi;
+        sq[i] = s2;
+        p[i] -= lr * (gi / (sqrtf(s2) + eps));
+    }
+}
+
 // forward BatchNorm coefficients from the batch sums (one workgroup): k2 = gamma * invstd, k3 = beta - mean * k2; mean / invstd kept in
 // double for the backward; running statistics updated like nn.BatchNorm2d in training mode (unbiased variance, momentum).
 __global__ __launch_bounds__(256) void nastar_bn_coef_fwd_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
@@ -439,10 +515,11 @@ __global__ __launch_bounds__(256) void nastar_bn_coef_bwd_kernel(const double* _
                                                                  const double* __restrict__ mean, const double* __restrict__ invstd,
                                                                  const float* __restrict__ gamma, double npix, float* __restrict__ gscale,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, int C)
+                                                                 float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ c3, int C,
+                                                                 const float* __restrict__ gscale_in = nullptr)
 {
     __shared__ float red[4];
-    const double S = (double)gscale[0];
+    const double S = (double)(gscale_in ? gscale_in[0] : gscale[0]);  // gscale_in: read the scale there, leave it alone, write the new one to gscale
     float kmax = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) kmax = fmaxf(kmax, fabsf((float)((double)gamma[c] * invstd[c])));
     kmax = block_max_256(kmax, red);

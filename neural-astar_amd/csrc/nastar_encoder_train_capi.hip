@@ -201,8 +201,29 @@ int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* st
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(scal, 0, (size_t)n * 3 * sizeof(float), s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
-    hipLaunchKernelGGL(nastar_absmax_multi_kernel, dim3(8, (unsigned)n), dim3(256), 0, s, table, scal);
+    hipLaunchKernelGGL(nastar_absmax_multi_kernel, dim3(64, (unsigned)n), dim3(256), 0, s, table, scal);  // 64 x 256 lanes per tensor (the U-Net's 2.4 M-element weights)
     e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int split, float* scal, uint16_t* flat16, float* flatf, void* stream)
+{
+    if (!table || !scal || !flat16 || !flatf) return NASTAR_ERR_NULL;
+    if (n <= 0 || n > 65535) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_pack_weight_multi_kernel, dim3(1024, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, split,
+                       scal, flat16, flatf);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_rmsprop_multi_f32(const long long* table, int n, float lr, float alpha, float eps, void* stream)
+{
+    if (!table) return NASTAR_ERR_NULL;
+    if (n <= 0 || n > 65535) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_rmsprop_multi_kernel, dim3(512, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, lr, alpha, eps);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;
 }
@@ -215,6 +236,19 @@ int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta
     if (C <= 0 || npix <= 0) return NASTAR_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(nastar_bn_coef_fwd_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums, gamma, beta, eps,
                        (double)npix, momentum, running_mean, running_var, k2, k3, mean_out, invstd_out, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn_coef_bwd_io(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
+                          long long npix, const float* gscale_in, float* gscale_out, float* dgamma, float* dbeta, float* c1, float* c2,
+                          float* c3, int C, void* stream)
+{
+    if (!sums || !amax_dy || !mean || !invstd || !gamma || !gscale_in || !gscale_out || !dgamma || !dbeta || !c1 || !c2 || !c3) return NASTAR_ERR_NULL;
+    if (C <= 0 || npix <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_bn_coef_bwd_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums, amax_dy, mean, invstd,
+                       gamma, (double)npix, gscale_out, dgamma, dbeta, c1, c2, c3, C, gscale_in);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;

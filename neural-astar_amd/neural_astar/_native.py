@@ -69,6 +69,8 @@ EXPORTED_SYMBOLS = (
     "nastar_chan_stats_f16",
     "nastar_chan_stats_workspace_bytes",
     "nastar_absmax_multi_f32",
+    "nastar_pack_conv_weights_multi_f16",
+    "nastar_rmsprop_multi_f32",
     "nastar_bn1_parts",
     "nastar_bn1_fwd_partial",
     "nastar_bn1_sigmoid_fwd",
@@ -79,6 +81,7 @@ EXPORTED_SYMBOLS = (
     "nastar_pack_conv_weight_f16",
     "nastar_bn_coef_fwd",
     "nastar_bn_coef_bwd",
+    "nastar_bn_coef_bwd_io",
     "nastar_grad_seed_f16",
     "nastar_maxpool2x2_bwd_f16",
     "nastar_upcat_f16",
@@ -191,6 +194,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_bn1_sigmoid_bwd.argtypes = [vp, vp, cll, vp, vp, vp, vp, vp, ci, cd, vp, vp, vp, vp, vp]
     lib.nastar_absmax_multi_f32.restype = ci
     lib.nastar_absmax_multi_f32.argtypes = [vp, ci, vp, vp]
+    lib.nastar_pack_conv_weights_multi_f16.restype = ci
+    lib.nastar_pack_conv_weights_multi_f16.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.nastar_rmsprop_multi_f32.restype = ci
+    lib.nastar_rmsprop_multi_f32.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
     lib.nastar_chan_stats_workspace_bytes.restype = cz
     lib.nastar_chan_stats_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
     lib.nastar_chan_stats_f16_ws.restype = ci
@@ -199,6 +206,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_pack_conv_weight_f16.restype = ci
     lib.nastar_pack_conv_weight_f16.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_bn_coef_bwd_io.restype = ci
+    lib.nastar_bn_coef_bwd_io.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_fwd.restype = ci
     lib.nastar_bn_coef_fwd.argtypes = [vp, vp, vp, cd, ctypes.c_longlong, cd, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_bwd.restype = ci

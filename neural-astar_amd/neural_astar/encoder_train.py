@@ -171,6 +171,43 @@ class _Lib:
         _native.check(rc, "nastar_absmax_multi_f32")
         return scal
 
+    def pack_all(self, specs, split, scal=None):
+        """every weight pack of a step in ONE launch.  specs: [(w, bias or None, transpose_flip, row of `scal`)]; ``scal``: the
+        [rows, 3] table of ``weight_maxima`` (split operands) or None.  Returns [(wpack, scale, shift, scal_row)] (views of two flat
+        buffers), or None when a tensor is not plain contiguous fp32 (the caller then packs one by one)."""
+        ws = [sp[0].detach() for sp in specs]
+        bs = [sp[1].detach() if sp[1] is not None else None for sp in specs]
+        if any(t is not None and (t.dtype != torch.float32 or not t.is_contiguous()) for t in ws + bs):
+            return None
+        rows = 1 + max(sp[3] for sp in specs)
+        if scal is None:
+            scal = torch.empty((rows, 3), dtype=torch.float32, device=self.dev)
+        key = ("pack", str(self.dev), bool(split)) + tuple((w.data_ptr(), b.data_ptr() if b is not None else 0, w.shape[0], w.shape[1],
+                                                             int(sp[2]), int(sp[3])) for w, b, sp in zip(ws, bs, specs))
+        ent = self._TABLES.get(key)
+        if ent is None:
+            if len(self._TABLES) > 64:
+                self._TABLES.clear()
+            rows_t, lay, o16, of = [], [], 0, 0
+            for w, b, sp in zip(ws, bs, specs):
+                co, ci = w.shape[:2]
+                cout_l, cin_l = (ci, co) if sp[2] else (co, ci)
+                cin_p, cout_p = _pad32(cin_l), _pad32(cout_l)
+                n16 = 9 * (3 if split else 1) * cin_p * cout_p
+                rows_t.append([w.data_ptr(), b.data_ptr() if b is not None else 0, co, ci, int(sp[2]), o16, of, int(sp[3])])
+                lay.append((o16, n16, of, cout_p))
+                o16 += n16
+                of += 2 * cout_p
+            ent = (torch.tensor(rows_t, dtype=torch.int64).to(self.dev), lay, o16, of)
+            self._TABLES[key] = ent
+        table, lay, n16_all, nf_all = ent
+        flat16 = torch.empty((n16_all,), dtype=torch.int16, device=self.dev)
+        flatf = torch.empty((nf_all,), dtype=torch.float32, device=self.dev)
+        rc = self.lib.nastar_pack_conv_weights_multi_f16(table.data_ptr(), len(specs), int(split), scal.data_ptr(), flat16.data_ptr(),
+                                                         flatf.data_ptr(), self.stream)
+        _native.check(rc, "nastar_pack_conv_weights_multi_f16")
+        return [(flat16[o:o + n], flatf[f:f + c], flatf[f + c:f + 2 * c], scal[sp[3]]) for (o, n, f, c), sp in zip(lay, specs)]
+
     IMG32 = {(32, 64), (64, 128), (128, 256), (256, 128), (128, 64)}
 
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None, src2=None, c2=0):
@@ -262,28 +299,32 @@ class _CnnTrunk(torch.autograd.Function):
         betas = list(params[3:4 * D:4])
         with torch.cuda.device(dev):
             acts, zs, rs, coef, scals = [x0], [], [], [], []
+            tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
             h, w = H, W
             wmax = L.weight_maxima(ws) if split else None  # one launch for all D + 1 weight maxima
+            # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs
+            packs = L.pack_all([(ws[l], bs[l], False, l) for l in range(D + 1)] + [(ws[l], None, True, l) for l in range(1, D + 1)],
+                               split, wmax)
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
                 npix = B * h * w
-                wpack, scale, shift, scal = L.pack(wt, False, split, bs[l], scal=wmax[l] if wmax is not None else None)
+                wpack, scale, shift, scal = packs[l] if packs is not None else L.pack(wt, False, split, bs[l], scal=wmax[l] if wmax is not None else None)
                 scals.append(scal)
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
                 L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
-                sums = L.stats(None, z, None, None, npix, cout, split)
-                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
-                k2, k3 = L.f32(cout), L.f32(cout)
-                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
-                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
                 bn = cfg["bns"][l]
                 track = bn is not None and bn.track_running_stats and bn.running_mean is not None
                 mom = 0.0
                 if track:  # nn.BatchNorm2d's training-mode side effect (unbiased variance), done inside the coefficient kernel
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
-                    bn.num_batches_tracked += 1
+                    tracked.append(bn.num_batches_tracked)
                 gam, bet = gammas[l].detach(), betas[l].detach()
+                sums = L.stats(None, z, None, None, npix, cout, split)
+                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
+                k2, k3 = L.f32(cout), L.f32(cout)
+                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
                 rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix_bn, float(mom),
                                               bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                               k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
@@ -304,12 +345,16 @@ class _CnnTrunk(torch.autograd.Function):
                 else:
                     acts.append(r)
             wl = ws[D]
-            wpackl, scalel, shiftl, scal = L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None)  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+            wpackl, scalel, shiftl, scal = (packs[D] if packs is not None else  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+                                            L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None))
             scals.append(scal)
             zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
             L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
+            if tracked:
+                torch._foreach_add_(tracked, 1)
         ctx.cfg = cfg
         ctx.acts, ctx.zs, ctx.rs, ctx.coef, ctx.scals = acts, zs, rs, coef, scals
+        ctx.tpacks = packs[D + 1:] if packs is not None else None  # input-gradient packs of blocks 1..D (the weights do not change in between)
         ctx.save_for_backward(*params)
         return zl.unsqueeze(1)
 
@@ -343,11 +388,11 @@ class _CnnTrunk(torch.autograd.Function):
                 cout, cin = wt.shape[:2]
                 cin_p = _pad32(cin)
                 grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, h, w, cur_co, cin_p, cout, cin, split, gscale)
-                grads[4 * l + 1] = torch.zeros_like(params[4 * l + 1])             # conv bias in front of a BatchNorm: exactly 0
+                grads[4 * l + 1] = torch.empty_like(params[4 * l + 1])             # conv bias in front of a BatchNorm: exactly 0 (zeroed below)
                 if l == 0:
                     break
                 # input gradient: the same convolution with W^T flipped (cin <-> cout; cout 1 of the last block padded to 32 inputs)
-                wpack, scale, shift, _ = L.pack(wt, True, split, scal=ctx.scals[l])
+                wpack, scale, shift, _ = ctx.tpacks[l - 1] if ctx.tpacks is not None else L.pack(wt, True, split, scal=ctx.scals[l])
                 da = torch.empty((npix * cin_p * mult,), dtype=torch.int16, device=dev)
                 L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
                 C = cin_p
@@ -376,6 +421,7 @@ class _CnnTrunk(torch.autograd.Function):
                 dzb = torch.empty_like(da)
                 L.affine(da, z, c1, c2, c3, k2f, k3f, dzb, npix, C, False, split)
                 cur_co = C
+            torch._foreach_zero_([grads[4 * l + 1] for l in range(D + 1)])  # one launch for all of them
         return (None, None) + tuple(grads)
 
 
@@ -579,11 +625,17 @@ class _UnetTrunk(torch.autograd.Function):
         sflag = CONV_SPLIT if split else 0
         acts = {"x0": (x0, 32)}
         saved = []
+        tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
         out = None
         with torch.cuda.device(dev):
             conv_steps = [st for st in cfg["plan"] if st["kind"] != "pool"]
             wmax = L.weight_maxima([params[st["w"]] for st in conv_steps]) if split else None  # one launch for all weight maxima
             wrow = {id(st): k for k, st in enumerate(conv_steps)}
+            # every weight pack of the step in one launch: the forward forms in plan order, then the input-gradient forms
+            tsteps = [st for st in conv_steps if st["src"] != "x0"]
+            packs = L.pack_all([(params[st["w"]], params[st["b"]] if st["b"] is not None else None, False, wrow[id(st)]) for st in conv_steps]
+                               + [(params[st["w"]], None, True, wrow[id(st)]) for st in tsteps], split, wmax)
+            tpack = {id(st): packs[len(conv_steps) + k] for k, st in enumerate(tsteps)} if packs is not None else None
             for st in cfg["plan"]:
                 h, w = H // st["div"], W // st["div"]
                 if st["kind"] == "pool":
@@ -602,7 +654,8 @@ class _UnetTrunk(torch.autograd.Function):
                 src2, c2 = acts[st["skip"]] if st["skip"] is not None else (None, 0)
                 ups = CONV_UPSAMPLE if st["ups"] else 0
                 npix = B * h * w
-                wpack, scale, shift, scal = L.pack(wt, False, split, bias, scal=wmax[wrow[id(st)]] if wmax is not None else None)
+                wpack, scale, shift, scal = (packs[wrow[id(st)]] if packs is not None else
+                                             L.pack(wt, False, split, bias, scal=wmax[wrow[id(st)]] if wmax is not None else None))
                 if st["final"]:
                     out = torch.empty((B, h, w), dtype=torch.float32, device=dev)
                     L.conv(src, wpack, scale, shift, B, h, w, c1, 32, sflag | CONV_FINAL | CONV_RAW, out_f32=out)
@@ -611,17 +664,17 @@ class _UnetTrunk(torch.autograd.Function):
                 cout = wt.shape[0]
                 z = L.i16(npix * cout * mult)
                 L.conv(src, wpack, scale, shift, B, h, w, c1, cout, sflag | ups, out=z, src2=src2, c2=c2)
-                sums = L.stats(None, z, None, None, npix, cout, split)
-                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
-                k2, k3 = L.f32(cout), L.f32(cout)
-                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
-                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
                 bn = st["bn"]
                 track = bn.track_running_stats and bn.running_mean is not None
                 mom = 0.0
                 if track:
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
-                    bn.num_batches_tracked += 1
+                    tracked.append(bn.num_batches_tracked)
+                sums = L.stats(None, z, None, None, npix, cout, split)
+                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
+                k2, k3 = L.f32(cout), L.f32(cout)
+                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
                 rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
                                               float(bn.eps), npix_bn, float(mom), bn.running_mean.data_ptr() if track else None,
                                               bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
@@ -633,7 +686,9 @@ class _UnetTrunk(torch.autograd.Function):
                 saved.append({"z": z, "coef": (mean, invstd, k2, k3), "scal": scal})
                 if cfg.get("debug") is not None:  # ... and the ReLU mask of this block: [k2 z + k3 > 0]
                     cfg["debug"]["fwd:" + st["dst"]] = (z, k2, k3, (B, h, w, cout))
-        ctx.cfg, ctx.acts, ctx.saved = cfg, acts, saved
+            if tracked:
+                torch._foreach_add_(tracked, 1)
+        ctx.cfg, ctx.acts, ctx.saved, ctx.tpack = cfg, acts, saved, tpack
         ctx.save_for_backward(*params)
         return out.unsqueeze(1)
 
@@ -662,6 +717,7 @@ class _UnetTrunk(torch.autograd.Function):
             _native.check(rc, "nastar_grad_add_f16")
             grads[name] = (out, So)
 
+        zero_bias = []
         with torch.cuda.device(dev):
             amax = L.f32(1)
             for idx in range(len(cfg["plan"]) - 1, -1, -1):
@@ -695,27 +751,28 @@ class _UnetTrunk(torch.autograd.Function):
                     g, S_in = grads.pop(st["dst"])
                     if cfg.get("debug") is not None:  # dev probe: the gradient w.r.t. this block's output, as it arrives
                         cfg["debug"][st["dst"]] = (g.clone(), S_in.clone(), (B, h, w, cout))
-                    S = S_in.clone()  # the BatchNorm backward re-centres the scale in place
+                    S = L.f32(1)  # the BatchNorm backward re-centres the scale: S_in (possibly shared with a skip branch) -> S
                     z = sv["z"]
                     mean, invstd, k2f, k3f = sv["coef"]
                     sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
-                    world = _sync_sums(sums, S)
+                    world = _sync_sums(sums, S_in)
                     dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
-                    rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                  params[st["g"]].detach().data_ptr(), npix * world, S.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                  c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout, L.stream)
-                    _native.check(rc, "nastar_bn_coef_bwd")
+                    rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                     params[st["g"]].detach().data_ptr(), npix * world, S_in.data_ptr(), S.data_ptr(), dgamma.data_ptr(),
+                                                     dbeta.data_ptr(), c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout, L.stream)
+                    _native.check(rc, "nastar_bn_coef_bwd_io")
                     if world > 1:  # formed from the GLOBAL sums; the flat gradient all-reduce averages over ranks
                         dgamma /= world
                         dbeta /= world
-                    grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta
                     if cfg.get("debug") is not None:
                         cfg["debug"][st["dst"] + ":bn"] = (z, k2f, k3f, dbeta.clone(), dgamma.clone(), sums.clone(), S_in.clone())
+                    grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta
                     dzb = L.i16(npix * cout * mult)
                     L.affine(g, z, c1v, c2v, c3v, k2f, k3f, dzb, npix, cout, False, split)
                     cur_co = cout
                     if st["b"] is not None:
-                        grads_p[st["b"]] = torch.zeros_like(params[st["b"]])  # conv bias in front of a BatchNorm: exactly 0
+                        grads_p[st["b"]] = torch.empty_like(params[st["b"]])  # conv bias in front of a BatchNorm: exactly 0 (zeroed below)
+                        zero_bias.append(grads_p[st["b"]])
                 # the convolution's input as ONE tensor (the decoder's upsample + concat is materialised for the weight gradient)
                 cin_p = c1 + c2
                 if st["ups"]:
@@ -727,7 +784,7 @@ class _UnetTrunk(torch.autograd.Function):
                 grads_p[st["w"]] = L.wgrad(dzb, a_in, B, h, w, cur_co, cin_p, cout, cin, split, S)
                 if st["src"] == "x0":
                     continue
-                wpack, scale, shift, _ = L.pack(wt, True, split, scal=sv["scal"])
+                wpack, scale, shift, _ = ctx.tpack[id(st)] if ctx.tpack is not None else L.pack(wt, True, split, scal=sv["scal"])
                 da = L.i16(npix * cin_p * mult)
                 L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
                 if st["ups"]:
@@ -740,6 +797,8 @@ class _UnetTrunk(torch.autograd.Function):
                         accumulate(st["skip"], dsk, S, npix, c2)
                 else:
                     accumulate(st["src"], da, S, npix, cin_p)
+            if zero_bias:
+                torch._foreach_zero_(zero_bias)  # one launch for all of them
         return (None, None) + tuple(grads_p)
 
 

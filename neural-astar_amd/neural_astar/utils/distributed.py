@@ -141,7 +141,9 @@ class DataParallelTrainer:
                  coupling: str = "none", sync_bn: bool = False, buffer_sync_every: int = 0, force_collectives: bool = False):
         self.planner = planner
         self.group = group
-        self.optimizer = torch.optim.RMSprop(planner.parameters(), lr)  # reference training.py:52-53
+        # reference training.py:52-53: RMSprop(lr); on the device its step is one launch (utils/optim.py: same state, same update)
+        from .optim import FusedRMSprop
+        self.optimizer = FusedRMSprop(planner.parameters(), lr)
         if coupling not in ("none", "global", "local"):
             raise ValueError(coupling)
         self.coupling = coupling

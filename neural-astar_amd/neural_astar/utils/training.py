@@ -79,7 +79,8 @@ class PlannerModule(_ModuleBase):
         return self.planner(map_designs, start_maps, goal_maps)
 
     def configure_optimizers(self) -> torch.optim.Optimizer:
-        return torch.optim.RMSprop(self.planner.parameters(), self.config.params.lr)
+        from .optim import FusedRMSprop  # torch.optim.RMSprop with a one-launch step on the device (same state and update)
+        return FusedRMSprop(self.planner.parameters(), self.config.params.lr)
 
     def training_step(self, train_batch, batch_idx):
         map_designs, start_maps, goal_maps, opt_trajs = train_batch

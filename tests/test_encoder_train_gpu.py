@@ -581,3 +581,57 @@ def test_last_block_batchnorm_sigmoid_matches_torch_autograd(n_maps, hw, const):
     if cpar is not None:
         assert _rel(cd.grad, c64.grad) <= 2e-5
     assert _rel(bnd.running_mean, bn64.running_mean) <= 1e-6 and _rel(bnd.running_var, bn64.running_var) <= 1e-6
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_all_weight_packs_of_a_step_in_one_launch(split):
+    """nastar_pack_conv_weights_multi_f16 == nastar_pack_conv_weight_f16 per weight (forward and input-gradient forms, shared maxima)"""
+    from neural_astar import encoder_train as ET
+    dev = _dev()
+    L = ET._Lib(dev)
+    g = torch.Generator().manual_seed(9)
+    shapes = [(32, 2), (64, 32), (128, 64), (1, 128), (96, 40)]
+    ws = [(torch.randn((co, ci, 3, 3), generator=g) * (0.02 + 0.3 * k)).to(dev) for k, (co, ci) in enumerate(shapes)]
+    bs = [torch.randn(co, generator=g).to(dev) for co, _ in shapes]
+    wmax = L.weight_maxima(ws) if split else None
+    specs = [(ws[k], bs[k], False, k) for k in range(len(ws))] + [(ws[k], None, True, k) for k in range(1, len(ws))]
+    for _ in range(2):  # the second call takes the cached table
+        packs = L.pack_all(specs, split, wmax)
+    assert packs is not None and len(packs) == len(specs)
+    for (w, b, tf, k), (wpack, scale, shift, scal) in zip(specs, packs):
+        rp, rs, rsh, rscal = L.pack(w, tf, split, b)
+        torch.cuda.synchronize()
+        assert torch.equal(wpack, rp) and torch.equal(scale, rs) and torch.equal(shift, rsh), (tuple(w.shape), tf)
+        if split:
+            assert torch.equal(scal, rscal)
+    # a weight that is not plain fp32 declines (the caller packs one by one)
+    assert L.pack_all([(ws[0].double(), None, False, 0)], split, None) is None
+
+
+def test_fused_rmsprop_equals_torch_rmsprop():
+    """utils/optim.FusedRMSprop (one launch per step) against torch.optim.RMSprop on the same gradients: parameters and state"""
+    from neural_astar.utils.optim import FusedRMSprop
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(32, 2, 3, 3), (32,), (256, 128, 3, 3), (1,), (7, 5)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedRMSprop(pa, 1e-3), torch.optim.RMSprop(pb, 1e-3)
+    for step in range(5):
+        for x, y in zip(pa, pb):
+            gr = (torch.randn(x.shape, generator=g) * 10.0 ** (step - 3)).to(dev)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        if step == 3:  # a parameter without a gradient is skipped by both
+            pa[1].grad = pb[1].grad = None
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    for x, y in zip(pa, pb):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+        sa, sb = oa.state[x], ob.state[y]
+        assert float(sa["step"]) == float(sb["step"])
+        assert torch.allclose(sa["square_avg"], sb["square_avg"], rtol=2e-6, atol=1e-30)
+    # checkpoints are interchangeable
+    ob2 = torch.optim.RMSprop(pb, 1e-3)
+    ob2.load_state_dict(oa.state_dict())
+    assert torch.equal(ob2.state[pb[0]]["square_avg"], oa.state[pa[0]]["square_avg"])
