@@ -341,6 +341,17 @@ int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1
  */
 int nastar_pack_conv_weight_f16(const float* w, int co, int ci, int transpose_flip, int split, const float* bias, uint16_t* wpack,
                                 float* scale_out, float* shift_out, float* scal_out, int reuse_max, void* stream);
+/* One BatchNorm pass of the training step in TWO launches instead of three: nastar_chan_stats_f16_ws's partial pass, then ONE kernel that adds the
+ * partial rows (same fixed order) and turns each channel's sums into the coefficients of nastar_bn_coef_fwd / nastar_bn_coef_bwd (workspace:
+ * nastar_chan_stats_workspace_bytes; sums_out: optional double [C][2]; gscale_out must not alias gscale_in).  Data-parallel training with global statistics needs the sums between
+ * the halves (all-reduce) and keeps the separate entry points. */
+int nastar_bn_stats_coef_fwd_f16(const uint16_t* z, long long npix, int C, int split, const float* gamma, const float* beta, double eps,
+                                 double momentum, float* running_mean, float* running_var, float* k2, float* k3, double* mean_out,
+                                 double* invstd_out, double* sums_out, void* workspace, size_t workspace_bytes, void* stream);
+int nastar_bn_stats_coef_bwd_f16(const uint16_t* da, const uint16_t* z, const float* ms, const float* mt, long long npix, int C, int split,
+                                 const double* mean, const double* invstd, const float* gamma, const float* gscale_in, float* gscale_out,
+                                 float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* sums_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* nastar_bn_coef_bwd with the gradient scale read from gscale_in and the re-centred one written to gscale_out (a scale shared by two
  * branches of a U-Net is not overwritten: no copy launch per block) */
 int nastar_bn_coef_bwd_io(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,

@@ -58,6 +58,9 @@ __device__ __forceinline__ void store8(uint16_t* base, size_t pix, int stride, i
 // small launches they replaced (per BatchNorm pass at 100 maps: 27.7 / 38.2 us forward / backward against 31.9 / 32.5 in three launches;
 // U-Net 19.0 / 24.4 against 17.2 / 16.9; profiles/r03/census_one_launch_bn_rejected.txt): back-to-back launches in one stream have no gap
 // on this GPU, so merging launches only pays when it removes work.
+__device__ __forceinline__ float block_max_256(float v, float* red);
+__device__ __forceinline__ float pow2_scale(float amax, float target, int lo, int hi);
+
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                 const float* __restrict__ ms, const float* __restrict__ mt,
@@ -166,6 +169,82 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_finish_kernel(const dou
             __syncthreads();
         }
         if (threadIdx.x == 0) amax_out[0] = red[0];
+    }
+}
+
+// finish + BatchNorm coefficients in ONE launch (the per-channel arithmetic of nastar_bn_coef_{fwd,bwd}_kernel needs only that channel's two
+// sums): grid = ceil(C / 4) workgroups of 256 = 8 outputs x 32 lanes as in nastar_chan_stats_finish_kernel, then lanes 0..3 turn the four
+// channels' sums into coefficients.  kBwd: every workgroup reduces the partial maxima and max|gamma invstd| itself (a few KB), workgroup 0
+// writes the re-centred gradient scale.  Same sums (same order) as the two-launch form; sums_out (optional) receives them.
+template <bool kBwd>
+__global__ __launch_bounds__(256) void nastar_bn_finish_coef_kernel(const double* __restrict__ part, const float* __restrict__ amax_part, int nblk,
+                                                                    int C, double* __restrict__ sums_out, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, double eps, double npix, double momentum,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                    float* __restrict__ k2, float* __restrict__ k3, double* __restrict__ mean_out,
+                                                                    double* __restrict__ invstd_out, const double* __restrict__ mean,
+                                                                    const double* __restrict__ invstd, const float* __restrict__ gscale_in,
+                                                                    float* __restrict__ gscale_out, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2,
+                                                                    float* __restrict__ c3)
+{
+    __shared__ double fs[8];
+    __shared__ float red4[4];
+    const int C2 = 2 * C;
+    const int o = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    double acc = 0.0;
+    if (o < C2)
+        for (int b = l; b < nblk; b += 32) acc += part[(size_t)b * (size_t)C2 + o];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);
+    if (l == 0) {
+        fs[threadIdx.x >> 5] = acc;
+        if (o < C2 && sums_out) sums_out[o] = acc;
+    }
+    float r = 1.f;
+    double S = 1.0;
+    if constexpr (kBwd) {
+        float m = 0.f, kmax = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += 256) m = fmaxf(m, amax_part[b]);
+        for (int c = threadIdx.x; c < C; c += 256) kmax = fmaxf(kmax, fabsf((float)((double)gamma[c] * invstd[c])));
+        m = block_max_256(m, red4);
+        __syncthreads();
+        kmax = block_max_256(kmax, red4);
+        S = (double)gscale_in[0];
+        r = pow2_scale(2.f * kmax * m, 1024.f, -40, 40);
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 4 + (int)threadIdx.x;
+    if (threadIdx.x < 4 && c < C) {
+        const double s0 = fs[2 * threadIdx.x], s1 = fs[2 * threadIdx.x + 1];
+        if constexpr (!kBwd) {
+            const double mu = s0 / npix;
+            double var = s1 / npix - mu * mu;
+            var = var < 0.0 ? 0.0 : var;
+            const double is = 1.0 / sqrt(var + eps);
+            const double g = (double)gamma[c];
+            k2[c] = (float)(g * is);
+            k3[c] = (float)((double)beta[c] - mu * g * is);
+            mean_out[c] = mu;
+            invstd_out[c] = is;
+            if (running_mean) {
+                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * var * (npix / (npix > 1.0 ? npix - 1.0 : 1.0)));
+            }
+        } else {
+            const double sdy = s0, sdyz = s1;
+            const double sdyx = (sdyz - mean[c] * sdy) * invstd[c];
+            dgamma[c] = (float)(sdyx / S);
+            dbeta[c] = (float)(sdy / S);
+            const double k1 = (double)gamma[c] * invstd[c];
+            const double m1 = sdy / npix, m2 = sdyx / npix;
+            c1[c] = (float)(k1 * r);
+            c2[c] = (float)(-k1 * m2 * invstd[c] * r);
+            c3[c] = (float)((-k1 * m1 + k1 * m2 * mean[c] * invstd[c]) * r);
+        }
+    }
+    if constexpr (kBwd) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) gscale_out[0] = (float)(S * (double)r);
     }
 }
 

@@ -150,6 +150,52 @@ int nastar_chan_stats_f16_ws(const uint16_t* u, const uint16_t* v, const float* 
     return NASTAR_OK;
 }
 
+// statistics (partial rows) + [finish + coefficients]: two launches instead of three per BatchNorm pass
+int nastar_bn_stats_coef_fwd_f16(const uint16_t* z, long long npix, int C, int split, const float* gamma, const float* beta, double eps,
+                                 double momentum, float* running_mean, float* running_var, float* k2, float* k3, double* mean_out,
+                                 double* invstd_out, double* sums_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!z || !gamma || !beta || !k2 || !k3 || !mean_out || !invstd_out || !workspace || (running_mean && !running_var)) return NASTAR_ERR_NULL;
+    if (npix <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < nastar_chan_stats_workspace_bytes(npix, C)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long grid = chan_stats_grid(npix, C);
+    double* part = static_cast<double*>(workspace);
+    if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, nullptr, nullptr, nullptr, nullptr, npix, C, part, nullptr);
+    else hipLaunchKernelGGL(nastar_chan_stats_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, nullptr, nullptr, nullptr, nullptr, npix, C, part, nullptr);
+    hipLaunchKernelGGL(nastar_bn_finish_coef_kernel<false>, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, part, nullptr, (int)grid, C, sums_out, gamma,
+                       beta, eps, (double)npix, momentum, running_mean, running_var, k2, k3, mean_out, invstd_out, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_bn_stats_coef_bwd_f16(const uint16_t* da, const uint16_t* z, const float* ms, const float* mt, long long npix, int C, int split,
+                                 const double* mean, const double* invstd, const float* gamma, const float* gscale_in, float* gscale_out,
+                                 float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* sums_out, void* workspace,
+                                 size_t workspace_bytes, void* stream)
+{
+    if (!da || !z || !ms || !mt || !mean || !invstd || !gamma || !gscale_in || !gscale_out || !dgamma || !dbeta || !c1 || !c2 || !c3 || !workspace)
+        return NASTAR_ERR_NULL;
+    if (npix <= 0 || C <= 0 || gscale_in == gscale_out) return NASTAR_ERR_BAD_SHAPE;  // every workgroup of the finishing kernel reads gscale_in
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < nastar_chan_stats_workspace_bytes(npix, C)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long grid = chan_stats_grid(npix, C);
+    double* part = static_cast<double*>(workspace);
+    float* amax_part = reinterpret_cast<float*>(part + (size_t)grid * (size_t)(2 * C));
+    if (split) hipLaunchKernelGGL(nastar_chan_stats_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, da, z, ms, mt, nullptr, nullptr, npix, C, part, amax_part);
+    else hipLaunchKernelGGL(nastar_chan_stats_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, da, z, ms, mt, nullptr, nullptr, npix, C, part, amax_part);
+    hipLaunchKernelGGL(nastar_bn_finish_coef_kernel<true>, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, part, amax_part, (int)grid, C, sums_out, gamma,
+                       nullptr, 0.0, (double)npix, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mean, invstd, gscale_in, gscale_out, dgamma,
+                       dbeta, c1, c2, c3);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 int nastar_chan_affine_f16(const uint16_t* u, const uint16_t* v, const float* k1, const float* k2, const float* k3, const float* ms,
                            const float* mt, uint16_t* out, long long npix, int C, int relu, int split, void* stream)
 {

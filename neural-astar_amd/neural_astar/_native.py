@@ -82,6 +82,8 @@ EXPORTED_SYMBOLS = (
     "nastar_bn_coef_fwd",
     "nastar_bn_coef_bwd",
     "nastar_bn_coef_bwd_io",
+    "nastar_bn_stats_coef_fwd_f16",
+    "nastar_bn_stats_coef_bwd_f16",
     "nastar_grad_seed_f16",
     "nastar_maxpool2x2_bwd_f16",
     "nastar_upcat_f16",
@@ -206,6 +208,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_pack_conv_weight_f16.restype = ci
     lib.nastar_pack_conv_weight_f16.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.nastar_bn_stats_coef_fwd_f16.restype = ci
+    lib.nastar_bn_stats_coef_fwd_f16.argtypes = [vp, ctypes.c_longlong, ci, ci, vp, vp, cd, cd, vp, vp, vp, vp, vp, vp, vp, vp, cz, vp]
+    lib.nastar_bn_stats_coef_bwd_f16.restype = ci
+    lib.nastar_bn_stats_coef_bwd_f16.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cz, vp]
     lib.nastar_bn_coef_bwd_io.restype = ci
     lib.nastar_bn_coef_bwd_io.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, vp, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.nastar_bn_coef_fwd.restype = ci

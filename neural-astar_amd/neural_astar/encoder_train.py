@@ -208,6 +208,34 @@ class _Lib:
         _native.check(rc, "nastar_pack_conv_weights_multi_f16")
         return [(flat16[o:o + n], flatf[f:f + c], flatf[f + c:f + 2 * c], scal[sp[3]]) for (o, n, f, c), sp in zip(lay, specs)]
 
+    def bn_fwd(self, z, npix, C, split, gamma, beta, eps, mom, rm, rv):
+        """batch statistics of z and the forward BatchNorm coefficients in two launches (partial rows; finish + coefficients):
+        (mean, invstd, k2, k3).  Not for SyncBatchNorm (the sums must be all-reduced between the halves)."""
+        k2, k3 = self.f32(C), self.f32(C)
+        mean = torch.empty((C,), dtype=torch.float64, device=self.dev)
+        invstd = torch.empty((C,), dtype=torch.float64, device=self.dev)
+        nbytes = int(self.lib.nastar_chan_stats_workspace_bytes(npix, C))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_bn_stats_coef_fwd_f16(z.data_ptr(), npix, C, int(split), gamma.data_ptr(), beta.data_ptr(), float(eps), float(mom),
+                                                   rm.data_ptr() if rm is not None else None, rv.data_ptr() if rv is not None else None,
+                                                   k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), None, ws.data_ptr(), nbytes,
+                                                   self.stream)
+        _native.check(rc, "nastar_bn_stats_coef_fwd_f16")
+        return mean, invstd, k2, k3
+
+    def bn_bwd(self, da, z, k2f, k3f, npix, C, split, mean, invstd, gamma, gscale_in, gscale_out, sums_out=None):
+        """(sum dy, sum dy z), max|dy| and the backward BatchNorm coefficients in two launches: (dgamma, dbeta, c1, c2, c3); the re-centred
+        gradient scale goes to ``gscale_out`` (a DIFFERENT tensor than ``gscale_in``: every workgroup of the finishing kernel reads the latter)"""
+        dgamma, dbeta, c1, c2, c3 = (self.f32(C) for _ in range(5))
+        nbytes = int(self.lib.nastar_chan_stats_workspace_bytes(npix, C))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_bn_stats_coef_bwd_f16(da.data_ptr(), z.data_ptr(), k2f.data_ptr(), k3f.data_ptr(), npix, C, int(split), mean.data_ptr(),
+                                                   invstd.data_ptr(), gamma.data_ptr(), gscale_in.data_ptr(), gscale_out.data_ptr(),
+                                                   dgamma.data_ptr(), dbeta.data_ptr(), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(),
+                                                   sums_out.data_ptr() if sums_out is not None else None, ws.data_ptr(), nbytes, self.stream)
+        _native.check(rc, "nastar_bn_stats_coef_bwd_f16")
+        return dgamma, dbeta, c1, c2, c3
+
     IMG32 = {(32, 64), (64, 128), (128, 256), (256, 128), (128, 64)}
 
     def conv(self, src, wpack, scale, shift, B, H, W, cin, cout, flags, out=None, out_f32=None, src2=None, c2=0):
@@ -300,6 +328,7 @@ class _CnnTrunk(torch.autograd.Function):
         with torch.cuda.device(dev):
             acts, zs, rs, coef, scals = [x0], [], [], [], []
             tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
+            sync = SyncBatchNorm.active()
             h, w = H, W
             wmax = L.weight_maxima(ws) if split else None  # one launch for all D + 1 weight maxima
             # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs
@@ -320,15 +349,19 @@ class _CnnTrunk(torch.autograd.Function):
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     tracked.append(bn.num_batches_tracked)
                 gam, bet = gammas[l].detach(), betas[l].detach()
-                sums = L.stats(None, z, None, None, npix, cout, split)
-                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
-                k2, k3 = L.f32(cout), L.f32(cout)
-                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
-                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
-                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix_bn, float(mom),
-                                              bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-                                              k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
-                _native.check(rc, "nastar_bn_coef_fwd")
+                if not sync:  # partial rows, then finish + coefficients in one kernel
+                    mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, gam, bet, cfg["eps"][l], mom, bn.running_mean if track else None,
+                                                    bn.running_var if track else None)
+                else:  # data parallel: the sums of the GLOBAL batch go through an all-reduce between the halves
+                    sums = L.stats(None, z, None, None, npix, cout, split)
+                    npix_bn = npix * _sync_sums(sums)
+                    k2, k3 = L.f32(cout), L.f32(cout)
+                    mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                    invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
+                    rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam.data_ptr(), bet.data_ptr(), float(cfg["eps"][l]), npix_bn, float(mom),
+                                                  bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                                  k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
+                    _native.check(rc, "nastar_bn_coef_fwd")
                 r = torch.empty_like(z)
                 L.affine(None, z, None, k2, k3, None, None, r, npix, cout, True, split)
                 zs.append(z)
@@ -406,16 +439,21 @@ class _CnnTrunk(torch.autograd.Function):
                 # ReLU mask + BatchNorm backward of hidden block l (pre-activation zs[l-1])
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
-                sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)         # (sum dy, sum dy z) * S, max|dy| * S
-                world = _sync_sums(sums, gscale)
-                dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
-                rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                              gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                              c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
-                _native.check(rc, "nastar_bn_coef_bwd")
-                if world > 1:  # the kernel formed dgamma / dbeta from the GLOBAL sums; the flat gradient all-reduce AVERAGES over ranks
-                    dgamma /= world
-                    dbeta /= world
+                if not SyncBatchNorm.active():  # (sum dy, sum dy z) * S, max|dy| * S: partial rows, then finish + coefficients in one kernel
+                    gs_new = L.f32(1)  # NOT in place: the finishing kernel has many workgroups, all of which read the incoming scale
+                    dgamma, dbeta, c1, c2, c3 = L.bn_bwd(da, z, k2f, k3f, npix, C, split, mean, invstd, gammas[l - 1].detach(), gscale, gs_new)
+                    gscale = gs_new
+                else:
+                    sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)
+                    world = _sync_sums(sums, gscale)
+                    dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
+                    rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                  gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                  c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
+                    _native.check(rc, "nastar_bn_coef_bwd")
+                    if world > 1:  # the kernel formed dgamma / dbeta from the GLOBAL sums; the flat gradient all-reduce AVERAGES over ranks
+                        dgamma /= world
+                        dbeta /= world
                 grads[4 * (l - 1) + 2] = dgamma
                 grads[4 * (l - 1) + 3] = dbeta
                 dzb = torch.empty_like(da)
@@ -626,6 +664,7 @@ class _UnetTrunk(torch.autograd.Function):
         acts = {"x0": (x0, 32)}
         saved = []
         tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
+        sync = SyncBatchNorm.active()
         out = None
         with torch.cuda.device(dev):
             conv_steps = [st for st in cfg["plan"] if st["kind"] != "pool"]
@@ -670,16 +709,20 @@ class _UnetTrunk(torch.autograd.Function):
                 if track:
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     tracked.append(bn.num_batches_tracked)
-                sums = L.stats(None, z, None, None, npix, cout, split)
-                npix_bn = npix * _sync_sums(sums)            # data parallel: statistics of the GLOBAL batch
-                k2, k3 = L.f32(cout), L.f32(cout)
-                mean = torch.empty((cout,), dtype=torch.float64, device=dev)
-                invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
-                rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
-                                              float(bn.eps), npix_bn, float(mom), bn.running_mean.data_ptr() if track else None,
-                                              bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
-                                              mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
-                _native.check(rc, "nastar_bn_coef_fwd")
+                if not sync:  # partial rows, then finish + coefficients in one kernel
+                    mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, params[st["g"]].detach(), params[st["be"]].detach(), bn.eps, mom,
+                                                    bn.running_mean if track else None, bn.running_var if track else None)
+                else:  # data parallel: statistics of the GLOBAL batch (all-reduce between the halves)
+                    sums = L.stats(None, z, None, None, npix, cout, split)
+                    npix_bn = npix * _sync_sums(sums)
+                    k2, k3 = L.f32(cout), L.f32(cout)
+                    mean = torch.empty((cout,), dtype=torch.float64, device=dev)
+                    invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
+                    rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
+                                                  float(bn.eps), npix_bn, float(mom), bn.running_mean.data_ptr() if track else None,
+                                                  bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
+                    _native.check(rc, "nastar_bn_coef_fwd")
                 a = L.i16(npix * cout * mult)
                 L.affine(None, z, None, k2, k3, None, None, a, npix, cout, True, split)
                 acts[st["dst"]] = (a, cout)
@@ -754,16 +797,24 @@ class _UnetTrunk(torch.autograd.Function):
                     S = L.f32(1)  # the BatchNorm backward re-centres the scale: S_in (possibly shared with a skip branch) -> S
                     z = sv["z"]
                     mean, invstd, k2f, k3f = sv["coef"]
-                    sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
-                    world = _sync_sums(sums, S_in)
-                    dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
-                    rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                     params[st["g"]].detach().data_ptr(), npix * world, S_in.data_ptr(), S.data_ptr(), dgamma.data_ptr(),
-                                                     dbeta.data_ptr(), c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout, L.stream)
-                    _native.check(rc, "nastar_bn_coef_bwd_io")
-                    if world > 1:  # formed from the GLOBAL sums; the flat gradient all-reduce averages over ranks
-                        dgamma /= world
-                        dbeta /= world
+                    sums = None
+                    if not SyncBatchNorm.active():  # partial rows, then finish + coefficients in one kernel
+                        if cfg.get("debug") is not None:
+                            sums = torch.empty((cout, 2), dtype=torch.float64, device=dev)
+                        dgamma, dbeta, c1v, c2v, c3v = L.bn_bwd(g, z, k2f, k3f, npix, cout, split, mean, invstd, params[st["g"]].detach(), S_in, S,
+                                                                sums_out=sums)
+                    else:
+                        sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
+                        world = _sync_sums(sums, S_in)
+                        dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
+                        rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                         params[st["g"]].detach().data_ptr(), npix * world, S_in.data_ptr(), S.data_ptr(),
+                                                         dgamma.data_ptr(), dbeta.data_ptr(), c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout,
+                                                         L.stream)
+                        _native.check(rc, "nastar_bn_coef_bwd_io")
+                        if world > 1:  # formed from the GLOBAL sums; the flat gradient all-reduce averages over ranks
+                            dgamma /= world
+                            dbeta /= world
                     if cfg.get("debug") is not None:
                         cfg["debug"][st["dst"] + ":bn"] = (z, k2f, k3f, dbeta.clone(), dgamma.clone(), sums.clone(), S_in.clone())
                     grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta

@@ -635,3 +635,48 @@ def test_fused_rmsprop_equals_torch_rmsprop():
     ob2 = torch.optim.RMSprop(pb, 1e-3)
     ob2.load_state_dict(oa.state_dict())
     assert torch.equal(ob2.state[pb[0]]["square_avg"], oa.state[pa[0]]["square_avg"])
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("B,H,W,C", [(1, 4, 4, 32), (6, 16, 8, 64), (300, 32, 32, 256)])
+def test_two_launch_batchnorm_pass_equals_the_three_launch_form(split, B, H, W, C):
+    """nastar_bn_stats_coef_{fwd,bwd}_f16 (partial rows, then ONE kernel that finishes the sums in the same fixed order and forms the
+    coefficients) against nastar_chan_stats_f16_ws + nastar_bn_coef_{fwd,bwd}: identical outputs."""
+    from neural_astar import _native, encoder_train as ET
+    dev = _dev()
+    L = ET._Lib(dev)
+    lib = L.lib
+    g = torch.Generator().manual_seed(31 + C)
+    npix = B * H * W
+    z = torch.randn((B, C, H, W), generator=g) * 1.5 + 0.2
+    da = torch.randn((B, C, H, W), generator=g) * 3.0
+    z_, da_ = _nhwc(z, split).to(dev), _nhwc(da, split).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+    eps, mom = 1e-5, 0.1
+    sums = L.stats(None, z_, None, None, npix, C, split)
+    k2r, k3r = L.f32(C), L.f32(C)
+    meanr = torch.empty((C,), dtype=torch.float64, device=dev)
+    invr = torch.empty((C,), dtype=torch.float64, device=dev)
+    rm_r, rv_r = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    _native.check(lib.nastar_bn_coef_fwd(sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, npix, mom, rm_r.data_ptr(), rv_r.data_ptr(),
+                                         k2r.data_ptr(), k3r.data_ptr(), meanr.data_ptr(), invr.data_ptr(), C, L.stream), "coef_fwd")
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd, k2, k3 = L.bn_fwd(z_, npix, C, split, gamma, beta, eps, mom, rm, rv)
+    torch.cuda.synchronize()
+    for a, b in ((mean, meanr), (invstd, invr), (k2, k2r), (k3, k3r), (rm, rm_r), (rv, rv_r)):
+        assert torch.equal(a, b)
+    amax = L.f32(1)
+    sums_b = L.stats(da_, z_, k2r, k3r, npix, C, split, amax=amax)
+    S_r = torch.full((1,), 4.0, device=dev)
+    dgr, dbr, c1r, c2r, c3r = (L.f32(C) for _ in range(5))
+    _native.check(lib.nastar_bn_coef_bwd(sums_b.data_ptr(), amax.data_ptr(), meanr.data_ptr(), invr.data_ptr(), gamma.data_ptr(), npix,
+                                         S_r.data_ptr(), dgr.data_ptr(), dbr.data_ptr(), c1r.data_ptr(), c2r.data_ptr(), c3r.data_ptr(), C,
+                                         L.stream), "coef_bwd")
+    S_in, S_out = torch.full((1,), 4.0, device=dev), torch.zeros(1, device=dev)
+    s_out = torch.empty((C, 2), dtype=torch.float64, device=dev)
+    dg, db, c1, c2, c3 = L.bn_bwd(da_, z_, k2r, k3r, npix, C, split, meanr, invr, gamma, S_in, S_out, sums_out=s_out)
+    torch.cuda.synchronize()
+    assert float(S_in) == 4.0 and torch.equal(S_out, S_r) and torch.equal(s_out, sums_b)
+    for a, b in ((dg, dgr), (db, dbr), (c1, c1r), (c2, c2r), (c3, c3r)):
+        assert torch.equal(a, b)
