@@ -1112,6 +1112,17 @@ def main():
                          "kernel_profile_us": kprof["avg_us"] if kprof else None,
                          "kernel_profile_source": kprof["source"] if kprof else None,
                          "frac_from_kernel_profile": (bytes_per_map * b_rank / (kprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kprof else None},
+            # the search is a serial chain of select + update steps with all state on-chip, so next to the HBM fraction the
+            # line carries the VALU-issue floor of the launch: (VALU wavefront-instructions of one launch, SQ_INSTS_VALU from the
+            # committed rocprofv3 --pmc pass) x 4 cycles each / 1024 SIMDs / 2.4 GHz -- what the launch would take if every SIMD issued
+            # a vector instruction every cycle it can
+            "issue_model": ({"bound": "valu-issue", "valu_wave_instructions_per_launch": kprof["valu_insts_per_launch"],
+                             "valu_per_expansion": kprof["valu_insts_per_launch"] / (float(iters.sum()) / len(run.sets)),
+                             "simds": 1024, "cycles_per_wave_instruction": 4, "clock_ghz": 2.4,
+                             "floor_us": kprof["valu_insts_per_launch"] * 4 / 1024 / 2.4e3,
+                             "achieved_us": avg_ms * 1e3, "frac": kprof["valu_insts_per_launch"] * 4 / 1024 / 2.4e3 / (avg_ms * 1e3),
+                             "source": kprof.get("counters_source")}
+                            if kprof and kprof.get("valu_insts_per_launch") and not strong else None),
             "expansions_per_s": float(iters.sum()) / len(run.sets) * n_gpus * args.steps / dt,
             "mean_iters_per_map": float(iters.mean()), "max_iters_per_map": int(iters.max()),
             "device_ms_per_step": dev_ms / args.steps,
@@ -1176,6 +1187,9 @@ def main():
                     ex[name] = fn()
                 except Exception as e:  # noqa: BLE001 - an extra never sinks the headline line
                     ex[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            if out.get("issue_model") and isinstance(ex.get("streams_sweep_maps_per_s"), dict):
+                best = max(v for v in ex["streams_sweep_maps_per_s"].values() if isinstance(v, (int, float)))
+                out["issue_model"]["frac_best_multi_stream"] = out["issue_model"]["floor_us"] / (B_PER_GPU / best * 1e6)
             out["extra"] = {**ex,
                             "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "
                                     "not the headline value, which times strictly serial launches on one stream"}
