@@ -1,0 +1,62 @@
+"""bench.py's contract with the driver: one JSON line with the agreed keys on a GPU box, a loud failure without a HIP device."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_refuses_to_run_without_a_hip_device():
+    """no CPU fallback in the measured path: on a box without a GPU the bench exits non-zero and says why"""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "HIP device" in (r.stderr + r.stdout)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-secondary"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["warmup"] == 2 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["unit"] == "maps/s" and j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "maze32" in j["config"]["workload"] and j["config"]["batch_per_gpu"] == 4096
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(j["value"] - 4096 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]  # value = units of the K steps / their wall time
+    im = j["issue_model"]
+    assert im["bound"] == "valu-issue" and 0.0 < im["frac"] < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["maze", "warcraft"])
+def test_train_bench_prints_one_json_line(config):
+    """`bench.py --mode train` (BASELINE config 5 and the maze configuration): one full training step per bench step"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--config", config, "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["unit"] == "maps/s" and j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["data"] == "synthetic"
+    assert j["config"]["batch_per_gpu"] == 100 and config in j["config"]["workload"]
+    assert j["roofline"]["bound"] == "mfma" and 0.0 < j["roofline"]["frac"] < 1.0
+    assert abs(j["value"] - 100 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    import math
+    assert math.isfinite(j["final_loss"])
