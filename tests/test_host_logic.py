@@ -339,3 +339,24 @@ def test_unet_training_plan_is_consistent_host_logic():
     multi = sorted(n for n, c in consumers.items() if c > 1)
     assert multi == ["e10", "e4", "e7"]                                # the three skip features: decoder block + next encoder stage
     assert ET.unet_supported(u, 32, 32) and ET.unet_supported(u, 64, 96) and not ET.unet_supported(u, 16, 16) and not ET.unet_supported(u, 36, 32)
+
+
+def test_fused_rmsprop_on_cpu_parameters_is_torch_rmsprop():
+    """utils/optim.FusedRMSprop takes torch's own step for anything its one-launch kernel does not cover (here: CPU parameters), so the
+    trainer and PlannerModule.configure_optimizers behave like the reference's optimiser on a box without a GPU"""
+    from neural_astar.utils.optim import FusedRMSprop
+    g = torch.Generator().manual_seed(3)
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((4, 3), (5,))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedRMSprop(pa, 1e-3), torch.optim.RMSprop(pb, 1e-3)
+    assert isinstance(oa, torch.optim.RMSprop)
+    for _ in range(3):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+    assert torch.equal(oa.state[pa[0]]["square_avg"], ob.state[pb[0]]["square_avg"])
+    ob.load_state_dict(oa.state_dict())  # same state layout
