@@ -311,10 +311,12 @@ int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* st
 /* One-launch forms of the training step's small work (round 3: at the reference's batch of 100 a U-Net step was 437 launches).
  * nastar_pack_conv_weights_multi_f16: every weight pack of a step at once.  table = device int64 [n][8]: {w, bias or 0, co, ci,
  *   transpose_flip, offset of the pack in flat16 (fp16 elements), offset in flatf (floats; scale[cout_p] then shift[cout_p]), row of
- *   scal}; scal [rows][3] as left by nastar_absmax_multi_f32 (same arithmetic as nastar_pack_conv_weight_f16 with reuse_max).
+ *   scal}; scal [rows][3] as left by nastar_absmax_multi_f32 (same arithmetic as nastar_pack_conv_weight_f16 with reuse_max); max_tiles =
+ *   max over the tensors of ceil(co / 32) * ceil(ci / 32) (a workgroup moves one 32 x 32 x 9 tile through LDS).
  * nastar_rmsprop_multi_f32: torch.optim.RMSprop's plain step (no momentum / centering / weight decay) for n tensors: table = device
  *   int64 [n][4]: {param, grad, square_avg, element count}. */
-int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int split, float* scal, uint16_t* flat16, float* flatf, void* stream);
+int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int max_tiles, int split, float* scal, uint16_t* flat16, float* flatf,
+                                       void* stream);
 int nastar_rmsprop_multi_f32(const long long* table, int n, float lr, float alpha, float eps, void* stream);
 
 /* Two-stage form of nastar_chan_stats_f16 (what the training path uses): per-workgroup partial sums in the caller's workspace

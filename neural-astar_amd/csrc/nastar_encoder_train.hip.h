@@ -496,10 +496,14 @@ __global__ __launch_bounds__(256) void nastar_pack_weight_kernel(const float* __
 
 // Every weight pack of a training step in ONE launch (the U-Net step had 47 of them, 12 us each): table row t = {w, bias or 0, co, ci,
 // transpose_flip, offset into flat16 (fp16 elements), offset into flatf (floats: scale[cout_p] then shift[cout_p]), row of `scal`}.
-// grid = (blocks per tensor, tensors); scal rows hold max|w| in [2] on entry (nastar_absmax_multi_f32) and get 2^-s, 2^s in [0], [1].
+// grid = (tiles, tensors); scal rows hold max|w| in [2] on entry (nastar_absmax_multi_f32) and get 2^-s, 2^s in [0], [1].
+// A workgroup moves one 32 x 32 x 9 tile of w through LDS: it is READ as 32 runs of 288 contiguous floats (w[row][col..col+31][0..8]) and
+// WRITTEN as 16-byte chunks of 8 consecutive input channels, 32 consecutive output channels = 512 contiguous bytes per (tap, segment,
+// chunk) -- the per-element form of nastar_pack_weight_kernel reads with a stride of 9 (or 9 ci) floats and stores 2 bytes per lane.
 __global__ __launch_bounds__(256) void nastar_pack_weight_multi_kernel(const long long* __restrict__ table, int split, float* __restrict__ scal_all,
                                                                        uint16_t* __restrict__ flat16, float* __restrict__ flatf)
 {
+    __shared__ float tile[32 * 289];  // [row (co)][col (ci)][tap], rows padded to 289 words: lanes that walk the rows hit 32 different banks
     const long long* row = table + 8 * (size_t)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(row[0]);
     const float* bias = reinterpret_cast<const float*>(row[1]);
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void nastar_pack_weight_multi_kernel(const lon
     const int cin_p = (cin_l + 31) & ~31, cout_p = (cout_l + 31) & ~31;
     float* shift_out = scale_out + cout_p;
     const int cinv = split ? 3 * cin_p : cin_p;
-    const int total = 9 * cinv * cout_p;
+    const int rb_n = (co + 31) >> 5, cb_n = (ci + 31) >> 5;  // tiles over the SOURCE rows (co) and columns (ci)
     const float sc = split ? pow2_scale(scal[2], 16384.f, 0, 24) : 1.f;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {  // the forward and the input-gradient pack of one weight write the same two values
@@ -523,23 +527,35 @@ __global__ __launch_bounds__(256) void nastar_pack_weight_multi_kernel(const lon
             shift_out[c] = (bias && c < cout_l) ? bias[c] : 0.f;
         }
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int e = i & 7;
-        int r = i >> 3;
-        const int n = r % cout_p; r /= cout_p;
-        const int cv8 = r % (cinv >> 3);
-        const int tap = r / (cinv >> 3);
-        const int v = cv8 * 8 + e;
-        const int seg = v / cin_p, c = v - seg * cin_p;
+    if ((int)blockIdx.x >= rb_n * cb_n) return;
+    const int r0 = ((int)blockIdx.x / cb_n) * 32, c0 = ((int)blockIdx.x % cb_n) * 32;
+    for (int q = threadIdx.x; q < 32 * 288; q += 256) {
+        const int r = q / 288, k = q - r * 288;  // k = col_local * 9 + tap
+        const int cl = k / 9;
         float x = 0.f;
-        if (n < cout_l && c < cin_l) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            x = transpose_flip ? w[((size_t)c * ci + n) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((size_t)n * ci + c) * 9 + tap];
-            x *= sc;
+        if (r0 + r < co && c0 + cl < ci) x = w[((size_t)(r0 + r) * ci + c0) * 9 + k] * sc;
+        tile[r * 289 + k] = x;
+    }
+    __syncthreads();
+    // logical output channel n / input channel c of a tile element: forward (n, c) = (row, col); input-gradient form (n, c) = (col, row), tap flipped
+    const int nseg = split ? 3 : 1;
+    const int n0 = transpose_flip ? c0 : r0, cc0 = transpose_flip ? r0 : c0;
+    for (int q = threadIdx.x; q < 9 * nseg * 4 * 32; q += 256) {
+        const int n = q & 31;
+        int t2 = q >> 5;
+        const int ch = t2 & 3; t2 >>= 2;
+        const int seg = t2 % nseg, tap = t2 / nseg;
+        const int stap = transpose_flip ? 8 - tap : tap;
+        union { uint4 v; _Float16 h[8]; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            const float x = transpose_flip ? tile[c * 289 + n * 9 + stap] : tile[n * 289 + c * 9 + stap];
+            const _Float16 hi = (_Float16)x;
+            o.h[e] = (seg == 2) ? (_Float16)(x - (float)hi) : hi;
         }
-        const _Float16 hi = (_Float16)x;
-        const _Float16 val = (seg == 2) ? (_Float16)(x - (float)hi) : hi;
-        wpack[i] = *reinterpret_cast<const uint16_t*>(&val);
+        const size_t cv8 = (size_t)(seg * cin_p + cc0) / 8 + ch;
+        *reinterpret_cast<uint4*>(wpack + (((size_t)tap * (cinv >> 3) + cv8) * cout_p + n0 + n) * 8) = o.v;
     }
 }
 

@@ -253,12 +253,14 @@ int nastar_absmax_multi_f32(const long long* table, int n, float* scal, void* st
     return NASTAR_OK;
 }
 
-int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int split, float* scal, uint16_t* flat16, float* flatf, void* stream)
+int nastar_pack_conv_weights_multi_f16(const long long* table, int n, int max_tiles, int split, float* scal, uint16_t* flat16, float* flatf,
+                                       void* stream)
 {
     if (!table || !scal || !flat16 || !flatf) return NASTAR_ERR_NULL;
     if (n <= 0 || n > 65535) return NASTAR_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(nastar_pack_weight_multi_kernel, dim3(1024, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), table, split,
-                       scal, flat16, flatf);
+    if (max_tiles <= 0 || max_tiles > 65535) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_pack_weight_multi_kernel, dim3((unsigned)max_tiles, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       table, split, scal, flat16, flatf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return NASTAR_OK;

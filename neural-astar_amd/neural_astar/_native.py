@@ -197,7 +197,7 @@ def load() -> ctypes.CDLL:
     lib.nastar_absmax_multi_f32.restype = ci
     lib.nastar_absmax_multi_f32.argtypes = [vp, ci, vp, vp]
     lib.nastar_pack_conv_weights_multi_f16.restype = ci
-    lib.nastar_pack_conv_weights_multi_f16.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.nastar_pack_conv_weights_multi_f16.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     lib.nastar_rmsprop_multi_f32.restype = ci
     lib.nastar_rmsprop_multi_f32.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
     lib.nastar_chan_stats_workspace_bytes.restype = cz

@@ -198,12 +198,13 @@ class _Lib:
                 lay.append((o16, n16, of, cout_p))
                 o16 += n16
                 of += 2 * cout_p
-            ent = (torch.tensor(rows_t, dtype=torch.int64).to(self.dev), lay, o16, of)
+            tiles = max(((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32) for w in ws)
+            ent = (torch.tensor(rows_t, dtype=torch.int64).to(self.dev), lay, o16, of, tiles)
             self._TABLES[key] = ent
-        table, lay, n16_all, nf_all = ent
+        table, lay, n16_all, nf_all, tiles = ent
         flat16 = torch.empty((n16_all,), dtype=torch.int16, device=self.dev)
         flatf = torch.empty((nf_all,), dtype=torch.float32, device=self.dev)
-        rc = self.lib.nastar_pack_conv_weights_multi_f16(table.data_ptr(), len(specs), int(split), scal.data_ptr(), flat16.data_ptr(),
+        rc = self.lib.nastar_pack_conv_weights_multi_f16(table.data_ptr(), len(specs), tiles, int(split), scal.data_ptr(), flat16.data_ptr(),
                                                          flatf.data_ptr(), self.stream)
         _native.check(rc, "nastar_pack_conv_weights_multi_f16")
         return [(flat16[o:o + n], flatf[f:f + c], flatf[f + c:f + 2 * c], scal[sp[3]]) for (o, n, f, c), sp in zip(lay, specs)]
