@@ -181,10 +181,14 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         if constexpr (ABL == -1) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
             int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
+            // searching wavefronts issue ahead of the ones still loading their map or already storing their result (the launch waits for the
+            // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each (profiles/r03/prio_*.json)
+            __builtin_amdgcn_s_setprio(3);
             if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            __builtin_amdgcn_s_setprio(0);
         } else if constexpr (ABL >= 300) {  // DEV timing probe of the round-3 stream (nastar_search_asm3_abl.hip.h): garbage results
 #if NASTAR_DEV_KERNELS
             s = compact_search_loop_asm3_abl<LOGW, ABL - 300>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW);
