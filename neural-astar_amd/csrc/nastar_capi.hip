@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
             int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
             // searching wavefronts issue ahead of the ones still loading their map or already storing their result (the launch waits for the
-            // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each (profiles/r03/prio_*.json)
+            // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each; 3-4 batches in flight unchanged at 57 M maps/s (profiles/r03/prio_*.json, prio_streams.txt)
             __builtin_amdgcn_s_setprio(3);
             if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
