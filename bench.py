@@ -537,8 +537,10 @@ def encoder_train_step_ms(pr, dev):
 def kernel_launch_ms(run, steps, dev):
     """Average duration of one launch from HIP events recorded on the stream the kernel is launched on
     (torch's current stream), one event pair per launch."""
+    steps = max(steps, 100)  # not the K timed steps of the contract: 20 event pairs right after an idle gap measure the gap
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    torch.cuda.synchronize(dev)
+    for _ in range(10):
+        run.step()
     evs[0].record()
     for i in range(steps):
         run.step()
