@@ -47,39 +47,77 @@ def _log(msg: str) -> None:
         print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def make_problem(kind: str, B: int, seed: int):
+def _synth(kind: str, B: int, seed: int):
+    from neural_astar.utils import synthetic as syn
+    if kind == "maze32":
+        return syn.maze_maps(B, 32, seed=seed)
+    if kind == "rand32":
+        return syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
+    if kind == "rand64":  # 64x64, p = 0.20 (the per-GPU shard of BASELINE config 4)
+        return syn.random_obstacle_maps(B, 64, 64, 0.20, seed=seed)
+    raise ValueError(kind)
+
+
+def make_problem(kind: str, B: int, seed: int, wait: bool = True):
+    """One seeded synthetic batch, cached under /tmp.  Several ranks of one node may ask for the same batch at once (strong
+    scaling: every rank touches chunks of ONE global batch): an exclusive file lock makes exactly one of them synthesise it, the
+    others load the finished file.  wait=False: return None instead of waiting when another process is building it."""
+    import fcntl
     from neural_astar.utils import synthetic as syn
     cache = os.path.join("/tmp", f"nastar_bench_{kind}_{B}_{seed}.npz")
-    if os.path.exists(cache):
+
+    def load():
         z = np.load(cache)
         return syn.Problems(z["m"], z["s"], z["g"])
-    if kind == "maze32":
-        pr = syn.maze_maps(B, 32, seed=seed)
-    elif kind == "rand32":
-        pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
-    elif kind == "rand64":  # 64x64, p = 0.20 (the per-GPU shard of BASELINE config 4)
-        pr = syn.random_obstacle_maps(B, 64, 64, 0.20, seed=seed)
-    else:
-        raise ValueError(kind)
+    if os.path.exists(cache):
+        return load()
     try:
-        np.savez(cache, m=pr.map_designs, s=pr.start_maps, g=pr.goal_maps)
-    except OSError:
-        pass
-    return pr
+        lock = open(cache + ".lock", "w")
+    except OSError:  # /tmp not writable: no cache, every caller synthesises
+        return _synth(kind, B, seed)
+    try:
+        try:
+            fcntl.flock(lock, fcntl.LOCK_EX | (0 if wait else fcntl.LOCK_NB))
+        except BlockingIOError:
+            return None
+        if os.path.exists(cache):  # built while this process waited for the lock
+            return load()
+        pr = _synth(kind, B, seed)
+        try:
+            tmp = f"{cache}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, m=pr.map_designs, s=pr.start_maps, g=pr.goal_maps)
+            os.replace(tmp, cache)  # atomic: a reader never sees a half-written file
+        except OSError:
+            pass
+        return pr
+    finally:
+        lock.close()
 
 
-def make_problem_rows(kind: str, total: int, seed: int, rows: np.ndarray):
+def make_problem_rows(kind: str, total: int, seed: int, rows: np.ndarray, rank: int = 0, world: int = 1):
     """Rows `rows` of a `total`-map global batch that is defined chunk-wise (1024 maps per chunk, chunk c seeded from (seed, c)),
-    so that a rank only synthesises the chunks its shard touches and every N sees the same global batch."""
+    so that a rank only synthesises the chunks its shard touches and every N sees the same global batch.  With interleaved shards
+    every rank touches every chunk: a first pass visits the chunks starting at a rank-dependent offset and skips the ones another
+    rank is already building (make_problem's file lock), so the ranks of a node synthesise DIFFERENT chunks in parallel; the second
+    pass loads (or waits for) all of them."""
     from neural_astar.utils import synthetic as syn
     CH = 1024
     rows = np.asarray(rows)
     assert (np.diff(rows) > 0).all(), "rows must be ascending"
+    chunks = [int(c) for c in np.unique(rows // CH)]
+
+    def chunk_args(c):
+        return kind, min(CH, total - c * CH), seed * 100003 + c
+    got = {}
+    k0 = (rank * len(chunks)) // max(world, 1)
+    for c in chunks[k0:] + chunks[:k0]:
+        pr = make_problem(*chunk_args(c), wait=False)
+        if pr is not None:
+            got[c] = pr
     parts = []
-    for c in np.unique(rows // CH):
-        n = min(CH, total - int(c) * CH)
-        pr = make_problem(kind, n, seed=seed * 100003 + int(c))
-        sel = rows[(rows // CH) == c] - int(c) * CH
+    for c in chunks:
+        pr = got.get(c) or make_problem(*chunk_args(c))
+        sel = rows[(rows // CH) == c] - c * CH
         parts.append(tuple(x[sel] for x in pr))
     return syn.Problems(*(np.concatenate([p[k] for p in parts]) for k in range(3)))
 
@@ -1024,7 +1062,7 @@ def main():
         assert args.global_batch % n_gpus == 0, "--global-batch must be a multiple of the number of GPUs"
         b_rank = args.global_batch // n_gpus
         rows = _par.shard_rows(args.global_batch, n_gpus, rank, args.shard).numpy()
-        prs = [make_problem_rows(args.workload, args.global_batch, 1234 + 1000 * k, rows) for k in range(N_ROTATE)]
+        prs = [make_problem_rows(args.workload, args.global_batch, 1234 + 1000 * k, rows, rank, n_gpus) for k in range(N_ROTATE)]
     else:
         b_rank = B_PER_GPU
         prs = [make_problem(args.workload, B_PER_GPU, seed=1234 + rank + 1000 * k) for k in range(N_ROTATE)]

@@ -862,6 +862,12 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         else if (fast) { NASTAR_CPICK(false, 0, 0, 0, true); }
         else { NASTAR_CPICK(false, 0, 0, 0, false); }
 #undef NASTAR_CPICK
+#if NASTAR_DEV_KERNELS
+        // dev probe (tools/session.sh r04_a): extra dynamic LDS per workgroup = fewer resident maps per CU, e.g. 9984 extra bytes = 8
+        // wavefronts per CU instead of 16 -- the contention level a two-maps-per-wavefront kernel would run at
+        static const int lds_pad = getenv("NASTAR_LDS_PAD") ? atoi(getenv("NASTAR_LDS_PAD")) : 0;
+        if (lds_pad > 0 && lds + (size_t)lds_pad <= kMaxLdsBytes) return launch(kern, B, lds + (size_t)lds_pad, s, c, rcp);
+#endif
         return launch(kern, B, lds, s, c, rcp);
     }
 #if !NASTAR_DEV_KERNELS

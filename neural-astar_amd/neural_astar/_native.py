@@ -12,7 +12,8 @@ import subprocess
 from typing import Optional
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # neural-astar_amd/
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libnastar_hip.so")
+# NASTAR_LIB: development switch -- another build of the same C ABI (e.g. lib/libnastar_hip_dev.so from `make DEV=1`)
+LIB_PATH = os.environ.get("NASTAR_LIB") or os.path.join(_PKG_ROOT, "lib", "libnastar_hip.so")
 CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
 
 NASTAR_OK = 0
