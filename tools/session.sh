@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU sessions as they were run (round 4 on): ONE parametrised script instead of a file per call.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/session.sh <name>'
+# Every session writes under gpurun_out/<round>/; what is kept as evidence is copied into profiles/<round>/ afterwards.
+set -u
+S=${1:?session name}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R"
+DEVLIB=$R/neural-astar_amd/lib/libnastar_hip_dev.so   # make -C neural-astar_amd/csrc DEV=1 BUILD=build_dev OUT=../lib/libnastar_hip_dev.so
+case "$S" in
+r04_a)
+  # Throughput regime of the search: what binds it, and what two maps per wavefront can and cannot buy.
+  #  1. aggregate issue rates of one CU (tools/ubench/rate.hip)
+  #  2. streams sweep + one-launch big batches, shipped kernel, all three workloads
+  #  3. DEV build: compiler-generated single-map step (flags 8) vs two maps per wavefront (flags 4) vs asm3 (flags 0), same probe
+  #  4. asm3 with HALF the resident maps per CU (NASTAR_LDS_PAD: 8 wavefronts per CU) = the contention level of a duo kernel
+  O=gpurun_out/r04/a; mkdir -p $O
+  (cd tools/ubench && ./rate) > $O/rate.txt 2>&1
+  python tools/probe_streams.py --workloads maze32,rand32,rand64 --flags 0 --streams 1,2,3,4,6,8 --bigb 2,4,8 > $O/streams_product.jsonl 2> $O/streams_product.err
+  NASTAR_LIB=$DEVLIB python tools/probe_streams.py --workloads maze32,rand32 --flags 0,8,4 --streams 1,2,4,6 --bigb 4 > $O/streams_dev.jsonl 2> $O/streams_dev.err
+  for pad in 2304 9984; do
+    NASTAR_LIB=$DEVLIB NASTAR_LDS_PAD=$pad python tools/probe_streams.py --workloads maze32,rand32 --flags 0 --streams 1,2,4,6,8 --bigb 4 > $O/streams_pad$pad.jsonl 2> $O/streams_pad$pad.err
+  done
+  tail -n +1 $O/rate.txt $O/*.jsonl; tail -3 $O/*.err
+  ;;
+*)
+  echo "unknown session $S"; exit 2;;
+esac
