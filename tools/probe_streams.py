@@ -48,7 +48,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     for w in a.workloads.split(","):
-        prs = [bench.make_problem(w, bench.B_PER_GPU, seed=1234 + 1000 * k) for k in range(8)]
+        prs = [bench.make_problem(w, bench.B_PER_GPU, seed=1234)] * 8  # k copies of ONE batch: same work per copy, distinct memory
         for f in a.flags.split(","):
             os.environ["NASTAR_FORWARD_FLAGS"] = f
             out = {"workload": w, "flags": int(f), "lib": os.environ.get("NASTAR_LIB", "product"), "streams": {}, "one_launch": {}}

@@ -18,7 +18,7 @@ r04_a)
   (cd tools/ubench && ./rate) > $O/rate.txt 2>&1
   python tools/probe_streams.py --workloads maze32,rand32,rand64 --flags 0 --streams 1,2,3,4,6,8 --bigb 2,4,8 > $O/streams_product.jsonl 2> $O/streams_product.err
   NASTAR_LIB=$DEVLIB python tools/probe_streams.py --workloads maze32,rand32 --flags 0,8,4 --streams 1,2,4,6 --bigb 4 > $O/streams_dev.jsonl 2> $O/streams_dev.err
-  for pad in 2304 9984; do
+  for pad in 3600 9984; do   # 12 and 8 wavefronts per CU instead of 16
     NASTAR_LIB=$DEVLIB NASTAR_LDS_PAD=$pad python tools/probe_streams.py --workloads maze32,rand32 --flags 0 --streams 1,2,4,6,8 --bigb 4 > $O/streams_pad$pad.jsonl 2> $O/streams_pad$pad.err
   done
   tail -n +1 $O/rate.txt $O/*.jsonl; tail -3 $O/*.err
