@@ -760,12 +760,13 @@ def cpu_baseline(pr, gpu_hist, gpu_paths):
 
 def through_module_ms(pr, dev, reps=30):
     """End to end through the drop-in boundary: ms per VanillaAstar.forward() call on the bench batch -- torch custom-op
-    dispatch, output allocation, the launch, and the solvability policy: the default defers the verdict to the next call (no host sync;
-    a device-side any() + an async copy), "sync" waits for the kernel in every call (round 2's default), False skips it."""
+    dispatch, output allocation, the launch, and the solvability policy: the default (True = "sync") waits for the kernel and raises in
+    the same call, "deferred" (opt-in) hands the verdict to a later call (no host sync; a device-side any() + an async copy), False skips
+    it."""
     from neural_astar.planner import VanillaAstar
     m, s_, g = (torch.from_numpy(x).to(dev) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
     out = {}
-    for label, chk in (("check_solvable_default_deferred", True), ("check_solvable_sync", "sync"), ("check_solvable_false", False)):
+    for label, chk in (("check_solvable_default_sync", True), ("check_solvable_deferred", "deferred"), ("check_solvable_false", False)):
         va = VanillaAstar().to(dev).eval()
         va.astar.check_solvable = chk
         with torch.no_grad():
@@ -901,9 +902,12 @@ def train_main(args, real_stdout):
     cfg = TRAIN_CONFIGS[args.config]
     torch.manual_seed(1234)
     planner = NeuralAstar(**cfg["kw"]).to(dev)
-    planner.encoder_backend = args.encoder_backend
+    planner.astar.check_solvable = "deferred"  # opt-in: no host sync inside the timed steps; the verdicts are collected after the loop
+    planner.encoder_backend = args.encoder_backend  # "auto" (the package default) resolves to hip_f16x3 on a HIP device
+    if args.encoder_backend == "auto":
+        args.encoder_backend = planner.effective_encoder_backend(torch.empty(0, device=dev))
     multi = dist.is_initialized() and (world > 1 or args.force_collate)  # --force-collate: the RCCL path in a 1-rank group
-    sync_bn = multi and args.encoder_backend.startswith("hip")
+    sync_bn = multi and args.encoder_backend.startswith(("hip", "auto"))
     trainer = D.DataParallelTrainer(planner, lr=1e-3, coupling="global" if multi else "local", sync_bn=sync_bn,
                                     force_collectives=args.force_collate)
     batches = [train_batch(args.config, B, 1234 + 17 * rank + 1000 * k, dev) for k in range(4)]  # a few distinct batches in rotation
@@ -930,6 +934,7 @@ def train_main(args, real_stdout):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    planner.astar.raise_if_unsolvable()  # the deferred verdicts of every step above
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1019,7 +1024,8 @@ def main():
                          "(BASELINE config 5 with --config warcraft)")
     ap.add_argument("--config", default="warcraft", choices=sorted(TRAIN_CONFIGS), help="--mode train: which reference training configuration")
     ap.add_argument("--batch-per-gpu", type=int, default=100, help="--mode train: maps per rank and step (the reference's batch_size is 100)")
-    ap.add_argument("--encoder-backend", default="hip_f16x3", choices=["hip_f16x3", "hip_f16", "torch"], help="--mode train")
+    ap.add_argument("--encoder-backend", default="hip_f16x3", choices=["auto", "hip_f16x3", "hip_f16", "torch"],
+                    help="--mode train (auto = the package default = hip_f16x3 on a HIP device)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="dev: gloo lets N ranks share ONE GPU (with --share-gpu) to exercise every world > 1 branch of this script on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="dev: every rank uses cuda:0 (only with --dist-backend gloo)")

@@ -22,7 +22,7 @@ where torch's autograd returns ~1e-10 of rounding noise.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -57,18 +57,27 @@ class SyncBatchNorm:
     def active(cls) -> bool:
         return cls.world() > 1 or (cls.force and cls.world() == 1 and cls.enabled and torch.distributed.is_initialized())
 
+    @classmethod
+    def snapshot(cls) -> Tuple[bool, object, int]:
+        """(active, group, world) as a forward pass sees them.  The autograd nodes keep this in ``ctx`` and their backward uses IT,
+        not the process-wide switch: a backward that runs after the trainer restored the switch (a retained graph, a caller that
+        runs ``loss.backward()`` itself) must all-reduce exactly as its forward did, or dz / dgamma / dbeta silently mix global
+        pixel counts with local sums and the ranks diverge."""
+        return cls.active(), cls.group, cls.world()
 
-def _sync_sums(sums: torch.Tensor, scale: Optional[torch.Tensor] = None) -> int:
+
+def _sync_sums(sums: torch.Tensor, scale: Optional[torch.Tensor] = None, state: Optional[Tuple[bool, object, int]] = None) -> int:
     """all-reduce (SUM) per-channel double sums over the ranks when SyncBatchNorm is on; returns the world size (1 = untouched).
     ``scale``: device scalar S the sums are multiplied by on THIS rank (the fp16 gradient scale differs per rank): they travel
-    unscaled and come back in this rank's scale (S is a power of two: exact)."""
-    world = SyncBatchNorm.world()
-    if not SyncBatchNorm.active():
+    unscaled and come back in this rank's scale (S is a power of two: exact).  ``state``: a ``SyncBatchNorm.snapshot()`` taken by the
+    forward pass (backward passes hand in the one their forward recorded); None = the process-wide switch as it is now."""
+    active, group, world = state if state is not None else SyncBatchNorm.snapshot()
+    if not active:
         return 1
     import torch.distributed as dist
     if scale is not None:
         sums.div_(scale.double())
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=SyncBatchNorm.group)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     if scale is not None:
         sums.mul_(scale.double())
     return world
@@ -82,7 +91,8 @@ class _SyncBatchNorm1(torch.autograd.Function):
         import torch.distributed as dist
         zd = z.double()
         st = torch.stack((zd.sum(), (zd * zd).sum()))
-        dist.all_reduce(st, group=SyncBatchNorm.group)
+        ctx.group = SyncBatchNorm.group
+        dist.all_reduce(st, group=ctx.group)
         n = z.numel() * SyncBatchNorm.world()
         mean = st[0] / n
         var = (st[1] / n - mean * mean).clamp_min(0.0)
@@ -97,7 +107,7 @@ class _SyncBatchNorm1(torch.autograd.Function):
         import torch.distributed as dist
         xhat, invstd = ctx.saved_tensors
         st = torch.stack((dy.double().sum(), (dy.double() * xhat.double()).sum()))
-        dist.all_reduce(st, group=SyncBatchNorm.group)
+        dist.all_reduce(st, group=ctx.group)
         m1, m2 = (st[0] / ctx.n).float(), (st[1] / ctx.n).float()
         return invstd * (dy - m1 - xhat * m2), None
 
@@ -329,7 +339,8 @@ class _CnnTrunk(torch.autograd.Function):
         with torch.cuda.device(dev):
             acts, zs, rs, coef, scals = [x0], [], [], [], []
             tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
-            sync = SyncBatchNorm.active()
+            ctx.sync_state = SyncBatchNorm.snapshot()  # the backward all-reduces iff this forward did
+            sync = ctx.sync_state[0]
             h, w = H, W
             wmax = L.weight_maxima(ws) if split else None  # one launch for all D + 1 weight maxima
             # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs
@@ -355,7 +366,7 @@ class _CnnTrunk(torch.autograd.Function):
                                                     bn.running_var if track else None)
                 else:  # data parallel: the sums of the GLOBAL batch go through an all-reduce between the halves
                     sums = L.stats(None, z, None, None, npix, cout, split)
-                    npix_bn = npix * _sync_sums(sums)
+                    npix_bn = npix * _sync_sums(sums, state=ctx.sync_state)
                     k2, k3 = L.f32(cout), L.f32(cout)
                     mean = torch.empty((cout,), dtype=torch.float64, device=dev)
                     invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
@@ -440,13 +451,13 @@ class _CnnTrunk(torch.autograd.Function):
                 # ReLU mask + BatchNorm backward of hidden block l (pre-activation zs[l-1])
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
-                if not SyncBatchNorm.active():  # (sum dy, sum dy z) * S, max|dy| * S: partial rows, then finish + coefficients in one kernel
+                if not ctx.sync_state[0]:  # (sum dy, sum dy z) * S, max|dy| * S: partial rows, then finish + coefficients in one kernel
                     gs_new = L.f32(1)  # NOT in place: the finishing kernel has many workgroups, all of which read the incoming scale
                     dgamma, dbeta, c1, c2, c3 = L.bn_bwd(da, z, k2f, k3f, npix, C, split, mean, invstd, gammas[l - 1].detach(), gscale, gs_new)
                     gscale = gs_new
                 else:
                     sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)
-                    world = _sync_sums(sums, gscale)
+                    world = _sync_sums(sums, gscale, ctx.sync_state)
                     dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                     rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                                   gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
@@ -496,9 +507,10 @@ class _LastBlock(torch.autograd.Function):
         with torch.cuda.device(dev):
             _native.check(lib.nastar_bn1_fwd_partial(zc.data_ptr(), n, part.data_ptr(), st), "nastar_bn1_fwd_partial")
             world = 1
-            if SyncBatchNorm.active():
+            ctx.sync_state = SyncBatchNorm.snapshot()
+            if ctx.sync_state[0]:
                 part = part.sum(0, keepdim=True)
-                world = _sync_sums(part)
+                world = _sync_sums(part, state=ctx.sync_state)
                 nparts = 1
             _native.check(lib.nastar_bn1_sigmoid_fwd(zc.data_ptr(), n, part.data_ptr(), nparts, float(n * world), g.data_ptr(), b.data_ptr(),
                                                      float(eps), c.data_ptr(), float(momentum),
@@ -528,9 +540,9 @@ class _LastBlock(torch.autograd.Function):
         with torch.cuda.device(dev):
             _native.check(lib.nastar_bn1_sigmoid_bwd_partial(zc.data_ptr(), d.data_ptr(), n, stat.data_ptr(), g.data_ptr(), b.data_ptr(),
                                                              c.data_ptr(), part.data_ptr(), st), "nastar_bn1_sigmoid_bwd_partial")
-            if ctx.world > 1 or SyncBatchNorm.active():
+            if ctx.sync_state[0]:  # as the forward did (ctx.n_total counts the GLOBAL pixels exactly then)
                 part = part.sum(0, keepdim=True)
-                _sync_sums(part)
+                _sync_sums(part, state=ctx.sync_state)
                 nparts = 1
             _native.check(lib.nastar_bn1_sigmoid_bwd(zc.data_ptr(), d.data_ptr(), n, stat.data_ptr(), g.data_ptr(), b.data_ptr(), c.data_ptr(),
                                                      part.data_ptr(), nparts, ctx.n_total, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
@@ -665,7 +677,8 @@ class _UnetTrunk(torch.autograd.Function):
         acts = {"x0": (x0, 32)}
         saved = []
         tracked = []  # the BatchNorm step counters: ONE multi-tensor increment instead of a launch per layer
-        sync = SyncBatchNorm.active()
+        ctx.sync_state = SyncBatchNorm.snapshot()  # the backward all-reduces iff this forward did
+        sync = ctx.sync_state[0]
         out = None
         with torch.cuda.device(dev):
             conv_steps = [st for st in cfg["plan"] if st["kind"] != "pool"]
@@ -715,7 +728,7 @@ class _UnetTrunk(torch.autograd.Function):
                                                     bn.running_mean if track else None, bn.running_var if track else None)
                 else:  # data parallel: statistics of the GLOBAL batch (all-reduce between the halves)
                     sums = L.stats(None, z, None, None, npix, cout, split)
-                    npix_bn = npix * _sync_sums(sums)
+                    npix_bn = npix * _sync_sums(sums, state=ctx.sync_state)
                     k2, k3 = L.f32(cout), L.f32(cout)
                     mean = torch.empty((cout,), dtype=torch.float64, device=dev)
                     invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
@@ -799,14 +812,14 @@ class _UnetTrunk(torch.autograd.Function):
                     z = sv["z"]
                     mean, invstd, k2f, k3f = sv["coef"]
                     sums = None
-                    if not SyncBatchNorm.active():  # partial rows, then finish + coefficients in one kernel
+                    if not ctx.sync_state[0]:  # partial rows, then finish + coefficients in one kernel
                         if cfg.get("debug") is not None:
                             sums = torch.empty((cout, 2), dtype=torch.float64, device=dev)
                         dgamma, dbeta, c1v, c2v, c3v = L.bn_bwd(g, z, k2f, k3f, npix, cout, split, mean, invstd, params[st["g"]].detach(), S_in, S,
                                                                 sums_out=sums)
                     else:
                         sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
-                        world = _sync_sums(sums, S_in)
+                        world = _sync_sums(sums, S_in, ctx.sync_state)
                         dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
                         rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                                          params[st["g"]].detach().data_ptr(), npix * world, S_in.data_ptr(), S.data_ptr(),

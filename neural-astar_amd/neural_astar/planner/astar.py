@@ -78,19 +78,29 @@ class NeuralAstar(VanillaAstar):
             print("WARNING: learn_obstacles has been set to True")
         self.g_ratio = g_ratio
         self.use_differentiable_astar = use_differentiable_astar
-        # "torch" (default, fp32 torch.nn), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder,
-        # csrc/nastar_encoder.hip.h), "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the matrix work, cost
-        # maps within 1e-5 of the fp32 encoder -- the only hip_* mode that meets the reference's float tolerance).  With a hip_*
-        # backend: eval mode under no_grad = the inference kernels (CNN of any depth / size, CNNDownSize, Unet); training mode with
-        # autograd on = the training kernels of neural_astar/encoder_train.py (forward, input and weight gradients, batch-statistics
-        # BatchNorm, max-pool, upsample-concat) for CNN of any depth / map size, CNNDownSize and the VggUnet definition of Unet;
-        # shapes those kernels do not take, and eval mode with gradients, stay on torch.nn.  Not part of the reference's constructor.
-        self.encoder_backend = "torch"
+        # Which kernels predict the cost map.  "auto" (default): on a HIP device "hip_f16x3", on CPU tensors "torch" -- decided per
+        # call from the input's device, before any BatchNorm state is touched, so that the reference's scripts/train.py:30-50
+        # (which constructs NeuralAstar(...) with no such knob) trains and validates on the MFMA kernels unmodified.  "torch" = fp32
+        # torch.nn (MIOpen), "hip_bf16" (bf16-MFMA inference kernels for the depth-4 CNN encoder, csrc/nastar_encoder.hip.h),
+        # "hip_f16" (plain fp16 operands) or "hip_f16x3" (split fp16 operands: 3x the matrix work, cost maps within 1e-5 of the fp32
+        # encoder -- the only hip_* mode that meets the reference's float tolerance, hence what "auto" picks).  With a hip_* backend:
+        # eval mode under no_grad = the inference kernels (CNN of any depth / size, CNNDownSize, Unet); training mode with autograd on
+        # = the training kernels of neural_astar/encoder_train.py (forward, input and weight gradients, batch-statistics BatchNorm,
+        # max-pool, upsample-concat) for CNN of any depth / map size, CNNDownSize and the VggUnet definition of Unet; shapes those
+        # kernels do not take, and eval mode with gradients, stay on torch.nn.  Not part of the reference's constructor.
+        self.encoder_backend = "auto"
         self._hip_encoder = None
+
+    def effective_encoder_backend(self, like: torch.Tensor) -> str:
+        """``encoder_backend`` with "auto" resolved for a tensor on ``like``'s device."""
+        if self.encoder_backend == "auto":
+            return "hip_f16x3" if like.is_cuda else "torch"
+        return self.encoder_backend
 
     def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
         """Predict cost maps (reference astar.py:154-180)."""
-        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+        backend = self.effective_encoder_backend(map_designs)
+        if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and isinstance(self.encoder, encoder.CNNDownSize)):
             # CNNDownSize (WarCraft): f32-input MFMA kernels at fp32 accuracy whatever the hip_* precision asked for
             convs = [m for m in self.encoder.model if isinstance(m, nn.Conv2d)]
@@ -102,18 +112,18 @@ class NeuralAstar(VanillaAstar):
                 if not isinstance(self._hip_encoder, _downsize_cls()):
                     self._hip_encoder = _downsize_cls()(self.encoder)
                 return self._hip_encoder(map_designs, start_maps, goal_maps, plus)
-        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+        if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and isinstance(self.encoder, encoder.Unet) and isinstance(self.encoder.model, encoder.VggUnet)
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % (1 << self.encoder.model.depth) == 0
                 and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0 and map_designs.shape[-1] <= 126):
             # Unet(vgg16_bn): generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h); "hip_f16x3" = split operands, fp32-grade
-            precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
+            precision = "f16x3" if backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipUnetEncoder
             if type(self._hip_encoder) is not HipUnetEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
-        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
+        if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
                 and map_designs.shape[-2:] == start_maps.shape[-2:]):
             from ..encoder_train import unet_supported, unet_train_forward
@@ -121,8 +131,8 @@ class NeuralAstar(VanillaAstar):
             if (unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
                     and first.in_channels == 1 + int("+" in self.encoder_input)):
                 return unet_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
-                                          "f16" if self.encoder_backend == "hip_f16" else "f16x3")
-        if (self.encoder_backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
+                                          "f16" if backend == "hip_f16" else "f16x3")
+        if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.CNN)):
             # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
             # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade).
@@ -135,23 +145,23 @@ class NeuralAstar(VanillaAstar):
                     and map_designs.shape[1] + int(plus) == convs[0].in_channels
                     and (pool or map_designs.shape[-2:] == start_maps.shape[-2:])):
                 return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus,
-                                         "f16" if self.encoder_backend == "hip_f16" else "f16x3")
-        tile = 32 if self.encoder_backend in ("hip_f16", "hip_f16x3") else 16
-        if (self.encoder_backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
+                                         "f16" if backend == "hip_f16" else "f16x3")
+        tile = 32 if backend in ("hip_f16", "hip_f16x3") else 16
+        if (backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % tile == 0 and map_designs.shape[-1] % 32 == 0
                 and isinstance(self.encoder, encoder.CNN) and not isinstance(self.encoder, encoder.CNNDownSize)
                 and _is_depth4_cnn(self.encoder)):
-            precision = self.encoder_backend[4:]
+            precision = backend[4:]
             from ..encoder_hip import HipCnnEncoder
             if type(self._hip_encoder) is not HipCnnEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipCnnEncoder(self.encoder, precision)
             return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
-        if (self.encoder_backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
+        if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and type(self.encoder) is encoder.CNN and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-1] <= 126 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
             # any other depth / map size: the generic fp16 MFMA convolution ("hip_f16x3" = split operands, otherwise plain fp16)
-            precision = "f16x3" if self.encoder_backend == "hip_f16x3" else "f16"
+            precision = "f16x3" if backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipFlatCnnEncoder
             if type(self._hip_encoder) is not HipFlatCnnEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipFlatCnnEncoder(self.encoder, precision)

@@ -45,8 +45,9 @@ class _PendingStatus:
     """status of an earlier call on its way to the host: a device-side any() + a non-blocking copy into pinned memory + an event, all on
     a SIDE stream that waits for the search launch -- the stream the caller keeps launching on never sees these three small ops"""
 
-    def __init__(self, status: torch.Tensor):
+    def __init__(self, status: torch.Tensor, seq: int = 0):
         self.status = status
+        self.seq = seq
         self.flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
         main = torch.cuda.current_stream(status.device)
         side = _side_stream(status.device)
@@ -63,7 +64,7 @@ class _PendingStatus:
     def raise_if_unsolvable(self) -> None:
         self.event.synchronize()
         if bool(self.flag[0]):
-            _raise_unsolvable(self.status)
+            _raise_unsolvable(self.status, self.seq, deferred=True)
 
 
 def _capturing(t: torch.Tensor) -> bool:
@@ -71,11 +72,12 @@ def _capturing(t: torch.Tensor) -> bool:
     return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
-def _raise_unsolvable(status: torch.Tensor) -> None:
+def _raise_unsolvable(status: torch.Tensor, seq: int = 0, deferred: bool = False) -> None:
     bad = torch.nonzero(status != 0).flatten().tolist()
+    where = f"search call #{seq} of this module" + (" (an EARLIER call: check_solvable='deferred' delivers verdicts late)" if deferred else "")
     raise UnsolvableMapError(
         f"{len(bad)} map(s) have no start->goal route or a non-one-hot start/goal map "
-        f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''})")
+        f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''} of {where})")
 
 
 class DifferentiableAstar(nn.Module):
@@ -86,12 +88,15 @@ class DifferentiableAstar(nn.Module):
             Tmax: fraction of W*W search steps allowed in training mode (reference :135,:200-202).
             check_solvable: what to do about maps whose open list ran empty (extension over the reference, which crashes with an
                 ``IndexError`` inside ``backtrack`` for the whole batch):
-                ``True`` / ``"deferred"`` (default) -- NO host synchronisation in ``forward()``: the per-map status travels to the
-                host asynchronously (a device-side any() + a copy into pinned memory + an event) and ``UnsolvableMapError`` is
-                raised by the first later ``forward()`` call that finds the verdict already on the host -- never waiting for it,
-                so the host keeps queueing launches ahead of the device -- or by ``raise_if_unsolvable()``, which waits (call it
-                after the last batch); ``"sync"`` -- wait for the kernel and raise in the same call (one device->host sync per
-                call: +25 % on a 4096-map 32x32 batch); ``False`` -- never raise.
+                ``True`` / ``"sync"`` (default) -- wait for the kernel and raise ``UnsolvableMapError`` IN THE SAME CALL, before
+                the caller can consume garbage histories or step an optimiser on them (one device->host sync per call: ~27 us on
+                a 4096-map 32x32 batch; the reference synchronises once per search ITERATION);
+                ``"deferred"`` (opt-in: benchmarks, pipelined inference loops) -- NO host synchronisation in ``forward()``: the
+                per-map status travels to the host asynchronously (a device-side any() + a copy into pinned memory + an event)
+                and the error is raised by the first LATER ``forward()`` call that finds the verdict already on the host, or by
+                ``raise_if_unsolvable()``, which waits (call it after the last batch / before consuming results); the message
+                names the call it belongs to;
+                ``False`` -- never raise.  Inside a hipGraph capture nothing is checked (nothing may synchronise there).
                 The per-map status of the latest call is always available as ``self.last_status``.
         """
         super().__init__()
@@ -106,6 +111,21 @@ class DifferentiableAstar(nn.Module):
         self.last_status: Optional[torch.Tensor] = None
         self.last_iters: Optional[torch.Tensor] = None
         self._pending: List[_PendingStatus] = []
+        self._calls = 0  # searches launched through this module (names the call in UnsolvableMapError)
+
+    # run-time bookkeeping (device events, pinned flags, the latest status tensors) is not module state: copy.deepcopy(planner)
+    # (EMA / best-model snapshots), pickling and torch.save(planner) must work after any forward()
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_pending"] = []
+        state["last_status"] = None
+        state["last_iters"] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("_pending", [])
+        self.__dict__.setdefault("_calls", 0)
 
     def raise_if_unsolvable(self, wait: bool = True) -> None:
         """Deliver the deferred verdicts: raise ``UnsolvableMapError`` if an earlier ``forward()`` call met an unsolvable map.
@@ -118,14 +138,15 @@ class DifferentiableAstar(nn.Module):
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
         step and the validation pair, which launch the search themselves)"""
         self.last_status, self.last_iters = status, iters
+        self._calls += 1
         mode = self.check_solvable
         if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
             return
-        if mode == "sync":
+        if mode != "deferred":  # True / "sync": the verdict belongs to THIS call
             if bool((status != 0).any()):
-                _raise_unsolvable(status)
+                _raise_unsolvable(status, self._calls)
             return
-        self._pending.append(_PendingStatus(status))
+        self._pending.append(_PendingStatus(status, self._calls))
         if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
             self._pending.pop(0).raise_if_unsolvable()
 

@@ -2,7 +2,7 @@
 
 Plain torch.nn modules that keep ``NeuralAstar`` constructible and checkpoint-compatible (state-dict keys
 ``encoder.model.<n>.*`` of the shipped ``mazes_032_moore_c8`` checkpoint load strictly) and hold the parameters.  With the
-default ``encoder_backend = "torch"`` their convolutions run on MIOpen; with a ``hip_*`` backend ``NeuralAstar.encode`` runs the
+``encoder_backend = "torch"`` (and on CPU tensors) their convolutions run on torch.nn / MIOpen; with a ``hip_*`` backend (the default "auto" = ``hip_f16x3`` on a HIP device) ``NeuralAstar.encode`` runs the
 same parameters through this package's MFMA kernels instead (``encoder_hip.py`` for inference, ``encoder_train.py`` for
 training: SURVEY.md section 8f "next #1").
 """

@@ -148,8 +148,8 @@ class DataParallelTrainer:
             raise ValueError(coupling)
         self.coupling = coupling
         self.sync_bn = bool(sync_bn)
-        if self.sync_bn and not str(getattr(planner, "encoder_backend", "torch")).startswith("hip"):
-            raise ValueError("sync_bn=True needs planner.encoder_backend = 'hip_f16x3' / 'hip_f16' (the BatchNorm statistics are "
+        if self.sync_bn and not str(getattr(planner, "encoder_backend", "torch")).startswith(("hip", "auto")):
+            raise ValueError("sync_bn=True needs planner.encoder_backend = 'auto' / 'hip_f16x3' / 'hip_f16' (the BatchNorm statistics are "
                              "all-reduced inside the HIP training path); for the torch.nn encoder convert it with "
                              "torch.nn.SyncBatchNorm.convert_sync_batchnorm instead")
         self.buffer_sync_every = int(buffer_sync_every)

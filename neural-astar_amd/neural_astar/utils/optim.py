@@ -10,11 +10,16 @@ import torch
 
 
 class FusedRMSprop(torch.optim.RMSprop):
-    _table_key = None
-    _table = None
+    _tables = None  # {id(group): (key, device table)}: one cached table per parameter group
 
     @torch.no_grad()
     def step(self, closure=None):
+        # the closure first (Lightning's runs zero_grad + backward inside it): eligibility and row pointers are taken from the
+        # gradients of THIS step, never from the previous step's
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         plain = all(g["momentum"] == 0 and not g["centered"] and g["weight_decay"] == 0 and not g.get("maximize", False)
                     and not g.get("differentiable", False) and not g.get("capturable", False) for g in self.param_groups)
         params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
@@ -24,15 +29,14 @@ class FusedRMSprop(torch.optim.RMSprop):
         if ok and len({p.device for p in params}) != 1:
             ok = False
         if not ok:
-            return super().step(closure)
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
+            super().step(None)  # torch's own step on the gradients the closure (if any) just produced
+            return loss
         from .. import _native
         lib = _native.load()
         dev = params[0].device
         stream = torch.cuda.current_stream(dev).cuda_stream
+        if self._tables is None:
+            self._tables = {}
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -45,12 +49,13 @@ class FusedRMSprop(torch.optim.RMSprop):
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 rows.append((p.data_ptr(), p.grad.data_ptr(), st["square_avg"].data_ptr(), p.numel()))
-            key = (id(group), tuple(rows))
-            if self._table_key != key:  # the caching allocator usually hands the gradients the same blocks every step
-                self._table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
-                self._table_key = key
+            key = tuple(rows)
+            cached = self._tables.get(id(group))
+            if cached is None or cached[0] != key:  # the caching allocator usually hands the gradients the same blocks every step
+                cached = (key, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True))
+                self._tables[id(group)] = cached
             with torch.cuda.device(dev):
-                rc = lib.nastar_rmsprop_multi_f32(self._table.data_ptr(), len(rows), float(group["lr"]), float(group["alpha"]),
+                rc = lib.nastar_rmsprop_multi_f32(cached[1].data_ptr(), len(rows), float(group["lr"]), float(group["alpha"]),
                                                   float(group["eps"]), stream)
             _native.check(rc, "nastar_rmsprop_multi_f32")
         return loss

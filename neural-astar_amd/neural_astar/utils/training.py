@@ -129,5 +129,5 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)
     loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
                                                          opt_trajs[:, 0], astar.g_ratio, max_iters)
-    astar.note_status(status, iters)  # same contract as DifferentiableAstar.forward (deferred verdict by default: no host sync)
+    astar.note_status(status, iters)  # same contract as DifferentiableAstar.forward (default: raises in THIS call, before any backward)
     return loss, AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), [])

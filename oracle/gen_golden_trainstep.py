@@ -20,7 +20,11 @@ cost maps, histories, paths, dL/dcost, EVERY parameter gradient, the BatchNorm r
 smallest gap between the selected node's priority and the runner-up's over the whole search (`sel_margin`): a map whose margin is
 below the encoder's float tolerance may legitimately take another route under a 1e-6 perturbation of its cost map.
 
-Usage:  python oracle/gen_golden_trainstep.py
+  trainloop_maze32_3steps   (round 4) THREE consecutive steps of the reference's training loop -- PlannerModule.training_step +
+                        configure_optimizers()'s RMSprop (utils/training.py:52-61) -- on three different 16-map batches: per step the
+                        loss, cost maps, histories, every parameter after the update, every BatchNorm buffer incl. num_batches_tracked
+
+Usage:  python oracle/gen_golden_trainstep.py [maze] [warcraft] [enc] [loop]
 """
 from __future__ import annotations
 
@@ -225,6 +229,89 @@ def trainstep_warcraft12(planner_mod, training_mod, syn):
                dict(B=B, H=12, W=12, Tmax=0.25, g_ratio=0.5, image_u8=img8, traj_bits=pack(traj.numpy()), sel_margin=marg))
 
 
+
+def trainloop_maze32(planner_mod, training_mod, syn, name="trainloop_maze32_3steps", seeds=(407, 408, 449), n_steps=3, scan=range(400, 460)):
+    """THREE consecutive optimiser steps of the reference's training loop (scripts/train.py:43-50 -> pl.Trainer.fit with automatic
+    optimisation = zero_grad, PlannerModule.training_step (utils/training.py:55-61), backward, configure_optimizers()'s RMSprop step
+    (utils/training.py:52-53, lr from scripts/config/train.yaml), a DIFFERENT 16-map batch per step as a DataLoader would deliver.
+    Stored per step: loss, cost maps, histories / paths, the batch, per-map selection margins, EVERY parameter after the update and
+    every BatchNorm buffer (running_mean, running_var, num_batches_tracked).  The batches are the first `n_steps` consecutive seeds
+    from `scan` for which every map of every step has a selection margin > 2e-5 under the reference's evolving weights (margins of a
+    few fp32 ulps are the norm, see trainstep_maze32), so that an implementation within the float tolerance follows the same routes
+    (seeds=None repeats the scan: 407, 408, then 449 after 41 rejected candidates; worst margin 2.8e-5)."""
+    z = np.load(os.path.join(OUT, "ckpt_mazes032_cnn.npz"))
+    sd0 = {k: torch.from_numpy(z[k]) for k in z.files}
+    cfg = types.SimpleNamespace(params=types.SimpleNamespace(lr=0.001))  # scripts/config/train.yaml: params.lr
+
+    def run(seed_list, record):
+        na = planner_mod.NeuralAstar(encoder_input="m+", encoder_arch="CNN", encoder_depth=4, Tmax=0.25)
+        na.load_state_dict(sd0, strict=True)
+        module = training_mod.PlannerModule(na, cfg)
+        module.train()
+        opt = module.configure_optimizers()
+        assert type(opt).__name__ == "RMSprop"
+        worst = np.inf
+        for k, seed in enumerate(seed_list):
+            pr = syn.maze_maps(16, 32, seed=seed)
+            m, s, g = (torch.from_numpy(x) for x in pr)
+            with torch.no_grad():
+                traj = planner_mod.VanillaAstar().eval()(m, s, g).paths.float()
+            captured = {}
+
+            def hook(mod, inp, out):
+                captured["cost"] = out.detach().clone()
+            h = na.encoder.register_forward_hook(hook)
+            opt.zero_grad()
+            loss = module.training_step((m, s, g, traj), k)
+            loss.backward()
+            h.remove()
+            cost = captured["cost"]
+            with torch.no_grad():
+                out = na.astar(cost, s, g, m)  # the step's own search on the step's own cost maps (training-mode budget)
+            marg, hist_np = selection_margins(cost.numpy(), pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, int(0.25 * 32 * 32))
+            assert np.array_equal(hist_np, out.histories.numpy()), "numpy re-walk disagrees with the reference"
+            worst = min(worst, float(marg.min()))
+            grads = {kk: v.grad.detach().numpy().copy() for kk, v in na.named_parameters() if v.grad is not None}
+            opt.step()
+            if record is not None:
+                t = f"step{k}/"
+                # the step's gradients, for CLASSIFYING elements only (RMSprop divides by sqrt(v) + 1e-8: where |g| is at the rounding
+                # noise of the backward pass the update's sign is noise too): fp16 of g / max|g| per tensor + the maximum
+                for kk, gv in grads.items():
+                    mx = float(np.abs(gv).max())
+                    record[t + "gradmax/" + kk] = np.float64(mx)
+                    record[t + "grad16/" + kk] = (gv / (mx if mx > 0 else 1.0)).astype(np.float16)
+                record[t + "loss"] = np.float64(loss.item())
+                record[t + "cost"] = cost.numpy().astype(np.float32)
+                record[t + "hist_bits"] = pack(out.histories.numpy())
+                record[t + "path_bits"] = pack(out.paths.numpy())
+                record[t + "map_bits"] = pack(pr.map_designs)
+                record[t + "traj_bits"] = pack(traj.numpy())
+                record[t + "start_idx"] = pr.start_maps.reshape(16, -1).argmax(1).astype(np.int32)
+                record[t + "goal_idx"] = pr.goal_maps.reshape(16, -1).argmax(1).astype(np.int32)
+                record[t + "sel_margin"] = marg
+                for kk, v in na.named_parameters():
+                    record[t + "param/" + kk] = v.detach().numpy().astype(np.float32).copy()
+                for kk, v in na.named_buffers():
+                    record[t + "buffer/" + kk] = v.detach().numpy().copy()
+        return worst
+
+    if seeds is None:
+        seeds = []
+        cand = iter(scan)
+        while len(seeds) < n_steps:
+            c = next(cand)
+            w = run(seeds + [c], None)
+            print(f"  candidate seed {c} after {seeds}: worst margin {w:.3e}")
+            if w > 2e-5:
+                seeds.append(c)
+    rec = dict(B=16, H=32, W=32, Tmax=0.25, g_ratio=0.5, lr=0.001, n_steps=n_steps, seeds=np.asarray(seeds, np.int64),
+               optimizer="torch.optim.RMSprop(planner.parameters(), lr) -- defaults alpha=0.99 eps=1e-8, no momentum")
+    w = run(list(seeds), rec)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: seeds={list(seeds)} losses={[rec[f'step{k}/loss'] for k in range(n_steps)]} worst margin={w:.3e}")
+
+
 def randomise_bn(model, gen):
     """non-trivial eval-mode BatchNorm: random running statistics and affine parameters"""
     for mod in model.modules():
@@ -274,7 +361,9 @@ def main():
     syn = synthetic_module()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["maze", "warcraft", "enc"]
+    which = sys.argv[1:] or ["maze", "warcraft", "enc", "loop"]
+    if "loop" in which:
+        trainloop_maze32(planner_mod, training_mod, syn)
     if "maze" in which:
         trainstep_maze32(planner_mod, training_mod, syn)
         trainstep_maze32(planner_mod, training_mod, syn, name="trainstep_maze32_tight", seed=303, param_grads=False)

@@ -8,6 +8,7 @@ from typing import NamedTuple, Optional
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NON_SEARCH_PREFIXES = ("ckpt_", "data_", "trainstep_", "trainloop_", "enc_")  # weight / dataset / training-step / encoder fixtures
 
 
 class Golden(NamedTuple):
@@ -47,7 +48,7 @@ def _onehot(idx, B, H, W):
 
 def names():
     """search fixtures (ckpt_*.npz are weight fixtures, data_*.npz dataset fixtures: not search cases)"""
-    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("ckpt_", "data_", "trainstep_", "enc_")))
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(NON_SEARCH_PREFIXES))
 
 
 def load(name: str) -> Golden:
@@ -66,7 +67,6 @@ def load(name: str) -> Golden:
 
 # ---- round 3: full-training-step and encoder goldens (oracle/gen_golden_trainstep.py, the reference package run end to end) ----
 
-NON_SEARCH_PREFIXES = ("ckpt_", "data_", "trainstep_", "enc_")
 
 
 class StepGolden(NamedTuple):

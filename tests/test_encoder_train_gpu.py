@@ -637,6 +637,35 @@ def test_fused_rmsprop_equals_torch_rmsprop():
     assert torch.equal(ob2.state[pb[0]]["square_avg"], oa.state[pa[0]]["square_avg"])
 
 
+def test_fused_rmsprop_closure_and_two_parameter_groups():
+    """step(closure) with zero_grad + backward INSIDE the closure (Lightning's automatic optimisation) and two parameter groups with
+    their own learning rates: the one-launch step uses this call's gradients and one cached device table per group."""
+    from neural_astar.utils.optim import FusedRMSprop
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    shapes = [(64, 32, 3, 3), (64,), (9, 5)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:2], "lr": 1e-3}, {"params": ps[2:], "lr": 5e-3}]  # noqa: E731
+    oa, ob = FusedRMSprop(groups(pa), 1e-3), torch.optim.RMSprop(groups(pb), 1e-3)
+    tgt = [torch.randn(s, generator=g).to(dev) for s in shapes]
+
+    def closure_for(params, opt):
+        def closure():
+            opt.zero_grad(set_to_none=True)
+            loss = sum(((p - t) ** 2).sum() for p, t in zip(params, tgt))
+            loss.backward()
+            return loss
+        return closure
+    for _ in range(4):
+        la, lb = oa.step(closure_for(pa, oa)), ob.step(closure_for(pb, ob))
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    torch.cuda.synchronize()
+    assert len(oa._tables) == 2  # one cached table per group, neither rebuilt by the other
+    for x, y in zip(pa, pb):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("B,H,W,C", [(1, 4, 4, 32), (6, 16, 8, 64), (300, 32, 32, 256)])
 def test_two_launch_batchnorm_pass_equals_the_three_launch_form(split, B, H, W, C):

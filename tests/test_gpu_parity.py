@@ -163,15 +163,21 @@ def test_unsolvable_and_degenerate_maps_report_status():
     assert iters[2] == 1 and hist[2].sum() == 1 and paths[2].sum() == 1
     from neural_astar.planner import VanillaAstar
     from neural_astar.planner.differentiable_astar import UnsolvableMapError
-    va = VanillaAstar().to(_dev())
-    va.astar.check_solvable = "sync"               # one host sync per call: raises in the same call
-    with pytest.raises(UnsolvableMapError):
+    va = VanillaAstar().to(_dev())                 # default: the verdict belongs to the call that met the map (like the reference,
+    with pytest.raises(UnsolvableMapError, match="call #1"):  # which fails inside the same forward()) -- ADVICE r3
         va(_t(m), _t(s), _t(g))
-    va = VanillaAstar().to(_dev())                 # default = deferred: forward() itself never waits for the kernel ...
+    assert va.astar.last_status.tolist() == [3, 0, 0]
+    va(_t(m[1:]), _t(s[1:]), _t(g[1:]))            # a solvable batch afterwards is fine: nothing is left pending
+    va.astar.raise_if_unsolvable()
+    va = VanillaAstar().to(_dev())
+    va.astar.check_solvable = "deferred"           # opt-in: forward() itself never waits for the kernel ...
     out = va(_t(m), _t(s), _t(g))
     assert out.histories.shape == (3, 1, 16, 16) and va.astar.last_status.tolist() == [3, 0, 0]
+    import copy
+    snap = copy.deepcopy(va)                       # ... and pending verdicts (events, pinned flags) never block deepcopy / pickling
+    assert snap.astar._pending == [] and snap.astar.last_status is None and snap.astar.check_solvable == "deferred"
     torch.cuda.synchronize()                       # (the verdict has certainly reached the host now)
-    with pytest.raises(UnsolvableMapError):        # ... a LATER call (or raise_if_unsolvable()) delivers the verdict
+    with pytest.raises(UnsolvableMapError, match="call #1 .*EARLIER"):  # ... a LATER call (or raise_if_unsolvable()) delivers it
         va(_t(m[1:]), _t(s[1:]), _t(g[1:]))
     va(_t(m[1:]), _t(s[1:]), _t(g[1:]))            # the solvable batch itself is fine
     va.astar.raise_if_unsolvable()
@@ -800,8 +806,9 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
 
 
 def test_vanilla_astar_forward_is_hipgraph_capturable_and_has_no_host_sync():
-    """The default forward() (deferred solvability verdict) must not synchronise the host: captured into a hipGraph on a side stream
-    and replayed on fresh inputs it reproduces the eager outputs (reference astar.py:73-102 is one module call per batch)."""
+    """forward() with the deferred solvability verdict must not synchronise the host, and inside a capture no mode may: captured into
+    a hipGraph on a side stream and replayed on fresh inputs it reproduces the eager outputs (reference astar.py:73-102 is one module
+    call per batch)."""
     from neural_astar.planner import VanillaAstar
     from neural_astar.utils import synthetic as syn
     dev = _dev()
@@ -809,6 +816,7 @@ def test_vanilla_astar_forward_is_hipgraph_capturable_and_has_no_host_sync():
     pr2 = syn.maze_maps(256, 32, seed=42)
     m, s, g = (_t(x).clone() for x in pr)
     va = VanillaAstar().to(dev).eval()
+    va.astar.check_solvable = "deferred"
     with torch.no_grad():
         ref2 = va(*(_t(x) for x in pr2))
         va.astar.raise_if_unsolvable()

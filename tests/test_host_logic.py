@@ -1,6 +1,7 @@
 """CPU: host-side logic -- module surface / state-dict compatibility, budget arithmetic, synthetic generators,
 mask packing and the world_size-2 sharded collation over gloo."""
 import os
+import types
 import sys
 
 import numpy as np
@@ -360,3 +361,44 @@ def test_fused_rmsprop_on_cpu_parameters_is_torch_rmsprop():
         assert torch.equal(x, y)
     assert torch.equal(oa.state[pa[0]]["square_avg"], ob.state[pb[0]]["square_avg"])
     ob.load_state_dict(oa.state_dict())  # same state layout
+
+
+def test_fused_rmsprop_runs_the_closure_before_it_looks_at_the_gradients():
+    """Lightning hands optimizer.step a closure that does zero_grad + backward: the step must use the gradients THAT call produced
+    (eligibility and row pointers were taken from the previous step's gradients).  CPU parameters = torch's own update."""
+    from neural_astar.utils.optim import FusedRMSprop
+    g = torch.Generator().manual_seed(4)
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((3, 2), (4,))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FusedRMSprop(pa, 1e-2), torch.optim.RMSprop(pb, 1e-2)
+    target = [torch.randn(p.shape, generator=g) for p in pa]
+
+    def closure_for(params, opt):
+        def closure():
+            opt.zero_grad(set_to_none=True)  # the previous step's gradients are GONE when the step looks
+            loss = sum(((p - t) ** 2).sum() for p, t in zip(params, target))
+            loss.backward()
+            return loss
+        return closure
+    for _ in range(4):
+        la, lb = oa.step(closure_for(pa, oa)), ob.step(closure_for(pb, ob))
+        assert float(la) == float(lb)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+
+
+def test_default_encoder_backend_is_auto_and_resolves_per_device():
+    """scripts/train.py:30-36 constructs NeuralAstar(...) with no backend knob: the default must route HIP tensors to the MFMA encoders
+     and CPU tensors to torch.nn (the search then rejects them -- there is no CPU search)."""
+    from neural_astar.planner import NeuralAstar
+    na = NeuralAstar(encoder_input="m+", encoder_arch="CNN", encoder_depth=4, Tmax=0.25)
+    assert na.encoder_backend == "auto"
+    assert na.effective_encoder_backend(torch.zeros(1)) == "torch"
+    fake_cuda = types.SimpleNamespace(is_cuda=True)
+    assert na.effective_encoder_backend(fake_cuda) == "hip_f16x3"
+    na.encoder_backend = "hip_bf16"
+    assert na.effective_encoder_backend(fake_cuda) == "hip_bf16" and na.effective_encoder_backend(torch.zeros(1)) == "hip_bf16"
+    x = torch.rand(2, 1, 32, 32)
+    na.encoder_backend = "auto"
+    c = na.eval().encode(x, torch.zeros_like(x), torch.zeros_like(x))  # CPU tensors: the torch.nn encoder, as the reference
+    assert c.shape == (2, 1, 32, 32)

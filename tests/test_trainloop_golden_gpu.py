@@ -1,0 +1,143 @@
+"""The training LOOP (not one step) against the reference's own loop.
+
+Golden = three consecutive iterations of what ``scripts/train.py:43-50`` runs: the reference package's ``PlannerModule.training_step``
+(utils/training.py:55-61) + ``configure_optimizers()``'s ``torch.optim.RMSprop`` (utils/training.py:52-53), a different 16-map batch per
+step, starting from the shipped ``mazes_032`` checkpoint (``oracle/gen_golden_trainstep.py loop`` -> ``trainloop_maze32_3steps.npz``).
+Here: a DEFAULT-constructed ``NeuralAstar`` (``encoder_backend = "auto"`` -> the MFMA training kernels, asserted) driven by this package's
+``PlannerModule.training_step`` + ``configure_optimizers()`` (``FusedRMSprop``).
+
+Bars per step: loss within 1e-6, cost maps within 1e-5, histories / paths identical (every map's selection margin is > 2e-5 in the
+golden), BatchNorm running statistics within 1e-5, ``num_batches_tracked`` equal.  Parameters after each update: RMSprop divides every
+element's gradient by its own running magnitude, so an element's update carries the RELATIVE error of that element's gradient -- the
+1e-4-of-the-tensor-maximum the step test grants becomes 1e-4 / rho for an element whose gradient is rho x the tensor's maximum.  The test
+therefore states both: the fraction of elements within 1e-5 of the tensor's parameter range (reported), and a per-element bound
+``1e-5 * max|p| + k * 0.01 * min(1, eps_g / rho)`` that every element must meet (0.01 = the largest step RMSprop(lr 1e-3, alpha 0.99) can
+take, k = steps so far, eps_g = 2e-4); elements whose reference gradient is below eps_g of the tensor maximum ("sign-noise" elements: the
+reference's own update direction is rounding noise there) are counted and reported, not hidden."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+NAME = "trainloop_maze32_3steps"
+EPS_G = 2e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _unpack(bits, B, H, W):
+    return np.unpackbits(bits, axis=1)[:, :H * W].reshape(B, 1, H, W)
+
+
+def _onehot(idx, B, H, W):
+    m = np.zeros((B, H * W), np.float32)
+    m[np.arange(B), idx] = 1
+    return m.reshape(B, 1, H, W)
+
+
+@pytest.mark.parametrize("backend", ["auto", "torch"])
+def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import training as T
+    from neural_astar.utils.optim import FusedRMSprop
+    dev = _dev()
+    z = np.load(os.path.join(G.GOLDEN_DIR, NAME + ".npz"))
+    B, H, W, n_steps = int(z["B"]), int(z["H"]), int(z["W"]), int(z["n_steps"])
+    ck = np.load(os.path.join(G.GOLDEN_DIR, "ckpt_mazes032_cnn.npz"))
+    na = NeuralAstar(encoder_input="m+", encoder_arch="CNN", encoder_depth=4, Tmax=0.25)  # scripts/train.py:33-39, no backend knob
+    assert na.encoder_backend == "auto"
+    na.load_state_dict({k: torch.from_numpy(ck[k]) for k in ck.files}, strict=True)
+    na = na.to(dev)
+    na.encoder_backend = backend
+    module = T.PlannerModule(na, types.SimpleNamespace(params=types.SimpleNamespace(lr=float(z["lr"]))))
+    module.train()
+    opt = module.configure_optimizers()
+    assert isinstance(opt, FusedRMSprop) and isinstance(opt, torch.optim.RMSprop)
+    # what the default-constructed planner actually runs: the MFMA training trunk, not torch.nn
+    from neural_astar import encoder_train as ET
+    trunk_calls = []
+    orig_trunk = ET.cnn_train_forward
+    seen = {}
+    orig_step = T.fused_l1_step
+
+    def spy_trunk(*a, **k):
+        trunk_calls.append(a[-1] if a else None)
+        return orig_trunk(*a, **k)
+
+    def spy_step(*a, **k):
+        loss, out = orig_step(*a, **k)
+        seen["out"] = out
+        return loss, out
+    ET.cnn_train_forward = spy_trunk
+    T.fused_l1_step = spy_step
+    enc = na.encode
+
+    def encode(*a, **k):
+        c = enc(*a, **k)
+        seen["cost"] = c.detach()
+        return c
+    na.encode = encode
+    report = []
+    try:
+        for k in range(n_steps):
+            t = f"step{k}/"
+            m = torch.from_numpy(_unpack(z[t + "map_bits"], B, H, W).astype(np.float32)).to(dev)
+            s = torch.from_numpy(_onehot(z[t + "start_idx"], B, H, W)).to(dev)
+            g = torch.from_numpy(_onehot(z[t + "goal_idx"], B, H, W)).to(dev)
+            traj = torch.from_numpy(_unpack(z[t + "traj_bits"], B, H, W).astype(np.float32)).to(dev)
+            assert float(z[t + "sel_margin"].min()) > 2e-5
+            opt.zero_grad()
+            loss = module.training_step((m, s, g, traj), k)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            cost_err = float((seen["cost"].cpu() - torch.from_numpy(z[t + "cost"])).abs().max())
+            assert cost_err <= 1e-5, (k, cost_err)
+            assert np.array_equal(seen["out"].histories.cpu().numpy(), _unpack(z[t + "hist_bits"], B, H, W).astype(np.float32)), f"step {k}: histories"
+            assert np.array_equal(seen["out"].paths.cpu().numpy(), _unpack(z[t + "path_bits"], B, H, W).astype(np.int64)), f"step {k}: paths"
+            assert abs(float(loss) - float(z[t + "loss"])) <= 1e-6, (k, float(loss), float(z[t + "loss"]))
+            n_el = n_in = n_noise = 0
+            worst_rel = 0.0
+            for name, p in na.named_parameters():
+                if not p.requires_grad:
+                    continue
+                ref = torch.from_numpy(z[t + "param/" + name]).double()
+                d = (p.detach().double().cpu() - ref).abs()
+                scale = float(ref.abs().max().clamp_min(1e-30))
+                tol0 = 1e-5 * scale
+                if t + "grad16/" + name in z.files:
+                    rho = torch.from_numpy(z[t + "grad16/" + name].astype(np.float32)).abs().double()
+                else:  # no gradient reached it in the reference either
+                    rho = torch.ones_like(ref)
+                bound = tol0 + (k + 1) * 0.01 * torch.clamp(EPS_G / rho.clamp_min(1e-30), max=1.0) * 1.05
+                assert bool((d <= bound).all()), (k, name, float((d - bound).max()))
+                n_el += d.numel()
+                n_in += int((d <= tol0).sum())
+                n_noise += int((rho < EPS_G).sum())
+                worst_rel = max(worst_rel, float(d.max()) / scale)
+            for name, b in na.named_buffers():
+                ref = torch.from_numpy(np.asarray(z[t + "buffer/" + name]))
+                if b.dtype.is_floating_point:
+                    e = float((b.double().cpu() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30))
+                    assert e <= 1e-5, (k, name, e)
+                else:
+                    assert int(b) == int(ref), (k, name)
+            report.append(dict(step=k, loss=float(loss), cost_err=cost_err, params_within_1e5=n_in / n_el, sign_noise_elements=n_noise,
+                               elements=n_el, worst_param_dev_rel=worst_rel))
+    finally:
+        ET.cnn_train_forward = orig_trunk
+        T.fused_l1_step = orig_step
+        del na.encode
+    print("TRAINLOOP", backend, report)
+    if backend == "auto":
+        assert len(trunk_calls) == n_steps and all(p == "f16x3" for p in trunk_calls), trunk_calls  # the MFMA training trunk ran every step
+    else:
+        assert not trunk_calls
