@@ -21,7 +21,15 @@ r04_a)
   for pad in 3600 9984; do   # 12 and 8 wavefronts per CU instead of 16
     NASTAR_LIB=$DEVLIB NASTAR_LDS_PAD=$pad python tools/probe_streams.py --workloads maze32,rand32 --flags 0 --streams 1,2,4,6,8 --bigb 4 > $O/streams_pad$pad.jsonl 2> $O/streams_pad$pad.err
   done
-  tail -n +1 $O/rate.txt $O/*.jsonl; tail -3 $O/*.err
+  tail -n +1 $O/rate.txt $O/*.jsonl; tail -n 3 $O/*.err
+  ;;
+r04_b)
+  # auto backend + 3-step training-loop golden + ADVICE fixes: the new test verbosely, then the whole GPU suite
+  O=gpurun_out/r04/b; mkdir -p $O
+  python -m pytest tests/test_trainloop_golden_gpu.py -q -s -m gpu > $O/trainloop.log 2>&1; echo "trainloop rc=$?"
+  grep -a "TRAINLOOP\|passed\|failed\|Error\|assert" $O/trainloop.log | cut -c1-1500 | tail -20
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"
+  tail -25 $O/all_gpu_tests.log
   ;;
 *)
   echo "unknown session $S"; exit 2;;
