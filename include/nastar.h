@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 300 /* 0.3.0: round-3 search instruction stream, two-stage statistics, closing-block kernels, dev kernels behind DEV=1 */
+#define NASTAR_VERSION 400 /* 0.4.0: round-4 search instruction stream, unit-cost LDS layout (NASTAR_FLAG_UNIT_COST) */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0
@@ -48,6 +48,8 @@ extern "C" {
 #define NASTAR_ERR_HIP 4         /* a HIP runtime call failed; see nastar_last_error()               */
 #define NASTAR_ERR_NULL 5        /* a required pointer is NULL                                       */
 #define NASTAR_ERR_WORKSPACE 6   /* workspace_bytes smaller than nastar_workspace_bytes()            */
+#define NASTAR_ERR_NOT_UNIT_COST 7 /* per-map status only: NASTAR_FLAG_UNIT_COST was passed but this map holds a value other than 0.0 / 1.0;
+                                      its outputs are all-zero -- run it again without the flag */
 
 /* flags for nastar_workspace_bytes / nastar_forward / nastar_backward */
 #define NASTAR_FLAG_NONE 0
@@ -57,6 +59,13 @@ extern "C" {
 #define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
 #define NASTAR_FLAG_NO_DIVE 32   /* forward, 64x64 maps: the round-3 stream without its "dive" fast path (A/B) */
 #define NASTAR_FLAG_DUO 4        /* forward: two maps per wavefront (nastar_search_duo.hip.h), a measured non-improvement */
+#define NASTAR_FLAG_UNIT_COST 64 /* forward: the caller promises that `cost` and `passable` are ONE binary tensor (VanillaAstar, reference
+                                    astar.py:93-94; pass the same pointer twice): the LDS state drops the per-cell cost word (5.5 instead
+                                    of 9.75 B/cell, 29 instead of 16 resident 32x32 maps per CU).  Same outputs as without the flag; the
+                                    kernel checks every map while loading it and marks a map that breaks the promise with status
+                                    NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
+                                    wanted or the map is not 32x32 / 64x64 */
+#define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
 
 int nastar_version(void);
 

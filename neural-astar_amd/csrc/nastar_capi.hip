@@ -21,6 +21,8 @@
 #endif
 #include "nastar_search_asm.hip.h"
 #include "nastar_search_asm3.hip.h"
+#include "nastar_search_asm4.hip.h"
+#include "nastar_search_unit.hip.h"
 #if NASTAR_DEV_KERNELS
 #include "nastar_search_asm3_abl.hip.h"
 #endif
@@ -176,7 +178,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (start_idx < 0 || goal_idx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
     } else {
-        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, asm3);
+        // round-4 stream (nastar_search_asm4.hip.h) wherever the round-3 one applies; NASTAR_FLAG_ASM_V3 keeps the round-3 stream (A/B);
+        // half: g_ratio == 0.5 -- the two products of f = g_ratio g + (1 - g_ratio) h are exact and drop out of the key
+        const bool asm4 = ABL == -1 && asm3 && !(a.flags & NASTAR_FLAG_ASM_V3);
+        const bool half = asm4 && d.gr == 0.5f && d.omg == 0.5f;
+        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, asm3, half);
         int s = 0;
         if constexpr (ABL == -1) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
@@ -184,6 +190,14 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             // searching wavefronts issue ahead of the ones still loading their map or already storing their result (the launch waits for the
             // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each; 3-4 batches in flight unchanged at 57 M maps/s (profiles/r03/prio_*.json, prio_streams.txt)
             __builtin_amdgcn_s_setprio(3);
+            constexpr bool kD = CPL_T == 4;  // only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
+            if (asm4 && kD && (a.flags & NASTAR_FLAG_NO_DIVE)) {
+                if (half) s = search_loop_asm4<LOGW, kLog, false, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+                else s = search_loop_asm4<LOGW, kLog, false, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            } else if (asm4) {
+                if (half) s = search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+                else s = search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            } else
             if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
@@ -231,6 +245,63 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
                                         a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
+}
+
+// ---- forward, UNIT-COST layout (nastar_search_unit.hip.h; NASTAR_FLAG_UNIT_COST): cost map == obstacle map, every value 0.0 or 1.0 ----
+// 5.5 B/cell: 29 maps of 32x32 per CU instead of 16 -- with several batches in flight throughput follows the resident maps per CU.
+template <int LOGW, bool kDive>
+__global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs a, const float rcp_sqrtW)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int W = 1 << LOGW, HW = W * W;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const CompactDims& d = a.d;
+    const UnitLds l = carve_unit_lds<LOGW>(smem);
+    const size_t off = (size_t)b * (size_t)HW;
+    int start_idx, goal_idx;
+    bool bad;
+    unit_load_map<LOGW>(l, a.cost + off, a.start + off, a.goal + off, lane, start_idx, goal_idx, bad);
+    const int gi = goal_idx < 0 ? 0 : goal_idx;
+    const int goal_r = gi >> LOGW, goal_c = gi & (W - 1);
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    if (bad) {
+        status = NASTAR_ERR_NOT_UNIT_COST;  // the caller's promise does not hold for this map: empty outputs, never a wrong search
+    } else if (start_idx < 0 || goal_idx < 0) {
+        status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
+    } else {
+        const bool half = d.gr == 0.5f && d.omg == 0.5f;
+        if (half) unit_open_start<LOGW, true>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
+        else unit_open_start<LOGW, false>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
+        __builtin_amdgcn_s_setprio(3);
+        int s;
+        if (half) s = search_loop_asm4<LOGW, false, kDive, true, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
+        else s = search_loop_asm4<LOGW, false, kDive, false, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
+        __builtin_amdgcn_s_setprio(0);
+        if (s != -2) {
+            if (s < 0) {
+                status = NASTAR_ERR_UNSOLVABLE;
+            } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
+                ++iters;
+                solved = true;
+                if (lane == 0) l.g[s] = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
+            }
+        }
+    }
+    wave_sync();
+    unit_store_hist<LOGW>(l, lane, a.hist + off, bad);
+    if (lane == 0) {
+        a.iters[b] = iters;
+        a.status[b] = status;
+    }
+    if (goal_idx >= 0 && !bad) {
+        CompactLds cl;  // the backtrack reads and marks parents only
+        cl.gc = nullptr; cl.cmin = l.cmin; cl.dump = nullptr; cl.pdir = l.pdir;
+        compact_backtrack<LOGW>(d, cl, lane, start_idx, goal_idx, solved ? HW : iters - 1);
+    }
+    unit_store_paths<LOGW>(l, lane, a.paths + off, a.packed ? a.packed + (size_t)b * (size_t)(HW >> 2) : nullptr, bad);
 }
 
 #if NASTAR_DEV_KERNELS  // measured non-improvements kept for the record (make DEV=1): two maps per wavefront, register-resident state
@@ -847,6 +918,14 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         }
 #endif
         const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
+        // unit-cost layout: the caller promises cost == passable with values in {0, 1} (checked per map by the kernel); taken when the
+        // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
+        if ((flags & NASTAR_FLAG_UNIT_COST) && cost == passable && use_asm && !(flags & (NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3)) && !lg && vec4 && fast &&
+            g_ratio >= 0.0 && g_ratio <= 1.0 && H == W && (W == 32 || W == 64)) {
+            if (W == 32) return launch(&nastar_forward_unit_kernel<5, false>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
+            if (flags & NASTAR_FLAG_NO_DIVE) return launch(&nastar_forward_unit_kernel<6, false>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
+            return launch(&nastar_forward_unit_kernel<6, true>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
+        }
         if (use_asm && vec4 && fast && H == 32 && W == 32)
             kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, -1>;
         else if (use_asm && vec4 && fast && H == 16 && W == 16)

@@ -173,22 +173,26 @@ __device__ __forceinline__ void compact_load_map(const CompactDims& d, const Com
         }
     }
     for (int i = d.HW + lane; i < d.HWp; i += 64) l.gc[i] = make_float2(NASTAR_NEG_INF, 0.f);  // tail of the last chunk: never open
-    for (int c = lane; c < d.NCp; c += 64) l.cmin[c] = ~0ull;
     start_idx = wave_max_i32(sidx);
     goal_idx = wave_max_i32(gidx);
+    // idle chunk entries: key all ones; the cell field names the GOAL (round-4 stream, nastar_search_asm4.hip.h: an empty open list
+    // then leaves through the goal exit -- every other selection path tests the key first and never looks at an idle entry's cell)
+    const unsigned long long idle = cmin_entry(0xFFFFFFFFu, (uint32_t)(goal_idx < 0 ? 0 : goal_idx));
+    for (int c = lane; c < d.NCp; c += 64) l.cmin[c] = idle;
     if (any_signed != nullptr) *any_signed = __ballot(sgn) != 0ull;
     wave_sync();
 }
 
 // open list = {start} (:187), g[start] = 0 (:193).  raw_key: the key is the bit pattern of q itself (nastar_search_asm3.hip.h, q >= +0)
+// half_key: g_ratio == 0.5 form of the round-4 stream -- the key of q' = fl(fl(g + h) / sqrt(W)) = 2 q (nastar_search_asm4.hip.h)
 template <bool kFastDiv>
 __device__ __forceinline__ void compact_open_start(const CompactDims& d, const CompactLds& l, int lane, int sidx, int goal_r,
-                                                   int goal_c, float rcp_sqrtW, bool raw_key = false)
+                                                   int goal_c, float rcp_sqrtW, bool raw_key = false, bool half_key = false)
 {
     if (lane == 0) {
         const int r = (int)div_magic((uint32_t)sidx, d.magicW);
         const int c = sidx - r * d.W;
-        const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + l.gc[sidx].y);  // :191-192 h = h0 + cost ; :206
+        const float hh = (half_key ? 1.0f : d.omg) * (heuristic0_fast(r, c, goal_r, goal_c) + l.gc[sidx].y);  // :191-192 h = h0 + cost ; :206
         uint32_t k0 = compact_key<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
         if (raw_key) k0 = __float_as_uint(ord_to_f32(k0));
         l.gc[sidx].x = 0.0f;

@@ -32,6 +32,8 @@ def _require_device(*tensors: torch.Tensor) -> None:
             raise TypeError(f"expected float32 maps, got {t.dtype}")
 
 
+FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
+STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
 # development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
 # development knob: NASTAR_BACKWARD=reselect keeps the round-1 backward kernels (A/B measurements)
@@ -51,8 +53,9 @@ def _maps3(t: torch.Tensor) -> torch.Tensor:
 
 @torch.library.custom_op("nastar::astar_forward", mutates_args=())
 def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
-                  g_ratio: float, max_iters: int, want_log: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Returns (histories [B,H,W] f32, paths [B,H,W] i64, iters [B] i32, status [B] i32, sel_log [B,T] i32 or [0])."""
+                  g_ratio: float, max_iters: int, want_log: bool, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Returns (histories [B,H,W] f32, paths [B,H,W] i64, iters [B] i32, status [B] i32, sel_log [B,T] i32 or [0]).
+    ``flags``: NASTAR_FLAG_* of include/nastar.h (e.g. ``FLAG_UNIT_COST`` when cost and passable are ONE binary tensor)."""
     _require_device(cost, start, goal, passable)
     lib = _native.load()
     cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
@@ -64,20 +67,21 @@ def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, p
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     # entries at positions >= iters[b] are never read (the backward replays iters[b] steps, _intermediate_results masks by iters)
     sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
-    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, FORWARD_FLAGS))  # > 0 only for maps too large for LDS
+    flags = int(flags) | FORWARD_FLAGS
+    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, flags))  # > 0 only for maps too large for LDS
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     with torch.cuda.device(dev):
         rc = lib.nastar_forward(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
                                 float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
                                 sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
-                                workspace.data_ptr() if workspace is not None else None, ws_bytes, FORWARD_FLAGS,
+                                workspace.data_ptr() if workspace is not None else None, ws_bytes, flags,
                                 _stream_ptr(dev))
     _native.check(rc, "nastar_forward")
     return hist, paths, iters, status, sel_log
 
 
 @astar_forward.register_fake
-def _(cost, start, goal, passable, g_ratio, max_iters, want_log):
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0):
     B, H, W = cost.shape
     return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
             cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
@@ -139,7 +143,7 @@ def _(grad_hist, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters
 
 
 def _setup_context(ctx, inputs, output):
-    cost, start, goal, passable, g_ratio, max_iters, _ = inputs
+    cost, start, goal, passable, g_ratio, max_iters = inputs[:6]
     _, _, iters, _, sel_log = output
     ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
     ctx.g_ratio = g_ratio
@@ -150,7 +154,7 @@ def _setup_context(ctx, inputs, output):
 def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
     cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
     if g_hist is None:
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
     # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
     # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
     t_batch = BatchCoupling.t_batch(iters)
@@ -164,7 +168,7 @@ def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
                                "kernels are only in development builds (make -C neural-astar_amd/csrc DEV=1)")
         grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
                                                     ctx.max_iters, iters, t_batch)
-    return grad_cost, None, None, None, None, None, None
+    return grad_cost, None, None, None, None, None, None, None
 
 
 astar_forward.register_autograd(_backward, setup_context=_setup_context)

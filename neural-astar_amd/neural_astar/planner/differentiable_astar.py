@@ -73,6 +73,10 @@ def _capturing(t: torch.Tensor) -> bool:
 
 
 def _raise_unsolvable(status: torch.Tensor, seq: int = 0, deferred: bool = False) -> None:
+    nu = torch.nonzero(status == ops.STATUS_NOT_UNIT_COST).flatten().tolist()
+    if nu:
+        raise ValueError(f"unit_cost=True, but {len(nu)} map(s) hold values other than 0.0 / 1.0 (batch rows {nu[:16]}"
+                         f"{'...' if len(nu) > 16 else ''} of search call #{seq}): their outputs are empty; use unit_cost='auto' or False")
     bad = torch.nonzero(status != 0).flatten().tolist()
     where = f"search call #{seq} of this module" + (" (an EARLIER call: check_solvable='deferred' delivers verdicts late)" if deferred else "")
     raise UnsolvableMapError(
@@ -80,8 +84,13 @@ def _raise_unsolvable(status: torch.Tensor, seq: int = 0, deferred: bool = False
         f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''} of {where})")
 
 
+def _search(cost, start, goal, passable, g_ratio, max_iters, want_log, flags):
+    """the one launch (csrc/nastar_capi.hip::nastar_forward) behind DifferentiableAstar.forward"""
+    return torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log, flags)
+
+
 class DifferentiableAstar(nn.Module):
-    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, check_solvable=True):
+    def __init__(self, g_ratio: float = 0.5, Tmax: float = 1.0, check_solvable=True, unit_cost="auto"):
         """
         Args:
             g_ratio: weight of g(v) in f = g_ratio*g + (1-g_ratio)*h; 0 = best-first search (reference :129-135).
@@ -98,6 +107,15 @@ class DifferentiableAstar(nn.Module):
                 names the call it belongs to;
                 ``False`` -- never raise.  Inside a hipGraph capture nothing is checked (nothing may synchronise there).
                 The per-map status of the latest call is always available as ``self.last_status``.
+            unit_cost: the UNIT-COST search kernel (``NASTAR_FLAG_UNIT_COST``, csrc/nastar_search_unit.hip.h) for calls in which
+                the cost map and the obstacle map are ONE tensor -- ``VanillaAstar.forward`` (reference astar.py:93-94) -- and no
+                gradient or selection log is wanted.  On binary maps every cell the search can touch then costs 1.0, the LDS state
+                needs no cost word, and 29 instead of 16 maps of 32x32 are resident per CU: same outputs, ~1.5x the maps/s with
+                several batches in flight.  The kernel CHECKS the promise per map.  ``"auto"`` (default): taken whenever this call
+                reads the status itself (``check_solvable`` True / "sync", no graph capture) -- a batch with a non-binary map is then
+                re-run on the general kernel inside the same call, so the result never depends on the promise; ``True``: always
+                (a map that breaks the promise raises ``ValueError``, with "deferred" checking possibly from a later call);
+                ``False``: never.
         """
         super().__init__()
         nf = torch.ones(1, 1, 3, 3)
@@ -108,6 +126,7 @@ class DifferentiableAstar(nn.Module):
         assert (Tmax > 0) & (Tmax <= 1), "Tmax must be within (0, 1]"
         self.Tmax = Tmax
         self.check_solvable = check_solvable
+        self.unit_cost = unit_cost
         self.last_status: Optional[torch.Tensor] = None
         self.last_iters: Optional[torch.Tensor] = None
         self._pending: List[_PendingStatus] = []
@@ -134,16 +153,17 @@ class DifferentiableAstar(nn.Module):
         while self._pending and (wait or self._pending[0].done()):
             self._pending.pop(0).raise_if_unsolvable()
 
-    def note_status(self, status: torch.Tensor, iters: torch.Tensor) -> None:
+    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None) -> None:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
-        step and the validation pair, which launch the search themselves)"""
+        step and the validation pair, which launch the search themselves).  ``clean``: the caller has already read ``status`` on the
+        host (True = all zero, False = some map failed) -- the "sync" policy then does not wait a second time."""
         self.last_status, self.last_iters = status, iters
         self._calls += 1
         mode = self.check_solvable
         if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
             return
         if mode != "deferred":  # True / "sync": the verdict belongs to THIS call
-            if bool((status != 0).any()):
+            if (not clean) if clean is not None else bool((status != 0).any()):
                 _raise_unsolvable(status, self._calls)
             return
         self._pending.append(_PendingStatus(status, self._calls))
@@ -170,9 +190,23 @@ class DifferentiableAstar(nn.Module):
             torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
         if not _capturing(cost_maps):
             self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
-        hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(
-            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log)
-        self.note_status(status, iters)
+        # VanillaAstar hands ONE tensor over as cost and obstacle map: the unit-cost kernel (see __init__) applies when it is binary,
+        # which the kernel itself checks; in "auto" mode only when this call reads the status anyway and can fall back
+        same = (cost.data_ptr() == passable.data_ptr() and cost.shape == passable.shape and cost.stride() == passable.stride())
+        sync_check = self.check_solvable in (True, "sync") and not _capturing(cost_maps)
+        unit = (same and not want_log and not (torch.is_grad_enabled() and cost_maps.requires_grad)
+                and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
+        hist, paths, iters, status, sel_log = _search(
+            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0)
+        clean = None
+        if unit and self.unit_cost == "auto":
+            clean = not bool((status != 0).any())  # the ONE device->host wait of this call (note_status does not wait again)
+            if not clean and bool((status == ops.STATUS_NOT_UNIT_COST).any()):
+                # a map with values other than 0 / 1: the whole batch again on the general kernel (same call, same outputs contract)
+                hist, paths, iters, status, sel_log = _search(
+                    cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, 0)
+                clean = None
+        self.note_status(status, iters, clean)
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:

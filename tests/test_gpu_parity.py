@@ -776,25 +776,31 @@ def test_cnn_downsize_encoder_f32_mfma_matches_torch_fp32(enc_in, C, H, W, depth
 @pytest.mark.parametrize("kind,H,B", [("maze", 32, 4096), ("rand", 32, 4096), ("rand", 64, 512), ("rand", 16, 1024)])
 def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind, H, B):
     """The hand-scheduled step loops name fixed registers as clobbers; nothing but output equality guards them against a compiler
-    upgrade.  Round-3 stream (default where every cost >= 0), round-2 stream (NASTAR_FLAG_ASM_V2; also what signed costs take) and
-    hipcc's own code for the same step (NASTAR_FLAG_NO_ASM) must give identical histories, paths, step counts AND selection logs on
-    the full bench batches: cost = map, U(0,1) costs, and costs shifted below zero (raw-bit keys would misorder those)."""
+    upgrade.  Round-4 stream (default where every cost >= 0; its g_ratio == 0.5 form and its general form), round-3 stream
+    (NASTAR_FLAG_ASM_V3), round-2 stream (NASTAR_FLAG_ASM_V2; also what signed costs take) and hipcc's own code for the same step
+    (NASTAR_FLAG_NO_ASM) must give identical histories, paths, step counts AND selection logs on the full bench batches: cost = map,
+    U(0,1) costs, costs shifted below zero (raw-bit keys would misorder those), a truncated budget, g_ratio 0.3; the log-free
+    instantiations (a different instruction stream: no log store) are compared on histories / paths / step counts."""
     from neural_astar import ops
     from neural_astar.utils import synthetic as syn
     pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=1234)
     u = syn.random_costs(B, H, H, seed=5)
     prev = ops.FORWARD_FLAGS
     try:
-        for label, cost, mi in (("vanilla", pr.map_designs, H * H), ("ucost", u, H * H), ("signed", u - np.float32(0.3), H * H),
-                                ("budget", u, H * H // 4)):
+        for label, cost, mi, gr, log in (("vanilla", pr.map_designs, H * H, 0.5, True), ("ucost", u, H * H, 0.5, True),
+                                         ("signed", u - np.float32(0.3), H * H, 0.5, True), ("budget", u, H * H // 4, 0.5, True),
+                                         ("g03", u, H * H, 0.3, True), ("vanilla_nolog", pr.map_designs, H * H, 0.5, False),
+                                         ("g08_nolog", u, H * H, 0.8, False)):
             outs = {}
-            for flags in (0, 16, 8):
+            for flags in (0, 128, 16, 8):
                 ops.FORWARD_FLAGS = flags
-                outs[flags] = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, 0.5, mi, want_log=True)
-            for flags in (16, 8):
+                outs[flags] = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, mi, want_log=log)
+            for flags in (128, 16, 8):
                 for k, name in enumerate(("histories", "paths", "iters", "status", "sel_log")):
                     a, b = outs[0][k], outs[flags][k]
                     if name == "sel_log":  # entries past a map's own step count are unwritten
+                        if not log:
+                            continue
                         it = outs[0][2]
                         mask = np.arange(a.shape[1])[None, :] < it[:, None]
                         a, b = np.where(mask, a, -1), np.where(mask, b, -1)
@@ -803,6 +809,95 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
                 assert (outs[0][3] == 0).all()
     finally:
         ops.FORWARD_FLAGS = prev
+
+
+def _run_aliased(maps, start, goal, g_ratio, max_iters, flags):
+    """cost and passable are ONE device tensor (what VanillaAstar.forward hands over, reference astar.py:93-94)"""
+    from neural_astar import ops  # noqa: F401
+    m, s, g = (_t(x[:, 0]) for x in (maps, start, goal))
+    hist, paths, iters, status, _ = torch.ops.nastar.astar_forward(m, s, g, m, float(g_ratio), int(max_iters), False, int(flags))
+    torch.cuda.synchronize()
+    return hist.cpu().numpy(), paths.cpu().numpy(), iters.cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind,H,B", [("maze", 32, 4096), ("rand", 32, 4096), ("rand", 64, 1024)])
+def test_unit_cost_kernel_equals_the_general_kernel_and_the_oracle(kind, H, B):
+    """NASTAR_FLAG_UNIT_COST (csrc/nastar_search_unit.hip.h: no per-cell cost word in LDS, 29 instead of 16 resident 32x32 maps per CU)
+    on the bench batches: histories, paths, step counts and status equal the general kernel's for g_ratio 0.5 (the two-multiplies-
+    shorter key), 0.2 and 1.0, a truncated budget, and -- on 512 rows -- the CPU oracle's (differentiable_astar.py:150-267)."""
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=1234)
+    for gr, mi in ((0.5, H * H), (0.2, H * H), (1.0, H * H), (0.5, H * H // 4)):
+        ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 0)
+        got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 64)
+        for k, name in enumerate(("histories", "paths", "iters", "status")):
+            assert np.array_equal(ref[k], got[k]), (gr, mi, name)
+        assert (got[3] == 0).all()
+    n = 512
+    o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], 0.5, H * H, mode="sm")
+    got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 64)
+    assert np.array_equal(got[0][:n], o.histories) and np.array_equal(got[1][:n], o.paths) and np.array_equal(got[2][:n], o.iters)
+
+
+def test_unit_cost_kernel_edge_cases_and_the_promise_check():
+    """(a) a start placed on an OBSTACLE (the reference expands it, :187; its cost is 0), (b) an unsolvable map, (c) a map that breaks
+    the promise (a value that is neither 0 nor 1) gets NASTAR_ERR_NOT_UNIT_COST and all-zero outputs while its neighbours in the batch
+    are searched normally, (d) the flag is ignored when cost and passable are different tensors, (e) VanillaAstar takes the kernel by
+    itself and falls back inside the same call when a map is not binary."""
+    from neural_astar import ops
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    H = 32
+    pr = syn.random_obstacle_maps(8, H, H, 0.25, seed=77)
+    m, s, g = pr.map_designs.copy(), pr.start_maps.copy(), pr.goal_maps.copy()
+    si = int(s[0].reshape(-1).argmax())
+    m[0].reshape(-1)[si] = 0.0                      # (a) map 0: the start sits on an obstacle
+    m[1, 0, :, 16] = 0.0                            # (b) map 1: a wall between ...
+    s[1] = 0; s[1, 0, 5, 3] = 1; m[1, 0, 5, 3] = 1  # ... start (left)
+    g[1] = 0; g[1, 0, 7, 28] = 1; m[1, 0, 7, 28] = 1  # ... and goal (right)
+    ref = _run_aliased(m, s, g, 0.5, H * H, 0)
+    got = _run_aliased(m, s, g, 0.5, H * H, 64)
+    assert ref[3].tolist() == [0, 3, 0, 0, 0, 0, 0, 0]
+    for k, name in enumerate(("histories", "paths", "iters", "status")):
+        assert np.array_equal(ref[k], got[k]), name
+    o = O.forward(m[:1], s[:1], g[:1], m[:1], 0.5, H * H, mode="sm")
+    assert np.array_equal(got[0][:1], o.histories) and np.array_equal(got[1][:1], o.paths)
+    m2 = pr.map_designs.copy()
+    m2[3, 0, 9, 9] = 0.5                            # (c)
+    got = _run_aliased(m2, pr.start_maps, pr.goal_maps, 0.5, H * H, 64)
+    gen = _run_aliased(m2, pr.start_maps, pr.goal_maps, 0.5, H * H, 0)
+    assert got[3].tolist() == [0, 0, 0, 7, 0, 0, 0, 0]
+    assert got[0][3].sum() == 0 and got[1][3].sum() == 0 and got[2][3] == 0
+    keep = [0, 1, 2, 4, 5, 6, 7]
+    assert np.array_equal(got[0][keep], gen[0][keep]) and np.array_equal(got[1][keep], gen[1][keep])
+    prev = ops.FORWARD_FLAGS
+    try:                                            # (d) separate tensors: the flag does nothing, non-binary values are ordinary costs
+        ops.FORWARD_FLAGS = 64
+        sep = _run_capi(m2, pr.start_maps, pr.goal_maps, m2, 0.5, H * H)
+    finally:
+        ops.FORWARD_FLAGS = prev
+    assert np.array_equal(sep[0], gen[0]) and np.array_equal(sep[1], gen[1]) and (sep[3] == 0).all()
+    va = VanillaAstar().to(_dev()).eval()           # (e)
+    seen = []
+    import neural_astar.planner.differentiable_astar as DA
+    orig = DA._search
+
+    def spy(*a):
+        seen.append(int(a[7]))
+        return orig(*a)
+    DA._search = spy
+    try:
+        with torch.no_grad():
+            out = va(_t(pr.map_designs), _t(pr.start_maps), _t(pr.goal_maps))
+            out2 = va(_t(m2), _t(pr.start_maps), _t(pr.goal_maps))
+    finally:
+        DA._search = orig
+    assert seen == [64, 64, 0], seen                # binary batch: unit kernel; non-binary batch: unit kernel, then the general one
+    full = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 0)
+    assert np.array_equal(out.histories[:, 0].cpu().numpy(), full[0]) and np.array_equal(out.paths[:, 0].cpu().numpy(), full[1])
+    assert np.array_equal(out2.histories[:, 0].cpu().numpy(), gen[0]) and np.array_equal(out2.paths[:, 0].cpu().numpy(), gen[1])
 
 
 def test_vanilla_astar_forward_is_hipgraph_capturable_and_has_no_host_sync():

@@ -31,6 +31,26 @@ r04_b)
   python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"
   tail -25 $O/all_gpu_tests.log
   ;;
+r04_c)
+  # round-4 stream (asm4) + unit-cost kernel: parity first, then serial and in-flight throughput per flags value
+  #   flags 0 = asm4 (default), 128 = asm3 (round 3), 64 = unit-cost layout (cost == passable in the probe / bench: same tensor)
+  O=gpurun_out/r04/c; mkdir -p $O
+  python -m pytest tests/test_gpu_parity.py -q -m gpu -k "instruction_streams or unit_cost or golden or oracle or planner_modules or unsolvable" > $O/parity.log 2>&1; echo "parity rc=$?"
+  tail -15 $O/parity.log
+  python tools/probe_streams.py --workloads maze32,rand32,rand64 --flags 0,128,64 --streams 1,2,4,6,8 --bigb 4,8 > $O/streams.jsonl 2> $O/streams.err
+  cat $O/streams.jsonl; tail -n 3 $O/streams.err
+  for f in 0 128 64; do for w in maze32 rand32 rand64; do
+    NASTAR_FORWARD_FLAGS=$f python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 10 --workload $w > $O/serial_${w}_f$f.json 2>> $O/serial.err
+  done; done
+  python - <<'P'
+import json
+for w in ("maze32","rand32","rand64"):
+    for f in (0,128,64):
+        try:
+            j=json.load(open(f"gpurun_out/r04/c/serial_{w}_f{f}.json")); print(w,"flags",f,round(j["value"]/1e6,2),"M maps/s", round(j["ms_per_step"]*1e3,1),"us/step", round(j["roofline"]["launch_ms_avg"]*1e3,1),"us launch avg")
+        except Exception as e: print(w,f,"ERR",e)
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
