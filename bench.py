@@ -128,7 +128,7 @@ class Runner:
     `prs` may be a list of problem sets (same shape): step i works on set i % len(prs), each with its own input AND output
     buffers, so consecutive timed steps do not re-read a cache-resident batch (>256 MB in rotation)."""
 
-    def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None):
+    def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None, flags=None):
         from neural_astar import _native
         self.lib = _native.load()
         self._check = _native.check
@@ -149,7 +149,8 @@ class Runner:
         self.B, self.H, self.W = self.sets[0]["m"].shape
         self.g_ratio = float(g_ratio)
         self.max_iters = int(max_iters) if max_iters is not None else self.W * self.W  # eval mode: search to the goal
-        self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))  # dev A/B switch (include/nastar.h NASTAR_FLAG_*)
+        # NASTAR_FLAG_* of include/nastar.h; default: the dev A/B switch NASTAR_FORWARD_FLAGS (0 = the general kernel)
+        self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0")) if flags is None else int(flags)
         self.packed = None  # set by enable_packed(): the step then also emits the bit-packed masks (all-gather payload)
         self._i = 0
         self._bind(0)
@@ -235,8 +236,8 @@ def timed_loop(run, steps, warmup, world, dev, collate=None):
     return dt, dev_ms
 
 
-def multi_stream_throughput(pr, steps, dev, nstreams):
-    runs = [Runner(pr, dev) for _ in range(nstreams)]
+def multi_stream_throughput(pr, steps, dev, nstreams, flags=None, runs=None):
+    runs = runs if runs is not None else [Runner(pr, dev, flags=flags) for _ in range(nstreams)]
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     for i in range(2 * nstreams):
         with torch.cuda.stream(streams[i % nstreams]):
@@ -248,6 +249,84 @@ def multi_stream_throughput(pr, steps, dev, nstreams):
             runs[i % nstreams].step()
     torch.cuda.synchronize(dev)
     return runs[0].B * steps / (time.perf_counter() - t0)
+
+
+FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
+LONE_STEP_NS = 280.0  # lone-wavefront step of the 32x32 stream on a long maze search (tools/probe_latency.py, profiles/r04/lat_asm4.txt)
+FIXED_US = 8.0  # map load + backtrack + output stores of that wavefront
+
+
+def throughput_regime(dev, steps, workloads=("maze32", "rand32", "rand64"), ks=(2, 3, 4, 6, 8)):
+    """What the search sustains when the GPU always has a next batch (a planning service, an evaluation sweep, config 4's 32768-map
+    batch): (a) the bench's 4096-map launches issued round-robin over k HIP streams, each stream with its own input AND output buffers
+    -- the tail of one batch (its longest search) overlaps the bulk of the next; (b) ONE launch over 32768 maps (8 distinct-memory copies
+    of the batch) on one stream: there `hbm_frac` is the roofline fraction in the bench line's own definition (algorithmic bytes of the
+    launch / the launch's duration).  Per workload for the general kernel and for the unit-cost LDS layout (NASTAR_FLAG_UNIT_COST:
+    cost and passable are one binary tensor, i.e. VanillaAstar; 29 instead of 16 resident 32x32 maps per CU).  Not the headline."""
+    from neural_astar.utils import synthetic as syn
+    out = []
+    for w in workloads:
+        pr = make_problem(w, B_PER_GPU, seed=1234)
+        for label, flags in (("general", 0), ("unit_cost", FLAG_UNIT_COST)):
+            runs = [Runner(pr, dev, flags=flags) for _ in range(max(ks))]
+            prewarm(runs[0], dev, 0.1)
+            nbytes = 28 * runs[0].H * runs[0].W
+            sweep = {str(k): multi_stream_throughput(pr, steps, dev, k, runs=runs[:k]) for k in ks}
+            best_k = max(sweep, key=sweep.get)
+            ok = all(int(r.status.abs().sum().item()) == 0 for r in runs)
+            del runs
+            big = syn.Problems(*(np.concatenate([x] * 8) for x in pr))
+            rb = Runner(big, dev, flags=flags)
+            for _ in range(3):
+                rb.step()
+            torch.cuda.synchronize(dev)
+            nbig = max(10, steps // 8)
+            t0 = time.perf_counter()
+            for _ in range(nbig):
+                rb.step()
+            torch.cuda.synchronize(dev)
+            ms_big = (time.perf_counter() - t0) / nbig * 1e3
+            ok = ok and int(rb.status.abs().sum().item()) == 0
+            del rb, big
+            out.append({"workload": f"{w}: {B_PER_GPU} maps per launch", "kernel": label,
+                        "streams_sweep_maps_per_s": sweep, "best_streams": int(best_k), "maps_per_s": sweep[best_k],
+                        "hbm_frac": sweep[best_k] * nbytes / 1e9 / HBM_PEAK_GBS,
+                        "one_launch_32768_maps": {"ms": ms_big, "maps_per_s": 8 * B_PER_GPU / (ms_big * 1e-3),
+                                                  "hbm_frac": 8 * B_PER_GPU * nbytes / (ms_big * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "all_status_ok": ok})
+        del pr
+    return out
+
+
+# ---- what a launch costs the CU's pipes (SURVEY 8d: "report expansions/s against an issue model") ------------------------------------
+# Instruction classes of ONE step of the shipped 32x32 stream (nastar_search_asm4.hip.h, g_ratio 0.5 form; counted in the disassembly)
+# x the aggregate rates of one CU measured by tools/ubench/rate.hip (profiles/r04/rate.txt; cycles per wavefront instruction with
+# >= 2 wavefronts per SIMD / >= 16 per CU).  Round 3 priced every VALU instruction at 4 cycles; the measured machine issues a plain one
+# every 2.3 cycles per SIMD and only DPP / compare / lane-read forms at ~4, and the LDS pipe of the CU takes 2.45 (read) / 4.6 (write) /
+# 6.0 (64-bit atomic) cycles per instruction WHATEVER the number of active lanes.
+STEP_CLASSES = {"valu_plain": 27, "valu_dpp": 7, "valu_cmp": 4, "valu_readlane": 2, "valu_sqrt": 1, "salu_nop_wait_branch": 22, "lds_read": 3,
+                "lds_write": 4, "lds_atomic": 1}  # 71 instructions per step (round 3: 76)
+RATE_CYCLES = {"valu_plain": 2.3, "valu_dpp": 4.2, "valu_cmp": 4.0, "valu_readlane": 4.0, "valu_sqrt": 8.0, "lds_read": 2.45, "lds_write": 4.6, "lds_atomic": 6.0}
+
+
+def pipe_model(steps_per_launch, launch_us, max_iters, lone_step_ns, fixed_us):
+    valu_cyc = sum(STEP_CLASSES[k] * RATE_CYCLES[k] for k in STEP_CLASSES if k.startswith("valu"))
+    lds_cyc = sum(STEP_CLASSES[k] * RATE_CYCLES[k] for k in STEP_CLASSES if k.startswith("lds"))
+    clock = 2.4e3  # MHz
+    valu_floor = steps_per_launch * valu_cyc / 1024 / clock  # 1024 SIMDs
+    lds_floor = steps_per_launch * lds_cyc / 256 / clock  # one LDS pipe per CU
+    serial_floor = max_iters * lone_step_ns * 1e-3 + fixed_us
+    return {"bound": "serial chain (one launch) / LDS capacity (batches in flight)",
+            "steps_per_launch": steps_per_launch, "instructions_per_step": sum(STEP_CLASSES.values()),
+            "valu_cycles_per_step_per_simd": valu_cyc, "lds_cycles_per_step_per_cu": lds_cyc,
+            "valu_floor_us": valu_floor, "lds_floor_us": lds_floor, "achieved_us": launch_us,
+            "valu_busy_frac": valu_floor / launch_us, "lds_busy_frac": lds_floor / launch_us,
+            "serial_floor_us": serial_floor, "frac_of_serial_floor": serial_floor / launch_us,
+            "serial_floor_note": f"longest search of the batch ({max_iters} steps) x the lone-wavefront step ({lone_step_ns:.0f} ns, "
+                                 f"tools/probe_latency.py, profiles/r04) + {fixed_us:.0f} us load / backtrack / store: what ONE launch cannot beat "
+                                 "however empty the rest of the chip is",
+            "source": "instruction classes: disassembly of nastar_forward_compact_kernel<true,5,5,1,true,false,-1> (asm4, g_ratio 0.5); "
+                      "rates: profiles/r04/rate.txt (tools/ubench/rate.hip)"}
 
 
 def two_stream_throughput(pr, steps, dev):
@@ -638,6 +717,8 @@ def _reference_worker(path: str) -> None:
     # rate grows with the batch: start at 1024 maps, then the whole 4096-map batch if the budget allows
     best, spent, n = None, 0.0, (int(z["n_fixed"]) if "n_fixed" in z.files and int(z["n_fixed"]) > 0 else 1024)
     with torch.no_grad():
+        m, s_, g = (torch.from_numpy(z[k][:32]) for k in ("m", "s", "g"))
+        planner(m, s_, g, m)  # untimed: thread pool start-up, first-touch of the allocator (BASELINE config 1's size)
         while True:
             n = min(n, z["m"].shape[0])
             m, s_, g = (torch.from_numpy(z[k][:n]) for k in ("m", "s", "g"))
@@ -697,8 +778,10 @@ def cpu_baseline_spec_collect(handle, timeout_s=120.0):
 def cpu_baseline_reference(pr, gpu_hist, gpu_paths):
     """The reference's OWN DifferentiableAstar.forward() (eval mode, no_grad) on this box's host cores: the module file staged
     into the git-ignored oracle/_ref/ by `__graft_entry__.build()` in the authoring container (it is torch-only and travels with
-    gpurun like a built .so; /root/reference itself is never read here).  Bounded sample: one call on the first 1024 maps, then
-    on all 4096 if ~25 s allow, in a fresh child process with a hard time limit; the best rate is reported."""
+    gpurun like a built .so; /root/reference itself is never read here).  Bounded sample = BASELINE.md section 3's batch: ONE call on
+    all 4096 maps of the bench batch (~7 s at 32 threads) after an untimed 32-map call, in a fresh child process with a hard time
+    limit.  Threads: 32 of the host's cores -- ATen's elementwise kernels on [B,32,32] maps stop scaling long before 256 threads; the
+    all-cores configuration BASELINE.md names is attempted last as `spec_config`."""
     import subprocess
     import tempfile
     cores = os.cpu_count() or 1
@@ -706,7 +789,7 @@ def cpu_baseline_reference(pr, gpu_hist, gpu_paths):
     n = min(pr.map_designs.shape[0], 4096)
     path = os.path.join(tempfile.mkdtemp(), "ref_in.npz")
     np.savez(path, m=pr.map_designs[:n], s=pr.start_maps[:n], g=pr.goal_maps[:n], hist=gpu_hist[:n], paths=gpu_paths[:n],
-             threads=threads, budget_s=25.0)
+             threads=threads, budget_s=25.0, n_fixed=n)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ref-worker", path], capture_output=True, text=True,
                        timeout=150, env=env)
@@ -715,8 +798,7 @@ def cpu_baseline_reference(pr, gpu_hist, gpu_paths):
     j = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": j["rate"], "unit": "maps/s", "cores": j["threads"], "kind": "reference",
             "sample": f"reference DifferentiableAstar.forward (torch {j['torch']} CPU, torch.set_num_threads({j['threads']}) of "
-                      f"{cores} host cores, eval, no_grad) on the first {j['n']} maps of the bench batch in one call, "
-                      f"{j['dt']:.2f} s (best of the 1024- / 4096-map calls that fit ~25 s)",
+                      f"{cores} host cores, eval, no_grad) on all {j['n']} maps of the bench batch in ONE call, {j['dt']:.2f} s",
             "gpu_matches_reference_on_sample": j["ok"]}
 
 
@@ -1111,6 +1193,10 @@ def main():
         ctx = torch.cuda.stream(hp)
         collate_note += ", search launched on a high-priority stream"
     with ctx:
+        # the contract's protocol to the letter first -- W warm-up + K timed steps straight after start-up, clocks as the idle GPU left
+        # them -- reported as `contract_exact_no_prewarm`; then PREWARM_S of untimed launches and the same W + K again = the headline
+        # (`config.prewarm_s`; ADVICE r3: label which is which)
+        dt_cold, _ = timed_loop(run, args.steps, args.warmup, world, dev, collate)
         prewarm(run, dev)
         dt, dev_ms = timed_loop(run, args.steps, args.warmup, world, dev, collate)
     torch.cuda.synchronize(dev)
@@ -1152,23 +1238,22 @@ def main():
                        "prewarm_s": PREWARM_S},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop, round-3 instruction stream: nastar_search_asm3.hip.h)",
+                         # the same fraction on the bytes the PMC counters saw instead of SURVEY 8(d)'s 28 B/cell (VanillaAstar hands ONE
+                         # tensor over as cost and passable map and the kernel loads it once: 24 B/cell really move)
+                         "frac_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop, round-4 instruction stream: nastar_search_asm4.hip.h)",
                          "algorithmic_bytes_per_launch": bytes_per_map * b_rank,
                          "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms,
                          "kernel_profile_us": kprof["avg_us"] if kprof else None,
                          "kernel_profile_source": kprof["source"] if kprof else None,
                          "frac_from_kernel_profile": (bytes_per_map * b_rank / (kprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kprof else None},
-            # the search is a serial chain of select + update steps with all state on-chip, so next to the HBM fraction the
-            # line carries the VALU-issue floor of the launch: (VALU wavefront-instructions of one launch, SQ_INSTS_VALU from the
-            # committed rocprofv3 --pmc pass) x 4 cycles each / 1024 SIMDs / 2.4 GHz -- what the launch would take if every SIMD issued
-            # a vector instruction every cycle it can
-            "issue_model": ({"bound": "valu-issue", "valu_wave_instructions_per_launch": kprof["valu_insts_per_launch"],
-                             "valu_per_expansion": kprof["valu_insts_per_launch"] / (float(iters.sum()) / len(run.sets)),
-                             "simds": 1024, "cycles_per_wave_instruction": 4, "clock_ghz": 2.4,
-                             "floor_us": kprof["valu_insts_per_launch"] * 4 / 1024 / 2.4e3,
-                             "achieved_us": avg_ms * 1e3, "frac": kprof["valu_insts_per_launch"] * 4 / 1024 / 2.4e3 / (avg_ms * 1e3),
-                             "source": kprof.get("counters_source")}
-                            if kprof and kprof.get("valu_insts_per_launch") and not strong else None),
+            # the search is a serial chain of select + update steps with all state on-chip, so next to the HBM fraction the line
+            # carries what the launch costs the CU's pipes and what its longest chain alone costs (pipe_model above)
+            "issue_model": (pipe_model(float(iters.sum()) / len(run.sets), avg_ms * 1e3, int(iters.max()), LONE_STEP_NS, FIXED_US)
+                            if (Hh, Ww) == (32, 32) and not strong else None),
+            "contract_exact_no_prewarm": {"value": total_maps / dt_cold, "ms_per_step": dt_cold / args.steps * 1e3,
+                                          "note": "the same W warm-up + K timed steps run FIRST, without the untimed pre-warm launches: "
+                                                  "the headline `value` is the second pass (clocks out of their idle state)"},
             "expansions_per_s": float(iters.sum()) / len(run.sets) * n_gpus * args.steps / dt,
             "mean_iters_per_map": float(iters.mean()), "max_iters_per_map": int(iters.max()),
             "device_ms_per_step": dev_ms / args.steps,
@@ -1227,20 +1312,21 @@ def main():
                              ("data_path_32x32", lambda: data_path_ms(dev)),
                              ("train_l1_step_Tmax025", lambda: {"batch_100": l1_training_step_ms(pr, dev, 100),
                                                                 "batch_4096": l1_training_step_ms(pr, dev, 4096)}),
-                             # (extras are not bound to the K timed steps of the contract: the driver's K = 20 is 3 ms, too short for a pipeline to fill)
-                             ("two_stream_pipelined_maps_per_s", lambda: two_stream_throughput(pr, max(args.steps, 240), dev)),
-                             ("streams_sweep_maps_per_s", lambda: {str(k): multi_stream_throughput(pr, max(args.steps, 240), dev, k) for k in (1, 2, 3, 4, 6)})):
+                             # (extras are not bound to the K timed steps of the contract: the driver's K = 20 is 3 ms, too short for a pipeline to fill;
+                             #  the multi-stream sweep moved to out["throughput_regime"], all workloads, both kernels)
+                             ):
                 _log(f"extra {name}")
                 try:
                     ex[name] = fn()
                 except Exception as e:  # noqa: BLE001 - an extra never sinks the headline line
                     ex[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-            if out.get("issue_model") and isinstance(ex.get("streams_sweep_maps_per_s"), dict):
-                best = max(v for v in ex["streams_sweep_maps_per_s"].values() if isinstance(v, (int, float)))
-                out["issue_model"]["frac_best_multi_stream"] = out["issue_model"]["floor_us"] / (B_PER_GPU / best * 1e6)
+            _log("throughput regime (all workloads, general + unit-cost kernels)")
+            try:
+                out["throughput_regime"] = throughput_regime(dev, max(args.steps, 240))
+            except Exception as e:  # noqa: BLE001 - never sinks the headline line
+                out["throughput_regime"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             out["extra"] = {**ex,
-                            "note": "same workload, launches alternated over 2 HIP streams (tail of batch i overlaps batch i+1); "
-                                    "not the headline value, which times strictly serial launches on one stream"}
+                            "note": "encoder / training / data-path figures on the headline batch; none of them is the headline value"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             # strictly LAST and alone: 256 ATen threads on [B,32,32] maps starve the GPU launch thread of anything timed beside them
             _log("cpu baseline in BASELINE.md's exact configuration (hard limit 45 s)")

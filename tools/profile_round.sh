@@ -2,11 +2,13 @@
 # Run on the GPU box (via gpurun): the evidence the bench line's roofline block is checked against.
 #   1. rocprofv3 kernel trace + stats of the exact default bench command (N=1)          -> kernel_stats
 #   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slot limit), kernel-trace only
-#   3. SQ counters of the shipped forward kernel and, for comparison, of the round-2 instruction stream (NASTAR_FORWARD_FLAGS=16)
+#   3. SQ counters of the shipped forward kernel and, for comparison, of other streams / layouts (SQ_FLAGS, default "0 128 64":
+#      round-4 stream, round-3 stream, unit-cost layout)
 #   4. kernel stats of the fused training step (forward with selection log + replay backward), 4096 maps, Tmax = 0.25
 # Usage: tools/profile_round.sh r03   -> writes gpurun_out/profiles_<tag>/ (copy the summaries into profiles/<tag>/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+SQ_FLAGS=${SQ_FLAGS:-0 128 64}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -18,7 +20,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 SQ2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU"
-for V in 0 16; do
+for V in $SQ_FLAGS; do
   NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ --kernel-trace -d $OUT/sq_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq_f$V.log 2>&1
   NASTAR_FORWARD_FLAGS=$V timeout 300 rocprofv3 --pmc $SQ2 --kernel-trace -d $OUT/sq2_f$V -o bench --output-format csv -- $B --steps 10 --warmup 2 > $OUT/sq2_f$V.log 2>&1
 done
@@ -55,7 +57,7 @@ def counters(pat):
     return {k: {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items() if "nastar" in k}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     out[c] = counters("$OUT/pmc_%s/**/*counter_collection.csv" % c)
-for V in ("0", "16"):
+for V in "$SQ_FLAGS".split():
     d = counters("$OUT/sq_f%s/**/*counter_collection.csv" % V)
     d2 = counters("$OUT/sq2_f%s/**/*counter_collection.csv" % V)
     for k in d2:

@@ -51,6 +51,16 @@ for w in ("maze32","rand32","rand64"):
         except Exception as e: print(w,f,"ERR",e)
 P
   ;;
+r04_prof)
+  # evidence for the bench line: kernel stats + FETCH/WRITE PMC + SQ counters (round-4 stream, round-3 stream, unit-cost layout),
+  # lone-wavefront step latency, and the bench line itself (driver's command)
+  O=gpurun_out/r04/prof; mkdir -p $O
+  bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1; tail -c 3000 $O/profile_round.log
+  python tools/probe_latency.py > $O/lat_asm4.txt 2>&1; NASTAR_FORWARD_FLAGS=128 python tools/probe_latency.py > $O/lat_asm3.txt 2>&1
+  head -4 $O/lat_asm4.txt $O/lat_asm3.txt
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench_n1_driver_command.err; echo "bench rc=$?"
+  tail -n 5 $O/bench_n1_driver_command.err; head -c 1500 $O/bench_n1_driver_command.json
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
