@@ -1021,6 +1021,28 @@ def train_main(args, real_stdout):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the same step WITHOUT sync BatchNorm (every rank normalises with its own rows: no per-layer collectives, only the flat gradient
+    # all-reduce) so that a scaling curve can separate the number of small collectives from wire time
+    dt_nosync = None
+    if multi and sync_bn:
+        trainer_ns = D.DataParallelTrainer(planner, lr=1e-3, coupling="global", sync_bn=False, force_collectives=args.force_collate)
+
+        def run_ns(n):
+            for i in range(n):
+                trainer_ns.train_step(*batches[i % len(batches)])
+        run_ns(max(2, args.warmup))
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run_ns(args.steps)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_nosync = float(t.item())
+        planner.astar.raise_if_unsolvable()
     if rank == 0:
         fwd_f, step_f = train_flops_per_map(args.config)
         ms = dt / args.steps * 1e3
@@ -1039,6 +1061,10 @@ def train_main(args, real_stdout):
                        "parallelism": (f"dp{n_gpus}: flat fp32 gradient all-reduce ({'RCCL' if args.dist_backend == 'nccl' else args.dist_backend}) + all-reduced BatchNorm sums (sync_bn={sync_bn}), "
                                        "coupling=global") if multi else "single"},
             "steps_per_s": args.steps / dt, "final_loss": float(loss),
+            "sync_bn": {"on_ms_per_step": ms if sync_bn else None, "off_ms_per_step": (dt_nosync / args.steps * 1e3) if dt_nosync else (None if sync_bn else ms),
+                        "note": "on = BatchNorm statistics of the GLOBAL batch (one small all-reduce per BatchNorm layer and direction: "
+                                "the single-device step on the concatenated batch); off = per-rank statistics, only the flat gradient "
+                                "all-reduce; `value` / `ms_per_step` are the sync_bn=on figures when n_gpus > 1"},
             "roofline": {"bound": "mfma", "achieved": B * step_f / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": B * step_f / (ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
                          "kernel": "WHOLE STEP, not one kernel: useful convolution FLOPs (forward + input gradient + weight gradient, "

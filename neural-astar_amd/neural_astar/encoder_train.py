@@ -71,16 +71,29 @@ def _sync_sums(sums: torch.Tensor, scale: Optional[torch.Tensor] = None, state: 
     ``scale``: device scalar S the sums are multiplied by on THIS rank (the fp16 gradient scale differs per rank): they travel
     unscaled and come back in this rank's scale (S is a power of two: exact).  ``state``: a ``SyncBatchNorm.snapshot()`` taken by the
     forward pass (backward passes hand in the one their forward recorded); None = the process-wide switch as it is now."""
-    active, group, world = state if state is not None else SyncBatchNorm.snapshot()
+    return _sync_sums_end(_sync_sums_begin(sums, scale, state), sums, scale, state)
+
+
+def _sync_sums_begin(sums: torch.Tensor, scale: Optional[torch.Tensor], state: Optional[Tuple[bool, object, int]]):
+    """first half of ``_sync_sums``: ISSUE the all-reduce (on the backend's own stream, behind everything queued so far) and return
+    at once, so that launches which do not need the sums run beside the collective; None when SyncBatchNorm is off"""
+    active, group, _ = state if state is not None else SyncBatchNorm.snapshot()
     if not active:
-        return 1
+        return None
     import torch.distributed as dist
     if scale is not None:
         sums.div_(scale.double())
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def _sync_sums_end(work, sums: torch.Tensor, scale: Optional[torch.Tensor], state: Optional[Tuple[bool, object, int]]) -> int:
+    """second half: make the current stream wait for the collective (no host sync), restore the rank's scale; returns the world size"""
+    if work is None:
+        return 1
+    work.wait()
     if scale is not None:
         sums.mul_(scale.double())
-    return world
+    return (state if state is not None else SyncBatchNorm.snapshot())[2]
 
 
 class _SyncBatchNorm1(torch.autograd.Function):
@@ -432,7 +445,12 @@ class _CnnTrunk(torch.autograd.Function):
                 wt = ws[l]
                 cout, cin = wt.shape[:2]
                 cin_p = _pad32(cin)
-                grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, h, w, cur_co, cin_p, cout, cin, split, gscale)
+                # data-parallel (sync) steps launch this layer's weight gradient BESIDE the all-reduce of the next BatchNorm backward's
+                # sums (below): it needs neither, and a small collective costs ~80 us of latency even in a 1-rank group
+                late_wgrad = ctx.sync_state[0] and l > 0
+                wg_h, wg_w = h, w  # (the pooling stacks change h, w before the deferred launch)
+                if not late_wgrad:
+                    grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, h, w, cur_co, cin_p, cout, cin, split, gscale)
                 grads[4 * l + 1] = torch.empty_like(params[4 * l + 1])             # conv bias in front of a BatchNorm: exactly 0 (zeroed below)
                 if l == 0:
                     break
@@ -457,7 +475,10 @@ class _CnnTrunk(torch.autograd.Function):
                     gscale = gs_new
                 else:
                     sums = L.stats(da, z, k2f, k3f, npix, C, split, amax=amax)
-                    world = _sync_sums(sums, gscale, ctx.sync_state)
+                    work = _sync_sums_begin(sums, gscale, ctx.sync_state)
+                    # ... the collective is in flight: this layer's weight gradient (dz of block l+1 x activations of block l) runs now
+                    grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, wg_h, wg_w, cur_co, cin_p, cout, cin, split, gscale)
+                    world = _sync_sums_end(work, sums, gscale, ctx.sync_state)
                     dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                     rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                                   gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),

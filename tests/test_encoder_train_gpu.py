@@ -245,31 +245,6 @@ def test_cnn_encoder_training_step_matches_torch_autograd(precision, tol_grad, t
             assert int(b) == int(c), name
 
 
-def test_neural_astar_training_step_runs_end_to_end_on_hip_kernels():
-    """fused search training step (forward + L1 + replay backward) feeding the HIP encoder backward: parameters move, loss is finite,
-    and the step agrees with the same step through the torch encoder (same search kernels) to 1e-4 relative on every gradient."""
-    from neural_astar.utils import synthetic as syn
-    from neural_astar.utils.training import fused_l1_step
-    dev = _dev()
-    pr = syn.maze_maps(32, 32, seed=5)
-    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
-    traj = (torch.rand((32, 1, 32, 32), generator=torch.Generator().manual_seed(2)) < 0.1).float().to(dev) * m
-    grads = {}
-    for backend in ("torch", "hip_f16x3"):
-        na = _shipped_cnn_planner().to(dev).train()
-        na.encoder_backend = backend
-        loss, _ = fused_l1_step(na, m, s, g, traj)
-        loss.backward()
-        assert bool(torch.isfinite(loss))
-        grads[backend] = {n: p.grad.clone() for n, p in na.encoder.named_parameters() if p.grad is not None}
-    big = max(float(v.abs().max()) for v in grads["torch"].values())
-    assert big > 0
-    for n, gt in grads["torch"].items():
-        if float(gt.abs().max()) < 1e-6 * big:
-            continue  # conv biases: noise in torch, exact zeros here
-        assert _rel(grads["hip_f16x3"][n], gt) <= 1e-2, n  # the cost maps differ by ~1e-6, a few searches take another route
-
-
 def _decision_margins(encoder):
     """Forward hooks on a float64 reference encoder: the smallest relative gap between the two largest values of a max-pool window
     (both positive) and the smallest |ReLU input|.  ReLU masks and pooling arg-maxes are DISCRETE decisions: where the float64
@@ -328,6 +303,10 @@ def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H
     ho, wo = (H >> depth, W >> depth) if arch == "CNNDownSize" else (H, W)
     R = torch.randn((B, 1, ho, wo), generator=g) / (B * ho * wo)
     margins, hooks = _decision_margins(ref.encoder)
+    seen_in = {}
+    for i, mod in enumerate(ref.encoder.model):  # what every ReLU / max-pool of the float64 reference saw, element by element
+        if isinstance(mod, (nn.ReLU, nn.MaxPool2d)):
+            hooks.append(mod.register_forward_hook(lambda m_, inp, out, i=i: seen_in.__setitem__(i, inp[0].detach().clone())))
     cost_ref = ref.encode(img.double(), s.double(), gl.double())
     for hk in hooks:
         hk.remove()
@@ -352,29 +331,41 @@ def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H
     assert len(worst) >= 2 * depth + 2 and max(worst.values()) <= (1e-4 if clear else 3e-2), (margins, worst)
     if seed == 1000:
         assert clear, margins  # this seed was chosen for its clear decisions: the strict bound must have been the one applied
-    if not clear or max(worst.values()) > 1e-4:
-        # the same function under the HIP path's own discrete decisions (ReLU masks, pooling arg-maxes), differentiated in float64: 1e-4
-        forced = copy.deepcopy(ref)
-        for p_ in forced.parameters():
-            p_.grad = None
-        mods = list(forced.encoder.model)
-        blk = 0
-        for i, mod in enumerate(mods):
-            if isinstance(mod, nn.ReLU):
-                z, k2, k3, r, shape = dbg[f"fwd:{blk}"]
-                mask = (k2.cpu().float().view(1, -1, 1, 1) * _unsplit(z, shape).float() + k3.cpu().float().view(1, -1, 1, 1)) > 0
-                forced.encoder.model[i] = _ForcedReLU(mask.double())
-                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.MaxPool2d):
-                    x = _unsplit(r, shape)
-                    Bn, Cn, Hn, Wn = x.shape
-                    win = x.reshape(Bn, Cn, Hn // 2, 2, Wn // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, Cn, Hn // 2, Wn // 2, 4)
-                    forced.encoder.model[i + 1] = _ForcedPool(nn.functional.one_hot(win.argmax(dim=-1), 4).double())
-                blk += 1
-        (forced.encode(img.double(), s.double(), gl.double()) * R.double()).sum().backward()
-        worst2 = {name: _rel(p.grad, q.grad) for (name, p), (_, q) in zip(na.encoder.named_parameters(), forced.encoder.named_parameters())
-                  if not (name.endswith("bias") and "model." in name and float(p.grad.abs().max()) == 0)}
-        print("GRADERR forced-decisions", " ".join(f"{k}={v:.1e}" for k, v in worst2.items()))
-        assert max(worst2.values()) <= 1e-4, worst2
+    # The float64 REFERENCE judges the discrete decisions, always: every ReLU mask bit / pooling arg-max that the
+    # reference takes clearly (|input| >= 1e-4; runner-up >= 1e-4 relative below the winner) must be the HIP path's too, element by
+    # element; only where the reference itself is ambiguous may the HIP path differ, and only those elements are then set to the HIP
+    # path's choice in the float64 module that bounds the gradients at 1e-4 -- a mask bug on a clear decision cannot be copied.
+    forced = copy.deepcopy(ref)
+    for p_ in forced.parameters():
+        p_.grad = None
+    mods = list(forced.encoder.model)
+    blk = n_amb = n_flip = 0
+    for i, mod in enumerate(mods):
+        if isinstance(mod, nn.ReLU):
+            z, k2, k3, r, shape = dbg[f"fwd:{blk}"]
+            hip = (k2.cpu().float().view(1, -1, 1, 1) * _unsplit(z, shape).float() + k3.cpu().float().view(1, -1, 1, 1)) > 0
+            x_ref = seen_in[i]
+            mine = x_ref > 0
+            ok = x_ref.abs() >= TAU_RELU
+            assert bool((hip == mine)[ok].all()), (blk, int((hip != mine)[ok].sum()), "clear ReLU decisions differ from float64")
+            forced.encoder.model[i] = _ForcedReLU(torch.where(ok, mine, hip).double())
+            n_amb += int((~ok).sum()); n_flip += int((hip != mine).sum())
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.MaxPool2d):
+                hipa = _window(_unsplit(r, shape)).argmax(dim=-1)
+                win = _window(seen_in[i + 1])
+                minea = win.argmax(dim=-1)
+                top = win.topk(2, dim=-1).values
+                okp = ((top[..., 0] - top[..., 1]) >= TAU_POOL * top[..., 0].abs().clamp_min(1e-30)) | (top[..., 0] <= 0)
+                assert bool((hipa == minea)[okp].all()), (blk, int((hipa != minea)[okp].sum()), "clear pooling decisions differ from float64")
+                forced.encoder.model[i + 1] = _ForcedPool(nn.functional.one_hot(torch.where(okp, minea, hipa), 4).double())
+                n_amb += int((~okp).sum()); n_flip += int((hipa != minea).sum())
+            blk += 1
+    (forced.encode(img.double(), s.double(), gl.double()) * R.double()).sum().backward()
+    worst2 = {name: _rel(p.grad, q.grad) for (name, p), (_, q) in zip(na.encoder.named_parameters(), forced.encoder.named_parameters())
+              if not (name.endswith("bias") and "model." in name and float(p.grad.abs().max()) == 0)}
+    print("GRADERR ambiguous-only forcing:", f"{n_amb} ambiguous decisions by the reference's margins, {n_flip} decided the other way;",
+          " ".join(f"{k}={v:.1e}" for k, v in worst2.items()))
+    assert max(worst2.values()) <= 1e-4, worst2
     for (name, b), (_, c) in zip(na.encoder.named_buffers(), ref.encoder.named_buffers()):
         if b.dtype.is_floating_point:
             assert _rel(b, c) <= 1e-5, name
@@ -458,23 +449,38 @@ def _unsplit(buf, shape):
     return (o[..., :C] + o[..., C:]).permute(0, 3, 1, 2)
 
 
-def test_unet_trains_on_the_hip_kernels():
+TAU_RELU = 1e-4  # |BatchNorm output| below which the float64 reference's own ReLU decision is "ambiguous": 10x what fp32-grade arithmetic
+TAU_POOL = 1e-4  # leaves on a normalised pre-activation (~1e-5); same, relative, for the two largest values of a pooling window
+
+
+def _window(x):
+    B, C, H, W = x.shape
+    return x.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+
+
+@pytest.mark.parametrize("seed", [4, 11, 23])
+def test_unet_trains_on_the_hip_kernels(seed):
     """Unet(vgg16_bn) (this package's VggUnet definition; reference encoder.py:37-57) in training mode: 23 conv + batch-statistics BatchNorm +
     ReLU blocks, four max-pools, four upsample + concat decoder blocks and the head -- forward and every parameter gradient on the MI355X
-    kernels against the torch module in float64.
+    kernels against the torch module in float64, over three seeds.
 
     A 26-layer network takes ~2.5 million discrete decisions per batch here (ReLU masks, pooling arg-maxes); fp32-grade arithmetic leaves
     ~1e-5 on the normalised pre-activations, so a handful of them legitimately fall the other way than in float64, and each moves a whole
-    gradient element (1/55 of a BatchNorm-bias gradient summed over 3072 pixels).  The parity statement is therefore made twice:
-    (1) against the plain float64 module: cost map within 2e-5, every gradient within 3e-2;
-    (2) against the float64 module FORCED to the HIP path's own decisions (same masks, same arg-maxes): every gradient within 2e-4."""
+    gradient element (1/55 of a BatchNorm-bias gradient summed over 3072 pixels).  The judge is the float64 REFERENCE, not the code
+    under test:
+    (1) every decision the reference itself takes CLEARLY (|BatchNorm output| >= 1e-4; pooling runner-up >= 1e-4 relative below the
+        winner) must be the HIP path's decision too -- compared element by element, no tolerance: a mask or arg-max bug cannot hide;
+    (2) against the plain float64 module: cost map within 2e-5, every gradient within 3e-2 (the handful of ambiguous decisions), and
+        the fraction of gradient tensors already within 2e-4 is printed ("unforced");
+    (3) against the float64 module whose AMBIGUOUS decisions only (by the reference's own margins) are set to the HIP path's: every
+        gradient within 2e-4.  Clear decisions stay the reference's own, so (3) cannot copy a bug into the judge."""
     from neural_astar.planner import NeuralAstar
     from neural_astar.utils import synthetic as syn
     from neural_astar import encoder_hip as E
     import test_unet_gpu as TU
     dev = _dev()
     B = 3
-    pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=4)
+    pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
     m, s, g = (torch.from_numpy(x) for x in pr)
     base = NeuralAstar(encoder_arch="Unet", encoder_depth=4)
     base.encoder = TU._calibrated_unet(seed=3)
@@ -482,7 +488,7 @@ def test_unet_trains_on_the_hip_kernels():
         if isinstance(mod, nn.ReLU):
             mod.inplace = False
     na = copy.deepcopy(base).to(dev).train()
-    R = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(9)) / (B * 1024)
+    R = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(9 + seed)) / (B * 1024)
     dbg = {}
     na.encoder._nastar_debug = dbg
     na.encoder_backend = "hip_f16x3"
@@ -503,48 +509,77 @@ def test_unet_trains_on_the_hip_kernels():
             worst[name] = _rel(p.grad, q.grad)
         return err_cost, worst
 
-    # (1) the plain float64 module
+    def decision_sites(model):
+        """[(container, index, kind, dbg key)] of every ReLU that follows a planned convolution and of every max-pool, in plan order"""
+        plan = E.unet_layer_plan(model)
+        conv_name = {id(st[4]): st[1] for st in plan if st[0] == "conv"}
+        sites = []
+        for seq in [mod for mod in model.modules() if isinstance(mod, nn.Sequential)]:
+            ch = list(seq)
+            for i, c in enumerate(ch):
+                if isinstance(c, nn.Conv2d) and id(c) in conv_name and "fwd:" + conv_name[id(c)] in dbg:
+                    for j in range(i + 1, min(i + 3, len(ch))):
+                        if isinstance(ch[j], nn.ReLU):
+                            sites.append((seq, j, "relu", "fwd:" + conv_name[id(c)]))
+        pools = [st for st in plan if st[0] == "pool"]
+        feats, pi = model.encoder.features, 0
+        for i, mod in enumerate(feats):
+            if isinstance(mod, nn.MaxPool2d) and pi < len(pools):
+                sites.append((feats, i, "pool", "fwd:" + pools[pi][1]))
+                pi += 1
+        return sites
+
+    # (2) the plain float64 module, with hooks that keep what every decision saw
     ref = copy.deepcopy(base).double().train()
+    seen_in = {}
+    hooks = []
+    ref_sites = decision_sites(ref.encoder.model)
+    assert sum(k == "relu" for _, _, k, _ in ref_sites) == 23 and sum(k == "pool" for _, _, k, _ in ref_sites) == 4
+    for n, (cont, idx, kind, key) in enumerate(ref_sites):
+        hooks.append(cont[idx].register_forward_hook(lambda mod, inp, out, n=n: seen_in.__setitem__(n, inp[0].detach().clone())))
     err_cost, worst = compare(ref)
-    print("GRADERR unet plain", "cost", err_cost, "n", len(worst), "max", max(worst.values()))
+    for h in hooks:
+        h.remove()
+    unforced_ok = sum(v <= 2e-4 for v in worst.values())
+    print("GRADERR unet plain seed", seed, "cost", err_cost, "n", len(worst), "max", max(worst.values()),
+          f"unforced: {unforced_ok}/{len(worst)} gradient tensors within 2e-4")
     assert err_cost <= 2e-5 and len(worst) >= 24 + 2 * 23 and max(worst.values()) <= 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
     for (name, b), (_, c) in zip(na.encoder.named_buffers(), ref.encoder.named_buffers()):
         if b.dtype.is_floating_point:
             assert _rel(b, c) <= 2e-5, name
         else:
             assert int(b) == int(c), name
-    # (2) the float64 module with the HIP path's decisions forced onto its ReLUs and max-pools
+    # (1) + (3): decisions judged by the reference's own margins
     forced = copy.deepcopy(base).double().train()
-    model = forced.encoder.model
-    plan = E.unet_layer_plan(model)
-    conv_name = {id(st[4]): st[1] for st in plan if st[0] == "conv"}
-    n_relu = 0
-    for seq in [mod for mod in model.modules() if isinstance(mod, nn.Sequential)]:
-        ch = list(seq)
-        for i, c in enumerate(ch):
-            if isinstance(c, nn.Conv2d) and id(c) in conv_name and "fwd:" + conv_name[id(c)] in dbg:
-                for j in range(i + 1, min(i + 3, len(ch))):
-                    if isinstance(ch[j], nn.ReLU):
-                        z, k2, k3, shape = dbg["fwd:" + conv_name[id(c)]]
-                        zz = _unsplit(z, shape)
-                        mask = (k2.cpu().float().view(1, -1, 1, 1) * zz.float() + k3.cpu().float().view(1, -1, 1, 1)) > 0  # the kernels' fp32 test
-                        seq[j] = _ForcedReLU(mask.double())
-                        n_relu += 1
-    feats = model.encoder.features
-    pools = [st for st in plan if st[0] == "pool"]
-    pi = 0
-    for i, mod in enumerate(feats):
-        if isinstance(mod, nn.MaxPool2d) and pi < len(pools):
-            src, shape = dbg["fwd:" + pools[pi][1]]
-            x = _unsplit(src, shape)
-            Bn, C, H, W = x.shape
-            win = x.reshape(Bn, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Bn, C, H // 2, W // 2, 4)
-            feats[i] = _ForcedPool(nn.functional.one_hot(win.argmax(dim=-1), 4).double())  # argmax: first maximum, the kernel's rule
-            pi += 1
-    assert n_relu == 23 and pi == 4
+    f_sites = decision_sites(forced.encoder.model)
+    n_dec = n_amb = n_flip = 0
+    for n, ((cont, idx, kind, key), (fcont, fidx, _, _)) in enumerate(zip(ref_sites, f_sites)):
+        x_ref = seen_in[n]
+        if kind == "relu":
+            z, k2, k3, shape = dbg[key]
+            hip = (k2.cpu().float().view(1, -1, 1, 1) * _unsplit(z, shape).float() + k3.cpu().float().view(1, -1, 1, 1)) > 0  # the kernels' fp32 test
+            mine = x_ref > 0
+            clear = x_ref.abs() >= TAU_RELU
+            assert bool((hip == mine)[clear].all()), (key, int((hip != mine)[clear].sum()), "clear ReLU decisions differ from float64")
+            fcont[fidx] = _ForcedReLU(torch.where(clear, mine, hip).double())
+        else:
+            src, shape = dbg[key]
+            hip = _window(_unsplit(src, shape)).argmax(dim=-1)  # argmax: first maximum, the kernel's rule
+            win = _window(x_ref)
+            mine = win.argmax(dim=-1)
+            top = win.topk(2, dim=-1).values
+            clear = (top[..., 0] - top[..., 1]) >= TAU_POOL * top[..., 0].abs().clamp_min(1e-30)
+            clear = clear | (top[..., 0] <= 0)  # an all-zero window (after ReLU): no gradient whichever element is taken
+            assert bool((hip == mine)[clear].all()), (key, int((hip != mine)[clear].sum()), "clear pooling decisions differ from float64")
+            fcont[fidx] = _ForcedPool(nn.functional.one_hot(torch.where(clear, mine, hip), 4).double())
+        n_dec += clear.numel()
+        n_amb += int((~clear).sum())
+        n_flip += int((hip != mine).sum())
     err_cost2, worst2 = compare(forced)
     w3 = sorted(worst2.items(), key=lambda kv: -kv[1])[:4]
-    print("GRADERR unet forced-decisions", "cost", err_cost2, "worst", " ".join(f"{k}={v:.1e}" for k, v in w3))
+    print("GRADERR unet seed", seed, f"decisions {n_dec}, ambiguous by the reference's own margins {n_amb}, decided the other way {n_flip};",
+          "ambiguous-only forcing: cost", err_cost2, "worst", " ".join(f"{k}={v:.1e}" for k, v in w3))
+    assert n_amb <= 2e-3 * n_dec, (n_amb, n_dec)
     assert max(worst2.values()) <= 2e-4, w3
 
 
