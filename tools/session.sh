@@ -61,6 +61,30 @@ r04_prof)
   python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench_n1_driver_command.err; echo "bench rc=$?"
   tail -n 5 $O/bench_n1_driver_command.err; head -c 1500 $O/bench_n1_driver_command.json
   ;;
+r04_d)
+  # (1) tests touched since r04_b; (2) the driver's three N = 8 shapes with EIGHT ranks sharing this GPU over gloo (code paths, ports,
+  # divisibility, synthesis time, memory -- the timings mean nothing); (3) 1-rank RCCL training step, sync-BN on / off
+  O=gpurun_out/r04/d; mkdir -p $O
+  python -m pytest tests/test_trainloop_golden_gpu.py tests/test_encoder_train_gpu.py tests/test_distributed_training.py tests/test_unet_gpu.py tests/test_trainstep_golden_gpu.py -q -s -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"
+  grep -a "TRAINLOOP\|GRADERR unet\|ambiguous-only\|passed\|failed\|^E  " $O/tests.log | cut -c1-900 | tail -40
+  run8() { name=$1; shift; port=$((29600 + RANDOM % 300)); t0=$(date +%s)
+    timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $port bench.py --gpus 8 --steps 20 --warmup 5 --dist-backend gloo --share-gpu "$@" > $O/world8_$name.json 2> $O/world8_$name.err
+    echo "world8 $name rc=$? $(( $(date +%s) - t0 )) s: $(head -c 300 $O/world8_$name.json)"; }
+  run8 maze32_weak
+  run8 rand64_contiguous --workload rand64 --global-batch 32768
+  run8 rand64_interleaved --workload rand64 --global-batch 32768 --shard interleaved
+  run8 train_warcraft --mode train --config warcraft
+  run8 train_maze --mode train --config maze
+  for c in maze warcraft; do
+    python bench.py --mode train --config $c --no-cpu-baseline > $O/train_${c}.json 2> $O/train_${c}.err
+    python bench.py --mode train --config $c --no-cpu-baseline --force-collate > $O/train_${c}_rccl1.json 2> $O/train_${c}_rccl1.err
+    python - <<P
+import json
+a=json.load(open("$O/train_${c}.json")); b=json.load(open("$O/train_${c}_rccl1.json"))
+print("$c", "single", round(a["ms_per_step"],3), "ms; 1-rank RCCL sync_bn on", round(b["ms_per_step"],3), "off", b.get("sync_bn"))
+P
+  done
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
