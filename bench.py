@@ -348,7 +348,7 @@ def two_stream_throughput(pr, steps, dev):
 
 
 def training_step_ms(pr, dev, reps=10):
-    """Extra: forward + straight-through backward (nastar_backward) of one 4096-map batch with U(0,1) costs in
+    """Extra: forward + straight-through backward (nastar_backward_replay) of one 4096-map batch with U(0,1) costs in
     training mode, Tmax = 0.25 (the reference's scripts/config/train.yaml), through the torch custom ops."""
     from neural_astar import ops  # noqa: F401
     from neural_astar.utils import synthetic as syn
@@ -361,18 +361,11 @@ def training_step_ms(pr, dev, reps=10):
     gh = torch.randn_like(hist)
     tb = (iters.amax() - 1).to(torch.int32).reshape(1)
 
-    def replay():  # round 2: the forward logs its selections, the backward replays them (nastar_backward_replay)
+    def replay():  # the forward logs its selections, the backward replays them (nastar_backward_replay)
         h, _, it, _, log = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, True)
         torch.ops.nastar.astar_backward_replay(gh, cost, s, g, m, log, G_RATIO, mi, it, tb)
-
-    def reselect():  # round 1 kernels
-        h, _, it, _, _ = torch.ops.nastar.astar_forward(cost, s, g, m, G_RATIO, mi, False)
-        torch.ops.nastar.astar_backward(gh, cost, s, g, m, G_RATIO, mi, it, tb)
     out = {}
-    from neural_astar import _native
     variants = [("replay_ms", replay)]
-    if _native.load().nastar_has_dev_kernels():  # `make DEV=1` builds only
-        variants.append(("round1_reselect_ms", reselect))
     for name, once in variants:
         for _ in range(2):
             once()
@@ -389,7 +382,7 @@ def training_step_ms(pr, dev, reps=10):
 
 def l1_training_step_ms(pr, dev, batch, reps=20):
     """Extra: the reference's training step on `batch` maps (utils/training.py:55-61, Tmax = 0.25, cost = leaf tensor):
-    L1Loss through autograd vs the fused node (nastar_l1_loss + nastar_backward_l1)."""
+    L1Loss through autograd vs the fused node (nastar_l1_loss + nastar_backward_l1_replay)."""
     from neural_astar import ops
     from neural_astar.utils import synthetic as syn
     m = torch.from_numpy(pr.map_designs[:batch, 0]).to(dev).contiguous()

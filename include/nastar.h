@@ -8,11 +8,11 @@
  *   nastar_forward          <- DifferentiableAstar.forward   differentiable_astar.py:150-267
  *                              (get_heuristic :26-52, _st_softmax_noexp :55-74, expand :77-93,
  *                               backtrack :96-125 all fused into one launch)
- *   nastar_backward         <- the autograd graph PyTorch records for that forward
+ *   nastar_backward_replay  <- the autograd graph PyTorch records for that forward
  *                              (what loss.backward() runs in utils/training.py:55-61)
  *   nastar_heuristic        <- get_heuristic                 differentiable_astar.py:26-52 (debug/parity)
  *   nastar_workspace_bytes  <- (new) workspace sizing; PyTorch owns every allocation
- *   nastar_l1_loss / nastar_backward_l1 <- loss = nn.L1Loss()(histories, opt_trajs); loss.backward()   utils/training.py:55-61
+ *   nastar_l1_loss / nastar_backward_l1_replay <- loss = nn.L1Loss()(histories, opt_trajs); loss.backward()   utils/training.py:55-61
  *   nastar_policy_rollout   <- MazeDataset.get_opt_traj / next_loc                                      utils/data.py:171-199,222-244
  *   nastar_encoder_cnn_forward <- NeuralAstar.encode with the CNN encoder in eval mode                  astar.py:154-180, encoder.py:32-34,60-78
  *   nastar_pack_outputs / nastar_unpack_outputs <- (new) multi-GPU collation payload, see below
@@ -51,14 +51,11 @@ extern "C" {
 #define NASTAR_ERR_NOT_UNIT_COST 7 /* per-map status only: NASTAR_FLAG_UNIT_COST was passed but this map holds a value other than 0.0 / 1.0;
                                       its outputs are all-zero -- run it again without the flag */
 
-/* flags for nastar_workspace_bytes / nastar_forward / nastar_backward */
+/* flags for nastar_workspace_bytes / nastar_forward / nastar_backward_replay */
 #define NASTAR_FLAG_NONE 0
-#define NASTAR_FLAG_FORCE_LDS 1 /* forward: round-1 LDS layout (17 B/cell, one map per wavefront); A/B measurements only */
-#define NASTAR_FLAG_FORCE_REG 2 /* forward: use the register-resident kernel where it applies (<= 1024 cells) */
 #define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
 #define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
 #define NASTAR_FLAG_NO_DIVE 32   /* forward, 64x64 maps: the round-3 stream without its "dive" fast path (A/B) */
-#define NASTAR_FLAG_DUO 4        /* forward: two maps per wavefront (nastar_search_duo.hip.h), a measured non-improvement */
 #define NASTAR_FLAG_UNIT_COST 64 /* forward: the caller promises that `cost` and `passable` are ONE binary tensor (VanillaAstar, reference
                                     astar.py:93-94; pass the same pointer twice): the LDS state drops the per-cell cost word (5.5 instead
                                     of 9.75 B/cell, 29 instead of 16 resident 32x32 maps per CU).  Same outputs as without the flag; the
@@ -68,11 +65,6 @@ extern "C" {
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
 
 int nastar_version(void);
-
-/* 1 when the library was built with `make DEV=1`: the superseded / negative-result kernels behind NASTAR_FLAG_FORCE_LDS, _FORCE_REG, _DUO and
- * the round-1 nastar_backward / nastar_backward_l1 are present.  0 (the product build): those flags and entry points return
- * NASTAR_ERR_UNSUPPORTED; use nastar_backward_replay / nastar_backward_l1_replay. */
-int nastar_has_dev_kernels(void);
 
 /* Human-readable description of the last NASTAR_ERR_HIP on this thread ("" if none). */
 const char* nastar_last_error(void);
@@ -108,30 +100,24 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
                           void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
- * Backward of `histories` w.r.t. `cost` (paths carry no gradient).  Replays the search on-chip and accumulates
+ * Backward of `histories` w.r.t. `cost` (paths carry no gradient):
  *   dL/dcost = sum_t (1-g_ratio) * (-1/sqrt(W)) * y_t * (G_t - <G_t, y_t>)       
  * including the reference's batch-coupled terms: a map that reaches its goal at step tau < t_batch keeps being
  * stepped at its fixed point until the slowest map of the batch finishes (differentiable_astar.py:251), which
  * (i) adds (t_batch - tau) copies of the fixed-point term and (ii) zeroes the upstream gradient of its goal cell
  * (torch.clamp backward at :223).
+ *   sel_log        [B,max_iters] int32  sel_log_out of the matching forward (required: the forward's selections ARE the tape)
  *   iters          [B] int32     iters_out of the matching forward
  *   t_batch_dev    device int32* holding t_batch = max(iters)-1 over the WHOLE logical batch (across shards if
  *                  the caller wants single-device semantics), or NULL to treat every map as its own batch
  *                  (t_batch = iters[b]-1: no fixed-point terms).
- *   grad_cost_out  [B,H,W] fp32
- */
-int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
-                    const float* passable, int B, int H, int W, double g_ratio, int max_iters,
-                    const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* workspace,
-                    size_t workspace_bytes, int flags, void* stream);
-
-/*
- * The same gradient by REPLAY of the forward's selection log (sel_log_out of nastar_forward, required): no selection is
- * repeated and the softmax is accounted per open-list event, O(9) work per step instead of O(open list)
- * (csrc/nastar_backward_replay.hip.h).  Any map of up to 65519 cells: the per-map state lives in LDS up to ~11.6 k cells and in
+ *   grad_cost_out  [B,H,W] fp32, fully written
+ * By REPLAY of the selection log: no selection is repeated and the softmax is accounted per open-list event, O(9) work per
+ * step instead of O(open list) (csrc/nastar_backward_replay.hip.h).  (Rounds 1-3 also exported nastar_backward /
+ * nastar_backward_l1, which repeated the selection instead of reading a log; superseded, removed in 0.4.0.)  Any map of up to 65519 cells: the per-map state lives in LDS up to ~11.6 k cells and in
  * the workspace beyond.  workspace: nastar_backward_workspace_bytes(B,H,W,max_iters) bytes (per-step history of the running
  * sums, 16 B per executed step, + the state slabs of maps too large for LDS).  grad_cost_out is fully written.
- * nastar_backward_l1_replay: the fused-L1 form (see nastar_backward_l1).
+ * nastar_backward_l1_replay: the fused-L1 form (see nastar_l1_loss below).
  */
 size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters);
 int nastar_backward_replay(const float* grad_histories, const float* cost, const float* start, const float* goal,
@@ -148,14 +134,11 @@ int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, co
  *   loss = nn.L1Loss()(outputs.histories, opt_trajs); loss.backward()
  * nastar_l1_loss: loss_out[0] = mean |histories - opt_trajs| over numel elements (fixed-order double reduction, bitwise
  *   reproducible); workspace >= 2048 bytes.
- * nastar_backward_l1: nastar_backward with dL/dhistories = (*grad_loss_dev or 1) * sign(histories - opt_trajs) / (B*H*W)
+ * nastar_backward_l1_replay: nastar_backward_replay with dL/dhistories = (*grad_loss_dev or 1) * sign(histories - opt_trajs) / (B*H*W)
  *   formed inside the kernel (no gradient tensor is materialised).  histories = the forward's own output.
  */
 int nastar_l1_loss(const float* histories, const float* opt_trajs, long long numel, float* loss_out, void* workspace,
                    size_t workspace_bytes, void* stream);
-int nastar_backward_l1(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
-                       const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
-                       int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream);
 
 /*
  * Dataset path (SURVEY.md 8f "next #4"; reference utils/data.py:171-199 MazeDataset.get_opt_traj, :222-244 next_loc): roll the

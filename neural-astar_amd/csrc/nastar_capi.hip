@@ -6,118 +6,19 @@
 #include <stdio.h>
 #include <string.h>
 
-#ifndef NASTAR_DEV_KERNELS
-#define NASTAR_DEV_KERNELS 0  // make DEV=1: also build the superseded / negative-result kernels kept for A/B measurements
-#endif
 #include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
-#if NASTAR_DEV_KERNELS
-#include "nastar_search_reg.hip.h"
-#endif
 #include "nastar_search_global.hip.h"
 #include "nastar_search_compact.hip.h"
-#if NASTAR_DEV_KERNELS
-#include "nastar_search_duo.hip.h"
-#endif
 #include "nastar_search_asm.hip.h"
 #include "nastar_search_asm3.hip.h"
 #include "nastar_search_asm4.hip.h"
 #include "nastar_search_unit.hip.h"
-#if NASTAR_DEV_KERNELS
-#include "nastar_search_asm3_abl.hip.h"
-#endif
 #include "nastar_backward_replay.hip.h"
 #include "nastar_backward_replay_asm.hip.h"
 
 namespace nastar {
 
-
-struct FwdArgs {
-    const float* cost;
-    const float* start;
-    const float* goal;
-    const float* passable;
-    float* hist;
-    long long* paths;
-    int* sel_log;
-    int* iters;
-    int* status;
-    uint8_t* packed;  // optional [B, 2*HW/8] bit-packed masks (fused in the vec4 LDS kernel), else nullptr
-    int max_iters;
-    MapDims d;
-};
-
-#if NASTAR_DEV_KERNELS  // round-1 17 B/cell kernel: A/B measurements only (make DEV=1)
-// ---- forward: DifferentiableAstar.forward (differentiable_astar.py:150-267), one wavefront per map ------
-// LOGH > 0 (together with LOGW > 0): the map is exactly (1<<LOGH) x (1<<LOGW), so every size, loop bound and LDS array
-// offset is a compile-time constant (immediate ds offsets, fully unrolled load/store loops).
-template <bool kVec4, bool kMultiChunk, int LOGW, bool kFastDiv, bool kLog, int LOGH = 0>
-__global__ __launch_bounds__(64) void nastar_forward_kernel(const FwdArgs a, const float rcp_sqrtW)
-{
-    // 1024-cell maps use 16-cell chunks (64 chunks, one per lane); everything else 64-cell chunks
-    constexpr int CL = (LOGH > 0 && LOGW > 0 && LOGH + LOGW == 10) ? 4 : 6;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    MapDims d = a.d;
-    if constexpr (LOGH > 0 && LOGW > 0) {
-        d.H = 1 << LOGH;
-        d.W = 1 << LOGW;
-        d.HW = 1 << (LOGH + LOGW);
-        d.nchunks = d.HW >> CL;
-        d.HWp = d.HW;
-        d.NCp = 64;
-        d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
-    }
-    const MapLds l = carve_map_lds(smem, d);
-    const size_t off = (size_t)b * (size_t)d.HW;
-
-    int start_idx, goal_idx;
-    load_map<kVec4, CL>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
-
-    const LaneConst lc = make_lane_const(d, lane);
-    int status = NASTAR_OK;
-    int iters = 0;
-    bool solved = false;
-    if (start_idx < 0 || goal_idx < 0) {
-        status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
-    } else {
-        int s = 0;
-        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
-            int C, cl;
-            uint32_t kv;
-            s = select_min<kMultiChunk, CL>(d, l, lane, C, cl, kv);
-            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
-            if constexpr (kLog) {
-                if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-            }
-            ++iters;
-            close_and_expand<LOGW, kFastDiv, CL>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
-        }
-        if (iters < a.max_iters) {
-            if (s < 0) {
-                status = NASTAR_ERR_UNSOLVABLE;
-            } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
-                if constexpr (kLog) {
-                    if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-                }
-                ++iters;
-                solved = true;
-                if (lane == 0) l.g[s] = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
-            }
-        }
-    }
-    wave_sync();
-    if (goal_idx >= 0) backtrack(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    store_outputs<kVec4>(d, l, lane, a.hist + off, a.paths + off,
-                         a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
-    if (lane == 0) {
-        a.iters[b] = iters;
-        a.status[b] = status;
-    }
-}
-
-#endif  // NASTAR_DEV_KERNELS
 
 // ---- forward, compact LDS state (nastar_search_compact.hip.h): the default for every map that fits LDS ------------------
 struct FwdCArgs {
@@ -139,8 +40,8 @@ struct FwdCArgs {
 
 // LOGH > 0 && LOGW > 0: the map is exactly (1<<LOGH) x (1<<LOGW) (compile-time sizes, immediate ds offsets).
 // CPL_T: chunk minima per lane (1 or 4) when known at compile time, 0 = runtime.
-// ABL == -1: the selection/expansion loop is the hand-scheduled instruction stream of nastar_search_asm.hip.h
-template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, int ABL = 0>
+// kAsm: the selection/expansion loop is a hand-scheduled instruction stream (nastar_search_asm4 / _asm3 / _asm.hip.h; 16x16, 32x32, 64x64)
+template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, bool kAsm = false>
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,8 +66,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     bool any_signed = true;
     // round-3 instruction stream (raw-bit keys): every cost >= +0 and 0 <= g_ratio <= 1 so that every priority is >= +0
     compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx,
-                                       (ABL == -1 || ABL >= 300) ? &any_signed : nullptr);
-    const bool asm3 = (ABL == -1 || ABL >= 300) && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
+                                       kAsm ? &any_signed : nullptr);
+    const bool asm3 = kAsm && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
     const int gi = goal_idx < 0 ? 0 : goal_idx;
     const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
     const int goal_c = gi - goal_r * d.W;
@@ -180,11 +81,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     } else {
         // round-4 stream (nastar_search_asm4.hip.h) wherever the round-3 one applies; NASTAR_FLAG_ASM_V3 keeps the round-3 stream (A/B);
         // half: g_ratio == 0.5 -- the two products of f = g_ratio g + (1 - g_ratio) h are exact and drop out of the key
-        const bool asm4 = ABL == -1 && asm3 && !(a.flags & NASTAR_FLAG_ASM_V3);
+        const bool asm4 = asm3 && !(a.flags & NASTAR_FLAG_ASM_V3);
         const bool half = asm4 && d.gr == 0.5f && d.omg == 0.5f;
         compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, asm3, half);
         int s = 0;
-        if constexpr (ABL == -1) {
+        if constexpr (kAsm) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
             int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
             // searching wavefronts issue ahead of the ones still loading their map or already storing their result (the launch waits for the
@@ -203,26 +104,18 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             __builtin_amdgcn_s_setprio(0);
-        } else if constexpr (ABL >= 300) {  // DEV timing probe of the round-3 stream (nastar_search_asm3_abl.hip.h): garbage results
-#if NASTAR_DEV_KERNELS
-            s = compact_search_loop_asm3_abl<LOGW, ABL - 300>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW);
-#endif
         } else
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
-            s = compact_select<CPL_T, ABL>(d, l, lane, mine);
-            if constexpr (ABL != 0) {  // timing probe: always run the whole budget
-                if (s < 0 || s >= d.HW) s = iters & (d.HW - 1);
-            } else {
-                if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
-            }
+            s = compact_select<CPL_T>(d, l, lane, mine);
+            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
             if constexpr (kLog) {
                 if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
             }
             ++iters;
-            compact_expand<LOGW, kFastDiv, CPL_T, ABL>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
+            compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
         }
-        if ((ABL == -1 || ABL >= 300) ? (s != -2) : (iters < a.max_iters)) {
+        if (kAsm ? (s != -2) : (iters < a.max_iters)) {
             if (s < 0) {
                 status = NASTAR_ERR_UNSOLVABLE;
             } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
@@ -304,354 +197,7 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
     unit_store_paths<LOGW>(l, lane, a.paths + off, a.packed ? a.packed + (size_t)b * (size_t)(HW >> 2) : nullptr, bad);
 }
 
-#if NASTAR_DEV_KERNELS  // measured non-improvements kept for the record (make DEV=1): two maps per wavefront, register-resident state
-// ---- forward, two maps per wavefront (nastar_search_duo.hip.h): the default wherever two compact states fit one CU's LDS ----
-// a.d.CPL / a.d.NCp count chunk minima per 32-lane half here.
-template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog>
-__global__ __launch_bounds__(64) void nastar_forward_duo_kernel(const FwdCArgs a, const float rcp_sqrtW)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int half = lane >> 5, hl = lane & 31;
-    const int bq = 2 * (int)blockIdx.x + half;
-    const bool valid = bq < a.B;            // odd B: the second half of the last wavefront shadows the first (stores masked)
-    const int b = valid ? bq : a.B - 1;
-    CompactDims d = a.d;
-    if constexpr (LOGH > 0 && LOGW > 0) {
-        d.H = 1 << LOGH;
-        d.W = 1 << LOGW;
-        d.HW = 1 << (LOGH + LOGW);
-        d.nchunks = d.HW >> CCL;
-        d.HWp = d.HW;
-        d.CPL = (d.nchunks + 31) / 32;
-        d.NCp = d.CPL * 32;
-        d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
-    }
-    const CompactLds l = carve_duo_lds(smem, d, half);
-    const size_t off = (size_t)b * (size_t)d.HW;
 
-    int start_idx, goal_idx;
-    duo_load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, hl, start_idx, goal_idx);
-    const int gi = goal_idx < 0 ? 0 : goal_idx;
-    const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
-    const int goal_c = gi - goal_r * d.W;
-
-    const DuoLane lc = make_duo_lane(d, hl);
-    int status = NASTAR_OK;
-    int iters = 0;
-    bool solved = false;
-    bool live = (start_idx >= 0) & (goal_idx >= 0);
-    if (!live) status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
-    if (live & (hl == 0)) {  // open list = {start} (:187), g[start] = 0 (:193)
-        const int r = (int)div_magic((uint32_t)start_idx, d.magicW);
-        const int c = start_idx - r * d.W;
-        const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + l.gc[start_idx].y);
-        const uint32_t k0 = compact_key<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
-        l.gc[start_idx].x = 0.0f;
-        l.cmin[start_idx >> CCL] = cmin_entry(k0, (uint32_t)start_idx);
-        l.pdir[start_idx] = (uint8_t)(PARENT_UNSET | P_PASS);  // the start is expanded even if it sits on an obstacle
-    }
-    wave_sync();
-    int* const log_row = kLog ? a.sel_log + (size_t)b * (size_t)a.max_iters : nullptr;
-    for (;;) {
-        const bool can = live & (iters < a.max_iters);  // :203 for t in range(Tmax)
-        if (__ballot(can) == 0) break;
-        bool empty;
-        uint2 e0, e1;
-        int s = duo_select<CPL_T>(d, l, half, hl, empty, e0, e1);
-        const bool hit = can & (empty | (s == goal_idx));  // open list empty (:68 would divide by zero) or goal selected
-        const bool reached = hit & !empty;
-        const bool act = can & !hit;
-        if (hit & empty) status = NASTAR_ERR_UNSOLVABLE;
-        if (reached) solved = true;  // :219-220,:251: every later step of the reference is a fixed point
-        if constexpr (kLog) {
-            if ((act | reached) & (hl == 0) & valid) log_row[iters] = s;
-        }
-        if (act | reached) ++iters;
-        if (reached & (hl == 0)) l.gc[s].x = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
-        if (hit) live = false;
-        if (__ballot(act) == 0) continue;
-        s = act ? s : 0;
-        duo_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, half, hl, s, act, goal_r, goal_c, rcp_sqrtW, e0, e1);
-    }
-    wave_sync();
-    duo_backtrack(d, l, hl, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    if (valid) {
-        duo_store_outputs<kVec4>(d, l, hl, a.hist + off, a.paths + off,
-                                 a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
-        if (hl == 0) {
-            a.iters[b] = iters;
-            a.status[b] = status;
-        }
-    }
-}
-
-// ---- forward, register-resident variant for maps of <= 1024 cells (nastar_search_reg.hip.h) ----------------
-template <int NSTEP, bool kLog, bool kFastDiv, int LOGW>
-__global__ __launch_bounds__(64) void nastar_forward_reg_kernel(const FwdArgs a, const float rcp_sqrtW)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t pdir[REG_MAX_CELLS + 64];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const MapDims d = a.d;
-    const size_t off = (size_t)b * (size_t)d.HW;
-    RegState st;
-    int start_idx, goal_idx;
-    reg_load_map(d, st, pdir, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
-
-    int status = NASTAR_OK;
-    int iters = 0;
-    bool solved = false;
-    int gC = 0, gcl = 0;
-    if (start_idx < 0 || goal_idx < 0) {
-        status = NASTAR_ERR_UNSOLVABLE;
-    } else {
-        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
-            int C, cl;
-            const int s = reg_select(st, C, cl);
-            if (s < 0) {  // open list empty: the reference divides by zero here (:68)
-                status = NASTAR_ERR_UNSOLVABLE;
-                break;
-            }
-            if constexpr (kLog) {
-                if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-            }
-            ++iters;
-            if (s == goal_idx) {  // :219-220,:251 reached; every later step of the reference is a fixed point
-                solved = true;
-                gC = C;
-                gcl = cl;
-                break;
-            }
-            reg_expand<NSTEP, kFastDiv, LOGW>(d, st, pdir, lane, s, C, cl, /*keep_open=*/false, rcp_sqrtW);
-        }
-    }
-    if (solved) reg_close_only(st, lane, gC, gcl);
-    wave_sync();
-    uint32_t pathbits = 0;
-    if (goal_idx >= 0) pathbits = reg_backtrack(d, pdir, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
-    reg_store_outputs(d, st, pathbits, lane, a.hist + off, a.paths + off);
-    if (lane == 0) {
-        a.iters[b] = iters;
-        a.status[b] = status;
-    }
-}
-
-#endif  // NASTAR_DEV_KERNELS
-
-#if NASTAR_DEV_KERNELS  // round-1 backward (repeats the selection, full softmax per step): superseded by the replay kernels; make DEV=1
-struct BwdArgs {
-    const float* grad_hist;  // upstream dL/dhistories, or nullptr: L1 loss fused (below)
-    const float* l1_hist;    // fused L1 (training.py:58): dL/dhistories = l1_scale * *l1_up * sign(histories - opt_trajs)
-    const float* l1_traj;
-    const float* l1_up;      // device scalar dL/dloss (nullptr = 1)
-    float l1_scale;          // 1 / numel (nn.L1Loss reduction='mean')
-    const float* cost;
-    const float* start;
-    const float* goal;
-    const float* passable;
-    const int* iters;    // [B] iters_out of the forward (needed with t_batch)
-    const int* t_batch;  // device scalar or nullptr
-    float* grad_cost;
-    int max_iters;
-    float kfac;   // (1-g_ratio) * (-1/sqrt(W))
-    MapDims d;
-};
-
-// upstream gradient of one cell: given, or the L1 loss's sign gradient computed in place (torch: grad * sign(x - y) / numel)
-__device__ __forceinline__ float upstream_grad(const BwdArgs& a, size_t i)
-{
-    if (a.grad_hist != nullptr) return a.grad_hist[i];
-    const float dlt = a.l1_hist[i] - a.l1_traj[i];
-    const float sg = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
-    return sg * (a.l1_scale * (a.l1_up != nullptr ? *a.l1_up : 1.f));
-}
-
-// y_t = softmax over the open list of -f/sqrt(W) (:207-209,:67-68); acc += scale * kfac * y * (G - <G,y>).
-// Only chunks that hold an open cell are visited (chunkmin != KEY_INF): the open list is a thin frontier, typically
-// 2-5 of the 16 chunks of a 32x32 map, so this is ~4x less work than sweeping every cell twice per step.
-__device__ __forceinline__ void softmax_accumulate(const MapDims& d, const MapLds& l, const float* gh, float* acc,
-                                                   float* vbuf, int lane, float kfac, float scale)
-{
-    float ls = 0.f, ld = 0.f;
-    for (int c0 = 0; c0 < d.nchunks; c0 += 64) {
-        const uint32_t cmv = l.chunkmin[c0 + lane];  // padded with KEY_INF up to a multiple of 64
-        unsigned long long act = __ballot(cmv != KEY_INF);
-        while (act) {
-            const int c = c0 + __builtin_ctzll(act);
-            act &= act - 1;
-            const int i = c * CHUNK + lane;
-            const uint32_t k = l.key[i];
-            const float v = (k != KEY_INF) ? expf(-ord_to_f32(k)) : 0.f;  // key holds q = f/sqrt(W)
-            vbuf[i] = v;
-            ls += v;
-            ld += v * gh[i];
-        }
-    }
-    const float S = wave_sum_f32(ls);
-    const float D = wave_sum_f32(ld);
-    const float dot = D / S;
-    const float w = scale * kfac;
-    for (int c0 = 0; c0 < d.nchunks; c0 += 64) {
-        const uint32_t cmv = l.chunkmin[c0 + lane];
-        unsigned long long act = __ballot(cmv != KEY_INF);
-        while (act) {
-            const int c = c0 + __builtin_ctzll(act);
-            act &= act - 1;
-            const int i = c * CHUNK + lane;
-            const float v = vbuf[i];
-            acc[i] += w * (v / S) * (gh[i] - dot);  // v == 0 for cells that are not open: adds exactly 0
-        }
-    }
-    wave_sync();
-}
-
-// ---- backward: replays the search, accumulating dL/dcost --------------------------------
-template <bool kVec4, bool kMultiChunk>
-__global__ __launch_bounds__(64) void nastar_backward_kernel(const BwdArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const MapDims d = a.d;
-    const MapLds l = carve_map_lds(smem, d);
-    float* gh = reinterpret_cast<float*>(smem + ((map_lds_bytes(d.HWp, d.NCp) + 15) & ~(size_t)15));
-    float* acc = gh + d.HWp;
-    float* vbuf = acc + d.HWp;
-    const size_t off = (size_t)b * (size_t)d.HW;
-
-    int start_idx, goal_idx;
-    load_map<kVec4>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
-    for (int i = lane; i < d.HWp; i += 64) {
-        gh[i] = (i < d.HW) ? upstream_grad(a, off + i) : 0.f;
-        acc[i] = 0.f;
-    }
-    wave_sync();
-
-    if (start_idx >= 0 && goal_idx >= 0) {
-        // The reference keeps stepping a finished map at its fixed point until the slowest map of the batch is done
-        // (:251).  extra = number of such steps = t_batch - tau with tau = iters[b]-1.  When extra > 0 the goal cell
-        // is re-selected while already closed, and torch.clamp's backward (:223) zeroes its upstream gradient.
-        const LaneConst lc = make_lane_const(d, lane);
-        int extra = 0;
-        if (a.t_batch != nullptr && a.iters != nullptr) extra = *a.t_batch - (a.iters[b] - 1);
-        if (extra > 0 && lane == 0) gh[goal_idx] = 0.f;
-        wave_sync();
-        int iters = 0;
-        while (iters < a.max_iters) {
-            softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, 1.0f);
-            int C, cl;
-            uint32_t kv;
-            const int s = select_min<kMultiChunk>(d, l, lane, C, cl, kv);
-            if (s < 0) break;
-            ++iters;
-            if (s == goal_idx) {
-                if (extra > 0) {
-                    // goal's own expansion (it stays open, :224), then `extra` identical fixed-point steps
-                    close_and_expand<0, false>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/true, 0.f);
-                    wave_sync();
-                    softmax_accumulate(d, l, gh, acc, vbuf, lane, a.kfac, (float)extra);
-                }
-                break;
-            }
-            close_and_expand<0, false>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, 0.f);
-            wave_sync();
-        }
-    }
-    for (int i = lane; i < d.HW; i += 64) a.grad_cost[off + i] = acc[i];
-}
-
-// ---- backward, compile-time sized maps of <= 1024 cells (the 32x32 training case) -----------------------------------
-// Same replay, but the three per-cell backward arrays (upstream gradient, gradient accumulator, softmax numerators) live
-// in REGISTERS: cell i <-> lane (i & 63), slot (i >> 6) with the slot loop fully unrolled, so every index is static.  The
-// LDS footprint drops from 29 to 17 B/cell (9 maps per CU instead of 5) and the softmax of a step touches only the chunks
-// that hold an open cell, with exp2-based exponentials (|rel err| ~1e-6, the contract tolerance is 1e-5).
-template <int LOGW, int LOGH, bool kFastDiv>
-__global__ __launch_bounds__(64) void nastar_backward_small_kernel(const BwdArgs a, const float rcp_sqrtW)
-{
-    constexpr int HW = 1 << (LOGW + LOGH);
-    constexpr int NCH = HW / CHUNK;
-    static_assert(NCH >= 1 && NCH <= 16, "register-resident backward state: at most 16 slots");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    MapDims d = a.d;
-    d.H = 1 << LOGH;
-    d.W = 1 << LOGW;
-    d.HW = HW;
-    d.nchunks = NCH;
-    d.HWp = HW;
-    d.NCp = 64;
-    d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
-    const MapLds l = carve_map_lds(smem, d);
-    const size_t off = (size_t)b * (size_t)HW;
-
-    int start_idx, goal_idx;
-    load_map<true>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx);
-    float gh[NCH], acc[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        gh[c] = upstream_grad(a, off + c * CHUNK + lane);
-        acc[c] = 0.f;
-    }
-
-    if (start_idx >= 0 && goal_idx >= 0) {
-        const LaneConst lc = make_lane_const(d, lane);
-        int extra = 0;  // fixed-point steps the reference adds after this map's goal step (:251), see the generic kernel
-        if (a.t_batch != nullptr && a.iters != nullptr) extra = *a.t_batch - (a.iters[b] - 1);
-        if (extra > 0) {  // torch.clamp backward (:223) zeroes the goal cell's upstream gradient
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                if (c == (goal_idx >> 6) && lane == (goal_idx & 63)) gh[c] = 0.f;
-        }
-        // y_t = softmax over the open list; acc += scale * kfac * y * (G - <G,y>)   (:207-209, :67-68)
-        auto softmax_step = [&](float scale) {
-            const uint32_t cmv = l.chunkmin[lane];                  // lanes >= NCH read KEY_INF padding
-            const uint32_t act = (uint32_t)__ballot(cmv != KEY_INF);  // bit c: chunk c holds an open cell
-            float v[NCH];
-            float ls = 0.f, ld = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                v[c] = 0.f;
-                if ((act >> c) & 1u) {  // wave-uniform
-                    const uint32_t k = l.key[c * CHUNK + lane];
-                    const float e = __builtin_amdgcn_exp2f(ord_to_f32(k) * -1.4426950408889634f);  // exp(-q), key holds q
-                    v[c] = (k != KEY_INF) ? e : 0.f;
-                    ls += v[c];
-                    ld += v[c] * gh[c];
-                }
-            }
-            const float S = wave_sum_f32(ls);
-            const float D = wave_sum_f32(ld);
-            const float dot = D / S;
-            const float w = scale * a.kfac / S;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                if ((act >> c) & 1u) acc[c] += w * v[c] * (gh[c] - dot);
-        };
-        int iters = 0;
-        while (iters < a.max_iters) {
-            softmax_step(1.0f);
-            int C, cl;
-            uint32_t kv;
-            const int s = select_min<false>(d, l, lane, C, cl, kv);
-            if (s < 0) break;
-            ++iters;
-            if (s == goal_idx) {
-                if (extra > 0) {  // the goal's own expansion (it stays open, :224), then `extra` identical steps
-                    close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/true, rcp_sqrtW);
-                    softmax_step((float)extra);
-                }
-                break;
-            }
-            close_and_expand<LOGW, kFastDiv>(d, l, lc, lane, s, C, cl, kv, /*keep_open=*/false, rcp_sqrtW);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) a.grad_cost[off + c * CHUNK + lane] = acc[c];
-}
-
-#endif  // NASTAR_DEV_KERNELS
 
 // ---- get_heuristic standalone (parity/debug) ------------------------------------------------------------
 __global__ __launch_bounds__(64) void nastar_heuristic_kernel(const float* goal, float* out, int H, int W, uint32_t magicW)
@@ -741,45 +287,8 @@ static bool needs_global_state(int H, int W)
     return compact_lds_bytes((int)(nchunks * CCSZ), (int)(((nchunks + 63) / 64) * 64)) > kMaxLdsBytes;
 }
 
-// round-1 layout (17 B/cell, 64-cell chunks): kept behind NASTAR_FLAG_FORCE_LDS for A/B measurements
-__attribute__((unused)) static bool fits_legacy_lds(int H, int W)
-{
-    const long long HW = (long long)H * W;
-    if (HW > 65535) return false;
-    const long long nchunks = (HW + 63) / 64;
-    return map_lds_bytes((int)(nchunks * 64), (int)(((nchunks + 63) / 64) * 64)) <= kMaxLdsBytes;
-}
 
-__attribute__((unused)) static int make_dims(int B, int H, int W, int max_iters, double g_ratio, MapDims& d)
-{
-    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (H > 65535 || W > 65535 || (long long)H * W > 65535) return NASTAR_ERR_UNSUPPORTED;
-    d.H = H;
-    d.W = W;
-    d.HW = H * W;
-    d.nchunks = (d.HW + CHUNK - 1) / CHUNK;
-    d.HWp = d.nchunks * CHUNK;
-    d.NCp = ((d.nchunks + 63) / 64) * 64;
-    d.magicW = (uint32_t)((1ull << 32) / (unsigned)W) + 1u;
-    d.gr = (float)g_ratio;
-    d.omg = (float)(1.0 - g_ratio);  // python evaluates (1 - g_ratio) in double, ATen casts the scalar to fp32
-    d.sqrtW = (float)sqrt((double)W);  // math.sqrt(W) in double, then the fp32 scalar of the division (:207)
-    return NASTAR_OK;
-}
 
-// largest number of 64-cell slots the (clipped) 3x3 neighbourhood of any cell spans, for the register-resident kernel
-__attribute__((unused)) static int reg_max_slot_steps(int H, int W)
-{
-    int best = 1;
-    for (int r = 0; r < H; ++r)
-        for (int c = 0; c < W; ++c) {
-            const int r_lo = r > 0 ? r - 1 : 0, r_hi = r < H - 1 ? r + 1 : r;
-            const int c_lo = c > 0 ? c - 1 : 0, c_hi = c < W - 1 ? c + 1 : c;
-            const int n = (((r_hi * W + c_hi) >> 6) - ((r_lo * W + c_lo) >> 6)) + 1;
-            if (n > best) best = n;
-        }
-    return best;
-}
 
 // map widths for which the FMA-based division by fl32(sqrt(W)) was verified bit-exact against IEEE division for
 // every fp32 f in [2^-100, FLT_MAX] (tools/fastdiv_check.c); widths whose sqrt is a power of two divide exactly.
@@ -799,15 +308,6 @@ using namespace nastar;
 extern "C" {
 
 int nastar_version(void) { return NASTAR_VERSION; }
-
-int nastar_has_dev_kernels(void)
-{
-#if NASTAR_DEV_KERNELS
-    return 1;
-#else
-    return 0;
-#endif
-}
 
 const char* nastar_last_error(void) { return g_last_error; }
 
@@ -848,13 +348,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         return NASTAR_OK;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#if NASTAR_DEV_KERNELS
-    const bool legacy = (flags & (NASTAR_FLAG_FORCE_LDS | NASTAR_FLAG_FORCE_REG)) && B > 0 && H > 0 && W > 0 && fits_legacy_lds(H, W);
-#else
-    if (flags & (NASTAR_FLAG_FORCE_LDS | NASTAR_FLAG_FORCE_REG | NASTAR_FLAG_DUO)) return NASTAR_ERR_UNSUPPORTED;  // make DEV=1
-    const bool legacy = false;
-#endif
-    if (!legacy) {
+    {
         FwdCArgs c;
         int rc = make_cdims(B, H, W, max_iters, g_ratio, c.d);
         if (rc) return rc;
@@ -876,47 +370,8 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const bool lg = sel_log_out != nullptr;
         void (*kern)(const FwdCArgs, const float) = nullptr;
         c.B = B;
-#if NASTAR_DEV_KERNELS
-        // two maps per wavefront (opt-in, NASTAR_FLAG_DUO): measured no faster in bulk and slower per step than one map per
-        // wavefront, kept for the record
-        const int dcpl = (c.d.nchunks + 31) / 32;
-        const size_t dlds = duo_lds_bytes(c.d.HWp, dcpl * 32);
-        if (dlds <= kMaxLdsBytes && (flags & NASTAR_FLAG_DUO)) {
-            c.d.CPL = dcpl;
-            c.d.NCp = dcpl * 32;
-#define NASTAR_DPICK(V4, LW, LH, CPL, FD) \
-    kern = lg ? &nastar_forward_duo_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_duo_kernel<V4, LW, LH, CPL, FD, false>
-            if (vec4 && fast && H == 32 && W == 32) { NASTAR_DPICK(true, 5, 5, 2, true); }
-            else if (vec4 && fast && H == 64 && W == 64) { NASTAR_DPICK(true, 6, 6, 8, true); }
-            else if (vec4 && fast && H == 16 && W == 16) { NASTAR_DPICK(true, 4, 4, 1, true); }
-            else if (vec4 && fast && dcpl == 1) { NASTAR_DPICK(true, 0, 0, 1, true); }
-            else if (vec4 && fast && dcpl == 2) { NASTAR_DPICK(true, 0, 0, 2, true); }
-            else if (vec4 && fast) { NASTAR_DPICK(true, 0, 0, 0, true); }
-            else if (vec4) { NASTAR_DPICK(true, 0, 0, 0, false); }
-            else if (fast) { NASTAR_DPICK(false, 0, 0, 0, true); }
-            else { NASTAR_DPICK(false, 0, 0, 0, false); }
-#undef NASTAR_DPICK
-            return launch(kern, (B + 1) / 2, dlds, s, c, rcp);
-        }
-#endif
 #define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
     kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
-#if NASTAR_DEV_KERNELS
-        static const int ablate = getenv("NASTAR_ABLATE") ? atoi(getenv("NASTAR_ABLATE")) : 0;  // dev timing probe only
-        if (ablate && vec4 && fast && H == 32 && W == 32 && !lg) {
-            switch (ablate) {
-#define NASTAR_ABL(N) case N: kern = &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, N>; break;
-                NASTAR_ABL(128) NASTAR_ABL(129) NASTAR_ABL(130) NASTAR_ABL(132) NASTAR_ABL(136) NASTAR_ABL(144) NASTAR_ABL(160) NASTAR_ABL(192)
-                NASTAR_ABL(142) NASTAR_ABL(175) NASTAR_ABL(255)
-                NASTAR_ABL(300) NASTAR_ABL(301) NASTAR_ABL(302) NASTAR_ABL(303) NASTAR_ABL(304) NASTAR_ABL(305) NASTAR_ABL(306) NASTAR_ABL(307)
-                NASTAR_ABL(308) NASTAR_ABL(309) NASTAR_ABL(310) NASTAR_ABL(311) NASTAR_ABL(312) NASTAR_ABL(313) NASTAR_ABL(314) NASTAR_ABL(315)
-                NASTAR_ABL(316) NASTAR_ABL(317) NASTAR_ABL(318)
-#undef NASTAR_ABL
-                default: return NASTAR_ERR_UNSUPPORTED;
-            }
-            return launch(kern, B, lds, s, c, rcp);
-        }
-#endif
         const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
         // unit-cost layout: the caller promises cost == passable with values in {0, 1} (checked per map by the kernel); taken when the
         // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
@@ -927,11 +382,11 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             return launch(&nastar_forward_unit_kernel<6, true>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
         }
         if (use_asm && vec4 && fast && H == 32 && W == 32)
-            kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, -1>;
+            kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, true> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, true>;
         else if (use_asm && vec4 && fast && H == 16 && W == 16)
-            kern = lg ? &nastar_forward_compact_kernel<true, 4, 4, 1, true, true, -1> : &nastar_forward_compact_kernel<true, 4, 4, 1, true, false, -1>;
+            kern = lg ? &nastar_forward_compact_kernel<true, 4, 4, 1, true, true, true> : &nastar_forward_compact_kernel<true, 4, 4, 1, true, false, true>;
         else if (use_asm && vec4 && fast && H == 64 && W == 64)
-            kern = lg ? &nastar_forward_compact_kernel<true, 6, 6, 4, true, true, -1> : &nastar_forward_compact_kernel<true, 6, 6, 4, true, false, -1>;
+            kern = lg ? &nastar_forward_compact_kernel<true, 6, 6, 4, true, true, true> : &nastar_forward_compact_kernel<true, 6, 6, 4, true, false, true>;
         else if (vec4 && fast && H == 32 && W == 32) { NASTAR_CPICK(true, 5, 5, 1, true); }
         else if (vec4 && fast && H == 64 && W == 64) { NASTAR_CPICK(true, 6, 6, 4, true); }
         else if (vec4 && fast && H == 16 && W == 16) { NASTAR_CPICK(true, 4, 4, 1, true); }
@@ -941,76 +396,9 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         else if (fast) { NASTAR_CPICK(false, 0, 0, 0, true); }
         else { NASTAR_CPICK(false, 0, 0, 0, false); }
 #undef NASTAR_CPICK
-#if NASTAR_DEV_KERNELS
-        // dev probe (tools/session.sh r04_a): extra dynamic LDS per workgroup = fewer resident maps per CU, e.g. 9984 extra bytes = 8
-        // wavefronts per CU instead of 16 -- the contention level a two-maps-per-wavefront kernel would run at
-        static const int lds_pad = getenv("NASTAR_LDS_PAD") ? atoi(getenv("NASTAR_LDS_PAD")) : 0;
-        if (lds_pad > 0 && lds + (size_t)lds_pad <= kMaxLdsBytes) return launch(kern, B, lds + (size_t)lds_pad, s, c, rcp);
-#endif
         return launch(kern, B, lds, s, c, rcp);
     }
-#if !NASTAR_DEV_KERNELS
     return NASTAR_ERR_UNSUPPORTED;
-#else
-    FwdArgs a;
-    int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
-    if (rc) return rc;
-    const size_t lds = map_lds_bytes(a.d.HWp, a.d.NCp);
-    if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
-    a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
-    a.hist = histories_out; a.paths = reinterpret_cast<long long*>(paths_out);
-    a.sel_log = sel_log_out; a.iters = iters_out; a.status = status_out; a.max_iters = max_iters;
-    a.packed = nullptr;
-    const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
-                      aligned16(histories_out) && aligned16(paths_out);
-    const bool multi = a.d.nchunks > 64;
-    const int nstep = reg_max_slot_steps(H, W);
-    if (a.d.HW <= REG_MAX_CELLS && nstep <= 3 && (flags & NASTAR_FLAG_FORCE_REG)) {
-        const float rcp = 1.0f / a.d.sqrtW;
-        const bool fast = fastdiv_verified(W);
-        const bool lg = sel_log_out != nullptr;
-        void (*kern)(const FwdArgs, const float);
-#define NASTAR_PICK(NS, LW)                                                                                   \
-    kern = fast ? (lg ? &nastar_forward_reg_kernel<NS, true, true, LW> : &nastar_forward_reg_kernel<NS, false, true, LW>) \
-                : (lg ? &nastar_forward_reg_kernel<NS, true, false, LW> : &nastar_forward_reg_kernel<NS, false, false, LW>)
-        if (W == 32) { NASTAR_PICK(2, 5); }
-        else if (W == 16) { NASTAR_PICK(2, 4); }
-        else if (W == 64) { NASTAR_PICK(3, 6); }
-        else if (nstep <= 2) { NASTAR_PICK(2, 0); }
-        else { NASTAR_PICK(3, 0); }
-#undef NASTAR_PICK
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), 0, s, a, rcp);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "kernel launch");
-        return NASTAR_OK;
-    }
-    {
-        const float rcp = 1.0f / a.d.sqrtW;
-        const bool fast = fastdiv_verified(W);
-        const bool lg = sel_log_out != nullptr;
-        if (packed_out && vec4 && (a.d.HW % 8 == 0)) {  // fused emission of the bit-packed masks
-            a.packed = packed_out;
-            *packed_done = true;
-        }
-        void (*kern)(const FwdArgs, const float) = nullptr;
-        // hot configurations: aligned, <= 64 chunks, power-of-two width, verified fast division
-#define NASTAR_PICK_LW(LW)                                                                                      \
-    kern = lg ? &nastar_forward_kernel<true, false, LW, true, true> : &nastar_forward_kernel<true, false, LW, true, false>
-        if (vec4 && fast && W == 32 && H == 32)
-            kern = lg ? &nastar_forward_kernel<true, false, 5, true, true, 5> : &nastar_forward_kernel<true, false, 5, true, false, 5>;
-        else if (vec4 && fast && W == 64 && H == 64)
-            kern = lg ? &nastar_forward_kernel<true, false, 6, true, true, 6> : &nastar_forward_kernel<true, false, 6, true, false, 6>;
-        else if (vec4 && !multi && fast && W == 32) { NASTAR_PICK_LW(5); }
-        else if (vec4 && !multi && fast && W == 64) { NASTAR_PICK_LW(6); }
-        else if (vec4 && !multi && fast && W == 16) { NASTAR_PICK_LW(4); }
-#undef NASTAR_PICK_LW
-        else if (vec4 && !multi) kern = lg ? &nastar_forward_kernel<true, false, 0, false, true> : &nastar_forward_kernel<true, false, 0, false, false>;
-        else if (vec4 && multi) kern = lg ? &nastar_forward_kernel<true, true, 0, false, true> : &nastar_forward_kernel<true, true, 0, false, false>;
-        else if (!vec4 && !multi) kern = lg ? &nastar_forward_kernel<false, false, 0, false, true> : &nastar_forward_kernel<false, false, 0, false, false>;
-        else kern = lg ? &nastar_forward_kernel<false, true, 0, false, true> : &nastar_forward_kernel<false, true, 0, false, false>;
-        return launch(kern, B, lds, s, a, rcp);
-    }
-#endif  // NASTAR_DEV_KERNELS
 }
 
 int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
@@ -1036,73 +424,6 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);  // shapes the fused path skips
 }
 
-#if NASTAR_DEV_KERNELS
-static int backward_impl(BwdArgs& a, const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
-                         int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
-                         float* grad_cost_out, void* stream)
-{
-    if (t_batch_dev && !iters) return NASTAR_ERR_NULL;
-    if (!cost || !start || !goal || !passable || !grad_cost_out) return NASTAR_ERR_NULL;
-    int rc = make_dims(B, H, W, max_iters, g_ratio, a.d);
-    if (rc) return rc;
-    const size_t lds = ((map_lds_bytes(a.d.HWp, a.d.NCp) + 15) & ~(size_t)15) + (size_t)a.d.HWp * 12;
-    if (lds > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
-    a.cost = cost; a.start = start; a.goal = goal; a.passable = passable;
-    a.iters = iters; a.t_batch = t_batch_dev; a.grad_cost = grad_cost_out; a.max_iters = max_iters;
-    a.kfac = a.d.omg * (-1.0f / a.d.sqrtW);
-    const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable);
-    const bool multi = a.d.nchunks > 64;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (vec4 && H == 32 && W == 32 && fastdiv_verified(W)) {  // training configuration of the reference (mazes_032)
-        const size_t lds17 = map_lds_bytes(a.d.HWp, a.d.NCp);
-        return launch(nastar_backward_small_kernel<5, 5, true>, B, lds17, s, a, 1.0f / a.d.sqrtW);
-    }
-    if (vec4 && H == 16 && W == 16) {
-        const size_t lds17 = map_lds_bytes(a.d.HWp, a.d.NCp);
-        return launch(nastar_backward_small_kernel<4, 4, true>, B, lds17, s, a, 1.0f / a.d.sqrtW);
-    }
-    if (vec4 && !multi) return launch(nastar_backward_kernel<true, false>, B, lds, s, a);
-    if (vec4 && multi) return launch(nastar_backward_kernel<true, true>, B, lds, s, a);
-    if (!vec4 && !multi) return launch(nastar_backward_kernel<false, false>, B, lds, s, a);
-    return launch(nastar_backward_kernel<false, true>, B, lds, s, a);
-}
-#endif  // NASTAR_DEV_KERNELS
-
-int nastar_backward(const float* grad_histories, const float* cost, const float* start, const float* goal,
-                    const float* passable, int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters,
-                    const int32_t* t_batch_dev, float* grad_cost_out, void* workspace, size_t workspace_bytes,
-                    int flags, void* stream)
-{
-    (void)workspace; (void)workspace_bytes; (void)flags;
-#if !NASTAR_DEV_KERNELS
-    (void)grad_histories; (void)cost; (void)start; (void)goal; (void)passable; (void)B; (void)H; (void)W; (void)g_ratio; (void)max_iters;
-    (void)iters; (void)t_batch_dev; (void)grad_cost_out; (void)stream;
-    return NASTAR_ERR_UNSUPPORTED;  // round-1 kernel: development builds only (make DEV=1); use nastar_backward_replay
-#else
-    if (!grad_histories) return NASTAR_ERR_NULL;
-    BwdArgs a;
-    a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
-    return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
-#endif
-}
-
-int nastar_backward_l1(const float* histories, const float* opt_trajs, const float* grad_loss_dev, const float* cost,
-                       const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
-                       int max_iters, const int32_t* iters, const int32_t* t_batch_dev, float* grad_cost_out, void* stream)
-{
-#if !NASTAR_DEV_KERNELS
-    (void)histories; (void)opt_trajs; (void)grad_loss_dev; (void)cost; (void)start; (void)goal; (void)passable; (void)B; (void)H; (void)W;
-    (void)g_ratio; (void)max_iters; (void)iters; (void)t_batch_dev; (void)grad_cost_out; (void)stream;
-    return NASTAR_ERR_UNSUPPORTED;  // round-1 kernel: development builds only (make DEV=1); use nastar_backward_l1_replay
-#else
-    if (!histories || !opt_trajs) return NASTAR_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
-    BwdArgs a;
-    a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
-    a.l1_scale = (float)(1.0 / ((double)B * H * W));
-    return backward_impl(a, cost, start, goal, passable, B, H, W, g_ratio, max_iters, iters, t_batch_dev, grad_cost_out, stream);
-#endif
-}
 
 // ---- backward by replay of the forward's selection log (nastar_backward_replay.hip.h) ------------------------------------
 static int bwdr_hist_len(int HW, int max_iters) { return (max_iters < HW + 1 ? max_iters : HW + 1) + 2; }

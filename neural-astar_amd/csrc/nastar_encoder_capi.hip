@@ -505,44 +505,10 @@ int nastar_conv3x3_img32_f16(const uint16_t* in, const uint16_t* wpack, const fl
 // ---- generic fp16 / f16x3 building blocks (nastar_conv_flat.hip.h): any image size, any channel count -------------------------------
 namespace nastar {
 
-#ifndef NASTAR_DEV_KERNELS
-#define NASTAR_DEV_KERNELS 0
-#endif
-#if NASTAR_DEV_KERNELS
-// (make DEV=1 only) The DMA-fed 512-pixel kernel (one 8-wave workgroup per CU, two LDS buffers fed by global_load_lds) is a measured NON-improvement:
-// +5..14 % on the 256- to 1024-channel layers of the U-Net, -10 % on the few-slice full-resolution layers, +-2 % on the whole U-Net
-// (fp16), -4 % with split operands -- the register-staged kernel with two 4-wave workgroups per CU stays the default.  Opt-in for A/B
-// runs: NASTAR_ENCODER_FLAGS bit 2048 = wherever its LDS buffers fit, bit 4096 = for layers with >= 256 input channels only.
-template <int NT, bool kFinal, bool kSplit>
-static int launch_flat2(FlatConvArgs fa, hipStream_t s)
-{
-    auto kern = &nastar_conv3x3_flat2_kernel<NT, kFinal, kSplit>;
-    const int nslot = FC2_TP + 2 * (fa.W + 1);
-    const size_t lds = (size_t)2 * fc2_buf_bytes(nslot, NT) + (size_t)NT * 8;
-    int rc = ensure_lds(kern, lds);
-    if (rc) return rc;
-    fa.ntiles = (fa.npix + FC2_TP - 1) / FC2_TP;
-    const unsigned grid = (unsigned)(((fa.ntiles + 7) / 8) * 8 * (fa.COUT / NT));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FC2_THREADS), lds, s, fa);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return NASTAR_OK;
-}
-
-#endif  // NASTAR_DEV_KERNELS
 
 template <int NT, bool kFinal, bool kSplit>
 static int launch_flat(const FlatConvArgs& fa, hipStream_t s)
 {
-#if NASTAR_DEV_KERNELS
-    {
-        const int nslot2 = FC2_TP + 2 * (fa.W + 1);
-        const size_t lds2 = (size_t)2 * fc2_buf_bytes(nslot2, NT) + (size_t)NT * 8;
-        const bool fits = lds2 <= kMaxLdsBytes && (nslot2 * 4 + 63) / 64 <= 8 * FC2_NPQ && 9 * 4 * NT / 64 <= 8 * FC2_NWQ;
-        const int ef = enc_flags();
-        if (fits && ((ef & 2048) || ((ef & 4096) && fa.C1 + fa.C2 >= 256))) return launch_flat2<NT, kFinal, kSplit>(fa, s);
-    }
-#endif
     auto kern = &nastar_conv3x3_flat_kernel<NT, kFinal, kSplit>;
     const size_t lds = (size_t)FC_PIXB + (size_t)(FC_TP + 2 * (fa.W + 1)) * FC_PIXB + (size_t)9 * 4 * NT * 16 + (size_t)NT * 8;
     int rc = ensure_lds(kern, lds);

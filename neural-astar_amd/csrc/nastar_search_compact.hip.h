@@ -205,8 +205,7 @@ __device__ __forceinline__ void compact_open_start(const CompactDims& d, const C
 // ---- selection: first flat index of the minimal key; returns -1 when the open list is empty --------------------------
 // CPL_T > 0: chunk minima per lane known at compile time (1: <= 1024 cells, 4: <= 4096 cells); 0: runtime d.CPL.
 // Lane l owns the CONTIGUOUS entries [l*CPL, (l+1)*CPL): first lane == first chunk == first cell.
-// ABL: timing-only ablation switches of the dev probe tools/probe_ablate.py (results are garbage when ABL != 0)
-template <int CPL_T, int ABL = 0>
+template <int CPL_T>
 __device__ __forceinline__ int compact_select(const CompactDims& d, const CompactLds& l, int lane, uint2& mine)
 {
     uint2 best;  // .x = cell index, .y = key
@@ -232,7 +231,7 @@ __device__ __forceinline__ int compact_select(const CompactDims& d, const Compac
         }
     }
     mine = best;
-    const uint32_t M = (ABL & 32) ? (uint32_t)__builtin_amdgcn_readlane((int)best.y, 0) : wave_min_scalar_u32(best.y);
+    const uint32_t M = wave_min_scalar_u32(best.y);
     const int L = __builtin_ctzll(__ballot(best.y == M));  // never empty: M is one of the lanes' keys
     const int s = __builtin_amdgcn_readlane((int)best.x, L);
     return M == KEY_INF ? -1 : s;  // open list empty
@@ -258,7 +257,7 @@ __device__ __forceinline__ CompactLane make_compact_lane(const CompactDims& d, i
 
 // ---- close s (:222-225) and relax its <= 8 Moore neighbours (:228-249); re-minimise the chunk of s without it ----------
 // CPL_T == 1: `mine` is this lane's own cmin entry as read by compact_select (nothing has touched it since).
-template <int LOGW, bool kFastDiv, int CPL_T, int ABL = 0>
+template <int LOGW, bool kFastDiv, int CPL_T>
 __device__ __forceinline__ void compact_expand(const CompactDims& d, const CompactLds& l, const CompactLane& lc, int lane, int s,
                                                int goal_r, int goal_c, float rcp_sqrtW, const uint2 mine)
 {
@@ -276,14 +275,8 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
     // the cell this lane looks at: its neighbour of s*, its cell of the chunk, or s* itself (idle lanes)
     const int il = inb ? s + lc.off : (lc.is_chk ? cbase + (lane & (CCSZ - 1)) : s);
     // one batch of LDS reads: (g, cost) of s* (broadcast) and of this lane's cell
-    float2 gs, gl;
-    if constexpr (ABL & 64) {
-        gs = make_float2((float)s, 1.0f);
-        gl = make_float2((float)il, 1.0f);
-    } else {
-        gs = l.gc[s];
-        gl = l.gc[il];
-    }
+    const float2 gs = l.gc[s];
+    const float2 gl = l.gc[il];
     // position of il (independent of the reads: overlaps their latency)
     int rl, cl;
     if constexpr (LOGW) {
@@ -293,7 +286,7 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
         rl = (int)div_magic((uint32_t)il, d.magicW);
         cl = il - rl * d.W;
     }
-    const float h0 = (ABL & 1) ? (float)(rl + cl) : heuristic0_fast(rl, cl, goal_r, goal_c);
+    const float h0 = heuristic0_fast(rl, cl, goal_r, goal_c);
     const float hh = d.omg * (h0 + gl.y);  // :191-192 h = h0 + cost ; :206 (1-g_ratio)*h
     // g2 = g[s*] + cost[s*]  (:234: expand((g + cost_maps) * selected)) -- step cost of the node being LEFT
     const float g2 = gs.x + gs.y;
@@ -304,28 +297,18 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
     // chunk minimum without s*: open <=> finite g
     const bool open_l = lc.is_chk & (fabsf(gl.x) < NASTAR_POS_INF) & (il != s);
     const uint32_t kk = open_l ? k : KEY_INF;
-    uint32_t Mc, ci;
-    if constexpr (ABL & 2) {
-        Mc = (uint32_t)__builtin_amdgcn_readlane((int)kk, 17);
-        ci = (uint32_t)cbase + 1u;
-    } else {
-        const uint32_t mc = row_min16_u32(kk);
-        const unsigned long long firstm = __ballot(lc.is_chk & (kk == mc));  // bits 16..31; never empty
-        Mc = (uint32_t)__builtin_amdgcn_readlane((int)mc, 16);
-        ci = (uint32_t)(cbase + __builtin_ctzll(firstm) - 16);
-    }
+    const uint32_t mc = row_min16_u32(kk);
+    const unsigned long long firstm = __ballot(lc.is_chk & (kk == mc));  // bits 16..31; never empty
+    const uint32_t Mc = (uint32_t)__builtin_amdgcn_readlane((int)mc, 16);
+    const uint32_t ci = (uint32_t)(cbase + __builtin_ctzll(firstm) - 16);
     // All stores are unconditional: a lane with nothing to write targets its private dump word / a no-op atomic.
     uint32_t* const dmp = l.dump + lane;
     float* const g_dst = upd ? &l.gc[il].x : ((lane == 8) ? &l.gc[s].x : reinterpret_cast<float*>(dmp));
     uint8_t* const p_dst = upd ? &l.pdir[il] : reinterpret_cast<uint8_t*>(dmp);
-    if constexpr (!(ABL & 16)) {
-        *g_dst = upd ? g2 : NASTAR_NEG_INF;  // :238 g update          | :222-225 s* joins the closed list, leaves the open list
-        *p_dst = (uint8_t)lc.pcode;          // :246-249 parent = s*
-    }
+    *g_dst = upd ? g2 : NASTAR_NEG_INF;  // :238 g update          | :222-225 s* joins the closed list, leaves the open list
+    *p_dst = (uint8_t)lc.pcode;          // :246-249 parent = s*
     // exact minimum of the chunk without s* (must land before the atomics below; LDS executes a wave's ops in order)
-    if constexpr (ABL & 4) {
-        if (lane == 63) l.dump[0] = Mc + ci;
-    } else if constexpr (CPL_T == 1) {
+    if constexpr (CPL_T == 1) {
         // every lane rewrites its own entry -- unchanged, except the owner of chunk C: one unmasked ds_write_b64
         const bool owner = lane == (s >> CCL);
         uint2 e;
@@ -336,11 +319,7 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
         if (lane == 16) l.cmin[s >> CCL] = cmin_entry(Mc, ci);
     }
     // :242 (re)opened neighbours enter their chunk's minimum; idle lanes issue min(x, ~0) on their own entry: a no-op
-    if constexpr (ABL & 8) {
-        if (lane == 62) l.dump[1] = k;
-    } else {
-        atomicMin(upd ? &l.cmin[il >> CCL] : &l.cmin[lane], upd ? cmin_entry(k, (uint32_t)il) : ~0ull);
-    }
+    atomicMin(upd ? &l.cmin[il >> CCL] : &l.cmin[lane], upd ? cmin_entry(k, (uint32_t)il) : ~0ull);
     wave_order();
 }
 

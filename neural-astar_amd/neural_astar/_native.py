@@ -36,13 +36,10 @@ _ERR_NAMES = {
 # every symbol include/nastar.h declares -- tests check the library exports all of them
 EXPORTED_SYMBOLS = (
     "nastar_version",
-    "nastar_has_dev_kernels",
     "nastar_last_error",
     "nastar_workspace_bytes",
     "nastar_forward",
     "nastar_forward_packed",
-    "nastar_backward",
-    "nastar_backward_l1",
     "nastar_backward_workspace_bytes",
     "nastar_backward_replay",
     "nastar_backward_l1_replay",
@@ -119,8 +116,6 @@ def load() -> ctypes.CDLL:
     vp, ci, cd, cz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
     lib.nastar_version.restype = ci
     lib.nastar_version.argtypes = []
-    lib.nastar_has_dev_kernels.restype = ci
-    lib.nastar_has_dev_kernels.argtypes = []
     lib.nastar_last_error.restype = ctypes.c_char_p
     lib.nastar_last_error.argtypes = []
     lib.nastar_workspace_bytes.restype = cz
@@ -129,10 +124,6 @@ def load() -> ctypes.CDLL:
     lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_forward_packed.restype = ci
     lib.nastar_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp]
-    lib.nastar_backward.restype = ci
-    lib.nastar_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
-    lib.nastar_backward_l1.restype = ci
-    lib.nastar_backward_l1.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp]
     lib.nastar_backward_workspace_bytes.restype = cz
     lib.nastar_backward_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.nastar_backward_replay.restype = ci

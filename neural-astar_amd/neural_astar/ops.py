@@ -1,6 +1,6 @@
 """PyTorch-ROCm custom ops over the C ABI (``include/nastar.h``).
 
-``torch.ops.nastar.astar_forward`` / ``astar_backward`` hand raw device pointers and torch's current HIP stream to
+``torch.ops.nastar.astar_forward`` / ``astar_backward_replay`` hand raw device pointers and torch's current HIP stream to
 ``libnastar_hip.so``.  PyTorch is plumbing here (allocation, streams, autograd bookkeeping); the search itself is
 the hand-written HIP kernel.  There is no CPU path: CPU tensors raise.
 """
@@ -13,7 +13,7 @@ import torch
 
 from . import _native
 
-__all__ = ["astar_forward", "astar_backward", "astar_backward_replay", "astar_backward_l1", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
+__all__ = ["astar_forward", "astar_backward_replay", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
 
 
 def max_iters_for(W: int, Tmax: float, training: bool) -> int:
@@ -36,8 +36,6 @@ FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
 # development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
-# development knob: NASTAR_BACKWARD=reselect keeps the round-1 backward kernels (A/B measurements)
-BACKWARD_MODE = os.environ.get("NASTAR_BACKWARD", "replay")
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -88,30 +86,6 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0):
             cost.new_empty((B, max_iters) if want_log else (0,), dtype=torch.int32))
 
 
-@torch.library.custom_op("nastar::astar_backward", mutates_args=())
-def astar_backward(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
-                   passable: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
-                   t_batch: Optional[torch.Tensor]) -> torch.Tensor:
-    _require_device(grad_hist, cost, start, goal, passable)
-    lib = _native.load()
-    grad_hist, cost, start, goal, passable = (x.contiguous() for x in (grad_hist, cost, start, goal, passable))
-    B, H, W = cost.shape
-    dev = cost.device
-    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        rc = lib.nastar_backward(grad_hist.data_ptr(), cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
-                                 passable.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
-                                 t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(),
-                                 None, 0, 0, _stream_ptr(dev))
-    _native.check(rc, "nastar_backward")
-    return grad_cost
-
-
-@astar_backward.register_fake
-def _(grad_hist, cost, start, goal, passable, g_ratio, max_iters, iters, t_batch):
-    return torch.empty_like(cost)
-
-
 @torch.library.custom_op("nastar::astar_backward_replay", mutates_args=())
 def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
                           passable: torch.Tensor, sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
@@ -158,16 +132,11 @@ def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
     # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
     # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
     t_batch = BatchCoupling.t_batch(iters)
-    if sel_log.numel() > 0 and BACKWARD_MODE != "reselect":  # the forward logged its selections: replay them
-        grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
-                                                           ctx.g_ratio, ctx.max_iters, iters, t_batch)
-    else:  # round-1 kernels: repeat the selection and sweep the open list every step (LDS-resident maps only; `make DEV=1` builds)
-        if not _native.load().nastar_has_dev_kernels():
-            raise RuntimeError("backward needs the forward's selection log: call astar_forward(..., want_log=True) "
-                               "(DifferentiableAstar.forward does whenever cost_maps.requires_grad); the log-free round-1 backward "
-                               "kernels are only in development builds (make -C neural-astar_amd/csrc DEV=1)")
-        grad_cost = torch.ops.nastar.astar_backward(g_hist.contiguous(), cost, start, goal, passable, ctx.g_ratio,
-                                                    ctx.max_iters, iters, t_batch)
+    if sel_log.numel() == 0:
+        raise RuntimeError("backward needs the forward's selection log: call astar_forward(..., want_log=True) "
+                           "(DifferentiableAstar.forward does whenever cost_maps.requires_grad)")
+    grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
+                                                       ctx.g_ratio, ctx.max_iters, iters, t_batch)
     return grad_cost, None, None, None, None, None, None, None
 
 
@@ -217,38 +186,13 @@ def _(histories, opt_trajs):
     return histories.new_empty((1,))
 
 
-@torch.library.custom_op("nastar::astar_backward_l1", mutates_args=())
-def astar_backward_l1(histories: torch.Tensor, opt_trajs: torch.Tensor, grad_loss: Optional[torch.Tensor], cost: torch.Tensor,
-                      start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor, g_ratio: float, max_iters: int,
-                      iters: torch.Tensor, t_batch: Optional[torch.Tensor]) -> torch.Tensor:
-    """dL/dcost for L = grad_loss * mean|histories - opt_trajs|: the sign gradient is formed inside the backward kernel."""
-    _require_device(histories, opt_trajs, cost, start, goal, passable)
-    lib = _native.load()
-    histories, opt_trajs, cost, start, goal, passable = (x.contiguous() for x in (histories, opt_trajs, cost, start, goal, passable))
-    B, H, W = cost.shape
-    dev = cost.device
-    gl = grad_loss.reshape(1).to(torch.float32).contiguous() if grad_loss is not None else None
-    grad_cost = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        rc = lib.nastar_backward_l1(histories.data_ptr(), opt_trajs.data_ptr(), gl.data_ptr() if gl is not None else None,
-                                    cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
-                                    float(g_ratio), int(max_iters), iters.data_ptr(),
-                                    t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(), _stream_ptr(dev))
-    _native.check(rc, "nastar_backward_l1")
-    return grad_cost
-
-
-@astar_backward_l1.register_fake
-def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, g_ratio, max_iters, iters, t_batch):
-    return torch.empty_like(cost)
-
-
 @torch.library.custom_op("nastar::astar_backward_l1_replay", mutates_args=())
 def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, grad_loss: Optional[torch.Tensor],
                              cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
                              sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
                              t_batch: Optional[torch.Tensor]) -> torch.Tensor:
-    """astar_backward_l1 through the replay kernel (the sign gradient is formed while loading)."""
+    """dL/dcost for L = grad_loss * mean|histories - opt_trajs| by replay of the selection log: the sign gradient is formed while the
+    upstream values are loaded (no gradient tensor is materialised)."""
     _require_device(histories, opt_trajs, cost, start, goal, passable)
     lib = _native.load()
     histories, opt_trajs, cost, start, goal, passable, sel_log = (
@@ -275,13 +219,12 @@ def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, sel_log, g_r
 
 
 class _AstarL1Loss(torch.autograd.Function):
-    """search + L1 loss as ONE autograd node: forward = nastar_forward + nastar_l1_loss, backward = nastar_backward_l1."""
+    """search + L1 loss as ONE autograd node: forward = nastar_forward + nastar_l1_loss, backward = nastar_backward_l1_replay."""
 
     @staticmethod
     def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters):
         with torch.no_grad():
-            want_log = BACKWARD_MODE != "reselect"
-            hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log)
+            hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, True)
             loss = torch.ops.nastar.l1_loss(hist, opt_trajs)
         ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
@@ -294,12 +237,8 @@ class _AstarL1Loss(torch.autograd.Function):
         cost, start, goal, passable, opt_trajs, hist, iters, sel_log = ctx.saved_tensors
         if g_loss is None:
             return None, None, None, None, None, None, None
-        if sel_log.numel() > 0:
-            grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
-                                                                  ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters))
-        else:
-            grad_cost = torch.ops.nastar.astar_backward_l1(hist, opt_trajs, g_loss, cost, start, goal, passable, ctx.g_ratio,
-                                                           ctx.max_iters, iters, BatchCoupling.t_batch(iters))
+        grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
+                                                              ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters))
         return grad_cost, None, None, None, None, None, None
 
 

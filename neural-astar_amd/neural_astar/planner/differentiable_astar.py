@@ -187,7 +187,7 @@ class DifferentiableAstar(nn.Module):
         # the selection log doubles as the tape of the backward (replayed by nastar_backward_replay): keep it whenever
         # autograd will need it
         want_log = bool(store_intermediate_results) or (
-            torch.is_grad_enabled() and cost_maps.requires_grad and ops.BACKWARD_MODE != "reselect")
+            torch.is_grad_enabled() and cost_maps.requires_grad)
         if not _capturing(cost_maps):
             self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
         # VanillaAstar hands ONE tensor over as cost and obstacle map: the unit-cost kernel (see __init__) applies when it is binary,

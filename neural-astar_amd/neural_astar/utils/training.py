@@ -7,7 +7,7 @@ The reference's ``PlannerModule.training_step`` (``utils/training.py:55-61``) is
 
 followed by ``loss.backward()``: autograd materialises ``sign(histories - opt_trajs) / numel`` and hands it to the search's
 backward.  That code keeps working unchanged against this package.  ``fused_l1_step`` is the same computation as ONE autograd
-node: the loss is a fixed-order device reduction and the sign gradient is formed inside ``nastar_backward_l1`` -- no gradient
+node: the loss is a fixed-order device reduction and the sign gradient is formed inside ``nastar_backward_l1_replay`` -- no gradient
 tensor, three fewer elementwise launches per step (they are a visible fraction of a 100-map training batch).
 """
 from __future__ import annotations

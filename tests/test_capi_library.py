@@ -46,19 +46,11 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, one, 16, 0, None) == _native.NASTAR_ERR_WORKSPACE
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
-    dev_build = bool(lib.nastar_has_dev_kernels())  # round-1 backward entry points: `make DEV=1` builds only, UNSUPPORTED in the product library
-    assert lib.nastar_backward(one, one, one, one, one, 1, 8, 8, 0.5, 64, None, one, one, None, 0, 0, None) == (
-        _native.NASTAR_ERR_NULL if dev_build else _native.NASTAR_ERR_UNSUPPORTED)
     assert lib.nastar_backward_replay(None, one, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, one, 64, 0, None) == _native.NASTAR_ERR_NULL
-    for flag in (1, 2, 4):  # NASTAR_FLAG_FORCE_LDS / _FORCE_REG / _DUO: development kernels
-        rc = lib.nastar_forward(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, flag, None)
-        assert rc == (_native.NASTAR_ERR_BAD_SHAPE if dev_build else _native.NASTAR_ERR_UNSUPPORTED), (flag, rc)
+    for sym in ("nastar_backward", "nastar_backward_l1", "nastar_has_dev_kernels"):  # rounds 1-3 legacy entry points: gone in 0.4.0
+        assert not hasattr(lib, sym), sym
     assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL
     # training / data-path / encoder entry points
-    assert lib.nastar_backward_l1(None, one, None, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, None) == (
-        _native.NASTAR_ERR_NULL if dev_build else _native.NASTAR_ERR_UNSUPPORTED)
-    assert lib.nastar_backward_l1(one, one, None, one, one, one, one, 0, 8, 8, 0.5, 64, one, None, one, None) == (
-        _native.NASTAR_ERR_BAD_SHAPE if dev_build else _native.NASTAR_ERR_UNSUPPORTED)
     assert lib.nastar_l1_loss(one, None, 64, one, one, 2048, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_l1_loss(one, one, 0, one, one, 2048, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_l1_loss(one, one, 64, one, one, 8, None) == _native.NASTAR_ERR_WORKSPACE

@@ -15,13 +15,6 @@ pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-5  # north_star: "within 1e-5 for float cost/loss"
 
 
-def _need_dev_kernels():
-    """round-1 / negative-result kernels live in `make DEV=1` builds only (csrc/Makefile); the product library reports 0 here"""
-    from neural_astar import _native
-    if not _native.load().nastar_has_dev_kernels():
-        pytest.skip("superseded kernel: built only by `make -C neural-astar_amd/csrc DEV=1`")
-
-
 def _dev():
     assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
     return torch.device("cuda:0")
@@ -72,21 +65,13 @@ def test_forward_matches_reference_golden(name):
             assert np.array_equal(log[b, :n], g.sel_log[b, :n])
 
 
-@pytest.mark.parametrize("mode", ["replay", "reselect"])
 @pytest.mark.parametrize("name", [n for n in G.names() if n.startswith("grad_")])
-def test_backward_matches_reference_autograd(name, mode, monkeypatch):
+def test_backward_matches_reference_autograd(name):
     """dL/dcost of the reference's autograd (differentiable_astar.py:203-252) for every size class of the backward launchers:
-    32x32 (register kernel), 64x64 / 12x12 / 16x16 / 20x45 / 24x40 / 7x5 (generic kernels) and 96x96 / 100x100 (replay only:
-    the round-1 `reselect` kernels keep their state + three softmax arrays in LDS and stop at ~5.4 k cells).
-    replay = nastar_backward_replay (selection log + event accounting), reselect = nastar_backward (round 1)."""
-    from neural_astar import ops
+    32x32 / 16x16 (hand-scheduled replay loop), 64x64 / 12x12 / 20x45 / 24x40 / 7x5 (generic LDS kernels) and 96x96 / 100x100
+    (state in the HBM workspace): nastar_backward_replay = the forward's selection log + per-event accounting."""
     from neural_astar.planner.differentiable_astar import DifferentiableAstar
     g = G.load(name)
-    if mode == "reselect":
-        _need_dev_kernels()
-    if mode == "reselect" and g.H * g.W > 5400:
-        pytest.skip("round-1 backward kernels: LDS-resident maps only")
-    monkeypatch.setattr(ops, "BACKWARD_MODE", mode)
     m = DifferentiableAstar(g_ratio=g.g_ratio, Tmax=g.Tmax).to(_dev())
     m.train(g.training)
     cost = _t(g.cost_maps).requires_grad_(True)
@@ -377,26 +362,6 @@ def test_fused_packed_output_equals_pack_kernel():
         assert torch.equal(packed, ref), (H, W)
         h2, p2 = parallel.unpack_masks(packed, H, W)
         assert torch.equal(h2[:, 0], hist) and torch.equal(p2[:, 0], paths)
-
-
-def test_register_resident_kernel_variant_still_matches_reference():
-    """The opt-in VGPR-resident kernel (NASTAR_FLAG_FORCE_REG) is kept correct even though it is not the default."""
-    from neural_astar import _native
-    _need_dev_kernels()
-    lib = _native.load()
-    dev = _dev()
-    for name in ("rand32_ucost_g050", "maze32_vanilla_g050", "rand32_qcost_g050", "rand20x45_ucost_g050", "maze32_train_T025"):
-        g = G.load(name)
-        c, s, go, p = (_t(x[:, 0]) for x in (g.cost_maps, g.start_maps, g.goal_maps, g.passable))
-        hist = torch.empty((g.B, g.H, g.W), device=dev)
-        paths = torch.empty((g.B, g.H, g.W), dtype=torch.int64, device=dev)
-        iters = torch.empty((g.B,), dtype=torch.int32, device=dev)
-        status = torch.empty((g.B,), dtype=torch.int32, device=dev)
-        rc = lib.nastar_forward(c.data_ptr(), s.data_ptr(), go.data_ptr(), p.data_ptr(), g.B, g.H, g.W, g.g_ratio, g.max_iters,
-                                hist.data_ptr(), paths.data_ptr(), None, iters.data_ptr(), status.data_ptr(), None, 0, 2,
-                                torch.cuda.current_stream(dev).cuda_stream)
-        assert rc == 0
-        assert np.array_equal(hist.cpu().numpy(), g.histories[:, 0]) and np.array_equal(paths.cpu().numpy(), g.paths[:, 0]), name
 
 
 def test_validation_pair_launch_equals_two_separate_searches():

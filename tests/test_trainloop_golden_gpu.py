@@ -8,12 +8,14 @@ Here: a DEFAULT-constructed ``NeuralAstar`` (``encoder_backend = "auto"`` -> the
 
 Bars per step: loss within 1e-6, cost maps within 1e-5, histories / paths identical (every map's selection margin is > 2e-5 in the
 golden), BatchNorm running statistics within 1e-5, ``num_batches_tracked`` equal.  Parameters after each update: RMSprop divides every
-element's gradient by its own running magnitude, so an element's update carries the RELATIVE error of that element's gradient -- the
-1e-4-of-the-tensor-maximum the step test grants becomes 1e-4 / rho for an element whose gradient is rho x the tensor's maximum.  The test
-therefore states both: the fraction of elements within 1e-5 of the tensor's parameter range (reported), and a per-element bound
-``1e-5 * max|p| + k * 0.01 * min(1, eps_g / rho)`` that every element must meet (0.01 = the largest step RMSprop(lr 1e-3, alpha 0.99) can
-take, k = steps so far, eps_g = 2e-4); elements whose reference gradient is below eps_g of the tensor maximum ("sign-noise" elements: the
-reference's own update direction is rounding noise there) are counted and reported, not hidden."""
+element's gradient by its own running magnitude (+ 1e-8), so an element's update is NOT a smooth function of the gradient tensor: where
+|g| is within a few orders of 1e-7 -- or of the rounding noise of the backward pass -- a gradient error far inside the step test's bar
+(1e-4 of the tensor's maximum) moves the update by up to the whole step, 0.01.  The test therefore states both: the fraction of elements
+within 1e-5 of the tensor's parameter range (reported, per step), and a per-element bound that every element must meet: 1e-5 of the
+range + 1.5 x the deviation RMSprop ITSELF produces when the reference's gradients of steps 0..k are all shifted by +eps or by -eps,
+eps = 1e-4 of that step's tensor maximum (the optimiser is simulated in float64 on the stored gradients).  Elements whose reference
+gradient is below eps ("sign-noise" elements: the direction of the reference's own update is rounding noise there) are counted and
+reported, not hidden; conv biases in front of a BatchNorm (true gradient exactly 0) are handled apart."""
 import os
 import types
 
@@ -25,7 +27,19 @@ import golden_util as G
 
 pytestmark = pytest.mark.gpu
 NAME = "trainloop_maze32_3steps"
-EPS_G = 2e-4
+EPS_G = 1e-4  # the gradient accuracy the one-step golden test grants per tensor (max |diff| / max |ref|)
+
+
+def _rmsprop_paths(gs, lr, alpha=0.99, eps=1e-8):
+    """parameter displacement after each step of torch.optim.RMSprop (no momentum, not centered) for the gradient sequence `gs`"""
+    v = np.zeros_like(gs[0])
+    p = np.zeros_like(gs[0])
+    out = []
+    for g in gs:
+        v = alpha * v + (1.0 - alpha) * g * g
+        p = p - lr * g / (np.sqrt(v) + eps)
+        out.append(p.copy())
+    return out
 
 
 def _dev():
@@ -59,6 +73,7 @@ def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
     na.encoder_backend = backend
     module = T.PlannerModule(na, types.SimpleNamespace(params=types.SimpleNamespace(lr=float(z["lr"]))))
     module.train()
+    lr = float(z["lr"])
     opt = module.configure_optimizers()
     assert isinstance(opt, FusedRMSprop) and isinstance(opt, torch.optim.RMSprop)
     # what the default-constructed planner actually runs: the MFMA training trunk, not torch.nn
@@ -123,15 +138,20 @@ def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
                 d = (p.detach().double().cpu() - ref).abs()
                 scale = float(ref.abs().max().clamp_min(1e-30))
                 tol0 = 1e-5 * scale
-                if t + "grad16/" + name in z.files:
-                    rho = torch.from_numpy(z[t + "grad16/" + name].astype(np.float32)).abs().double()
-                else:  # no gradient reached it in the reference either
-                    rho = torch.ones_like(ref)
-                bound = tol0 + (k + 1) * 0.01 * torch.clamp(EPS_G / rho.clamp_min(1e-30), max=1.0) * 1.05
-                assert bool((d <= bound).all()), (k, name, float((d - bound).max()))
+                gs, es = [], []
+                for j in range(k + 1):  # the reference's gradients of steps 0..k (fp16 of g / max|g| + the maximum: 5e-4 relative, ample here)
+                    tj = f"step{j}/"
+                    mx = float(z[tj + "gradmax/" + name])
+                    gs.append(z[tj + "grad16/" + name].astype(np.float64) * mx)
+                    es.append(EPS_G * mx)
+                base = _rmsprop_paths(gs, lr)[-1]
+                up = _rmsprop_paths([g_ + e_ for g_, e_ in zip(gs, es)], lr)[-1]
+                dn = _rmsprop_paths([g_ - e_ for g_, e_ in zip(gs, es)], lr)[-1]
+                bound = tol0 + 1.5 * torch.from_numpy(np.maximum(np.abs(up - base), np.abs(dn - base)))
+                assert bool((d <= bound).all()), (k, name, float((d - bound).max()), float(d.max()))
                 n_el += d.numel()
                 n_in += int((d <= tol0).sum())
-                n_noise += int((rho < EPS_G).sum())
+                n_noise += int((np.abs(gs[-1]) < es[-1]).sum())
                 worst_rel = max(worst_rel, float(d.max()) / scale)
             for name, b in na.named_buffers():
                 ref = torch.from_numpy(np.asarray(z[t + "buffer/" + name]))

@@ -6,7 +6,9 @@ set -u
 S=${1:?session name}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"
-DEVLIB=$R/neural-astar_amd/lib/libnastar_hip_dev.so   # make -C neural-astar_amd/csrc DEV=1 BUILD=build_dev OUT=../lib/libnastar_hip_dev.so
+# r04_a only: a build of commit 87d8995's tree with the development kernels of rounds 1-3 (make DEV=1 BUILD=build_dev OUT=../lib/libnastar_hip_dev.so);
+# those kernels -- two maps per wavefront among them -- were measured there one last time and then deleted (NOTES.md)
+DEVLIB=$R/neural-astar_amd/lib/libnastar_hip_dev.so
 case "$S" in
 r04_a)
   # Throughput regime of the search: what binds it, and what two maps per wavefront can and cannot buy.
@@ -84,6 +86,14 @@ a=json.load(open("$O/train_${c}.json")); b=json.load(open("$O/train_${c}_rccl1.j
 print("$c", "single", round(a["ms_per_step"],3), "ms; 1-rank RCCL sync_bn on", round(b["ms_per_step"],3), "off", b.get("sync_bn"))
 P
   done
+  ;;
+r04_e)
+  # after the legacy (DEV) kernels and entry points were removed: the whole GPU suite, smoke, the training-loop golden verbosely
+  O=gpurun_out/r04/e; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -8 $O/all_gpu_tests.log
+  python -m pytest tests/test_trainloop_golden_gpu.py -q -s -m gpu > $O/trainloop.log 2>&1; echo "trainloop rc=$?"
+  grep -a "TRAINLOOP\|passed\|failed\|^E  " $O/trainloop.log | cut -c1-1200 | tail -12
+  python __graft_entry__.py smoke 2>&1 | tail -2
   ;;
 *)
   echo "unknown session $S"; exit 2;;
