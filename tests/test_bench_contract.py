@@ -40,8 +40,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(j["value"] - 4096 * 4 / (j["ms_per_step"] * 4e-3)) < 1e-6 * j["value"]  # value = units of the K steps / their wall time
-    im = j["issue_model"]
-    assert im["bound"] == "valu-issue" and 0.0 < im["frac"] < 1.0
+    im = j["issue_model"]  # pipe model: what the launch costs the VALU / LDS pipes, and what its longest chain alone costs
+    assert 0.0 < im["valu_busy_frac"] < 1.0 and 0.0 < im["lds_busy_frac"] < 1.0 and 0.0 < im["frac_of_serial_floor"] < 1.5
+    assert im["instructions_per_step"] == 71 and im["serial_floor_us"] > 0
+    assert rf["frac_counter_bytes"] is None or 0.0 < rf["frac_counter_bytes"] < rf["frac"]
+    ce = j["contract_exact_no_prewarm"]  # the W + K protocol run first, before the untimed pre-warm launches
+    assert ce["value"] > 0 and abs(ce["value"] - 4096 * 4 / (ce["ms_per_step"] * 4e-3)) < 1e-6 * ce["value"]
 
 
 @pytest.mark.gpu

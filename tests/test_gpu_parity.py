@@ -757,10 +757,10 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
                                          ("g03", u, H * H, 0.3, True), ("vanilla_nolog", pr.map_designs, H * H, 0.5, False),
                                          ("g08_nolog", u, H * H, 0.8, False)):
             outs = {}
-            for flags in (0, 128, 16, 8):
+            for flags in (0, 32, 128, 16, 8):  # 32 = without the dive (64x64) / without the per-map dive switch (32x32, 16x16)
                 ops.FORWARD_FLAGS = flags
                 outs[flags] = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, mi, want_log=log)
-            for flags in (128, 16, 8):
+            for flags in (32, 128, 16, 8):
                 for k, name in enumerate(("histories", "paths", "iters", "status", "sel_log")):
                     a, b = outs[0][k], outs[flags][k]
                     if name == "sel_log":  # entries past a map's own step count are unwritten
@@ -793,12 +793,13 @@ def test_unit_cost_kernel_equals_the_general_kernel_and_the_oracle(kind, H, B):
     from neural_astar.utils import synthetic as syn
     from oracle import oracle as O
     pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=1234)
-    for gr, mi in ((0.5, H * H), (0.2, H * H), (1.0, H * H), (0.5, H * H // 4)):
-        ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 0)
-        got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 64)
-        for k, name in enumerate(("histories", "paths", "iters", "status")):
-            assert np.array_equal(ref[k], got[k]), (gr, mi, name)
-        assert (got[3] == 0).all()
+    for gr, mi in ((0.5, H * H), (0.2, H * H), (1.0, H * H), (0.5, H * H // 4), (0.5, 20)):
+        ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 8)   # hipcc's own code for the step, general layout
+        for fl in (64, 64 | 32):  # unit-cost layout with and without the dive / the per-map dive switch
+            got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, fl)
+            for k, name in enumerate(("histories", "paths", "iters", "status")):
+                assert np.array_equal(ref[k], got[k]), (gr, mi, fl, name)
+            assert (got[3] == 0).all()
     n = 512
     o = O.forward(pr.map_designs[:n], pr.start_maps[:n], pr.goal_maps[:n], pr.map_designs[:n], 0.5, H * H, mode="sm")
     got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 64)

@@ -101,6 +101,7 @@ def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
         return c
     na.encode = encode
     report = []
+    violations = []
     conv_bias_before_bn = {n + ".bias" for n, mod in na.named_modules() if isinstance(mod, torch.nn.Conv2d)}
     try:
         for k in range(n_steps):
@@ -148,7 +149,12 @@ def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
                 up = _rmsprop_paths([g_ + e_ for g_, e_ in zip(gs, es)], lr)[-1]
                 dn = _rmsprop_paths([g_ - e_ for g_, e_ in zip(gs, es)], lr)[-1]
                 bound = tol0 + 1.5 * torch.from_numpy(np.maximum(np.abs(up - base), np.abs(dn - base)))
-                assert bool((d <= bound).all()), (k, name, float((d - bound).max()), float(d.max()))
+                bad = d > bound
+                if bool(bad.any()):  # say WHICH elements and how far their gradient would have to be off, then fail
+                    i = int(torch.argmax((d - bound).flatten()))
+                    violations.append(dict(step=k, name=name, n=int(bad.sum()), of=d.numel(), worst_excess=float((d - bound).flatten()[i]),
+                                           d=float(d.flatten()[i]), bound=float(bound.flatten()[i]), rho=float(abs(gs[-1].flatten()[i]) / max(es[-1] / EPS_G, 1e-300)),
+                                           gradmax=es[-1] / EPS_G))
                 n_el += d.numel()
                 n_in += int((d <= tol0).sum())
                 n_noise += int((np.abs(gs[-1]) < es[-1]).sum())
@@ -167,6 +173,8 @@ def test_three_steps_of_the_training_loop_match_the_reference_loop(backend):
         T.fused_l1_step = orig_step
         del na.encode
     print("TRAINLOOP", backend, report)
+    print("TRAINLOOP violations", backend, violations)
+    assert not violations, violations
     if backend == "auto":
         assert len(trunk_calls) == n_steps and all(p == "f16x3" for p in trunk_calls), trunk_calls  # the MFMA training trunk ran every step
     else:
