@@ -95,6 +95,25 @@ r04_e)
   grep -a "TRAINLOOP\|passed\|failed\|^E  " $O/trainloop.log | cut -c1-1200 | tail -12
   python __graft_entry__.py smoke 2>&1 | tail -2
   ;;
+r04_f)
+  # per-map dive switch: parity, then serial timing with / without (flags 32); training-loop golden diagnostics; bench contract
+  O=gpurun_out/r04/f; mkdir -p $O
+  python -m pytest tests/test_gpu_parity.py -q -m gpu -k "instruction_streams or unit_cost or golden" > $O/parity.log 2>&1; echo "parity rc=$?"; tail -4 $O/parity.log
+  python -m pytest tests/test_trainloop_golden_gpu.py tests/test_bench_contract.py -q -s -m gpu > $O/trainloop.log 2>&1; echo "trainloop rc=$?"
+  grep -a "TRAINLOOP\|passed\|failed" $O/trainloop.log | cut -c1-2500 | tail -8
+  for rep in 1 2; do for f in 0 32 64 96; do for w in maze32 rand32; do
+    NASTAR_FORWARD_FLAGS=$f python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 10 --workload $w > $O/serial_${w}_f${f}_$rep.json 2>> $O/serial.err
+  done; done; done
+  python - <<'P'
+import json
+for w in ("maze32","rand32"):
+    for f in (0,32,64,96):
+        for rep in (1,2):
+            try:
+                j=json.load(open(f"gpurun_out/r04/f/serial_{w}_f{f}_{rep}.json")); print(w,"flags",f,"rep",rep,round(j["value"]/1e6,2),"M maps/s", round(j["ms_per_step"]*1e3,1),"us/step", round(j["roofline"]["launch_ms_avg"]*1e3,1),"us launch avg")
+            except Exception as e: print(w,f,"ERR",e)
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
