@@ -55,7 +55,7 @@ extern "C" {
 #define NASTAR_FLAG_NONE 0
 #define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
 #define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
-#define NASTAR_FLAG_NO_DIVE 32   /* forward: the hand-scheduled stream without its "dive" fast path (64x64: always on; 32x32 / 16x16: a per-map switch) (A/B) */
+#define NASTAR_FLAG_NO_DIVE 32   /* forward, 64x64 maps: the hand-scheduled stream without its "dive" fast path (A/B) */
 #define NASTAR_FLAG_UNIT_COST 64 /* forward: the caller promises that `cost` and `passable` are ONE binary tensor (VanillaAstar, reference
                                     astar.py:93-94; pass the same pointer twice): the LDS state drops the per-cell cost word (5.5 instead
                                     of 9.75 B/cell, 29 instead of 16 resident 32x32 maps per CU).  Same outputs as without the flag; the

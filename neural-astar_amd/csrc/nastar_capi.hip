@@ -92,12 +92,9 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each; 3-4 batches in flight unchanged at 57 M maps/s (profiles/r03/prio_*.json, prio_streams.txt)
             __builtin_amdgcn_s_setprio(3);
             constexpr bool kD = CPL_T == 4;  // only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
-            if (asm4 && (a.flags & NASTAR_FLAG_NO_DIVE)) {
+            if (asm4 && kD && (a.flags & NASTAR_FLAG_NO_DIVE)) {
                 if (half) s = search_loop_asm4<LOGW, kLog, false, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
                 else s = search_loop_asm4<LOGW, kLog, false, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-            } else if (asm4 && !kD && !(a.flags & NASTAR_FLAG_NO_DIVE)) {  // 32x32 / 16x16: the map decides whether it dives (asm4: per-map switch)
-                if (half) s = search_loop_asm4_switch<LOGW, kLog, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-                else s = search_loop_asm4_switch<LOGW, kLog, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             } else if (asm4) {
                 if (half) s = search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
                 else s = search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
@@ -173,13 +170,8 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
         else unit_open_start<LOGW, false>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW);
         __builtin_amdgcn_s_setprio(3);
         int s;
-        if constexpr (LOGW <= 5 && kDive) {  // one chunk minimum per lane: the map decides whether it dives
-            if (half) s = search_loop_asm4_switch<LOGW, false, true, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
-            else s = search_loop_asm4_switch<LOGW, false, false, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
-        } else {
-            if (half) s = search_loop_asm4<LOGW, false, kDive, true, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
-            else s = search_loop_asm4<LOGW, false, kDive, false, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
-        }
+        if (half) s = search_loop_asm4<LOGW, false, kDive, true, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
+        else s = search_loop_asm4<LOGW, false, kDive, false, true>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, nullptr);
         __builtin_amdgcn_s_setprio(0);
         if (s != -2) {
             if (s < 0) {
@@ -385,8 +377,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
         if ((flags & NASTAR_FLAG_UNIT_COST) && cost == passable && use_asm && !(flags & (NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3)) && !lg && vec4 && fast &&
             g_ratio >= 0.0 && g_ratio <= 1.0 && H == W && (W == 32 || W == 64)) {
-            if (W == 32 && (flags & NASTAR_FLAG_NO_DIVE)) return launch(&nastar_forward_unit_kernel<5, false>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
-            if (W == 32) return launch(&nastar_forward_unit_kernel<5, true>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
+            if (W == 32) return launch(&nastar_forward_unit_kernel<5, false>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
             if (flags & NASTAR_FLAG_NO_DIVE) return launch(&nastar_forward_unit_kernel<6, false>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
             return launch(&nastar_forward_unit_kernel<6, true>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
         }

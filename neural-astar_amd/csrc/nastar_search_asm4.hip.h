@@ -104,7 +104,7 @@ struct AsmLayoutUnit {
         "v_min_u32_dpp v56, v55, v56 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t" \
         "v_min_u32 v56, v56, v57\n\t" \
         "s_add_u32 %[it], %[it], 1\n\t" \
-        "s_add_u32 %[hits], %[hits], 1\n\t" /* dives taken (the per-map switch of the 32x32 / 16x16 kernels reads it after 32 steps) */ \
+        "s_nop 0\n\t" \
         "v_min_u32_dpp v56, v56, v56 row_half_mirror row_mask:0xf bank_mask:0xf\n\t" \
         "s_nop 0\n\t" \
         "v_readfirstlane_b32 s56, v56\n\t" \
@@ -134,7 +134,7 @@ struct AsmLayoutUnit {
         NASTAR_ASM4_EXITS
 
 #define NASTAR_ASM4_OPERANDS \
-        : [it] "+s"(it), [sel] "=s"(sel), [mkey] "=s"(mkey), [hits] "+s"(nh) \
+        : [it] "+s"(it), [sel] "=s"(sel), [mkey] "=s"(mkey) \
         : [l8] "v"(v_l8), [dr] "v"(v_dr), [cmask] "v"(v_cmask), [dcc] "v"(v_dcc), [pcode] "v"(v_pcode), [cls] "v"(v_cls), \
           [vminf] "v"(v_minf), [goal] "s"(goal_idx), [gr] "s"(goal_r), [gc] "s"(goal_c), \
           [maxit] "s"(max_iters), [cgr] "s"(cgr), [comg] "s"(comg), [csq] "s"(csq), [crcp] "s"(rcp_sqrtW), \
@@ -150,11 +150,10 @@ struct AsmLayoutUnit {
 // Preconditions: every cost >= +0, 0 <= g_ratio <= 1 (keys are raw float bits); idle chunk entries hold (key all ones, cell = goal);
 // kHalf: g_ratio == 0.5 exactly (the start's key must have been formed the same way, compact_open_start with gr = omg = 1);
 // kUnit: the LDS holds the unit-cost layout (AsmLayoutUnit).
-// kDive: the "dive" fast path of nastar_search_asm3.hip.h (the next selection is a just-relaxed neighbour whose key beats the previous
-// minimum); `hits` (optional) is incremented once per dive taken.
+// kDive: the "dive" fast path of nastar_search_asm3.hip.h (the next selection is a just-relaxed neighbour whose key beats the previous minimum)
 template <int LOGW, bool kLog, bool kDive, bool kHalf, bool kUnit>
 __device__ __forceinline__ int search_loop_asm4(float cgr, float comg, float csq, int lane, int goal_idx, int goal_r, int goal_c,
-                                                int max_iters, int& iters, float rcp_sqrtW, int* log_row, int* hits = nullptr)
+                                                int max_iters, int& iters, float rcp_sqrtW, int* log_row)
 {
     using LG = AsmLayout<LOGW>;
     using LU = AsmLayoutUnit<LOGW>;
@@ -179,7 +178,6 @@ __device__ __forceinline__ int search_loop_asm4(float cgr, float comg, float csq
     goal_c = __builtin_amdgcn_readfirstlane(goal_c);
     max_iters = __builtin_amdgcn_readfirstlane(max_iters);
     int sel;
-    int nh = 0;
     uint32_t mkey = 0;
     unsigned long long logp = reinterpret_cast<unsigned long long>(log_row);
 #define NASTAR_A4_SH_G "3"
@@ -228,29 +226,13 @@ __device__ __forceinline__ int search_loop_asm4(float cgr, float comg, float csq
 #undef NASTAR_A4_BODY
 #undef NASTAR_A4_EXPAND
     iters = it;
-    if (hits != nullptr) *hits += nh;
     return (sel >= 0 && mkey == 0xFFFFFFFFu) ? -1 : sel;
 }
 
-// ---- per-map dive switch (32x32 / 16x16: one chunk minimum per lane) ---------------------------------------------------------------
-// Whether the dive pays depends on the MAP: its one-instruction test costs every step, a hit saves the selection (a third of the step).
-// Random-obstacle maps dive on 50-78 % of their steps (-3 % per launch), mazes on ~27 % (+0.7 %: profiles/r03/dv2_*.json), which is why
-// round 3 shipped the dive at 64x64 only.  Here every map runs its first DIVE_PROBE steps with the dive and counts the hits; the rest of
-// its search takes the diving loop only if at least DIVE_MIN_HITS of them were (searches that end inside the probe -- most random
-// 32x32 maps -- never leave it).  Both loops are the same state machine: the switch changes timing, never results.
-constexpr int DIVE_PROBE = 32, DIVE_MIN_HITS = 12;
-
-template <int LOGW, bool kLog, bool kHalf, bool kUnit>
-__device__ __forceinline__ int search_loop_asm4_switch(float cgr, float comg, float csq, int lane, int goal_idx, int goal_r, int goal_c,
-                                                       int max_iters, int& iters, float rcp_sqrtW, int* log_row)
-{
-    int hits = 0;
-    const int probe = max_iters < DIVE_PROBE ? max_iters : DIVE_PROBE;
-    int s = search_loop_asm4<LOGW, kLog, true, kHalf, kUnit>(cgr, comg, csq, lane, goal_idx, goal_r, goal_c, probe, iters, rcp_sqrtW, log_row, &hits);
-    if (s != -2 || iters >= max_iters) return s;
-    if (__builtin_amdgcn_readfirstlane(hits) >= DIVE_MIN_HITS)
-        return search_loop_asm4<LOGW, kLog, true, kHalf, kUnit>(cgr, comg, csq, lane, goal_idx, goal_r, goal_c, max_iters, iters, rcp_sqrtW, log_row);
-    return search_loop_asm4<LOGW, kLog, false, kHalf, kUnit>(cgr, comg, csq, lane, goal_idx, goal_r, goal_c, max_iters, iters, rcp_sqrtW, log_row);
-}
+// Measured and dropped (round 4, profiles/r04/dive_switch_*.json): a per-map dive switch for the one-chunk-minimum sizes -- every map ran
+// its first 32 steps in the diving loop (a hit counter in the lookup), the rest in the diving or the plain loop according to the hit
+// count (>= 12).  Same results by construction (stream-equality test), but maze32 151.3 vs 148.9 us per 4096-map launch (+1.6 %: the
+// probe's test instruction and the second loop entry) for rand32 70.5 vs 71.4 us (-1.3 %): the headline batch is mazes.  32x32 and 16x16
+// keep the plain loop, 64x64 always dives.
 
 }  // namespace nastar
