@@ -14,7 +14,8 @@ element's gradient by its own running magnitude (+ 1e-8), so an element's update
 (1e-4 of the tensor's maximum) moves the update by up to the whole step, 0.01.  The test therefore states both: the fraction of elements
 within 1e-5 of the tensor's parameter range (reported, per step), and a per-element bound that every element must meet: 1e-5 of the
 range + 1.5 x the deviation RMSprop ITSELF produces when the reference's gradients of steps 0..k are all shifted by +eps or by -eps,
-eps = 1e-4 of that step's tensor maximum (the optimiser is simulated in float64 on the stored gradients).  Elements whose reference
+eps = 1e-4 of that step's tensor maximum + 5e-8 (the optimiser is simulated in float64 on the stored gradients; the absolute part is
+the measured distance of single gradient elements between ANY device path and the CPU reference, see ABS_G).  Elements whose reference
 gradient is below eps ("sign-noise" elements: the direction of the reference's own update is rounding noise there) are counted and
 reported, not hidden; conv biases in front of a BatchNorm (true gradient exactly 0) are handled apart."""
 import os
@@ -29,6 +30,10 @@ import golden_util as G
 pytestmark = pytest.mark.gpu
 NAME = "trainloop_maze32_3steps"
 EPS_G = 1e-4  # the gradient accuracy the one-step golden test grants per tensor (max |diff| / max |ref|)
+# ... plus an ABSOLUTE floor: with the loss a mean over 16 x 1024 cells the weight gradients of this configuration peak at 1e-6 .. 3e-5, i.e.
+# INSIDE the range where RMSprop's eps = 1e-8 matters (|g| ~ 1e-8 .. 1e-6), and the device paths (MFMA kernels and torch.nn alike: they share
+# the search's dL/dcost, 2e-6 of its maximum from the reference's autograd) sit ~2e-8 from the CPU reference on single elements (measured)
+ABS_G = 5e-8
 
 
 def _rmsprop_paths(gs, lr, alpha=0.99, eps=1e-8):
@@ -137,7 +142,7 @@ def _run_loop(backend, forced):
                     tj = f"step{j}/"
                     mx = float(z[tj + "gradmax/" + name])
                     gs.append(z[tj + "grad16/" + name].astype(np.float64) * mx)
-                    es.append(EPS_G * mx)
+                    es.append(EPS_G * mx + ABS_G)
                 paths = [_rmsprop_paths([g_ + sg * e_ for g_, e_ in zip(gs, es)], lr) for sg in (0.0, 1.0, -1.0)]
                 # (forced runs restart every step from the reference's parameters: only step k's own displacement counts)
                 disp = [(pp[-1] - (pp[-2] if (forced and k > 0) else 0.0)) for pp in paths]
@@ -147,7 +152,7 @@ def _run_loop(backend, forced):
                     i = int(torch.argmax((d - bound).flatten()))
                     violations.append(dict(step=k, name=name, n=int(bad.sum()), of=d.numel(), excess=float((d - bound).flatten()[i]),
                                            d=float(d.flatten()[i]), bound=float(bound.flatten()[i]),
-                                           rho=float(abs(gs[-1].flatten()[i]) / max(es[-1] / EPS_G, 1e-300)), gradmax=es[-1] / EPS_G))
+                                           g_ref=float(gs[-1].flatten()[i]), gradmax=(es[-1] - ABS_G) / EPS_G))
                 n_el += d.numel()
                 n_in += int((d <= tol0).sum())
                 n_noise += int((np.abs(gs[-1]) < es[-1]).sum())
