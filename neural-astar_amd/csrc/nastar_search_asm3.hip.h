@@ -135,7 +135,7 @@ namespace nastar {
         "s_or_b64 exec, exec, s[58:59]\n\t" \
         "ds_min_u64 v50, v[46:47] offset:%[CMIN]\n\t" /* :242 relaxed neighbours AND the chunk's open cells enter the chunk minima: ONE atomic */ \
         "s_mov_b64 exec, -1\n\t"
-/* the expansion = its sections in program order (split so that tools/probe_ablate3.py can time the step with one section removed) */
+/* the expansion = its sections in program order (the round-4 stream, nastar_search_asm4.hip.h, reuses CLOSE / HEUR / WAIT / RELAX) */
 #define NASTAR_ASM3_EXPAND_(INIT55, SET55) \
     NASTAR_ASM3_X_PREFIX NASTAR_ASM3_X_CLOSE NASTAR_ASM3_X_READCELL INIT55 NASTAR_ASM3_X_HEUR NASTAR_ASM3_X_WAIT NASTAR_ASM3_X_KEY \
         NASTAR_ASM3_X_RELAX(SET55)
@@ -200,7 +200,7 @@ namespace nastar {
         ".Lend%=:\n\t"
 
 // ---- measured and dropped on top of this loop (round 3, profiles/r03/INDEX.md) -----------------------------------------------------
-// tools/probe_ablate3.py (`make DEV=1`, nastar_search_asm3_abl.hip.h; profiles/r03/ablate3_step_sections.txt) times the step with one
+// The round-3 ablation probe (deleted in round 4 with the other development kernels; profiles/r03/ablate3_step_sections.txt) timed the step with one
 // section removed at a time.  Lone wavefront, ns per step out of ~230: the four row-level reduction stages 22, the whole reduction 26,
 // compare + find-first of the pick 17, the address prefix 29, closing s* 15, the relaxation's three LDS instructions 32 (the atomic
 // alone 6), the read-back of the chunk minima 18 exposed, the cell read 7 exposed, one taken branch 10, the reduction's wait states 13,
