@@ -114,6 +114,15 @@ for w in ("maze32","rand32"):
             except Exception as e: print(w,f,"ERR",e)
 P
   ;;
+r04_final)
+  # the final build: whole GPU suite, smoke, profile round, the driver's bench command
+  O=gpurun_out/r04/final; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -4 $O/all_gpu_tests.log
+  python __graft_entry__.py smoke 2>&1 | tail -1
+  bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench_n1_driver_command.err; echo "bench rc=$?"
+  tail -n 3 $O/bench_n1_driver_command.err; head -c 600 $O/bench_n1_driver_command.json
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
