@@ -123,6 +123,32 @@ r04_final)
   python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench_n1_driver_command.err; echo "bench rc=$?"
   tail -n 3 $O/bench_n1_driver_command.err; head -c 600 $O/bench_n1_driver_command.json
   ;;
+r04_tp)
+  # throughput regime under rocprofv3: ONE launch of 32768 maps per step (kernel duration -> roofline fraction by the bench line's own
+  # definition), general and unit-cost kernels, all workloads; FETCH / WRITE traffic of the rand64 unit-cost launch
+  O=$R/gpurun_out/r04/tp; mkdir -p $O
+  cd /tmp && export TMPDIR=/tmp
+  for f in 0 64; do
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_f$f -o tp --output-format csv -- python $R/tools/probe_streams.py --workloads maze32,rand32,rand64 --flags $f --streams 1 --bigb 8 --steps 80 > $O/probe_f$f.jsonl 2> $O/probe_f$f.err
+  done
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o tp --output-format csv -- python $R/tools/probe_streams.py --workloads rand64 --flags 64 --streams 1 --bigb 8 --steps 40 > $O/pmc_$C.jsonl 2> $O/pmc_$C.err
+  done
+  python - <<P
+import csv, glob, collections
+for f in (0, 64):
+    for path in glob.glob("$O/trace_f%d/**/*kernel_stats.csv" % f, recursive=True):
+        for r in list(csv.DictReader(open(path)))[:4]:
+            print("flags", f, r["Name"][:70], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    for path in glob.glob("$O/pmc_%s/**/*counter_collection.csv" % C, recursive=True):
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"][:60], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k, {c: (len(v), sum(v) / len(v)) for c, v in d.items()})
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
