@@ -345,7 +345,8 @@ def test_fused_packed_output_equals_pack_kernel():
     from neural_astar.utils import synthetic as syn
     lib = _native.load()
     dev = _dev()
-    for (H, W, B) in [(32, 32, 96), (64, 64, 8), (20, 45, 5), (7, 5, 4), (16, 16, 32)]:
+    for (H, W, B, flags) in [(32, 32, 96, 0), (64, 64, 8, 0), (20, 45, 5, 0), (7, 5, 4, 0), (16, 16, 32, 0),
+                             (32, 32, 96, 64), (64, 64, 8, 64)]:  # 64 = NASTAR_FLAG_UNIT_COST: the unit-cost kernel emits them too
         pr = syn.random_obstacle_maps(B, H, W, 0.2, seed=H * W)
         m, s, g = (_t(x[:, 0]) for x in pr)
         hist = torch.empty((B, H, W), device=dev)
@@ -356,12 +357,15 @@ def test_fused_packed_output_equals_pack_kernel():
         packed = torch.zeros((B, 2 * nb), dtype=torch.uint8, device=dev)
         rc = lib.nastar_forward_packed(m.data_ptr(), s.data_ptr(), g.data_ptr(), m.data_ptr(), B, H, W, 0.5, W * W,
                                        hist.data_ptr(), paths.data_ptr(), None, iters.data_ptr(), status.data_ptr(),
-                                       packed.data_ptr(), None, 0, 0, torch.cuda.current_stream(dev).cuda_stream)
-        assert rc == 0
+                                       packed.data_ptr(), None, 0, flags, torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0 and int(status.abs().sum()) == 0
         ref = parallel.pack_masks(hist.unsqueeze(1), paths.unsqueeze(1))
-        assert torch.equal(packed, ref), (H, W)
+        assert torch.equal(packed, ref), (H, W, flags)
         h2, p2 = parallel.unpack_masks(packed, H, W)
         assert torch.equal(h2[:, 0], hist) and torch.equal(p2[:, 0], paths)
+        if flags:  # ... and they are the general kernel's
+            ref_out = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, W * W, 0)
+            assert np.array_equal(hist.cpu().numpy(), ref_out[0]) and np.array_equal(paths.cpu().numpy(), ref_out[1])
 
 
 def test_validation_pair_launch_equals_two_separate_searches():
