@@ -256,7 +256,7 @@ LONE_STEP_NS = 280.0  # lone-wavefront step of the 32x32 stream on a long maze s
 FIXED_US = 8.0  # map load + backtrack + output stores of that wavefront
 
 
-def throughput_regime(dev, steps, workloads=("maze32", "rand32", "rand64"), ks=(2, 3, 4, 6, 8)):
+def throughput_regime(dev, steps, workloads=("maze32", "rand32", "rand64"), ks=(2, 3, 4, 6, 8, 12)):
     """What the search sustains when the GPU always has a next batch (a planning service, an evaluation sweep, config 4's 32768-map
     batch): (a) the bench's 4096-map launches issued round-robin over k HIP streams, each stream with its own input AND output buffers
     -- the tail of one batch (its longest search) overlaps the bulk of the next; (b) ONE launch over 32768 maps (8 distinct-memory copies
