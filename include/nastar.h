@@ -62,8 +62,6 @@ extern "C" {
                                     kernel checks every map while loading it and marks a map that breaks the promise with status
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
-#define NASTAR_FLAG_PERSISTENT 256 /* forward: launch at most as many wavefronts as the chip holds at once (256 CUs x the maps that fit one CU's LDS);
-                                      each works through maps b, b + grid, ...: no workgroup dispatch between maps.  Same outputs */
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
 
 int nastar_version(void);

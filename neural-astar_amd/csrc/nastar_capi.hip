@@ -45,6 +45,7 @@ template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, b
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
     const int lane = threadIdx.x;
     CompactDims d = a.d;
     if constexpr (LOGH > 0 && LOGW > 0) {
@@ -58,9 +59,6 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         d.magicW = (uint32_t)((1ull << 32) >> LOGW) + 1u;
     }
     const CompactLds l = carve_compact_lds(smem, d);
-    // grid = B (one wavefront per map) or, with NASTAR_FLAG_PERSISTENT on a batch larger than the chip holds, the resident capacity:
-    // every wavefront then works through maps b, b + grid, ... itself (no workgroup dispatch between maps)
-    for (int b = blockIdx.x; b < a.B; b += (int)gridDim.x) {
     const size_t off = (size_t)b * (size_t)d.HW;
 
     int start_idx, goal_idx;
@@ -140,8 +138,6 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
                                         a.packed ? a.packed + (size_t)b * (size_t)(d.HW >> 2) : nullptr);
-    wave_sync();  // the next map overwrites this LDS state
-    }
 }
 
 // ---- forward, UNIT-COST layout (nastar_search_unit.hip.h; NASTAR_FLAG_UNIT_COST): cost map == obstacle map, every value 0.0 or 1.0 ----
@@ -151,10 +147,10 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W = 1 << LOGW, HW = W * W;
+    const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const CompactDims& d = a.d;
     const UnitLds l = carve_unit_lds<LOGW>(smem);
-    for (int b = blockIdx.x; b < a.B; b += (int)gridDim.x) {  // see nastar_forward_compact_kernel
     const size_t off = (size_t)b * (size_t)HW;
     int start_idx, goal_idx;
     bool bad;
@@ -199,8 +195,6 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
         compact_backtrack<LOGW>(d, cl, lane, start_idx, goal_idx, solved ? HW : iters - 1);
     }
     unit_store_paths<LOGW>(l, lane, a.paths + off, a.packed ? a.packed + (size_t)b * (size_t)(HW >> 2) : nullptr, bad);
-    wave_sync();  // the next map overwrites this LDS state
-    }
 }
 
 
@@ -381,19 +375,11 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
         // unit-cost layout: the caller promises cost == passable with values in {0, 1} (checked per map by the kernel); taken when the
         // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
-        // NASTAR_FLAG_PERSISTENT: at most as many wavefronts as the chip holds at once, each working through its share of the batch
-        auto grid_for = [&](size_t lds_bytes) {
-            if (!(flags & NASTAR_FLAG_PERSISTENT)) return B;
-            int per_cu = (int)(kMaxLdsBytes / lds_bytes);
-            if (per_cu > 32) per_cu = 32;  // wavefront slots of a CU
-            const long long cap = 256ll * (per_cu < 1 ? 1 : per_cu);
-            return (int)(B < cap ? B : cap);
-        };
         if ((flags & NASTAR_FLAG_UNIT_COST) && cost == passable && use_asm && !(flags & (NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3)) && !lg && vec4 && fast &&
             g_ratio >= 0.0 && g_ratio <= 1.0 && H == W && (W == 32 || W == 64)) {
-            if (W == 32) return launch(&nastar_forward_unit_kernel<5, false>, grid_for(AsmLayoutUnit<5>::BYTES), (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
-            if (flags & NASTAR_FLAG_NO_DIVE) return launch(&nastar_forward_unit_kernel<6, false>, grid_for(AsmLayoutUnit<6>::BYTES), (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
-            return launch(&nastar_forward_unit_kernel<6, true>, grid_for(AsmLayoutUnit<6>::BYTES), (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
+            if (W == 32) return launch(&nastar_forward_unit_kernel<5, false>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
+            if (flags & NASTAR_FLAG_NO_DIVE) return launch(&nastar_forward_unit_kernel<6, false>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
+            return launch(&nastar_forward_unit_kernel<6, true>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
         }
         if (use_asm && vec4 && fast && H == 32 && W == 32)
             kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, true> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, true>;
@@ -410,7 +396,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         else if (fast) { NASTAR_CPICK(false, 0, 0, 0, true); }
         else { NASTAR_CPICK(false, 0, 0, 0, false); }
 #undef NASTAR_CPICK
-        return launch(kern, grid_for(lds), lds, s, c, rcp);
+        return launch(kern, B, lds, s, c, rcp);
     }
     return NASTAR_ERR_UNSUPPORTED;
 }

@@ -810,20 +810,6 @@ def test_unit_cost_kernel_equals_the_general_kernel_and_the_oracle(kind, H, B):
     assert np.array_equal(got[0][:n], o.histories) and np.array_equal(got[1][:n], o.paths) and np.array_equal(got[2][:n], o.iters)
 
 
-@pytest.mark.parametrize("H,B", [(32, 9000), (64, 2100)])
-def test_persistent_launch_equals_one_wavefront_per_map(H, B):
-    """NASTAR_FLAG_PERSISTENT (256): a grid of at most the chip's resident capacity, every wavefront working through maps b, b + grid,
-    ... -- on batches LARGER than that capacity (so that wavefronts really take several maps), general and unit-cost kernels: same
-    histories, paths, step counts and status as one wavefront per map."""
-    from neural_astar.utils import synthetic as syn
-    pr = syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=99)
-    ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 0)
-    for fl in (256, 256 | 64):
-        got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, fl)
-        for k, name in enumerate(("histories", "paths", "iters", "status")):
-            assert np.array_equal(ref[k], got[k]), (fl, name)
-
-
 def test_unit_cost_kernel_edge_cases_and_the_promise_check():
     """(a) a start placed on an OBSTACLE (the reference expands it, :187; its cost is 0), (b) an unsolvable map, (c) a map that breaks
     the promise (a value that is neither 0 nor 1) gets NASTAR_ERR_NOT_UNIT_COST and all-zero outputs while its neighbours in the batch

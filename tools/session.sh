@@ -150,8 +150,8 @@ for k, d in acc.items():
 P
   ;;
 r04_h)
-  # NASTAR_FLAG_PERSISTENT (256): parity on batches larger than the resident capacity, then one 32768-map launch and 4096-map launches
-  # in flight with / without, general (0 / 256) and unit-cost (64 / 320) kernels
+  # NASTAR_FLAG_PERSISTENT (256; existed at commit 201811d only -- measured, dropped): parity on batches larger than the resident capacity,
+  # then one 32768-map launch and 4096-map launches in flight with / without, general (0 / 256) and unit-cost (64 / 320) kernels
   O=gpurun_out/r04/h; mkdir -p $O
   python -m pytest tests/test_gpu_parity.py -q -m gpu -k "persistent or packed" > $O/parity.log 2>&1; echo "parity rc=$?"; tail -3 $O/parity.log
   python tools/probe_streams.py --workloads maze32,rand32,rand64 --flags 0,256,64,320 --streams 1,4 --bigb 2,8 --steps 160 > $O/streams.jsonl 2> $O/streams.err
