@@ -286,264 +286,7 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     }
 }
 
-// ---- second form of the same convolution: LDS filled by the DMA path (global_load_lds), double-buffered ----------------------------------
-// The kernel above is bound by its LDS traffic, not by the matrix pipe (SQ counters, profiles/r02: MFMA busy ~40 %): per 256-pixel tile and
-// slice it re-writes the 37 KB of weights with ds_write_b128 (13 cycles per wave instruction, ~80 B/clk) next to 72 KB of fragment reads
-// per wavefront.  Here a workgroup is 8 wavefronts x 64 pixels = 512 pixels (weights staged once per 512 pixels), and both tiles are
-// filled by gfx950's global_load_lds (16 bytes per lane straight from L2 into LDS: no staging VGPRs, no ds_write pass) into TWO buffers:
-// slice s+1 streams in while slice s is multiplied.  Measured semantics (tools/ubench/glds.hip): lane i's 16 bytes land at
-// (wave-uniform LDS base) + 16 i; masked-off lanes leave their 16 bytes untouched; the immediate offset moves BOTH addresses.  The LDS
-// image is therefore lane-linear and the chunk rotation of the pixel tile is applied on the SOURCE side: LDS position (slot, cpos) is
-// fetched from channel chunk (cpos - slot/4) & 3.  Pixels outside the batch are never fetched (their slots are never read: the zero
-// slot serves every out-of-image neighbour), each buffer starts with its own 64-byte zero slot.
-constexpr int FC2_TP = 512, FC2_THREADS = 512, FC2_NPQ = 6, FC2_NWQ = 5;
-
-__device__ __forceinline__ void fc2_glds16(const uint16_t* g, unsigned char* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// LDS bytes of one buffer: zero slot | pixel slots | weights
-__host__ __device__ constexpr int fc2_buf_bytes(int nslot, int NT) { return FC_PIXB + nslot * FC_PIXB + 9 * 2 * 2 * NT * 16; }
-
-template <int NT, bool kFinal, bool kSplit>
-__global__ __launch_bounds__(FC2_THREADS) void nastar_conv3x3_flat2_kernel(const FlatConvArgs a)
-{
-    constexpr int NB = NT / 32;
-    constexpr int NWC = 9 * 2 * 2 * NT;  // 16-byte weight chunks per slice
-    constexpr int NWI = NWC / 64;        // wave instructions that move them
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int halo = a.W + 1;
-    const int nslot = FC2_TP + 2 * halo;
-    const int BUFB = fc2_buf_bytes(nslot, NT);
-    float* ss = reinterpret_cast<float*>(smem + 2 * BUFB);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk_total = a.COUT / NT;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int tile = (j / nblk_total) * 8 + xcd;
-    const int nblk = j % nblk_total;
-    if (tile >= a.ntiles) return;
-    const int p0 = tile * FC2_TP, n0 = nblk * NT;
-    const int q0 = p0 - halo;
-
-    const int CIN = a.C1 + a.C2;
-    const int NSL = CIN / FC_KS;
-    const int NSLICE = kSplit ? 3 * NSL : NSL;
-    const int CINV = kSplit ? 3 * CIN : CIN;
-    const int st1 = kSplit ? 2 * a.C1 : a.C1, st2 = kSplit ? 2 * a.C2 : a.C2;
-    const int HW = a.H * a.W;
-
-    if (tid < 32) reinterpret_cast<uint32_t*>(smem + (tid >> 4) * BUFB)[tid & 15] = 0u;  // the two zero slots
-
-    // ---- DMA plan: wave w issues pixel instructions w, w+8, ... and weight instructions w, w+8, ...; per lane the source offset ----
-    const int NPI = (nslot * 4 + 63) / 64;
-    int psrc1[FC2_NPQ], psrc2[FC2_NPQ], wsrc[FC2_NWQ];
-#pragma unroll
-    for (int k = 0; k < FC2_NPQ; ++k) {
-        const int instr = wave + 8 * k;
-        const int i = instr * 64 + lane;
-        const int slot = i >> 2, cpos = i & 3;
-        const int c = (cpos - (slot >> 2)) & 3;  // the source chunk that belongs at this LDS position
-        const int q = q0 + slot;
-        const bool ok = instr < NPI && slot < nslot && q >= 0 && q < a.npix;
-        int o1 = -1, o2 = -1;
-        if (ok) {
-            if (a.ups) {
-                const int b = q / HW, r = q - b * HW;
-                const int y = r / a.W, x = r - y * a.W;
-                o1 = ((b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * (st1 >> 3) + c;
-            } else {
-                o1 = q * (st1 >> 3) + c;
-            }
-            o2 = q * (st2 >> 3) + c;
-        }
-        psrc1[k] = o1;
-        psrc2[k] = o2;
-    }
-#pragma unroll
-    for (int k = 0; k < FC2_NWQ; ++k) {
-        const int instr = wave + 8 * k;
-        const int q = instr * 64 + lane;
-        const int n = q % NT;
-        int r = q / NT;
-        const int h = r & 1; r >>= 1;
-        const int kk = r & 1; r >>= 1;  // r = tap
-        wsrc[k] = instr < NWI ? ((r * (CINV >> 3) + kk * 2 + h) * a.COUT + n0 + n) * 8 : -1;
-    }
-    auto issue_slice = [&](int s, int buf) {
-        const int seg = kSplit ? s / NSL : 0;
-        const int ch = (kSplit ? s - seg * NSL : s) * FC_KS;
-        const bool first = ch < a.C1;
-        const uint16_t* base = first ? a.in + ch + (seg == 1 ? a.C1 : 0) : a.in2 + (ch - a.C1) + (seg == 1 ? a.C2 : 0);
-        unsigned char* pb = smem + buf * BUFB + FC_PIXB;  // pixel slots
-#pragma unroll
-        for (int k = 0; k < FC2_NPQ; ++k) {
-            const int o = first ? psrc1[k] : psrc2[k];
-            if (o >= 0) fc2_glds16(base + (size_t)o * 8, pb + (wave + 8 * k) * 1024);
-        }
-        const uint16_t* wb = a.wpack + (size_t)s * (FC_KS / 8) * a.COUT * 8;
-        unsigned char* wl = smem + buf * BUFB + FC_PIXB + nslot * FC_PIXB;
-#pragma unroll
-        for (int k = 0; k < FC2_NWQ; ++k)
-            if (wsrc[k] >= 0) fc2_glds16(wb + wsrc[k], wl + (wave + 8 * k) * 1024);
-    };
-
-    // ---- read plan: fragment addresses relative to the buffer start (zero slot at 0) ----
-    const int px = lane & 31, kh = lane >> 5;
-    int baddr[9][2];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int lp = wave * 64 + pb * 32 + px;
-        const int p = p0 + lp;
-        const int r = p % HW;
-        const int y = r / a.W, x = r - y * a.W;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const bool ok = p < a.npix && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
-            const int slot = lp + halo + dy * a.W + dx;
-            baddr[tap][pb] = ok ? fc_slot_off(slot, kh) : (kh << 4);
-        }
-    }
-
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[pb][n][r] = 0.f;
-
-    if (tid < NT) {
-        ss[tid] = a.scale[n0 + tid];
-        ss[NT + tid] = a.shift[n0 + tid];
-    }
-    issue_slice(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = 0; s < NSLICE; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < NSLICE) issue_slice(s + 1, buf ^ 1);  // streams into the other buffer during the MFMAs below
-        const unsigned char* bb = smem + buf * BUFB;
-        const unsigned char* wl = bb + FC_PIXB + nslot * FC_PIXB;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                bf16x8 xb[2], wa[NB];
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) xb[pb] = *reinterpret_cast<const bf16x8*>(bb + (baddr[tap][pb] ^ (kk << 5)));
-#pragma unroll
-                for (int n = 0; n < NB; ++n)
-                    wa[n] = *reinterpret_cast<const bf16x8*>(wl + ((((tap * 2 + kk) * 2 + kh) * NT) + n * 32 + px) * 16);
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) acc[pb][n] = mfma16<true>(wa[n], xb[pb], acc[pb][n]);
-            }
-        }
-        if (s + 1 < NSLICE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of slice s+1 has landed
-            __syncthreads();                                   // ... everybody's has, and everybody is done reading slice s
-        }
-    }
-
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int p = p0 + wave * 64 + pb * 32 + px;
-        if (p >= a.npix) continue;
-        if constexpr (kFinal) {
-            if (kh == 0 && nblk == 0) {
-                const float z = acc[pb][0][0] * ss[0] + ss[NT];
-                a.out_f32[p] = a.raw ? z : a.final_mul / (1.0f + __expf(-z));
-            }
-        } else {
-            const size_t ob = (size_t)p * (kSplit ? 2 * a.COUT : a.COUT);
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = n * 32 + 8 * g + 4 * kh;
-                    const float4 sc = *reinterpret_cast<const float4*>(ss + cl);
-                    const float4 sh = *reinterpret_cast<const float4*>(ss + NT + cl);
-                    float v0 = acc[pb][n][4 * g + 0] * sc.x + sh.x;
-                    float v1 = acc[pb][n][4 * g + 1] * sc.y + sh.y;
-                    float v2 = acc[pb][n][4 * g + 2] * sc.z + sh.z;
-                    float v3 = acc[pb][n][4 * g + 3] * sc.w + sh.w;
-                    if (a.relu) {
-                        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                    }
-                    v0 = f16_clamp(v0); v1 = f16_clamp(v1); v2 = f16_clamp(v2); v3 = f16_clamp(v3);
-                    uint2 o;
-                    o.x = pack_f16x2(v0, v1);
-                    o.y = pack_f16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(a.out + ob + n0 + cl) = o;
-                    if constexpr (kSplit) {
-                        uint2 l;
-                        l.x = pack_f16x2(f16_residual(v0), f16_residual(v1));
-                        l.y = pack_f16x2(f16_residual(v2), f16_residual(v3));
-                        *reinterpret_cast<uint2*>(a.out + ob + a.COUT + n0 + cl) = l;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---- 2x2 max-pool, NHWC fp16 (VGG stages of the U-Net encoder).  Split form: a value is the pair (hi, lo); hi + lo is exact in fp32
-// (11 + 11 significant bits inside 24), so the pair with the larger sum is the larger value. -------------------------------------------
-template <bool kSplit>
-__global__ __launch_bounds__(256) void nastar_maxpool2x2_f16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
-                                                                    int H, int W, int C)
-{
-    const int Ho = H >> 1, Wo = W >> 1, CC = C >> 3;  // 8-channel chunks
-    const long long total = (long long)B * Ho * Wo * CC;
-    const int stride = kSplit ? 2 * C : C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % CC);
-        long long t = i / CC;
-        const int xo = (int)(t % Wo); t /= Wo;
-        const int yo = (int)(t % Ho);
-        const int b = (int)(t / Ho);
-        nastar_f16x8 best_hi, best_lo;
-        float best[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t pin = ((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
-            const nastar_f16x8 hi = *reinterpret_cast<const nastar_f16x8*>(in + pin * stride + cc * 8);
-            nastar_f16x8 lo = hi;
-            if constexpr (kSplit) lo = *reinterpret_cast<const nastar_f16x8*>(in + pin * stride + C + cc * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = kSplit ? (float)hi[e] + (float)lo[e] : (float)hi[e];
-                if (k == 0 || v > best[e]) {
-                    best[e] = v;
-                    best_hi[e] = hi[e];
-                    best_lo[e] = lo[e];
-                }
-            }
-        }
-        const size_t po = ((size_t)b * Ho + yo) * Wo + xo;
-        *reinterpret_cast<nastar_f16x8*>(out + po * stride + cc * 8) = best_hi;
-        if constexpr (kSplit) *reinterpret_cast<nastar_f16x8*>(out + po * stride + C + cc * 8) = best_lo;
-    }
-}
-
-// ---- input assembly (astar.py:171-177): x0[p] = (map, start + goal, 0 ...) as CP-channel fp16 NHWC; split form appends CP zero lo
-// halves (the inputs are 0 / 1 / 2: exact in fp16) ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nastar_encoder_prep_f16_kernel(const float* __restrict__ map, const float* __restrict__ start,
-                                                                      const float* __restrict__ goal, uint16_t* __restrict__ out,
-                                                                      long long npix, int plus, int CP, int split)
-{
-    const int stride = split ? 2 * CP : CP;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
-        uint16_t* o = out + i * stride;
-        const float sg = plus ? start[i] + goal[i] : 0.f;
-        const uint32_t w0 = pack_f16x2(map[i], sg);
-        for (int c = 0; c < stride; c += 2) *reinterpret_cast<uint32_t*>(o + c) = (c == 0) ? w0 : 0u;
-    }
-}
+// (A second form of this kernel -- LDS filled by gfx950's global_load_lds into two buffers, 512-pixel workgroups -- was measured in round 2
+// and never beat the one above; it was deleted in round 4 with the other development kernels: NOTES.md section 4.9, git history.)
 
 }  // namespace nastar

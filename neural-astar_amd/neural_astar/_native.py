@@ -12,7 +12,7 @@ import subprocess
 from typing import Optional
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # neural-astar_amd/
-# NASTAR_LIB: development switch -- another build of the same C ABI (e.g. lib/libnastar_hip_dev.so from `make DEV=1`)
+# NASTAR_LIB: development switch -- another build of the same C ABI (make BUILD=build_x OUT=../lib/libnastar_hip_x.so)
 LIB_PATH = os.environ.get("NASTAR_LIB") or os.path.join(_PKG_ROOT, "lib", "libnastar_hip.so")
 CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
 
