@@ -289,4 +289,58 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
 // (A second form of this kernel -- LDS filled by gfx950's global_load_lds into two buffers, 512-pixel workgroups -- was measured in round 2
 // and never beat the one above; it was deleted in round 4 with the other development kernels: NOTES.md section 4.9, git history.)
 
+// ---- 2x2 max-pool, NHWC fp16 (VGG stages of the U-Net encoder).  Split form: a value is the pair (hi, lo); hi + lo is exact in fp32
+// (11 + 11 significant bits inside 24), so the pair with the larger sum is the larger value. -------------------------------------------
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_maxpool2x2_f16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
+                                                                    int H, int W, int C)
+{
+    const int Ho = H >> 1, Wo = W >> 1, CC = C >> 3;  // 8-channel chunks
+    const long long total = (long long)B * Ho * Wo * CC;
+    const int stride = kSplit ? 2 * C : C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CC);
+        long long t = i / CC;
+        const int xo = (int)(t % Wo); t /= Wo;
+        const int yo = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        nastar_f16x8 best_hi, best_lo;
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t pin = ((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1);
+            const nastar_f16x8 hi = *reinterpret_cast<const nastar_f16x8*>(in + pin * stride + cc * 8);
+            nastar_f16x8 lo = hi;
+            if constexpr (kSplit) lo = *reinterpret_cast<const nastar_f16x8*>(in + pin * stride + C + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = kSplit ? (float)hi[e] + (float)lo[e] : (float)hi[e];
+                if (k == 0 || v > best[e]) {
+                    best[e] = v;
+                    best_hi[e] = hi[e];
+                    best_lo[e] = lo[e];
+                }
+            }
+        }
+        const size_t po = ((size_t)b * Ho + yo) * Wo + xo;
+        *reinterpret_cast<nastar_f16x8*>(out + po * stride + cc * 8) = best_hi;
+        if constexpr (kSplit) *reinterpret_cast<nastar_f16x8*>(out + po * stride + C + cc * 8) = best_lo;
+    }
+}
+
+// ---- input assembly (astar.py:171-177): x0[p] = (map, start + goal, 0 ...) as CP-channel fp16 NHWC; split form appends CP zero lo
+// halves (the inputs are 0 / 1 / 2: exact in fp16) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nastar_encoder_prep_f16_kernel(const float* __restrict__ map, const float* __restrict__ start,
+                                                                      const float* __restrict__ goal, uint16_t* __restrict__ out,
+                                                                      long long npix, int plus, int CP, int split)
+{
+    const int stride = split ? 2 * CP : CP;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        uint16_t* o = out + i * stride;
+        const float sg = plus ? start[i] + goal[i] : 0.f;
+        const uint32_t w0 = pack_f16x2(map[i], sg);
+        for (int c = 0; c < stride; c += 2) *reinterpret_cast<uint32_t*>(o + c) = (c == 0) ? w0 : 0u;
+    }
+}
+
 }  // namespace nastar
