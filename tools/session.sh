@@ -157,6 +157,43 @@ r04_h)
   python tools/probe_streams.py --workloads maze32,rand32,rand64 --flags 0,256,64,320 --streams 1,4 --bigb 2,8 --steps 160 > $O/streams.jsonl 2> $O/streams.err
   cat $O/streams.jsonl; tail -n 2 $O/streams.err
   ;;
+r04_enc)
+  # encoder training / inference census: per-kernel time of the f16x3 4096-map and 100-map encoder steps
+  O=gpurun_out/r04/enc${2:-}; mkdir -p $O
+  export TMPDIR=/tmp
+  python tools/probe_train.py 100,4096 hip_f16x3 > $O/probe_train.txt 2>&1; tail -3 $O/probe_train.txt
+  for B in 4096 100; do
+    timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_b$B -o t --output-format csv -- python tools/probe_train.py $B hip_f16x3 > $O/trace_b$B.txt 2>&1
+    python - <<P
+import csv, glob
+for path in glob.glob("$O/trace_b$B/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print("B=$B total kernel ms over 6 steps", round(tot / 1e6, 2))
+    for r in rows[:26]:
+        print("%-100s %4s %9.1f us avg %5.1f%%" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+P
+  done
+  ;;
+r04_spec)
+  # two selections per step (NASTAR_FLAG_SPEC2 = 256, csrc/nastar_search_spec.hip.h): stream equality on whole batches, then the serial
+  # launch and batches in flight against the shipped stream (flags 0)
+  O=gpurun_out/r04/spec${2:-}; mkdir -p $O
+  python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "instruction_streams" > $O/parity.log 2>&1; echo "parity rc=$?"; tail -5 $O/parity.log
+  for f in 0 8 256 512; do for w in maze32 rand32; do
+    NASTAR_FORWARD_FLAGS=$f python bench.py --no-cpu-baseline --no-secondary --steps 200 --warmup 10 --workload $w > $O/serial_${w}_f$f.json 2>> $O/serial.err
+  done; done
+  python - <<P
+import json
+for w in ("maze32","rand32"):
+    for f in (0,8,256,512):
+        try:
+            j=json.load(open("$O/serial_%s_f%d.json" % (w, f))); print(w,"flags",f,round(j["value"]/1e6,2),"M maps/s", round(j["ms_per_step"]*1e3,1),"us/step", round(j["roofline"]["launch_ms_avg"]*1e3,1),"us launch avg")
+        except Exception as e: print(w,f,"ERR",e)
+P
+  python tools/probe_streams.py --workloads maze32,rand32 --flags 0,512 --streams 1,4 --bigb 4 > $O/streams.jsonl 2> $O/streams.err
+  cat $O/streams.jsonl; tail -n 2 $O/streams.err
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
