@@ -62,8 +62,6 @@ extern "C" {
                                     kernel checks every map while loading it and marks a map that breaks the promise with status
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
-#define NASTAR_FLAG_SPEC2 256    /* forward, 32x32 maps: two selections per step where the sequential order allows it (nastar_search_spec.hip.h) */
-#define NASTAR_FLAG_LOOKAHEAD 512 /* forward, 32x32 maps: the next selection from the step's own candidates + the previous runner-up (nastar_search_spec.hip.h) */
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
 
 int nastar_version(void);

@@ -14,7 +14,6 @@
 #include "nastar_search_asm3.hip.h"
 #include "nastar_search_asm4.hip.h"
 #include "nastar_search_unit.hip.h"
-#include "nastar_search_spec.hip.h"
 #include "nastar_backward_replay.hip.h"
 #include "nastar_backward_replay_asm.hip.h"
 
@@ -93,21 +92,6 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each; 3-4 batches in flight unchanged at 57 M maps/s (profiles/r03/prio_*.json, prio_streams.txt)
             __builtin_amdgcn_s_setprio(3);
             constexpr bool kD = CPL_T == 4;  // only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
-            bool spec_done = false;
-            if constexpr (LOGW == 5 && CPL_T == 1) {
-                if (asm4 && (a.flags & NASTAR_FLAG_SPEC2)) {  // two selections per step where the sequential order allows it (nastar_search_spec.hip.h)
-                    int pairs = 0;
-                    if (half) s = search_loop_spec2<LOGW, kLog, true>(d, l, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row, pairs);
-                    else s = search_loop_spec2<LOGW, kLog, false>(d, l, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row, pairs);
-                    spec_done = true;
-                } else if (asm4 && (a.flags & NASTAR_FLAG_LOOKAHEAD)) {  // selection off the critical path (nastar_search_spec.hip.h)
-                    if (half) s = search_loop_lookahead<LOGW, kLog, true>(d, l, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-                    else s = search_loop_lookahead<LOGW, kLog, false>(d, l, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-                    spec_done = true;
-                }
-            }
-            if (spec_done) {
-            } else
             if (asm4 && kD && (a.flags & NASTAR_FLAG_NO_DIVE)) {
                 if (half) s = search_loop_asm4<LOGW, kLog, false, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
                 else s = search_loop_asm4<LOGW, kLog, false, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);

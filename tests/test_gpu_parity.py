@@ -761,10 +761,10 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
                                          ("g03", u, H * H, 0.3, True), ("vanilla_nolog", pr.map_designs, H * H, 0.5, False),
                                          ("g08_nolog", u, H * H, 0.8, False)):
             outs = {}
-            for flags in (0, 32, 128, 16, 8, 256, 512):  # 256 = two selections per step, 512 = selection off the critical path (32x32); 32 = without the dive (64x64) / without the per-map dive switch (32x32, 16x16)
+            for flags in (0, 32, 128, 16, 8):  # 32 = without the dive (64x64) / without the per-map dive switch (32x32, 16x16)
                 ops.FORWARD_FLAGS = flags
                 outs[flags] = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, mi, want_log=log)
-            for flags in (32, 128, 16, 8, 512, 256):
+            for flags in (32, 128, 16, 8):
                 for k, name in enumerate(("histories", "paths", "iters", "status", "sel_log")):
                     a, b = outs[0][k], outs[flags][k]
                     if name == "sel_log":  # entries past a map's own step count are unwritten

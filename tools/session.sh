@@ -176,8 +176,9 @@ P
   done
   ;;
 r04_spec)
-  # two selections per step (NASTAR_FLAG_SPEC2 = 256, csrc/nastar_search_spec.hip.h): stream equality on whole batches, then the serial
-  # launch and batches in flight against the shipped stream (flags 0)
+  # (flags 256 / 512 and csrc/nastar_search_spec.hip.h existed at commit 38d47f3 only -- measured, dropped: NOTES.md "Round 4")
+  # two selections per step (256) and a selection that leaves the critical path (512), compiler-generated: stream equality on whole
+  # batches, then the serial launch and batches in flight against the shipped stream (0) and hipcc's single-selection step (8)
   O=gpurun_out/r04/spec${2:-}; mkdir -p $O
   python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "instruction_streams" > $O/parity.log 2>&1; echo "parity rc=$?"; tail -5 $O/parity.log
   for f in 0 8 256 512; do for w in maze32 rand32; do
