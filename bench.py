@@ -128,7 +128,7 @@ class Runner:
     `prs` may be a list of problem sets (same shape): step i works on set i % len(prs), each with its own input AND output
     buffers, so consecutive timed steps do not re-read a cache-resident batch (>256 MB in rotation)."""
 
-    def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None, flags=None):
+    def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None, flags=None, placement=None):
         from neural_astar import _native
         self.lib = _native.load()
         self._check = _native.check
@@ -152,6 +152,14 @@ class Runner:
         # NASTAR_FLAG_* of include/nastar.h; default: the dev A/B switch NASTAR_FORWARD_FLAGS (0 = the general kernel)
         self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0")) if flags is None else int(flags)
         self.packed = None  # set by enable_packed(): the step then also emits the bit-packed masks (all-gather payload)
+        # placement "hinted": every batch set remembers the order its searches finished in at its previous visit and the next visit
+        # starts the longest first (nastar_forward_ordered, include/nastar.h): what a validation loop over a fixed set has every epoch
+        # after the first.  "natural": workgroup i searches map i (a batch never seen before).
+        self.placement = (PLACEMENT if placement is None else placement)
+        if self.placement == "hinted":
+            for z in self.sets:
+                z["ord"] = [torch.zeros((self.B + 1,), dtype=torch.int32, device=dev) for _ in range(2)]
+                z["k"], z["seen"] = 0, False
         self._i = 0
         self._bind(0)
 
@@ -168,6 +176,22 @@ class Runner:
     def step(self):
         self._bind(self._i % len(self.sets))
         self._i += 1
+        if self.placement == "hinted":
+            z = self.sets[(self._i - 1) % len(self.sets)]
+            cur = z["ord"][z["k"]] if z["seen"] else None
+            z["k"] ^= 1
+            z["seen"] = True
+            pk = None
+            if self.packed is not None:
+                self._pk ^= 1
+                pk = self.packed[self._pk].data_ptr()
+            rc = self.lib.nastar_forward_ordered(
+                self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
+                self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
+                self.status.data_ptr(), pk, None, 0, self.flags, cur.data_ptr() if cur is not None else None,
+                z["ord"][z["k"]].data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
+            self._check(rc, "nastar_forward_ordered")
+            return
         if self.packed is not None:
             self._pk ^= 1  # double buffer: the previous step's payload may still be in flight in the all-gather
             rc = self.lib.nastar_forward_packed(
@@ -185,6 +209,7 @@ class Runner:
         self._check(rc, "nastar_forward")
 
 
+PLACEMENT = "hinted"  # default of Runner(placement=None); main() sets it from --placement
 PREWARM_S = 0.3  # untimed launches before the W warm-up steps: the driver times 20 steps (~3 ms) after 5 warm-up steps, which on a GPU fresh out
                  # of problem synthesis measures the clock ramp, not the kernel (same process: 23.6 M maps/s first, 25.9 M a minute later)
 
@@ -252,7 +277,8 @@ def multi_stream_throughput(pr, steps, dev, nstreams, flags=None, runs=None):
 
 
 FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
-LONE_STEP_NS = 280.0  # lone-wavefront step of the 32x32 stream on a long maze search (tools/probe_latency.py, profiles/r04/lat_asm4.txt)
+LONE_STEP_NS = 219.0  # step of a wavefront that has its SIMD to itself, chip at working clocks: slope of the launch time over the length of ONE maze
+                      # search among 4095 two-step maps (tools/probe_latency.py, profiles/r04/lat_working_clocks.txt; on an otherwise IDLE chip: 280)
 FIXED_US = 8.0  # map load + backtrack + output stores of that wavefront
 
 
@@ -322,9 +348,9 @@ def pipe_model(steps_per_launch, launch_us, max_iters, lone_step_ns, fixed_us):
             "valu_floor_us": valu_floor, "lds_floor_us": lds_floor, "achieved_us": launch_us,
             "valu_busy_frac": valu_floor / launch_us, "lds_busy_frac": lds_floor / launch_us,
             "serial_floor_us": serial_floor, "frac_of_serial_floor": serial_floor / launch_us,
-            "serial_floor_note": f"longest search of the batch ({max_iters} steps) x the lone-wavefront step ({lone_step_ns:.0f} ns, "
-                                 f"tools/probe_latency.py, profiles/r04) + {fixed_us:.0f} us load / backtrack / store: what ONE launch cannot beat "
-                                 "however empty the rest of the chip is",
+            "serial_floor_note": f"longest search of the batch ({max_iters} steps) x the step of a wavefront that has its SIMD to itself "
+                                 f"({lone_step_ns:.0f} ns at working clocks, tools/probe_latency.py, profiles/r04/lat_working_clocks.txt) + {fixed_us:.0f} us "
+                                 "load / backtrack / store: what ONE launch cannot beat; frac_of_serial_floor = floor / achieved",
             "source": "instruction classes: disassembly of nastar_forward_compact_kernel<true,5,5,1,true,false,-1> (asm4, g_ratio 0.5); "
                       "rates: profiles/r04/rate.txt (tools/ubench/rate.hip)"}
 
@@ -1113,6 +1139,10 @@ def main():
                          "--global-batch 32768); default 0 = weak scaling, 4096 maps per GPU")
     ap.add_argument("--shard", default="contiguous", choices=["contiguous", "interleaved"],
                     help="strong scaling: which rows a rank owns (parallel.shard_rows)")
+    ap.add_argument("--placement", default="hinted", choices=["hinted", "natural"],
+                    help="hinted (default): every batch set is searched longest-first by the order its searches finished in at its previous "
+                         "visit (nastar_forward_ordered; the natural-order figures are reported beside it); natural: workgroup i = map i")
+    ap.add_argument("--no-natural", action="store_true", help="--placement hinted: skip the natural-order comparison passes (clean kernel profiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (clean kernel profiles)")
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
@@ -1131,6 +1161,8 @@ def main():
                     help="dev: gloo lets N ranks share ONE GPU (with --share-gpu) to exercise every world > 1 branch of this script on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="dev: every rank uses cuda:0 (only with --dist-backend gloo)")
     args = ap.parse_args()
+    global PLACEMENT
+    PLACEMENT = args.placement
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: re-launch one rank per GPU the way the driver does
@@ -1218,6 +1250,11 @@ def main():
         dt_cold, _ = timed_loop(run, args.steps, args.warmup, world, dev, collate)
         prewarm(run, dev)
         dt, dev_ms = timed_loop(run, args.steps, args.warmup, world, dev, collate)
+        dt_nat = None
+        if run.placement == "hinted" and not args.no_natural:  # the same W + K steps with workgroup i = map i: a batch that has never been searched before
+            run.placement = "natural"
+            dt_nat, _ = timed_loop(run, args.steps, args.warmup, world, dev, collate)
+            run.placement = "hinted"
     torch.cuda.synchronize(dev)
     _log(f"headline: {dt / args.steps * 1e3:.4f} ms/step")
     total_maps = n_gpus * b_rank * args.steps
@@ -1230,6 +1267,15 @@ def main():
         iters = torch.cat([z["iters"] for z in run.sets]).cpu().numpy()
         assert all(int(z["status"].abs().sum().item()) == 0 for z in run.sets), "unsolvable map in the synthetic batch"
         avg_ms, med_ms, min_ms = kernel_launch_ms(run, min(args.steps, 100), dev)
+        nat = None
+        if dt_nat is not None:
+            run.placement = "natural"
+            nat_ms = kernel_launch_ms(run, min(args.steps, 100), dev)[0]
+            run.placement = "hinted"
+            nat = {"value": total_maps / dt_nat, "ms_per_step": dt_nat / args.steps * 1e3, "launch_ms_avg": nat_ms,
+                   "roofline_frac": bytes_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "same W + K steps, workgroup i searches map i: what a batch costs at its FIRST visit (nothing is known about its "
+                           "searches yet); identical outputs"}
         achieved = bytes_per_map * b_rank / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -1254,7 +1300,12 @@ def main():
                                       if strong else "seeds 1234+rank+1000k"),
                        "batch_per_gpu": b_rank, "global_batch": n_gpus * b_rank, "H": Hh, "W": Ww,
                        "parallelism": f"shard{n_gpus}" if n_gpus > 1 else "single", "collate": collate_note,
-                       "prewarm_s": PREWARM_S},
+                       "prewarm_s": PREWARM_S,
+                       "placement": ("hinted: every batch set is searched longest-first by the order its searches FINISHED in at its previous visit "
+                                     "(nastar_forward_ordered writes that order itself: no extra launch, no host sync, identical outputs) -- what a "
+                                     "validation / evaluation loop over a fixed set has from its second epoch on; the first visit is `natural_order`"
+                                     if run.placement == "hinted" else "natural: workgroup i searches map i")},
+            "natural_order": nat,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # the same fraction on the bytes the PMC counters saw instead of SURVEY 8(d)'s 28 B/cell (VanillaAstar hands ONE
@@ -1300,8 +1351,15 @@ def main():
                 dt2, _ = timed_loop(run2, max(50, args.steps // 4), max(2, args.warmup // 4), 1, dev)
                 a2, _, _ = kernel_launch_ms(run2, 50, dev)
                 nbytes = 28 * run2.H * run2.W * B_PER_GPU
+                a2n = None
+                if run2.placement == "hinted" and not args.no_natural:
+                    run2.placement = "natural"
+                    a2n = kernel_launch_ms(run2, 50, dev)[0]
+                    run2.placement = "hinted"
                 sec.append({"workload": f"{other}: {B_PER_GPU} maps of {run2.H}x{run2.W}", "value": B_PER_GPU * max(50, args.steps // 4) / dt2,
                             "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "placement": run2.placement, "launch_ms_avg_natural_order": a2n,
+                            "hbm_frac_natural_order": (nbytes / (a2n * 1e-3) / 1e9 / HBM_PEAK_GBS) if a2n else None,
                             "mean_iters_per_map": float(run2.iters.float().mean().item()),
                             "max_iters_per_map": int(run2.iters.max().item()),
                             "gpu_matches_oracle_on_sample": oracle_check(pr2, run2.hist.cpu().numpy(), run2.paths.cpu().numpy(), 256),

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 400 /* 0.4.0: round-4 search instruction stream, unit-cost LDS layout (NASTAR_FLAG_UNIT_COST) */
+#define NASTAR_VERSION 401 /* 0.4.1: nastar_forward_ordered (placement); 0.4.0: round-4 search instruction stream, unit-cost LDS layout */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0
@@ -88,6 +88,27 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
                    int H, int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                    int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                    size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * nastar_forward with a PLACEMENT: workgroup i of the launch searches map order[i].  Outputs are indexed by map as always -- the
+ * placement changes when and where a map is searched, never what is computed (same histories, paths, iters, status, log).
+ * Why: one launch lasts as long as its longest search, and the hardware starts and arbitrates workgroups in index order.  With the
+ * longest searches first they start at t = 0 and are the oldest wavefronts of their SIMD (4096 mazes of 32x32: 149 -> 112 us per
+ * launch, 64x64 random maps 277 -> 234 us; profiles/r04/order_*.jsonl).  Nothing cheap predicts a search's length from its map, but
+ * a data set is searched once per epoch (reference scripts/train.py:43-50 validates after every epoch on a fixed, unshuffled
+ * loader, utils/data.py:40-47): the previous visit of the same batch is the predictor.
+ *   order      [B] int32 device, a permutation of 0..B-1, or NULL (identity)
+ *   order_out  [B+1] int32 device or NULL: receives the maps in REVERSE order of search completion in THIS launch = the `order`
+ *              to pass at the next visit of the same batch.  order_out[B] is the launch's counter: it must be 0 on entry and is
+ *              0 again when the launch has finished (zero the buffer once, then reuse it; one buffer per launch in flight).
+ *   packed_out NULL, or the bit-packed masks of nastar_forward_packed.
+ * Maps whose search state lives in HBM (nastar_workspace_bytes > 0) take no placement: NASTAR_ERR_UNSUPPORTED if either is given.
+ */
+int nastar_forward_ordered(const float* cost, const float* start, const float* goal, const float* passable, int B,
+                           int H, int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                           int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out,
+                           void* workspace, size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out,
+                           void* stream);
 
 /*
  * nastar_forward that ALSO emits the bit-packed masks (layout: see nastar_pack_outputs) in the same launch where the

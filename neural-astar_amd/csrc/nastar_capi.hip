@@ -32,6 +32,8 @@ struct FwdCArgs {
     int* iters;
     int* status;
     uint8_t* packed;
+    const int* order;  // optional placement: workgroup i runs map order[i] (a permutation of 0..B-1), nullptr = identity
+    int* order_out;    // optional [B + 1]: the maps in REVERSE order of search completion (the placement for the next visit); [B] = counter
     int max_iters;
     int B;
     int flags;
@@ -45,7 +47,8 @@ template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, b
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation: never read or write outside the batch
     const int lane = threadIdx.x;
     CompactDims d = a.d;
     if constexpr (LOGH > 0 && LOGW > 0) {
@@ -96,8 +99,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
                 if (half) s = search_loop_asm4<LOGW, kLog, false, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
                 else s = search_loop_asm4<LOGW, kLog, false, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
             } else if (asm4) {
-                if (half) s = search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-                else s = search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+                auto run = [&](int budget) {
+                    return half ? search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, budget, iters, rcp_sqrtW, log_row)
+                                : search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, budget, iters, rcp_sqrtW, log_row);
+                };
+                s = run(a.max_iters);
             } else
             if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
@@ -134,6 +140,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
+        if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
+            const int pos = atomicAdd(a.order_out + a.B, 1);
+            a.order_out[a.B - 1 - pos] = b;
+            if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
+        }
     }
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
@@ -147,7 +158,8 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W = 1 << LOGW, HW = W * W;
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation: never read or write outside the batch
     const int lane = threadIdx.x;
     const CompactDims& d = a.d;
     const UnitLds l = carve_unit_lds<LOGW>(smem);
@@ -188,6 +200,11 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
+        if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
+            const int pos = atomicAdd(a.order_out + a.B, 1);
+            a.order_out[a.B - 1 - pos] = b;
+            if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
+        }
     }
     if (goal_idx >= 0 && !bad) {
         CompactLds cl;  // the backtrack reads and marks parents only
@@ -322,7 +339,8 @@ size_t nastar_workspace_bytes(int B, int H, int W, int flags)
 static int forward_impl(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
                         int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                         int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
-                        size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done)
+                        size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done,
+                        const int32_t* order = nullptr, int32_t* order_out = nullptr)
 {
     *packed_done = false;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
@@ -358,6 +376,8 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.hist = histories_out; c.paths = reinterpret_cast<long long*>(paths_out);
         c.sel_log = sel_log_out; c.iters = iters_out; c.status = status_out; c.max_iters = max_iters;
         c.packed = nullptr;
+        c.order = order;
+        c.order_out = order_out;
         c.flags = flags;
         const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                           aligned16(histories_out) && aligned16(paths_out);
@@ -409,6 +429,19 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
     bool done;
     return forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
                         iters_out, status_out, workspace, workspace_bytes, flags, stream, nullptr, &done);
+}
+
+int nastar_forward_ordered(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
+                           int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
+                           int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out, void* workspace,
+                           size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out, void* stream)
+{
+    if ((order || order_out) && B > 0 && H > 0 && W > 0 && needs_global_state(H, W)) return NASTAR_ERR_UNSUPPORTED;  // LDS-resident searches only
+    bool done = false;
+    int rc = forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
+                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out);
+    if (rc != NASTAR_OK || done || !packed_out) return rc;
+    return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);
 }
 
 int nastar_forward_packed(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,

@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "nastar_workspace_bytes",
     "nastar_forward",
     "nastar_forward_packed",
+    "nastar_forward_ordered",
     "nastar_backward_workspace_bytes",
     "nastar_backward_replay",
     "nastar_backward_l1_replay",
@@ -122,6 +123,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.nastar_forward.restype = ci
     lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_forward_ordered.restype = ci
+    lib.nastar_forward_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp]
     lib.nastar_forward_packed.restype = ci
     lib.nastar_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_backward_workspace_bytes.restype = cz

@@ -86,6 +86,62 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0):
             cost.new_empty((B, max_iters) if want_log else (0,), dtype=torch.int32))
 
 
+@torch.library.custom_op("nastar::astar_forward_ordered", mutates_args=("order_out",))
+def astar_forward_ordered(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor, g_ratio: float,
+                          max_iters: int, want_log: bool, flags: int, order: Optional[torch.Tensor],
+                          order_out: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``astar_forward`` with a placement (include/nastar.h: nastar_forward_ordered): workgroup i searches map ``order[i]`` (int32
+    permutation of 0..B-1, or None = identity).  Same five outputs as ``astar_forward``.  ``order_out`` (int32 [B + 1] from
+    ``new_placement_buffer``, or None) receives in [:B] the maps in reverse order of search completion in this launch -- the ``order``
+    for the next visit of the same batch; its last cell is the launch's counter (0 before and after).  No autograd."""
+    _require_device(cost, start, goal, passable)
+    lib = _native.load()
+    cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
+    B, H, W = cost.shape
+    dev = cost.device
+    for name, t, n in (("order", order, B), ("order_out", order_out, B + 1)):
+        if t is not None and (t.dtype != torch.int32 or t.numel() < n or t.device != dev or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous int32 tensor of at least {n} elements on {dev}")
+    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    iters = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
+    flags = int(flags) | FORWARD_FLAGS
+    with torch.cuda.device(dev):
+        rc = lib.nastar_forward_ordered(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
+                                        float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
+                                        sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None, None, 0,
+                                        flags, order.data_ptr() if order is not None else None,
+                                        order_out.data_ptr() if order_out is not None else None, _stream_ptr(dev))
+    _native.check(rc, "nastar_forward_ordered")
+    return hist, paths, iters, status, sel_log
+
+
+@astar_forward_ordered.register_fake
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out):
+    B, H, W = cost.shape
+    return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
+            cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
+            cost.new_empty((B, max_iters) if want_log else (0,), dtype=torch.int32))
+
+
+def workspace_bytes(shape) -> int:
+    """bytes of HBM workspace a [B, H, W] search needs (0: the state of every map lives in LDS)"""
+    B, H, W = (int(x) for x in shape[-3:])
+    return int(_native.load().nastar_workspace_bytes(B, H, W, 0))
+
+
+def new_placement_buffer(B: int, device) -> torch.Tensor:
+    """an ``order_out`` buffer for ``astar_forward_ordered``: int32 [B + 1], zeroed (the trailing counter cell must start at 0)"""
+    return torch.zeros((B + 1,), dtype=torch.int32, device=device)
+
+
+def placement_from_iters(iters: torch.Tensor) -> torch.Tensor:
+    """an ``order`` for ``astar_forward_ordered`` from known (or predicted) step counts: longest searches first"""
+    return torch.argsort(iters, descending=True, stable=True).to(torch.int32)
+
+
 @torch.library.custom_op("nastar::astar_backward_replay", mutates_args=())
 def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
                           passable: torch.Tensor, sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,

@@ -84,9 +84,36 @@ def _raise_unsolvable(status: torch.Tensor, seq: int = 0, deferred: bool = False
         f"(batch rows {bad[:16]}{'...' if len(bad) > 16 else ''} of {where})")
 
 
-def _search(cost, start, goal, passable, g_ratio, max_iters, want_log, flags):
-    """the one launch (csrc/nastar_capi.hip::nastar_forward) behind DifferentiableAstar.forward"""
-    return torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log, flags)
+class Placement:
+    """Memory of ONE recurring batch (a validation batch, an evaluation set searched every epoch): the order in which its searches
+    finished at the previous visit.  ``planner.astar.placement = p`` before a call makes that call start the longest searches first
+    (``nastar_forward_ordered``, include/nastar.h) and leaves the order for the next visit in ``p`` -- no extra launch, no host
+    synchronisation, identical outputs.  The first visit (or a visit with another batch size) runs in the natural order."""
+
+    def __init__(self):
+        self.bufs: Optional[List[torch.Tensor]] = None
+        self.k = 0            # bufs[k] holds the order of the latest visit
+        self.valid = False    # ... once one visit has run
+
+    def buffers(self, B: int, device) -> "tuple[Optional[torch.Tensor], torch.Tensor]":
+        """(order to use now or None, buffer that receives the order of this visit); flips the pair"""
+        if self.bufs is None or self.bufs[0].numel() != B + 1 or self.bufs[0].device != device:
+            self.bufs = [ops.new_placement_buffer(B, device) for _ in range(2)]
+            self.k, self.valid = 0, False
+        cur = self.bufs[self.k] if self.valid else None
+        self.k ^= 1
+        self.valid = True
+        return cur, self.bufs[self.k]
+
+    def __getstate__(self):  # device scratch is not state (deepcopy / pickle of a planner that holds one)
+        return {"bufs": None, "k": 0, "valid": False}
+
+
+def _search(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order=None, order_out=None):
+    """the one launch (csrc/nastar_capi.hip::nastar_forward / nastar_forward_ordered) behind DifferentiableAstar.forward"""
+    if order is None and order_out is None:
+        return torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log, flags)
+    return torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out)
 
 
 class DifferentiableAstar(nn.Module):
@@ -131,6 +158,8 @@ class DifferentiableAstar(nn.Module):
         self.last_iters: Optional[torch.Tensor] = None
         self._pending: List[_PendingStatus] = []
         self._calls = 0  # searches launched through this module (names the call in UnsolvableMapError)
+        # placement memory of the batch the NEXT forward() searches (see Placement); consumed by that call
+        self.placement: Optional[Placement] = None
 
     # run-time bookkeeping (device events, pinned flags, the latest status tensors) is not module state: copy.deepcopy(planner)
     # (EMA / best-model snapshots), pickling and torch.save(planner) must work after any forward()
@@ -139,12 +168,14 @@ class DifferentiableAstar(nn.Module):
         state["_pending"] = []
         state["last_status"] = None
         state["last_iters"] = None
+        state["placement"] = None
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__.setdefault("_pending", [])
         self.__dict__.setdefault("_calls", 0)
+        self.__dict__.setdefault("placement", None)
 
     def raise_if_unsolvable(self, wait: bool = True) -> None:
         """Deliver the deferred verdicts: raise ``UnsolvableMapError`` if an earlier ``forward()`` call met an unsolvable map.
@@ -196,15 +227,21 @@ class DifferentiableAstar(nn.Module):
         sync_check = self.check_solvable in (True, "sync") and not _capturing(cost_maps)
         unit = (same and not want_log and not (torch.is_grad_enabled() and cost_maps.requires_grad)
                 and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
+        # a recurring batch starts its longest searches first (Placement); gradients need the autograd-registered op, and maps whose
+        # state lives in HBM take no placement
+        order = order_out = None
+        pl, self.placement = self.placement, None
+        if pl is not None and not (torch.is_grad_enabled() and cost_maps.requires_grad) and ops.workspace_bytes(cost.shape) == 0:
+            order, order_out = pl.buffers(cost.shape[0], cost.device)
         hist, paths, iters, status, sel_log = _search(
-            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0)
+            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0, order, order_out)
         clean = None
         if unit and self.unit_cost == "auto":
             clean = not bool((status != 0).any())  # the ONE device->host wait of this call (note_status does not wait again)
             if not clean and bool((status == ops.STATUS_NOT_UNIT_COST).any()):
                 # a map with values other than 0 / 1: the whole batch again on the general kernel (same call, same outputs contract)
                 hist, paths, iters, status, sel_log = _search(
-                    cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, 0)
+                    cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, 0, order, order_out)
                 clean = None
         self.note_status(status, iters, clean)
 

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..planner.astar import VanillaAstar
-from ..planner.differentiable_astar import AstarOutput
+from ..planner.differentiable_astar import AstarOutput, Placement
 from .metrics import plan_with_vanilla, validation_metrics
 
 try:  # the reference's trainer; optional here (not in the MI355X image)
@@ -70,6 +70,9 @@ class PlannerModule(_ModuleBase):
         self.vanilla_astar = VanillaAstar()
         self.config = config
         self.logged = {}
+        # validation batches recur every epoch in the same order (reference scripts/train.py:43-50: unshuffled loader, utils/data.py:40-47):
+        # each keeps the order its searches finished in, and the next epoch starts the longest first (planner/differentiable_astar.py: Placement)
+        self._val_placements = {}
 
     if pl is None:
         def log(self, name, value, *args, **kwargs):  # noqa: D401 - Lightning's signature
@@ -90,6 +93,9 @@ class PlannerModule(_ModuleBase):
 
     def validation_step(self, val_batch, batch_idx):
         map_designs, start_maps, goal_maps, opt_trajs = val_batch
+        astar = getattr(self.planner, "astar", None)
+        if astar is not None and hasattr(astar, "placement") and map_designs.is_cuda:
+            astar.placement = self._val_placements.setdefault(int(batch_idx), Placement())
         if map_designs.shape[1] == 1 and hasattr(self.planner, "encode"):  # shortest-path problems (:72-85)
             outputs, va_outputs = plan_with_vanilla(self.planner, map_designs, start_maps, goal_maps)
             loss = nn.L1Loss()(outputs.histories, opt_trajs)

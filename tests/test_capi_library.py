@@ -46,6 +46,11 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, one, 16, 0, None) == _native.NASTAR_ERR_WORKSPACE
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
+    # placement: argument checks of nastar_forward carry over; maps whose state lives in HBM take none
+    assert lib.nastar_forward_ordered(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, one, one, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_ordered(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, one, None, None) == _native.NASTAR_ERR_BAD_SHAPE
+    assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, None, one, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_backward_replay(None, one, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, one, 64, 0, None) == _native.NASTAR_ERR_NULL
     for sym in ("nastar_backward", "nastar_backward_l1", "nastar_has_dev_kernels"):  # rounds 1-3 legacy entry points: gone in 0.4.0
         assert not hasattr(lib, sym), sym

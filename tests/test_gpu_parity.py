@@ -921,3 +921,85 @@ def test_search_on_the_high_priority_stream_of_the_collated_path():
         torch.cuda.current_stream(dev).wait_stream(hp)
         va.astar.raise_if_unsolvable()
     assert torch.equal(out.histories, ref.histories) and torch.equal(out.paths, ref.paths)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,H,B", [("maze", 32, 4096), ("rand", 64, 700), ("rand", 20, 300)])
+def test_placement_changes_when_a_map_is_searched_never_what_is_computed(kind, H, B):
+    """nastar_forward_ordered (include/nastar.h): workgroup i searches map order[i].  Histories, paths, step counts, status and the
+    selection log must equal the natural-order launch for any permutation (reversed, random, longest-first), with the general and the
+    unit-cost kernel, on the hand-scheduled sizes and on one that takes the compiled loop (20x20); the order the launch writes out is a
+    permutation of the batch whose head is made of long searches, the counter cell is left at 0, and feeding it back (what
+    planner.Placement does every epoch) reproduces the same outputs again."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    pr = syn.maze_maps(B, H, seed=77) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.2, seed=77)
+    m, s, g = (_t(x[:, 0]) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    u = _t(syn.random_costs(B, H, H, seed=3)[:, 0])
+    rng = np.random.default_rng(5)
+    for cost, passable, flags, log in ((m, m, 0, True), (u, m, 0, True), (m, m, ops.FLAG_UNIT_COST, False)):
+        ref = torch.ops.nastar.astar_forward(cost, s, g, passable, 0.5, H * H, log, flags)
+        it = ref[2].cpu().numpy()
+        orders = [np.arange(B)[::-1].copy(), rng.permutation(B), np.argsort(-it, kind="stable")]
+        out_buf = ops.new_placement_buffer(B, m.device)
+        for o in orders:
+            ot = torch.from_numpy(o.astype(np.int32)).to(m.device)
+            got = torch.ops.nastar.astar_forward_ordered(cost, s, g, passable, 0.5, H * H, log, flags, ot, out_buf)
+            torch.cuda.synchronize()
+            for k, name in enumerate(("histories", "paths", "iters", "status")):
+                assert torch.equal(ref[k], got[k]), (flags, name)
+            if log:
+                mask = torch.arange(ref[4].shape[1], device=m.device)[None, :] < ref[2][:, None]
+                assert torch.equal(torch.where(mask, ref[4], -1), torch.where(mask, got[4], -1)), flags
+            w = out_buf.cpu().numpy()
+            assert w[B] == 0 and np.array_equal(np.sort(w[:B]), np.arange(B))
+        # the order a launch leaves: long searches first (rank correlation with the step counts), and it feeds the next visit
+        w = out_buf[:B].cpu().numpy()
+        first, last = it[w[:B // 8]].mean(), it[w[-(B // 8):]].mean()
+        assert first > last, (first, last)
+        nxt = ops.new_placement_buffer(B, m.device)
+        got = torch.ops.nastar.astar_forward_ordered(cost, s, g, passable, 0.5, H * H, log, flags, out_buf[:B].contiguous(), nxt)
+        for k in range(4):
+            assert torch.equal(ref[k], got[k])
+        assert int(nxt[B]) == 0 and np.array_equal(np.sort(nxt[:B].cpu().numpy()), np.arange(B))
+    # an order that is not a permutation must not touch memory outside the batch (rows it names twice / never are unspecified)
+    bad = torch.full((B,), B + 5, dtype=torch.int32, device=m.device)
+    bad[0] = 0
+    torch.ops.nastar.astar_forward_ordered(m, s, g, m, 0.5, H * H, False, 0, bad, None)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_placement_through_the_planner_and_the_validation_step():
+    """planner.astar.placement = Placement(): the first visit runs in natural order, later visits longest-first; outputs never change;
+    the placement is consumed by the call; PlannerModule.validation_step keeps one per batch index.  Maps whose state lives in HBM and
+    calls that need gradients ignore it."""
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.planner.differentiable_astar import Placement
+    from neural_astar.utils import synthetic as syn
+    pr = syn.maze_maps(512, 32, seed=9)
+    m, s, g = (_t(x) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    va = VanillaAstar().to(m.device).eval()
+    ref = va(m, s, g)
+    p = Placement()
+    for visit in range(3):
+        va.astar.placement = p
+        out = va(m, s, g)
+        assert va.astar.placement is None
+        assert torch.equal(out.histories, ref.histories) and torch.equal(out.paths, ref.paths)
+        assert p.valid and p.bufs is not None and int(p.bufs[p.k][512]) == 0
+    order = p.bufs[p.k][:512].cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(512))
+    it = va.astar.last_iters.cpu().numpy()
+    assert it[order[:64]].mean() > it[order[-64:]].mean()
+    # another batch size through the same Placement: starts over in natural order
+    va.astar.placement = p
+    out = va(m[:100], s[:100], g[:100])
+    assert torch.equal(out.histories, ref.histories[:100]) and p.bufs[0].numel() == 101
+    # gradients: the autograd-registered op is used, the placement is ignored (and consumed)
+    c = m.clone().requires_grad_(True)
+    va.train()
+    va.astar.placement = Placement()
+    o = va.astar(c, s, g, m)
+    o.histories.sum().backward()
+    assert c.grad is not None and va.astar.placement is None

@@ -402,3 +402,27 @@ def test_default_encoder_backend_is_auto_and_resolves_per_device():
     na.encoder_backend = "auto"
     c = na.eval().encode(x, torch.zeros_like(x), torch.zeros_like(x))  # CPU tensors: the torch.nn encoder, as the reference
     assert c.shape == (2, 1, 32, 32)
+
+
+def test_placement_memory_alternates_its_buffers_and_is_not_module_state():
+    """planner/differentiable_astar.py: Placement -- first visit natural order (no `order`), then the buffer the previous visit wrote;
+    another batch size starts over; deepcopy / pickle of a planner that holds one drops the device scratch"""
+    import copy
+    import pickle
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.planner.differentiable_astar import Placement
+    p = Placement()
+    cur, out = p.buffers(8, torch.device("cpu"))
+    assert cur is None and out.shape == (9,) and out.dtype == torch.int32 and int(out.abs().sum()) == 0
+    cur2, out2 = p.buffers(8, torch.device("cpu"))
+    assert cur2 is out and out2 is not out and out2.shape == (9,)
+    cur3, out3 = p.buffers(8, torch.device("cpu"))
+    assert cur3 is out2 and out3 is out
+    cur4, out4 = p.buffers(5, torch.device("cpu"))
+    assert cur4 is None and out4.shape == (6,)
+    va = VanillaAstar()
+    va.astar.placement = p
+    for clone in (copy.deepcopy(va), pickle.loads(pickle.dumps(va))):
+        assert clone.astar.placement is None
+    q = pickle.loads(pickle.dumps(p))
+    assert q.bufs is None and not q.valid

@@ -36,3 +36,27 @@ for B in (256, 1024, 2304, 4096):
     pr = syn.Problems(*(x[:B] for x in one))
     us, it = run(pr)
     print(f"same-map B={B}: {us:.1f} us iters each {it[0]} -> {us*1e3/it[0]:.1f} ns/iter-round, {it.sum()/us/1e3:.3f} Gexp/s")
+# ONE long search on a busy chip at its working clocks: the longest maze of the bench batch in workgroup 0, every other map of the 4096
+# solved in 2 steps (start next to goal) -- launch time = fixed part + max-iter x (step of a wavefront that has its SIMD to itself).
+# (The B = 1 line above runs on an otherwise idle GPU whose clocks never leave the idle state: ~280 ns per step there.)
+its_all = run(mz)[1]
+rank = np.argsort(-its_all)
+triv = syn.Problems(*(np.repeat(x[:1], 4096, 0).copy() for x in mz))
+triv.map_designs[:] = 1.0
+triv.start_maps[:] = 0.0
+triv.goal_maps[:] = 0.0
+triv.start_maps[:, 0, 5, 5] = 1.0
+triv.goal_maps[:, 0, 5, 6] = 1.0
+us_t, _ = run(triv, reps=200)
+print(f"4096 two-step maps: {us_t:.1f} us")
+pts = []
+for q in (0, 200, 1000, 2000, 3000):  # searches of decreasing length, each alone (workgroup 0) among the trivial ones
+    i = int(rank[q])
+    triv.map_designs[0], triv.start_maps[0], triv.goal_maps[0] = mz.map_designs[i], mz.start_maps[i], mz.goal_maps[i]
+    us, it = run(triv, reps=200)
+    pts.append((int(it.max()), us))
+    print(f"one maze of {it.max()} steps at workgroup 0 among 4095 two-step maps: {us:.1f} us")
+x = np.array([p[0] for p in pts], float)
+y = np.array([p[1] for p in pts], float)
+sl, ic = np.polyfit(x, y, 1)
+print(f"least-squares line through those points: {sl * 1e3:.1f} ns per step (a wavefront with its SIMD to itself, chip at working clocks) + {ic:.1f} us fixed")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the evidence the bench line's roofline block is checked against.
-#   1. rocprofv3 kernel trace + stats of the exact default bench command (N=1)          -> kernel_stats
+#   1. rocprofv3 kernel trace + stats of the default bench command (N=1; hinted placement, and once more with --placement natural) -> kernel_stats
 #   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slot limit), kernel-trace only
 #   3. SQ counters of the shipped forward kernel and, for comparison, of other streams / layouts (SQ_FLAGS, default "0 128 64":
 #      round-4 stream, round-3 stream, unit-cost layout)
@@ -13,8 +13,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-secondary"
+# (--no-natural: the default bench line also times the natural-order placement beside the hinted one; a kernel average must not mix the two)
+B="python $R/bench.py --no-cpu-baseline --no-secondary --no-natural"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $B --steps 50 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_natural -o bench --output-format csv -- $B --placement natural --steps 50 --warmup 5 > $OUT/bench_natural_under_rocprof.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- $B --steps 20 --warmup 2 > $OUT/pmc_$C.log 2>&1
 done
@@ -44,7 +46,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train --output-for
 python - <<PY
 import csv, glob, json, collections
 out = {}
-for tag, pat in (("bench_kernel_stats", "$OUT/trace/**/*kernel_stats.csv"), ("train_step_kernel_stats", "$OUT/train/**/*kernel_stats.csv")):
+for tag, pat in (("bench_kernel_stats", "$OUT/trace/**/*kernel_stats.csv"), ("bench_natural_order_kernel_stats", "$OUT/trace_natural/**/*kernel_stats.csv"),
+                 ("train_step_kernel_stats", "$OUT/train/**/*kernel_stats.csv")):
     for f in glob.glob(pat, recursive=True):
         rows = list(csv.DictReader(open(f)))
         out[tag] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in rows[:6]]

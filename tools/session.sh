@@ -195,6 +195,25 @@ P
   python tools/probe_streams.py --workloads maze32,rand32 --flags 0,512 --streams 1,4 --bigb 4 > $O/streams.jsonl 2> $O/streams.err
   cat $O/streams.jsonl; tail -n 2 $O/streams.err
   ;;
+r04_order)
+  # placement by known step counts (nastar_forward_ordered): us per 4096-map launch for several orders, general and unit-cost kernels
+  O=gpurun_out/r04/order${2:-}; mkdir -p $O
+  python tools/probe_order.py maze32,rand32,rand64 0 > $O/order_f0.jsonl 2> $O/order_f0.err; cat $O/order_f0.jsonl; tail -n 2 $O/order_f0.err
+  ;;
+r04_order2)
+  # placement, wired: parity tests, the lone-wavefront step at working clocks, the bench line (hinted headline + natural order beside it)
+  O=gpurun_out/r04/order2${2:-}; mkdir -p $O
+  python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "placement" > $O/parity.log 2>&1; echo "parity rc=$?"; tail -5 $O/parity.log
+  python tools/probe_latency.py > $O/lat.txt 2>&1; tail -4 $O/lat.txt
+  python bench.py --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
+  python - <<P
+import json
+j = json.load(open("$O/bench_driver_command.json"))
+print({k: j[k] for k in ("value", "ms_per_step")}, j["roofline"]["launch_ms_avg"], j["roofline"]["frac"], j["natural_order"])
+for s in j["secondary"]: print(s["workload"], s["launch_ms_avg"], s["hbm_frac"], s.get("launch_ms_avg_natural_order"), s.get("hbm_frac_natural_order"))
+print(j["issue_model"])
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
