@@ -36,6 +36,8 @@ struct BwdRArgs {
     const int* sel_log;   // [B, max_iters] selections of the forward
     const int* iters;     // [B]
     const int* t_batch;   // device scalar or nullptr
+    const int* order;     // optional placement (workgroup i replays map order[i]); nullptr = identity
+    int B_total;          // maps in the batch (bounds the placement)
     float* grad_cost;     // [B,H,W], fully written by this kernel
     double* hist;         // workspace: [B][hist_len][2]  (A, B) after each step; entry 0 = (0, 0)
     unsigned char* state; // workspace for maps whose state does not fit LDS (kGlobal), else nullptr
@@ -105,7 +107,8 @@ template <bool kGlobal, bool kHistLds, bool kFastDiv>
 __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)b >= (unsigned)a.B_total) return;  // not a permutation: never touch memory outside the batch
     const int lane = threadIdx.x;
     const CompactDims d = a.d;
     unsigned char* base = kGlobal ? a.state + (size_t)b * a.state_stride : smem;

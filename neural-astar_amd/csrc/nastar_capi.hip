@@ -482,6 +482,7 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
     if (workspace_bytes < nastar_backward_workspace_bytes(B, H, W, max_iters)) return NASTAR_ERR_WORKSPACE;
     a.d.HWp = ((a.d.HW + 63) / 64) * 64;
     a.cost = cost; a.start = start; a.goal = goal; a.passable = passable; a.sel_log = sel_log; a.iters = iters;
+    a.B_total = B;
     a.t_batch = t_batch_dev; a.grad_cost = grad_cost_out; a.max_iters = max_iters;
     a.kfac = a.d.omg * (-1.0f / a.d.sqrtW);
     a.hist = static_cast<double*>(workspace);
@@ -525,6 +526,7 @@ int nastar_backward_replay(const float* grad_histories, const float* cost, const
     if (!grad_histories) return NASTAR_ERR_NULL;
     BwdRArgs a;
     a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
+    a.order = nullptr;
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
                                 grad_cost_out, workspace, workspace_bytes, stream, flags);
 }
@@ -539,8 +541,26 @@ int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, co
     BwdRArgs a;
     a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
     a.l1_scale = (float)(1.0 / ((double)B * H * W));
+    a.order = nullptr;
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
                                 grad_cost_out, workspace, workspace_bytes, stream);
+}
+
+int nastar_backward_replay_ordered(const float* grad_histories, const float* histories, const float* opt_trajs, const float* grad_loss_dev,
+                                   const float* cost, const float* start, const float* goal, const float* passable, const int32_t* sel_log,
+                                   int B, int H, int W, double g_ratio, int max_iters, const int32_t* iters, const int32_t* t_batch_dev,
+                                   float* grad_cost_out, void* workspace, size_t workspace_bytes, int flags, const int32_t* order, void* stream)
+{
+    if (!grad_histories && (!histories || !opt_trajs)) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    BwdRArgs a;
+    a.grad_hist = grad_histories;
+    a.l1_hist = grad_histories ? nullptr : histories; a.l1_traj = grad_histories ? nullptr : opt_trajs;
+    a.l1_up = grad_histories ? nullptr : grad_loss_dev;
+    a.l1_scale = grad_histories ? 0.f : (float)(1.0 / ((double)B * H * W));
+    a.order = order;
+    return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
+                                grad_cost_out, workspace, workspace_bytes, stream, flags);
 }
 
 int nastar_pack_outputs(const float* histories, const int64_t* paths, int B, int H, int W, uint8_t* packed_out, void* stream)

@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "nastar_forward_ordered",
     "nastar_backward_workspace_bytes",
     "nastar_backward_replay",
+    "nastar_backward_replay_ordered",
     "nastar_backward_l1_replay",
     "nastar_l1_loss",
     "nastar_policy_rollout",
@@ -131,6 +132,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_backward_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.nastar_backward_replay.restype = ci
     lib.nastar_backward_replay.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
+    lib.nastar_backward_replay_ordered.restype = ci
+    lib.nastar_backward_replay_ordered.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp, vp]
     lib.nastar_backward_l1_replay.restype = ci
     lib.nastar_backward_l1_replay.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, vp]
     lib.nastar_l1_loss.restype = ci

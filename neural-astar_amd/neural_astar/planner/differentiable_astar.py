@@ -231,10 +231,16 @@ class DifferentiableAstar(nn.Module):
         # state lives in HBM take no placement
         order = order_out = None
         pl, self.placement = self.placement, None
-        if pl is not None and not (torch.is_grad_enabled() and cost_maps.requires_grad) and ops.workspace_bytes(cost.shape) == 0:
+        in_lds = ops.workspace_bytes(cost.shape) == 0
+        needs_grad = torch.is_grad_enabled() and cost_maps.requires_grad
+        if pl is not None and in_lds:
             order, order_out = pl.buffers(cost.shape[0], cost.device)
-        hist, paths, iters, status, sel_log = _search(
-            cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0, order, order_out)
+        if needs_grad and in_lds and (order_out is not None or cost.shape[0] >= ops.PLACEMENT_MIN_BATCH):
+            # large batches under autograd: the replay backward starts longest-first, by the order THIS forward's searches finish in
+            hist, paths, iters, status, sel_log = ops.astar_forward_placed(cost, start, goal, passable, self.g_ratio, max_iters, 0, order, order_out)
+        else:
+            hist, paths, iters, status, sel_log = _search(
+                cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0, order, order_out)
         clean = None
         if unit and self.unit_cost == "auto":
             clean = not bool((status != 0).any())  # the ONE device->host wait of this call (note_status does not wait again)

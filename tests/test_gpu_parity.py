@@ -1003,3 +1003,64 @@ def test_placement_through_the_planner_and_the_validation_step():
     o = va.astar(c, s, g, m)
     o.histories.sum().backward()
     assert c.grad is not None and va.astar.placement is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,H,B", [("maze", 32, 2048), ("rand", 64, 600)])
+def test_replay_backward_placement_leaves_every_gradient_bit_identical(kind, H, B):
+    """nastar_backward_replay_ordered: workgroup i replays map order[i].  For the forward's own completion order (what the training
+    paths pass), a random permutation and the reversed batch, dL/dcost equals the natural-order replay bit for bit -- upstream
+    gradient form and fused-L1 form; an order that is not a permutation touches nothing outside the batch."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    pr = syn.maze_maps(B, H, seed=21) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.2, seed=21)
+    m, s, g = (_t(x[:, 0]) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    cost = _t(syn.random_costs(B, H, H, seed=8)[:, 0])
+    T = H * H // 4
+    buf = ops.new_placement_buffer(B, m.device)
+    hist, paths, iters, status, log = torch.ops.nastar.astar_forward_ordered(cost, s, g, m, 0.5, T, True, 0, None, buf)
+    gh = torch.randn_like(cost)
+    traj = (torch.rand_like(cost) < 0.2).float() * m
+    tb = (iters.amax() - 1).to(torch.int32).reshape(1)
+    ref = torch.ops.nastar.astar_backward_replay(gh, cost, s, g, m, log, 0.5, T, iters, tb)
+    ref1 = torch.ops.nastar.astar_backward_l1_replay(hist, traj, None, cost, s, g, m, log, 0.5, T, iters, tb)
+    rng = np.random.default_rng(2)
+    for o in (buf, torch.from_numpy(rng.permutation(B).astype(np.int32)).to(m.device), torch.arange(B - 1, -1, -1, dtype=torch.int32, device=m.device)):
+        assert torch.equal(ref, torch.ops.nastar.astar_backward_replay(gh, cost, s, g, m, log, 0.5, T, iters, tb, o))
+        assert torch.equal(ref1, torch.ops.nastar.astar_backward_l1_replay(hist, traj, None, cost, s, g, m, log, 0.5, T, iters, tb, o))
+    bad = torch.full((B,), -3, dtype=torch.int32, device=m.device)
+    torch.ops.nastar.astar_backward_replay(gh, cost, s, g, m, log, 0.5, T, iters, tb, bad)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_training_paths_of_large_batches_use_the_placement_and_keep_their_gradients():
+    """B >= ops.PLACEMENT_MIN_BATCH: the fused L1 node and DifferentiableAstar.forward under autograd hand the forward's completion
+    order to the replay backward.  Loss, outputs and dL/dcost must equal the small-batch code path (threshold raised) bit for bit."""
+    from neural_astar import ops
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    B, H = 1280, 32
+    pr = syn.maze_maps(B, H, seed=31)
+    m, s, g = (_t(x) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    traj = ((torch.rand_like(m) < 0.2).float() * m).contiguous()
+    u = _t(syn.random_costs(B, H, H, seed=4))
+    va = VanillaAstar().to(m.device).train()
+    va.astar.Tmax = 0.25
+    res = {}
+    keep = ops.PLACEMENT_MIN_BATCH
+    try:
+        for label, thr in (("placed", keep), ("plain", 1 << 30)):
+            ops.PLACEMENT_MIN_BATCH = thr
+            c1 = u.clone().requires_grad_(True)
+            loss, hist, paths, iters, status = ops.astar_l1_loss(c1[:, 0], s[:, 0], g[:, 0], m[:, 0], traj[:, 0], 0.5, 256)
+            loss.backward()
+            c2 = u.clone().requires_grad_(True)
+            out = va.astar(c2, s, g, m)
+            (out.histories * traj).sum().backward()
+            res[label] = (loss.detach(), hist, paths, c1.grad, out.histories.detach(), c2.grad)
+    finally:
+        ops.PLACEMENT_MIN_BATCH = keep
+    assert B >= keep
+    for a, b in zip(res["placed"], res["plain"]):
+        assert torch.equal(a, b)
