@@ -111,6 +111,18 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
                            void* stream);
 
 /*
+ * A placement (the `order` of nastar_forward_ordered) for a batch that has never been searched: maps sorted, longest first, by the
+ * level at which a unit-cost 8-connected breadth-first wave from the start reaches the goal over passable cells -- the length of the
+ * shortest route (csrc/nastar_placement.hip.h).  A crude predictor of the search length (correlation 0.5-0.8) is as good as the
+ * exact step counts here: 4096 mazes 150 -> 115.5 us per search launch (exact: 114.8), 64x64 random maps 273 -> 229.  Two small
+ * launches (bit-parallel wave, one wavefront per map; counting sort, one workgroup); 32x32 and 64x64 maps, 16-byte aligned
+ * (NASTAR_ERR_UNSUPPORTED otherwise: search without a placement).  Maps of equal level come in arbitrary order.
+ *   order_out  [B] int32 device     workspace  >= 4 B bytes of device memory
+ */
+int nastar_placement_predict(const float* passable, const float* start, const float* goal, int B, int H, int W,
+                             int32_t* order_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * nastar_forward that ALSO emits the bit-packed masks (layout: see nastar_pack_outputs) in the same launch where the
  * shape allows it (W % 4 == 0, H*W % 8 == 0, LDS-resident), otherwise by one extra pack launch on the same stream.
  * This is what one rank of the multi-GPU path calls right before the all-gather.

@@ -14,6 +14,7 @@
 #include "nastar_search_asm3.hip.h"
 #include "nastar_search_asm4.hip.h"
 #include "nastar_search_unit.hip.h"
+#include "nastar_placement.hip.h"
 #include "nastar_backward_replay.hip.h"
 #include "nastar_backward_replay_asm.hip.h"
 
@@ -442,6 +443,23 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
                           iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out);
     if (rc != NASTAR_OK || done || !packed_out) return rc;
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);
+}
+
+int nastar_placement_predict(const float* passable, const float* start, const float* goal, int B, int H, int W, int32_t* order_out,
+                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!passable || !start || !goal || !order_out || !workspace) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (H != W || (W != 32 && W != 64) || !aligned16(passable) || !aligned16(start) || !aligned16(goal)) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < (size_t)B * sizeof(int)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int* level = static_cast<int*>(workspace);
+    if (W == 32) hipLaunchKernelGGL(nastar_bfs_level_kernel<5>, dim3((unsigned)B), dim3(64), 0, s, passable, start, goal, B, level);
+    else hipLaunchKernelGGL(nastar_bfs_level_kernel<6>, dim3((unsigned)B), dim3(64), 0, s, passable, start, goal, B, level);
+    hipLaunchKernelGGL(nastar_rank_levels_kernel, dim3(1), dim3(PLC_RANK_THREADS), 0, s, level, B, order_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
 }
 
 int nastar_forward_packed(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "nastar_forward",
     "nastar_forward_packed",
     "nastar_forward_ordered",
+    "nastar_placement_predict",
     "nastar_backward_workspace_bytes",
     "nastar_backward_replay",
     "nastar_backward_replay_ordered",
@@ -126,6 +127,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_forward_ordered.restype = ci
     lib.nastar_forward_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp]
+    lib.nastar_placement_predict.restype = ci
+    lib.nastar_placement_predict.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, cz, vp]
     lib.nastar_forward_packed.restype = ci
     lib.nastar_forward_packed.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_backward_workspace_bytes.restype = cz

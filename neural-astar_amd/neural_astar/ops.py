@@ -143,6 +143,29 @@ def workspace_bytes(shape) -> int:
     return int(_native.load().nastar_workspace_bytes(B, H, W, 0))
 
 
+def placement_supported(shape) -> bool:
+    """sizes ``placement_predict`` handles (csrc/nastar_placement.hip.h)"""
+    H, W = int(shape[-2]), int(shape[-1])
+    return H == W and W in (32, 64)
+
+
+def placement_predict(passable: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, return_levels: bool = False):
+    """``order`` ([B] int32) for ``astar_forward_ordered`` on a batch that has never been searched: maps sorted, longest first, by the
+    length of their shortest 8-connected route over passable cells (include/nastar.h: nastar_placement_predict; two small launches on
+    the current stream).  [B,H,W] or [B,1,H,W] fp32 maps, 32x32 or 64x64."""
+    _require_device(passable, start, goal)
+    lib = _native.load()
+    p, s, g = (_maps3(x) for x in (passable, start, goal))
+    B, H, W = p.shape
+    dev = p.device
+    order = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nastar_placement_predict(p.data_ptr(), s.data_ptr(), g.data_ptr(), B, H, W, order.data_ptr(), ws.data_ptr(), B * 4, _stream_ptr(dev))
+    _native.check(rc, "nastar_placement_predict")
+    return (order, ws) if return_levels else order
+
+
 def new_placement_buffer(B: int, device) -> torch.Tensor:
     """an ``order_out`` buffer for ``astar_forward_ordered``: int32 [B + 1], zeroed (the trailing counter cell must start at 0)"""
     return torch.zeros((B + 1,), dtype=torch.int32, device=device)

@@ -1064,3 +1064,48 @@ def test_training_paths_of_large_batches_use_the_placement_and_keep_their_gradie
     assert B >= keep
     for a, b in zip(res["placed"], res["plain"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,H,B", [("maze", 32, 700), ("rand", 32, 300), ("rand", 64, 300)])
+def test_placement_predictor_is_the_breadth_first_level_of_the_goal(kind, H, B):
+    """nastar_placement_predict (csrc/nastar_placement.hip.h): level of a unit-cost 8-connected wave from the start at the goal, over
+    passable cells -- checked against a numpy wave on every map incl. an unreachable goal (0), start == goal (0) and a start on an
+    obstacle; the order is a permutation sorted by that level, longest first; searching with it changes no output."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    pr = syn.maze_maps(B, H, seed=41) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25, seed=41)
+    m, s, g = (x[:, 0].copy() for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    m[0] = 1.0; m[0, H // 2, :] = 0.0  # a wall between start and goal: unreachable
+    s[0] = 0; g[0] = 0; s[0, 1, 1] = 1; g[0, H - 2, H - 2] = 1
+    g[1] = s[1]                          # start == goal
+    m[2][s[2] > 0] = 0.0                 # start on an obstacle (it is expanded all the same, reference :187)
+    vis = s > 0
+    goalm = g > 0
+    L = np.zeros(B, np.int64)
+    done = (vis & goalm).any((1, 2))
+    for lvl in range(1, H * H):
+        p = np.pad(vis, ((0, 0), (1, 1), (1, 1)))
+        nb = np.zeros_like(vis)
+        for dr in range(3):
+            for dc in range(3):
+                nb |= p[:, dr:dr + H, dc:dc + H]
+        new = (nb & (m > 0)) | vis
+        hit = (new & goalm).any((1, 2)) & ~done
+        L[hit] = lvl
+        done |= hit
+        if (new == vis).all():
+            break
+        vis = new
+    mt, st, gt = (_t(x) for x in (m, s, g))
+    order, lv = ops.placement_predict(mt, st, gt, return_levels=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(lv.cpu().numpy(), L)
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(B)) and (np.diff(L[o]) <= 0).all()
+    ok = torch.from_numpy(np.flatnonzero(L > 0)).to(mt.device)  # (map 0 has no route, map 1 needs no step: the search itself is tested elsewhere)
+    ref = torch.ops.nastar.astar_forward(mt, st, gt, mt, 0.5, H * H, False, 0)
+    got = torch.ops.nastar.astar_forward_ordered(mt, st, gt, mt, 0.5, H * H, False, 0, order, None)
+    for k in range(4):
+        assert torch.equal(ref[k], got[k])
+    assert ok.numel() > B // 2

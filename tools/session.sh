@@ -214,6 +214,18 @@ for s in j["secondary"]: print(s["workload"], s["launch_ms_avg"], s["hbm_frac"],
 print(j["issue_model"])
 P
   ;;
+r04_final2)
+  # the record after the placement work: whole GPU suite, lone-wavefront step at working clocks, training pair with placements,
+  # the driver's bench command, the profile round (kernel stats hinted + natural, PMC, SQ, training step)
+  O=gpurun_out/r04/final2; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_tests.log
+  python __graft_entry__.py smoke 2>&1 | tail -1
+  python tools/probe_latency.py > $O/lat_working_clocks.txt 2>&1; tail -8 $O/lat_working_clocks.txt
+  python tools/probe_order_train.py > $O/order_train_pair.json 2> $O/order_train_pair.err; cat $O/order_train_pair.json
+  python tools/probe_order.py maze32,rand32,rand64 0 > $O/order_placements_probe.jsonl 2>/dev/null
+  python bench.py --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench.err; echo "bench rc=$?"
+  bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1; tail -c 600 $O/profile_round.log
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
