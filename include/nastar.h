@@ -98,9 +98,11 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
  * a data set is searched once per epoch (reference scripts/train.py:43-50 validates after every epoch on a fixed, unshuffled
  * loader, utils/data.py:40-47): the previous visit of the same batch is the predictor.
  *   order      [B] int32 device, a permutation of 0..B-1, or NULL (identity)
- *   order_out  [B+1] int32 device or NULL: receives the maps in REVERSE order of search completion in THIS launch = the `order`
- *              to pass at the next visit of the same batch.  order_out[B] is the launch's counter: it must be 0 on entry and is
- *              0 again when the launch has finished (zero the buffer once, then reuse it; one buffer per launch in flight).
+ *   order_out  [B+1] int32 device or NULL: receives the `order` to pass at the next visit of the same batch -- the maps in REVERSE
+ *              order of search completion in THIS launch when all B maps are resident at once (one atomic per map inside the
+ *              kernel), sorted by their step counts (one more small launch on the same stream) when the launch takes several
+ *              rounds of workgroups.  order_out[B] is the launch's counter: it must be 0 on entry and is 0 again when the launch
+ *              has finished (zero the buffer once, then reuse it; one buffer per launch in flight).
  *   packed_out NULL, or the bit-packed masks of nastar_forward_packed.
  * Maps whose search state lives in HBM (nastar_workspace_bytes > 0) take no placement: NASTAR_ERR_UNSUPPORTED if either is given.
  */

@@ -278,6 +278,21 @@ thread_local char g_last_error[256] = "";
 
 constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
 
+// maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
+static long long resident_capacity(size_t lds_per_map)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    long long per_cu = (long long)(kMaxLdsBytes / (lds_per_map ? lds_per_map : 1));
+    if (per_cu > 32) per_cu = 32;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu * cus;
+}
+
 static int make_cdims(int B, int H, int W, int max_iters, double g_ratio, CompactDims& d)
 {
     if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
@@ -337,6 +352,16 @@ size_t nastar_workspace_bytes(int B, int H, int W, int flags)
     return (size_t)B * global_slab_bytes(H * W);
 }
 
+// order_out for a multi-round launch: maps sorted by their step counts, longest first (nastar_placement.hip.h: counting sort, one
+// workgroup, same stream); the trailing counter cell is not used and stays 0
+static int rank_order_after(const int32_t* iters, int B, int32_t* order_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(nastar_rank_levels_kernel, dim3(1), dim3(PLC_RANK_THREADS), 0, s, iters, B, order_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 static int forward_impl(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
                         int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                         int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
@@ -378,7 +403,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.sel_log = sel_log_out; c.iters = iters_out; c.status = status_out; c.max_iters = max_iters;
         c.packed = nullptr;
         c.order = order;
-        c.order_out = order_out;
+        c.order_out = order_out;  // (decided below: in-kernel completion order, or a rank of the step counts after the launch)
         c.flags = flags;
         const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                           aligned16(histories_out) && aligned16(paths_out);
@@ -398,9 +423,14 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
         if ((flags & NASTAR_FLAG_UNIT_COST) && cost == passable && use_asm && !(flags & (NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3)) && !lg && vec4 && fast &&
             g_ratio >= 0.0 && g_ratio <= 1.0 && H == W && (W == 32 || W == 64)) {
-            if (W == 32) return launch(&nastar_forward_unit_kernel<5, false>, B, (size_t)AsmLayoutUnit<5>::BYTES, s, c, rcp);
-            if (flags & NASTAR_FLAG_NO_DIVE) return launch(&nastar_forward_unit_kernel<6, false>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
-            return launch(&nastar_forward_unit_kernel<6, true>, B, (size_t)AsmLayoutUnit<6>::BYTES, s, c, rcp);
+            const size_t ulds = W == 32 ? (size_t)AsmLayoutUnit<5>::BYTES : (size_t)AsmLayoutUnit<6>::BYTES;
+            const bool rank_after = order_out && (long long)B > resident_capacity(ulds);
+            if (rank_after) c.order_out = nullptr;
+            int urc;
+            if (W == 32) urc = launch(&nastar_forward_unit_kernel<5, false>, B, ulds, s, c, rcp);
+            else if (flags & NASTAR_FLAG_NO_DIVE) urc = launch(&nastar_forward_unit_kernel<6, false>, B, ulds, s, c, rcp);
+            else urc = launch(&nastar_forward_unit_kernel<6, true>, B, ulds, s, c, rcp);
+            return (urc == NASTAR_OK && rank_after) ? rank_order_after(iters_out, B, order_out, s) : urc;
         }
         if (use_asm && vec4 && fast && H == 32 && W == 32)
             kern = lg ? &nastar_forward_compact_kernel<true, 5, 5, 1, true, true, true> : &nastar_forward_compact_kernel<true, 5, 5, 1, true, false, true>;
@@ -417,7 +447,12 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         else if (fast) { NASTAR_CPICK(false, 0, 0, 0, true); }
         else { NASTAR_CPICK(false, 0, 0, 0, false); }
 #undef NASTAR_CPICK
-        return launch(kern, B, lds, s, c, rcp);
+        // order_out: a launch whose maps are all resident at once ranks them by completion (one atomic per map, in the kernel); with
+        // several rounds of workgroups completion time says when a map was STARTED, not how long its search was -- rank the step counts
+        const bool rank_after = order_out && (long long)B > resident_capacity(lds);
+        if (rank_after) c.order_out = nullptr;
+        const int krc = launch(kern, B, lds, s, c, rcp);
+        return (krc == NASTAR_OK && rank_after) ? rank_order_after(iters_out, B, order_out, s) : krc;
     }
     return NASTAR_ERR_UNSUPPORTED;
 }

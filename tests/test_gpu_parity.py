@@ -1109,3 +1109,25 @@ def test_placement_predictor_is_the_breadth_first_level_of_the_goal(kind, H, B):
     for k in range(4):
         assert torch.equal(ref[k], got[k])
     assert ok.numel() > B // 2
+
+
+@pytest.mark.gpu
+def test_order_out_of_a_launch_larger_than_the_chip_ranks_the_step_counts():
+    """B above what is resident at once (several rounds of workgroups): completion time would say when a map was started, so order_out
+    is the maps sorted by their step counts, longest first (a counting sort after the launch); outputs as ever."""
+    from neural_astar import ops
+    from neural_astar.utils import synthetic as syn
+    B, H = 9000, 32
+    pr = syn.random_obstacle_maps(B, H, H, 0.25, seed=13)
+    m, s, g = (_t(x[:, 0]) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    ref = torch.ops.nastar.astar_forward(m, s, g, m, 0.5, H * H, False, 0)
+    for flags in (0, ops.FLAG_UNIT_COST):
+        buf = ops.new_placement_buffer(B, m.device)
+        got = torch.ops.nastar.astar_forward_ordered(m, s, g, m, 0.5, H * H, False, flags, None, buf)
+        torch.cuda.synchronize()
+        o = buf[:B].cpu().numpy()
+        it = got[2].cpu().numpy()
+        assert int(buf[B]) == 0 and np.array_equal(np.sort(o), np.arange(B)) and (np.diff(it[o]) <= 0).all()
+        again = torch.ops.nastar.astar_forward_ordered(m, s, g, m, 0.5, H * H, False, flags, buf[:B].contiguous(), None)
+        for k in range(4):
+            assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], again[k])
