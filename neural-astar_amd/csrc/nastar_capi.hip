@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         a.status[b] = status;
         if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
             const int pos = atomicAdd(a.order_out + a.B, 1);
-            a.order_out[a.B - 1 - pos] = b;
+            if ((unsigned)pos < (unsigned)a.B) a.order_out[a.B - 1 - pos] = b;  // (a counter that did not start at 0 must not write outside)
             if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
         }
     }
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
         a.status[b] = status;
         if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
             const int pos = atomicAdd(a.order_out + a.B, 1);
-            a.order_out[a.B - 1 - pos] = b;
+            if ((unsigned)pos < (unsigned)a.B) a.order_out[a.B - 1 - pos] = b;  // (a counter that did not start at 0 must not write outside)
             if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
         }
     }
