@@ -96,14 +96,17 @@ class Placement:
         self.valid = False    # ... once one visit has run
 
     def buffers(self, B: int, device) -> "tuple[Optional[torch.Tensor], torch.Tensor]":
-        """(order to use now or None, buffer that receives the order of this visit); flips the pair"""
+        """(order to use now or None, buffer that receives the order of this visit).  Nothing changes until ``commit()``: a call that
+        fails before its launch must not leave a half-initialised order behind for the next visit."""
         if self.bufs is None or self.bufs[0].numel() != B + 1 or self.bufs[0].device != device:
             self.bufs = [ops.new_placement_buffer(B, device) for _ in range(2)]
             self.k, self.valid = 0, False
-        cur = self.bufs[self.k] if self.valid else None
+        return (self.bufs[self.k] if self.valid else None), self.bufs[self.k ^ 1]
+
+    def commit(self) -> None:
+        """the launch that was handed ``buffers()`` has been issued: its output buffer is the order of the latest visit"""
         self.k ^= 1
         self.valid = True
-        return cur, self.bufs[self.k]
 
     def __getstate__(self):  # device scratch is not state (deepcopy / pickle of a planner that holds one)
         return {"bufs": None, "k": 0, "valid": False}
@@ -249,6 +252,8 @@ class DifferentiableAstar(nn.Module):
                 hist, paths, iters, status, sel_log = _search(
                     cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, 0, order, order_out)
                 clean = None
+        if pl is not None and order_out is not None:
+            pl.commit()
         self.note_status(status, iters, clean)
 
         intermediate_results: List[dict] = []

@@ -414,12 +414,17 @@ def test_placement_memory_alternates_its_buffers_and_is_not_module_state():
     p = Placement()
     cur, out = p.buffers(8, torch.device("cpu"))
     assert cur is None and out.shape == (9,) and out.dtype == torch.int32 and int(out.abs().sum()) == 0
+    cur_again, out_again = p.buffers(8, torch.device("cpu"))  # a call that failed before its launch: nothing has changed
+    assert cur_again is None and out_again is out and not p.valid
+    p.commit()
     cur2, out2 = p.buffers(8, torch.device("cpu"))
     assert cur2 is out and out2 is not out and out2.shape == (9,)
+    p.commit()
     cur3, out3 = p.buffers(8, torch.device("cpu"))
     assert cur3 is out2 and out3 is out
+    p.commit()
     cur4, out4 = p.buffers(5, torch.device("cpu"))
-    assert cur4 is None and out4.shape == (6,)
+    assert cur4 is None and out4.shape == (6,) and not p.valid
     va = VanillaAstar()
     va.astar.placement = p
     for clone in (copy.deepcopy(va), pickle.loads(pickle.dumps(va))):
