@@ -36,6 +36,7 @@ FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
 # development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
+CHECK_ORDER = os.environ.get("NASTAR_CHECK_ORDER", "0") not in ("", "0")  # verify every placement handed to astar_forward_ordered (debug)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -113,6 +114,10 @@ def astar_forward_ordered(cost: torch.Tensor, start: torch.Tensor, goal: torch.T
     for name, t, n in (("order", order, B), ("order_out", order_out, B + 1)):
         if t is not None and (t.dtype != torch.int32 or t.numel() < n or t.device != dev or not t.is_contiguous()):
             raise ValueError(f"{name} must be a contiguous int32 tensor of at least {n} elements on {dev}")
+    if CHECK_ORDER and order is not None and not torch.cuda.is_current_stream_capturing():
+        # debugging aid (NASTAR_CHECK_ORDER=1; one host synchronisation): a map that `order` never names is never searched
+        if not torch.equal(torch.sort(order[:B].long()).values, torch.arange(B, device=dev)):
+            raise ValueError("order is not a permutation of 0..B-1")
     hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
