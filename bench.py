@@ -1318,6 +1318,7 @@ def main():
                                      "validation / evaluation loop over a fixed set has from its second epoch on; the first visit is `natural_order`"
                                      if run.placement == "hinted" else "natural: workgroup i searches map i")},
             "natural_order": nat,
+            "value_natural_order": nat["value"] if nat else None,  # (the same figure at top level: maps/s when nothing is known about the batch)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # the same fraction on the bytes the PMC counters saw instead of SURVEY 8(d)'s 28 B/cell (VanillaAstar hands ONE
