@@ -404,6 +404,33 @@ int nastar_bn_coef_fwd(const double* sums, const float* gamma, const float* beta
 int nastar_bn_coef_bwd(const double* sums, const float* amax_dy, const double* mean, const double* invstd, const float* gamma,
                        long long npix, float* gscale, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, int C, void* stream);
 int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dzb, float* gscale, float* amax_scratch, void* stream);
+/*
+ * The 1-channel closing convolution of the CNN encoders in the training step as STREAMS (csrc/nastar_encoder_co1.hip.h; reference
+ * planner/encoder.py:77 `Conv2d(C, 1, 3, padding=1)` under autograd).  Padded to 32 output channels on the matrix cores, its forward,
+ * weight gradient and input gradient each spent 31/32 of their work on zeros.  C a power of two, 8 <= C <= 512; `a` = the layer's input
+ * [B,H,W,C] fp16 (split: [hi(C) | lo(C)]), `w` = torch's weight [1][C][3][3] fp32, `d` = dL/dz [B,H,W] fp32.
+ *   nastar_conv3x3_co1_f16        z [B,H,W] fp32 = conv(a, w) + bias[0]: per-pixel projection onto the 9 taps (every pixel read once)
+ *                                 + shifted sum; workspace nastar_conv3x3_co1_workspace_bytes
+ *   nastar_conv3x3_co1_wgrad_f16  dw [C][3][3] fp32 = sum_p d[p - off(tap)] a[p][c]  (fixed-order partial rows: bitwise reproducible)
+ *   nastar_grad_scale_f32         gscale[0] = 2^floor(log2(1024 / max|d|)): nastar_grad_seed_f16 without the padded fp16 tensor
+ *   nastar_bn_stats_coef_bwd_u1_f16 / nastar_chan_affine_u1_f16
+ *                                 nastar_bn_stats_coef_bwd_f16 / nastar_chan_affine_f16 (backward form) for the block in FRONT of the
+ *                                 closing convolution with da = gscale * (input gradient of d) formed on the fly from d and w: da is
+ *                                 never stored, and the two passes do not read it.
+ */
+size_t nastar_conv3x3_co1_workspace_bytes(int B, int H, int W, int C);
+int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, float* z_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, float* dw_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int nastar_grad_scale_f32(const float* d, long long npix, float* gscale, float* amax_scratch, void* stream);
+int nastar_bn_stats_coef_bwd_u1_f16(const float* d, const float* wlast, int B, int H, int W, const uint16_t* z, const float* ms,
+                                    const float* mt, int C, int split, const double* mean, const double* invstd, const float* gamma,
+                                    const float* gscale_in, float* gscale_out, float* dgamma, float* dbeta, float* c1, float* c2,
+                                    float* c3, double* sums_out, void* workspace, size_t workspace_bytes, void* stream);
+int nastar_chan_affine_u1_f16(const float* d, const float* wlast, const float* gscale, int B, int H, int W, const uint16_t* z,
+                              const float* k1, const float* k2, const float* k3, const float* ms, const float* mt, uint16_t* out, int C,
+                              int split, void* stream);
 /* 2x2 max-pool backward (CNNDownSize blocks, reference encoder.py:91-95 under autograd): r [B,H,W,C] the pool's input, dp [B,H/2,W/2,C]
  * the gradient w.r.t. its output -> dr [B,H,W,C]: dp at each window's FIRST maximum (torch's tie rule), 0 elsewhere. */
 int nastar_maxpool2x2_bwd_f16(const uint16_t* r, const uint16_t* dp, uint16_t* dr, int B, int H, int W, int C, int split, void* stream);

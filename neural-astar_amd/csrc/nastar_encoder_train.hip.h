@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "nastar_encoder.hip.h"
+#include "nastar_encoder_co1.hip.h"
 
 namespace nastar {
 
@@ -61,12 +62,13 @@ __device__ __forceinline__ void store8(uint16_t* base, size_t pix, int stride, i
 __device__ __forceinline__ float block_max_256(float v, float* red);
 __device__ __forceinline__ float pow2_scale(float amax, float target, int lo, int hi);
 
-template <bool kSplit>
+// kU1: u is not a tensor but the input gradient of the 1-channel closing convolution, formed on the fly (nastar_encoder_co1.hip.h)
+template <bool kSplit, bool kU1 = false>
 __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                 const float* __restrict__ ms, const float* __restrict__ mt,
                                                                 double* __restrict__ sums, unsigned int* __restrict__ amax_bits,
                                                                 long long npix, int C, double* __restrict__ part = nullptr,
-                                                                float* __restrict__ amax_part = nullptr)
+                                                                float* __restrict__ amax_part = nullptr, const U1Src u1 = U1Src())
 {
     __shared__ double red[256][16];
     const int stride = kSplit ? 2 * C : C;
@@ -77,13 +79,15 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.0;
     float fs[8], ft[8];
-    if (u) {
+    if (u || kU1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             fs[e] = ms[c8 * 8 + e];
             ft[e] = mt[c8 * 8 + e];
         }
     }
+    float wr[kU1 ? 9 : 1][8];
+    if constexpr (kU1) co1_weights(u1.w, c8, u1.gscale[0], wr);
     // two pixels per iteration: their loads are independent (2-4 sixteen-byte loads in flight per thread)
     const long long step = (long long)gridDim.x * NPL;
     for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += 2 * step) {
@@ -92,10 +96,15 @@ __global__ __launch_bounds__(256) void nastar_chan_stats_kernel(const uint16_t* 
         float x[8], y[8];
         load8<kSplit>(v, (size_t)p, stride, C, c8, x);
         load8<kSplit>(v, p2, stride, C, c8, y);
-        if (u) {
+        if (u || kU1) {
             float d[8], f[8];
-            load8<kSplit>(u, (size_t)p, stride, C, c8, d);
-            load8<kSplit>(u, p2, stride, C, c8, f);
+            if constexpr (kU1) {
+                u1_value(u1, p, wr, d);
+                u1_value(u1, (long long)p2, wr, f);
+            } else {
+                load8<kSplit>(u, (size_t)p, stride, C, c8, d);
+                load8<kSplit>(u, p2, stride, C, c8, f);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float dy = (fs[e] * x[e] + ft[e] > 0.f) ? d[e] : 0.f;
@@ -250,12 +259,12 @@ __global__ __launch_bounds__(256) void nastar_bn_finish_coef_kernel(const double
 
 // out = k1*u*[ms*v + mt > 0] + k2*v + k3, optionally ReLU'd.  u == nullptr drops the first term (forward: a = relu(k2*z + k3)).
 // A thread keeps ONE 8-channel group (its coefficients live in registers) and walks pixels: 256 threads = (256 / (C/8)) pixel lanes.
-template <bool kSplit>
+template <bool kSplit, bool kU1 = false>
 __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t* __restrict__ u, const uint16_t* __restrict__ v,
                                                                  const float* __restrict__ k1, const float* __restrict__ k2,
                                                                  const float* __restrict__ k3, const float* __restrict__ ms,
                                                                  const float* __restrict__ mt, uint16_t* __restrict__ out, long long npix,
-                                                                 int C, int relu)
+                                                                 int C, int relu, const U1Src u1 = U1Src())
 {
     const int stride = kSplit ? 2 * C : C;
     const int CG = C >> 3;
@@ -265,18 +274,21 @@ __global__ __launch_bounds__(256) void nastar_chan_affine_kernel(const uint16_t*
     for (int e = 0; e < 8; ++e) {
         f2[e] = k2[c8 * 8 + e];
         f3[e] = k3[c8 * 8 + e];
-        f1[e] = u ? k1[c8 * 8 + e] : 0.f;
-        fs[e] = u ? ms[c8 * 8 + e] : 0.f;
-        ft[e] = u ? mt[c8 * 8 + e] : 0.f;
+        f1[e] = (u || kU1) ? k1[c8 * 8 + e] : 0.f;
+        fs[e] = (u || kU1) ? ms[c8 * 8 + e] : 0.f;
+        ft[e] = (u || kU1) ? mt[c8 * 8 + e] : 0.f;
     }
+    float wr[kU1 ? 9 : 1][8];
+    if constexpr (kU1) co1_weights(u1.w, c8, u1.gscale[0], wr);
     for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += (long long)gridDim.x * NPL) {
         float x[8], r[8];
         load8<kSplit>(v, (size_t)p, stride, C, c8, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = f2[e] * x[e] + f3[e];
-        if (u) {
+        if (u || kU1) {
             float d[8];
-            load8<kSplit>(u, (size_t)p, stride, C, c8, d);
+            if constexpr (kU1) u1_value(u1, p, wr, d);
+            else load8<kSplit>(u, (size_t)p, stride, C, c8, d);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (fs[e] * x[e] + ft[e] > 0.f) r[e] += f1[e] * d[e];
@@ -805,6 +817,132 @@ __global__ __launch_bounds__(256) void nastar_bn1_sigmoid_bwd_kernel(const float
         const float dy = dcost[i] * c * sg * (1.0f - sg);
         dz[i] = k1 * (dy - m1 - xh * m2);
     }
+}
+
+
+// ---- the 1-channel closing convolution as streams (nastar_encoder_co1.hip.h) ------------------------------------------------------------
+// projection: P[p][tap] = sum_c w[c][tap] a[p][c] for every pixel; threads (pixel lane, 8-channel group), the C/8 groups of a pixel sit in
+// consecutive lanes (C/8 a power of two <= 64) and are summed by xor shuffles; lane `tap` of the group stores P[p][tap]
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_co1_proj_kernel(const uint16_t* __restrict__ a, const float* __restrict__ w, float* __restrict__ P,
+                                                              long long npix, int C)
+{
+    const int stride = kSplit ? 2 * C : C;
+    const int CG = C >> 3;
+    const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
+    float wr[9][8];
+    co1_weights(w, c8, 1.0f, wr);
+    const long long step = (long long)gridDim.x * NPL;
+    const long long rounds = (npix + step - 1) / step;  // every lane runs every round: the shuffles below need the whole group
+    for (long long k = 0; k < rounds; ++k) {
+        const long long p = k * step + (long long)blockIdx.x * NPL + pl;
+        const bool ok = p < npix;
+        float x[8], s[9];
+        if (ok) load8<kSplit>(a, (size_t)p, stride, C, c8, x);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(x[e], wr[t][e], acc);
+            s[t] = acc;
+        }
+        for (int off = CG >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += __shfl_xor(s[t], off);
+        }
+        if (ok) {
+            if (CG >= 16) {
+                float mine = s[0];
+#pragma unroll
+                for (int t = 1; t < 9; ++t) mine = (c8 == t) ? s[t] : mine;
+                if (c8 < 9) P[p * 9 + c8] = mine;
+            } else if (c8 == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) P[p * 9 + t] = s[t];
+            }
+        }
+    }
+}
+
+// z[q] = bias + sum_tap P[q + off(tap)][tap], zero padding
+__global__ __launch_bounds__(256) void nastar_co1_shift_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ z,
+                                                               long long npix, int H, int W)
+{
+    const float b0 = bias ? bias[0] : 0.f;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < npix; q += (long long)gridDim.x * 256) {
+        int y, x;
+        co1_yx(q, H, W, y, x);
+        float acc = b0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) acc += P[(q + (long long)(ky - 1) * W + (kx - 1)) * 9 + ky * 3 + kx];
+            }
+        z[q] = acc;
+    }
+}
+
+// weight gradient: dW[c][tap] = sum_p d[p - off(tap)] a[p][c]; per-workgroup partial rows part[blockIdx.x][C*9] (fp32), summed in a fixed
+// order by nastar_co1_wgrad_finish_kernel (double accumulation) -> dw [C][9] = torch's [1][C][3][3]
+template <bool kSplit>
+__global__ __launch_bounds__(256) void nastar_co1_wgrad_kernel(const float* __restrict__ d, const uint16_t* __restrict__ a, float* __restrict__ part,
+                                                               long long npix, int C, int H, int W)
+{
+    __shared__ float co1_red[2048];  // [NPL][C]: NPL * C = 2048 whatever C
+    const int stride = kSplit ? 2 * C : C;
+    const int CG = C >> 3;
+    const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += (long long)gridDim.x * NPL) {
+        float x[8], s[9];
+        load8<kSplit>(a, (size_t)p, stride, C, c8, x);
+        co1_taps_minus(d, p, H, W, s);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[t][e] = __builtin_fmaf(s[t], x[e], acc[t][e]);
+    }
+    // reduce over the NPL pixel lanes, one tap at a time: red[pl][c8*8 + e]
+    float* out = part + (size_t)blockIdx.x * (size_t)(C * 9);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) co1_red[pl * C + c8 * 8 + e] = acc[t][e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float sum = 0.f;
+            for (int k = 0; k < NPL; ++k) sum += co1_red[k * C + c];
+            out[c * 9 + t] = sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nastar_co1_wgrad_finish_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ dw)
+{
+    const int o = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    double acc = 0.0;
+    if (o < n)
+        for (int b = l; b < nblk; b += 32) acc += (double)part[(size_t)b * (size_t)n + o];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);
+    if (o < n && l == 0) dw[o] = (float)acc;
+}
+
+// gradient scale of the step from max|d| alone (nastar_grad_seed_kernel without the padded fp16 tensor)
+__global__ void nastar_grad_scale_kernel(const float* __restrict__ amax, float* __restrict__ gscale)
+{
+    if (threadIdx.x == 0) gscale[0] = pow2_scale(amax[0], 1024.f, -60, 60);
 }
 
 }  // namespace nastar

@@ -458,4 +458,131 @@ int nastar_bn1_sigmoid_bwd(const float* z, const float* dcost, long long n, cons
     return NASTAR_OK;
 }
 
+// ---- the 1-channel closing convolution of the CNN encoders as streams (nastar_encoder_co1.hip.h) ----------------------------------------
+static bool co1_shape_ok(int B, int H, int W, int C) { return B > 0 && H > 0 && W > 0 && C >= 8 && C <= 512 && (C & (C - 1)) == 0; }
+
+static long long co1_wgrad_grid(long long npix, int C)
+{
+    const long long per = 256 / (C / 8);
+    long long grid = (npix + per * 8 - 1) / (per * 8);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    return grid;
+}
+
+size_t nastar_conv3x3_co1_workspace_bytes(int B, int H, int W, int C)
+{
+    if (!co1_shape_ok(B, H, W, C)) return 0;
+    const long long npix = (long long)B * H * W;
+    const size_t proj = (size_t)npix * 9 * sizeof(float), wg = (size_t)co1_wgrad_grid(npix, C) * (size_t)C * 9 * sizeof(float);
+    return proj > wg ? proj : wg;
+}
+
+int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, float* z_out,
+                           void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!a || !w || !z_out || !workspace) return NASTAR_ERR_NULL;
+    if (!co1_shape_ok(B, H, W, C)) return (B <= 0 || H <= 0 || W <= 0 || C <= 0) ? NASTAR_ERR_BAD_SHAPE : NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    if (workspace_bytes < (size_t)npix * 9 * sizeof(float)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* P = static_cast<float*>(workspace);
+    const long long per = 256 / (C / 8);
+    long long grid = (npix + per * 4 - 1) / (per * 4);
+    if (grid > 2048) grid = 2048;
+    if (split) hipLaunchKernelGGL(nastar_co1_proj_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C);
+    else hipLaunchKernelGGL(nastar_co1_proj_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C);
+    long long g2 = (npix + 255) / 256;
+    if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(nastar_co1_shift_kernel, dim3((unsigned)g2), dim3(256), 0, s, P, bias, z_out, npix, H, W);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, float* dw_out, void* workspace,
+                                 size_t workspace_bytes, void* stream)
+{
+    if (!d || !a || !dw_out || !workspace) return NASTAR_ERR_NULL;
+    if (!co1_shape_ok(B, H, W, C)) return (B <= 0 || H <= 0 || W <= 0 || C <= 0) ? NASTAR_ERR_BAD_SHAPE : NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    const long long grid = co1_wgrad_grid(npix, C);
+    if (workspace_bytes < (size_t)grid * (size_t)C * 9 * sizeof(float)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    if (split) hipLaunchKernelGGL(nastar_co1_wgrad_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W);
+    else hipLaunchKernelGGL(nastar_co1_wgrad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W);
+    hipLaunchKernelGGL(nastar_co1_wgrad_finish_kernel, dim3((unsigned)((C * 9 + 7) / 8)), dim3(256), 0, s, part, (int)grid, C * 9, dw_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_grad_scale_f32(const float* d, long long npix, float* gscale, float* amax_scratch, void* stream)
+{
+    if (!d || !gscale || !amax_scratch) return NASTAR_ERR_NULL;
+    if (npix <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(amax_scratch, 0, sizeof(float), s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    const unsigned g1 = (unsigned)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
+    hipLaunchKernelGGL(nastar_absmax_kernel, dim3(g1), dim3(256), 0, s, d, npix, reinterpret_cast<unsigned int*>(amax_scratch));
+    hipLaunchKernelGGL(nastar_grad_scale_kernel, dim3(1), dim3(64), 0, s, amax_scratch, gscale);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+// nastar_bn_stats_coef_bwd_f16 / nastar_chan_affine_f16 for the block in FRONT of the closing convolution: `da` is not read, it is
+// gscale_in * (the closing convolution's input gradient of d), formed on the fly
+int nastar_bn_stats_coef_bwd_u1_f16(const float* d, const float* wlast, int B, int H, int W, const uint16_t* z, const float* ms, const float* mt,
+                                    int C, int split, const double* mean, const double* invstd, const float* gamma, const float* gscale_in,
+                                    float* gscale_out, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* sums_out,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!d || !wlast || !z || !ms || !mt || !mean || !invstd || !gamma || !gscale_in || !gscale_out || !dgamma || !dbeta || !c1 || !c2 || !c3 || !workspace)
+        return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || gscale_in == gscale_out) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    if (workspace_bytes < nastar_chan_stats_workspace_bytes(npix, C)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long grid = chan_stats_grid(npix, C);
+    double* part = static_cast<double*>(workspace);
+    float* amax_part = reinterpret_cast<float*>(part + (size_t)grid * (size_t)(2 * C));
+    U1Src u1;
+    u1.d = d; u1.w = wlast; u1.gscale = gscale_in; u1.H = H; u1.W = W;
+    if (split) hipLaunchKernelGGL((nastar_chan_stats_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, ms, mt, nullptr, nullptr, npix, C, part, amax_part, u1);
+    else hipLaunchKernelGGL((nastar_chan_stats_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, ms, mt, nullptr, nullptr, npix, C, part, amax_part, u1);
+    hipLaunchKernelGGL(nastar_bn_finish_coef_kernel<true>, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, part, amax_part, (int)grid, C, sums_out, gamma,
+                       nullptr, 0.0, (double)npix, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mean, invstd, gscale_in, gscale_out, dgamma,
+                       dbeta, c1, c2, c3);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+int nastar_chan_affine_u1_f16(const float* d, const float* wlast, const float* gscale, int B, int H, int W, const uint16_t* z, const float* k1,
+                              const float* k2, const float* k3, const float* ms, const float* mt, uint16_t* out, int C, int split, void* stream)
+{
+    if (!d || !wlast || !gscale || !z || !out || !k1 || !k2 || !k3 || !ms || !mt) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    const long long per = 256 / (C / 8);
+    long long grid = (npix + per * 16 - 1) / (per * 16);
+    if (grid < 1024) grid = (npix + per * 2 - 1) / (per * 2) < 1024 ? (npix + per * 2 - 1) / (per * 2) : 1024;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    U1Src u1;
+    u1.d = d; u1.w = wlast; u1.gscale = gscale; u1.H = H; u1.W = W;
+    if (split) hipLaunchKernelGGL((nastar_chan_affine_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, k1, k2, k3, ms, mt, out, npix, C, 0, u1);
+    else hipLaunchKernelGGL((nastar_chan_affine_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, z, k1, k2, k3, ms, mt, out, npix, C, 0, u1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
+
 }  // extern "C"

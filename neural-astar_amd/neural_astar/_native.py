@@ -86,6 +86,12 @@ EXPORTED_SYMBOLS = (
     "nastar_bn_stats_coef_fwd_f16",
     "nastar_bn_stats_coef_bwd_f16",
     "nastar_grad_seed_f16",
+    "nastar_conv3x3_co1_workspace_bytes",
+    "nastar_conv3x3_co1_f16",
+    "nastar_conv3x3_co1_wgrad_f16",
+    "nastar_grad_scale_f32",
+    "nastar_bn_stats_coef_bwd_u1_f16",
+    "nastar_chan_affine_u1_f16",
     "nastar_maxpool2x2_bwd_f16",
     "nastar_upcat_f16",
     "nastar_upcat_bwd_f16",
@@ -205,6 +211,18 @@ def load() -> ctypes.CDLL:
     lib.nastar_chan_stats_workspace_bytes.argtypes = [ctypes.c_longlong, ci]
     lib.nastar_chan_stats_f16_ws.restype = ci
     lib.nastar_chan_stats_f16_ws.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, vp, cz, vp]
+    lib.nastar_conv3x3_co1_workspace_bytes.restype = cz
+    lib.nastar_conv3x3_co1_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_conv3x3_co1_f16.restype = ci
+    lib.nastar_conv3x3_co1_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, cz, vp]
+    lib.nastar_conv3x3_co1_wgrad_f16.restype = ci
+    lib.nastar_conv3x3_co1_wgrad_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, cz, vp]
+    lib.nastar_grad_scale_f32.restype = ci
+    lib.nastar_grad_scale_f32.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
+    lib.nastar_bn_stats_coef_bwd_u1_f16.restype = ci
+    lib.nastar_bn_stats_coef_bwd_u1_f16.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cz, vp]
+    lib.nastar_chan_affine_u1_f16.restype = ci
+    lib.nastar_chan_affine_u1_f16.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.nastar_chan_affine_f16.restype = ci
     lib.nastar_chan_affine_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, ci, ci, ci, vp]
     lib.nastar_pack_conv_weight_f16.restype = ci

@@ -297,6 +297,48 @@ class _Lib:
                                              int(split), self.stream)
         _native.check(rc, "nastar_chan_affine_f16")
 
+    # ---- the 1-channel closing convolution as streams (csrc/nastar_encoder_co1.hip.h) ----
+    @staticmethod
+    def co1_ok(C: int, c_real: int) -> bool:
+        return C == c_real and 8 <= C <= 512 and (C & (C - 1)) == 0
+
+    def co1_ws(self, B, H, W, C):
+        n = int(self.lib.nastar_conv3x3_co1_workspace_bytes(B, H, W, C))
+        return torch.empty((n,), dtype=torch.uint8, device=self.dev), n
+
+    def conv_co1(self, a, w, bias, B, H, W, C, split):
+        z = torch.empty((B, H, W), dtype=torch.float32, device=self.dev)
+        ws, n = self.co1_ws(B, H, W, C)
+        wc, bc = _f32c(w), (_f32c(bias) if bias is not None else None)
+        rc = self.lib.nastar_conv3x3_co1_f16(a.data_ptr(), wc.data_ptr(), bc.data_ptr() if bc is not None else None, B, H, W, C, int(split),
+                                             z.data_ptr(), ws.data_ptr(), n, self.stream)
+        _native.check(rc, "nastar_conv3x3_co1_f16")
+        return z
+
+    def wgrad_co1(self, d, a, B, H, W, C, split):
+        dw = torch.empty((1, C, 3, 3), dtype=torch.float32, device=self.dev)
+        ws, n = self.co1_ws(B, H, W, C)
+        rc = self.lib.nastar_conv3x3_co1_wgrad_f16(d.data_ptr(), a.data_ptr(), B, H, W, C, int(split), dw.data_ptr(), ws.data_ptr(), n, self.stream)
+        _native.check(rc, "nastar_conv3x3_co1_wgrad_f16")
+        return dw
+
+    def bn_bwd_u1(self, d, wlast, B, H, W, z, k2f, k3f, C, split, mean, invstd, gamma, gscale_in, gscale_out):
+        """``bn_bwd`` for the block in front of the closing convolution: da = gscale_in * (its input gradient of d), never stored"""
+        dgamma, dbeta, c1, c2, c3 = (self.f32(C) for _ in range(5))
+        nbytes = int(self.lib.nastar_chan_stats_workspace_bytes(B * H * W, C))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_bn_stats_coef_bwd_u1_f16(d.data_ptr(), wlast.data_ptr(), B, H, W, z.data_ptr(), k2f.data_ptr(), k3f.data_ptr(), C, int(split),
+                                                      mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), gscale_in.data_ptr(), gscale_out.data_ptr(),
+                                                      dgamma.data_ptr(), dbeta.data_ptr(), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), None,
+                                                      ws.data_ptr(), nbytes, self.stream)
+        _native.check(rc, "nastar_bn_stats_coef_bwd_u1_f16")
+        return dgamma, dbeta, c1, c2, c3
+
+    def affine_u1(self, d, wlast, gscale, B, H, W, z, k1, k2, k3, ms, mt, out, C, split):
+        rc = self.lib.nastar_chan_affine_u1_f16(d.data_ptr(), wlast.data_ptr(), gscale.data_ptr(), B, H, W, z.data_ptr(), k1.data_ptr(), k2.data_ptr(),
+                                                k3.data_ptr(), ms.data_ptr(), mt.data_ptr(), out.data_ptr(), C, int(split), self.stream)
+        _native.check(rc, "nastar_chan_affine_u1_f16")
+
     def wgrad(self, dz, a, B, H, W, co, ci, co_real, ci_real, split, gscale):
         """dW in torch's [co_real, ci_real, 3, 3] layout, already divided by the device-side gradient scale"""
         dw = torch.empty((co_real, ci_real, 3, 3), dtype=torch.float32, device=self.dev)
@@ -306,6 +348,11 @@ class _Lib:
                                                1.0, gscale.data_ptr(), ws.data_ptr(), nbytes, self.stream)
         _native.check(rc, "nastar_conv3x3_wgrad_f16")
         return dw
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return t if t.is_contiguous() and t.dtype == torch.float32 else t.float().contiguous()
 
 
 def chunk_rows(H: int, W: int) -> int:
@@ -406,8 +453,14 @@ class _CnnTrunk(torch.autograd.Function):
             wpackl, scalel, shiftl, scal = (packs[D] if packs is not None else  # cout 1 -> 32 (padded channels: zero weights, zero shift)
                                             L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None))
             scals.append(scal)
-            zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
-            L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
+            # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros)
+            co1 = cfg.get("co1", True) and wl.shape[0] == 1 and L.co1_ok(_pad32(wl.shape[1]), wl.shape[1])
+            if co1:
+                zl = L.conv_co1(acts[-1], wl, bs[D], B, h, w, wl.shape[1], split)
+            else:
+                zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+                L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
+            ctx.co1 = co1
             if tracked:
                 torch._foreach_add_(tracked, 1)
         ctx.cfg = cfg
@@ -437,11 +490,35 @@ class _CnnTrunk(torch.autograd.Function):
             # gradients travel multiplied by a power of two S (device scalar `gscale`, re-centred per block): scaled values peak near
             # 2^10, so fp16 neither overflows nor loses the small terms; S is divided out inside the weight-gradient / coefficient kernels
             gscale, amax = L.f32(1), L.f32(1)
-            dzb = torch.empty((npix * 32 * mult,), dtype=torch.int16, device=dev)
-            rc = L.lib.nastar_grad_seed_f16(d.data_ptr(), npix, int(split), dzb.data_ptr(), gscale.data_ptr(), amax.data_ptr(), L.stream)
-            _native.check(rc, "nastar_grad_seed_f16")
-            cur_co = 32  # padded channel count of the current dz
-            for l in range(D, -1, -1):
+            top = D
+            # closing convolution as streams: its weight gradient from d itself, its input gradient never stored -- the BatchNorm backward
+            # of block D forms it on the fly (not for pooling stacks, whose gradient passes through the max-pool first, nor under sync-BN,
+            # whose sums take the separate entry points)
+            if getattr(ctx, "co1", False) and D >= 1 and not pool and not ctx.sync_state[0]:
+                wl = ws[D]
+                C = wl.shape[1]
+                rc = L.lib.nastar_grad_scale_f32(d.data_ptr(), npix, gscale.data_ptr(), amax.data_ptr(), L.stream)
+                _native.check(rc, "nastar_grad_scale_f32")
+                grads[4 * D] = L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
+                grads[4 * D + 1] = torch.empty_like(params[4 * D + 1])
+                z = ctx.zs[D - 1]
+                mean, invstd, k2f, k3f = ctx.coef[D - 1]
+                wlc = _f32c(wl)
+                gs_new = L.f32(1)
+                dgamma, dbeta, c1, c2, c3 = L.bn_bwd_u1(d, wlc, B, h, w, z, k2f, k3f, C, split, mean, invstd, gammas[D - 1].detach(), gscale, gs_new)
+                grads[4 * (D - 1) + 2] = dgamma
+                grads[4 * (D - 1) + 3] = dbeta
+                dzb = torch.empty((npix * C * mult,), dtype=torch.int16, device=dev)
+                L.affine_u1(d, wlc, gscale, B, h, w, z, c1, c2, c3, k2f, k3f, dzb, C, split)
+                gscale = gs_new
+                cur_co = C
+                top = D - 1
+            else:
+                dzb = torch.empty((npix * 32 * mult,), dtype=torch.int16, device=dev)
+                rc = L.lib.nastar_grad_seed_f16(d.data_ptr(), npix, int(split), dzb.data_ptr(), gscale.data_ptr(), amax.data_ptr(), L.stream)
+                _native.check(rc, "nastar_grad_seed_f16")
+                cur_co = 32  # padded channel count of the current dz
+            for l in range(top, -1, -1):
                 wt = ws[l]
                 cout, cin = wt.shape[:2]
                 cin_p = _pad32(cin)
