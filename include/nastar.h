@@ -412,6 +412,8 @@ int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dz
  *   nastar_conv3x3_co1_f16        z [B,H,W] fp32 = conv(a, w) + bias[0]: per-pixel projection onto the 9 taps (every pixel read once)
  *                                 + shifted sum; workspace nastar_conv3x3_co1_workspace_bytes
  *   nastar_conv3x3_co1_wgrad_f16  dw [C][3][3] fp32 = sum_p d[p - off(tap)] a[p][c]  (fixed-order partial rows: bitwise reproducible)
+ *   k2 / k3 (both or NULL)        `a` holds the PRE-activation z of the block in front and the layer's input relu(k2[c] z + k3[c]) is
+ *                                 formed while loading: that block's activation tensor is never written or read
  *   nastar_grad_scale_f32         gscale[0] = 2^floor(log2(1024 / max|d|)): nastar_grad_seed_f16 without the padded fp16 tensor
  *   nastar_bn_stats_coef_bwd_u1_f16 / nastar_chan_affine_u1_f16
  *                                 nastar_bn_stats_coef_bwd_f16 / nastar_chan_affine_f16 (backward form) for the block in FRONT of the
@@ -419,10 +421,10 @@ int nastar_grad_seed_f16(const float* d, long long npix, int split, uint16_t* dz
  *                                 never stored, and the two passes do not read it.
  */
 size_t nastar_conv3x3_co1_workspace_bytes(int B, int H, int W, int C);
-int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, float* z_out,
-                           void* workspace, size_t workspace_bytes, void* stream);
-int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, float* dw_out, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, const float* k2,
+                           const float* k3, float* z_out, void* workspace, size_t workspace_bytes, void* stream);
+int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, const float* k2, const float* k3,
+                                 float* dw_out, void* workspace, size_t workspace_bytes, void* stream);
 int nastar_grad_scale_f32(const float* d, long long npix, float* gscale, float* amax_scratch, void* stream);
 int nastar_bn_stats_coef_bwd_u1_f16(const float* d, const float* wlast, int B, int H, int W, const uint16_t* z, const float* ms,
                                     const float* mt, int C, int split, const double* mean, const double* invstd, const float* gamma,

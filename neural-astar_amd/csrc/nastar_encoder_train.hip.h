@@ -825,21 +825,34 @@ __global__ __launch_bounds__(256) void nastar_bn1_sigmoid_bwd_kernel(const float
 // consecutive lanes (C/8 a power of two <= 64) and are summed by xor shuffles; lane `tap` of the group stores P[p][tap]
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_co1_proj_kernel(const uint16_t* __restrict__ a, const float* __restrict__ w, float* __restrict__ P,
-                                                              long long npix, int C)
+                                                              long long npix, int C, const float* __restrict__ k2 = nullptr,
+                                                              const float* __restrict__ k3 = nullptr)
 {
     const int stride = kSplit ? 2 * C : C;
     const int CG = C >> 3;
     const int c8 = threadIdx.x % CG, pl = threadIdx.x / CG, NPL = 256 / CG;
     float wr[9][8];
     co1_weights(w, c8, 1.0f, wr);
+    // k2 != nullptr: `a` holds the PRE-activation z of the block in front and the layer's input relu(k2 z + k3) is formed while loading
+    float f2[8], f3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f2[e] = k2 ? k2[c8 * 8 + e] : 1.f;
+        f3[e] = k2 ? k3[c8 * 8 + e] : 0.f;
+    }
     const long long step = (long long)gridDim.x * NPL;
     const long long rounds = (npix + step - 1) / step;  // every lane runs every round: the shuffles below need the whole group
     for (long long k = 0; k < rounds; ++k) {
         const long long p = k * step + (long long)blockIdx.x * NPL + pl;
         const bool ok = p < npix;
         float x[8], s[9];
-        if (ok) load8<kSplit>(a, (size_t)p, stride, C, c8, x);
-        else {
+        if (ok) {
+            load8<kSplit>(a, (size_t)p, stride, C, c8, x);
+            if (k2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaxf(f2[e] * x[e] + f3[e], 0.f);
+            }
+        } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = 0.f;
         }
@@ -892,7 +905,8 @@ __global__ __launch_bounds__(256) void nastar_co1_shift_kernel(const float* __re
 // order by nastar_co1_wgrad_finish_kernel (double accumulation) -> dw [C][9] = torch's [1][C][3][3]
 template <bool kSplit>
 __global__ __launch_bounds__(256) void nastar_co1_wgrad_kernel(const float* __restrict__ d, const uint16_t* __restrict__ a, float* __restrict__ part,
-                                                               long long npix, int C, int H, int W)
+                                                               long long npix, int C, int H, int W, const float* __restrict__ k2 = nullptr,
+                                                               const float* __restrict__ k3 = nullptr)
 {
     __shared__ float co1_red[2048];  // [NPL][C]: NPL * C = 2048 whatever C
     const int stride = kSplit ? 2 * C : C;
@@ -903,9 +917,19 @@ __global__ __launch_bounds__(256) void nastar_co1_wgrad_kernel(const float* __re
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    float f2[8], f3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f2[e] = k2 ? k2[c8 * 8 + e] : 1.f;
+        f3[e] = k2 ? k3[c8 * 8 + e] : 0.f;
+    }
     for (long long p = (long long)blockIdx.x * NPL + pl; p < npix; p += (long long)gridDim.x * NPL) {
         float x[8], s[9];
         load8<kSplit>(a, (size_t)p, stride, C, c8, x);
+        if (k2) {  // `a` = the pre-activation z: the layer's input is relu(k2 z + k3)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaxf(f2[e] * x[e] + f3[e], 0.f);
+        }
         co1_taps_minus(d, p, H, W, s);
 #pragma unroll
         for (int t = 0; t < 9; ++t)

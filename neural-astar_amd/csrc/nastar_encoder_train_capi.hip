@@ -478,10 +478,10 @@ size_t nastar_conv3x3_co1_workspace_bytes(int B, int H, int W, int C)
     return proj > wg ? proj : wg;
 }
 
-int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, float* z_out,
-                           void* workspace, size_t workspace_bytes, void* stream)
+int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias, int B, int H, int W, int C, int split, const float* k2,
+                           const float* k3, float* z_out, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!a || !w || !z_out || !workspace) return NASTAR_ERR_NULL;
+    if (!a || !w || !z_out || !workspace || (k2 && !k3)) return NASTAR_ERR_NULL;
     if (!co1_shape_ok(B, H, W, C)) return (B <= 0 || H <= 0 || W <= 0 || C <= 0) ? NASTAR_ERR_BAD_SHAPE : NASTAR_ERR_UNSUPPORTED;
     const long long npix = (long long)B * H * W;
     if (workspace_bytes < (size_t)npix * 9 * sizeof(float)) return NASTAR_ERR_WORKSPACE;
@@ -490,8 +490,8 @@ int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias,
     const long long per = 256 / (C / 8);
     long long grid = (npix + per * 4 - 1) / (per * 4);
     if (grid > 2048) grid = 2048;
-    if (split) hipLaunchKernelGGL(nastar_co1_proj_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C);
-    else hipLaunchKernelGGL(nastar_co1_proj_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C);
+    if (split) hipLaunchKernelGGL(nastar_co1_proj_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C, k2, k3);
+    else hipLaunchKernelGGL(nastar_co1_proj_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a, w, P, npix, C, k2, k3);
     long long g2 = (npix + 255) / 256;
     if (g2 > 4096) g2 = 4096;
     hipLaunchKernelGGL(nastar_co1_shift_kernel, dim3((unsigned)g2), dim3(256), 0, s, P, bias, z_out, npix, H, W);
@@ -500,18 +500,18 @@ int nastar_conv3x3_co1_f16(const uint16_t* a, const float* w, const float* bias,
     return NASTAR_OK;
 }
 
-int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, float* dw_out, void* workspace,
-                                 size_t workspace_bytes, void* stream)
+int nastar_conv3x3_co1_wgrad_f16(const float* d, const uint16_t* a, int B, int H, int W, int C, int split, const float* k2, const float* k3,
+                                 float* dw_out, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!d || !a || !dw_out || !workspace) return NASTAR_ERR_NULL;
+    if (!d || !a || !dw_out || !workspace || (k2 && !k3)) return NASTAR_ERR_NULL;
     if (!co1_shape_ok(B, H, W, C)) return (B <= 0 || H <= 0 || W <= 0 || C <= 0) ? NASTAR_ERR_BAD_SHAPE : NASTAR_ERR_UNSUPPORTED;
     const long long npix = (long long)B * H * W;
     const long long grid = co1_wgrad_grid(npix, C);
     if (workspace_bytes < (size_t)grid * (size_t)C * 9 * sizeof(float)) return NASTAR_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
-    if (split) hipLaunchKernelGGL(nastar_co1_wgrad_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W);
-    else hipLaunchKernelGGL(nastar_co1_wgrad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W);
+    if (split) hipLaunchKernelGGL(nastar_co1_wgrad_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W, k2, k3);
+    else hipLaunchKernelGGL(nastar_co1_wgrad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, d, a, part, npix, C, H, W, k2, k3);
     hipLaunchKernelGGL(nastar_co1_wgrad_finish_kernel, dim3((unsigned)((C * 9 + 7) / 8)), dim3(256), 0, s, part, (int)grid, C * 9, dw_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "kernel launch");

@@ -214,9 +214,9 @@ def load() -> ctypes.CDLL:
     lib.nastar_conv3x3_co1_workspace_bytes.restype = cz
     lib.nastar_conv3x3_co1_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.nastar_conv3x3_co1_f16.restype = ci
-    lib.nastar_conv3x3_co1_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, cz, vp]
+    lib.nastar_conv3x3_co1_f16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, cz, vp]
     lib.nastar_conv3x3_co1_wgrad_f16.restype = ci
-    lib.nastar_conv3x3_co1_wgrad_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, cz, vp]
+    lib.nastar_conv3x3_co1_wgrad_f16.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, cz, vp]
     lib.nastar_grad_scale_f32.restype = ci
     lib.nastar_grad_scale_f32.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
     lib.nastar_bn_stats_coef_bwd_u1_f16.restype = ci

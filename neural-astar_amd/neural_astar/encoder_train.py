@@ -306,19 +306,24 @@ class _Lib:
         n = int(self.lib.nastar_conv3x3_co1_workspace_bytes(B, H, W, C))
         return torch.empty((n,), dtype=torch.uint8, device=self.dev), n
 
-    def conv_co1(self, a, w, bias, B, H, W, C, split):
+    def conv_co1(self, a, w, bias, B, H, W, C, split, k2=None, k3=None):
+        """z = conv(a, w) + bias for the 1-channel closing convolution; k2 / k3: ``a`` is the pre-activation of the block in front and
+        the layer's input relu(k2 a + k3) is formed while loading"""
         z = torch.empty((B, H, W), dtype=torch.float32, device=self.dev)
         ws, n = self.co1_ws(B, H, W, C)
         wc, bc = _f32c(w), (_f32c(bias) if bias is not None else None)
         rc = self.lib.nastar_conv3x3_co1_f16(a.data_ptr(), wc.data_ptr(), bc.data_ptr() if bc is not None else None, B, H, W, C, int(split),
+                                             k2.data_ptr() if k2 is not None else None, k3.data_ptr() if k3 is not None else None,
                                              z.data_ptr(), ws.data_ptr(), n, self.stream)
         _native.check(rc, "nastar_conv3x3_co1_f16")
         return z
 
-    def wgrad_co1(self, d, a, B, H, W, C, split):
+    def wgrad_co1(self, d, a, B, H, W, C, split, k2=None, k3=None):
         dw = torch.empty((1, C, 3, 3), dtype=torch.float32, device=self.dev)
         ws, n = self.co1_ws(B, H, W, C)
-        rc = self.lib.nastar_conv3x3_co1_wgrad_f16(d.data_ptr(), a.data_ptr(), B, H, W, C, int(split), dw.data_ptr(), ws.data_ptr(), n, self.stream)
+        rc = self.lib.nastar_conv3x3_co1_wgrad_f16(d.data_ptr(), a.data_ptr(), B, H, W, C, int(split),
+                                                   k2.data_ptr() if k2 is not None else None, k3.data_ptr() if k3 is not None else None,
+                                                   dw.data_ptr(), ws.data_ptr(), n, self.stream)
         _native.check(rc, "nastar_conv3x3_co1_wgrad_f16")
         return dw
 
@@ -348,6 +353,9 @@ class _Lib:
                                                1.0, gscale.data_ptr(), ws.data_ptr(), nbytes, self.stream)
         _native.check(rc, "nastar_conv3x3_wgrad_f16")
         return dw
+
+
+CO1_STREAMS = True  # the 1-channel closing convolution as streams (csrc/nastar_encoder_co1.hip.h); False: padded to 32 channels on the MFMA (A/B, tests)
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -406,6 +414,11 @@ class _CnnTrunk(torch.autograd.Function):
             # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs
             packs = L.pack_all([(ws[l], bs[l], False, l) for l in range(D + 1)] + [(ws[l], None, True, l) for l in range(1, D + 1)],
                                split, wmax)
+            # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros); where nothing
+            # else reads the activations of the block in front of it (no pooling, no sync-BN fall-back in the backward, no test probe),
+            # that block's BatchNorm + ReLU is applied while the stream loads its pre-activations and the activation tensor never exists
+            co1 = cfg.get("co1", CO1_STREAMS) and ws[D].shape[0] == 1 and L.co1_ok(_pad32(ws[D].shape[1]), ws[D].shape[1])
+            fuse_act = co1 and D >= 1 and not pool and not sync and cfg.get("debug") is None
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
@@ -434,10 +447,13 @@ class _CnnTrunk(torch.autograd.Function):
                                                   bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                                   k2.data_ptr(), k3.data_ptr(), mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
                     _native.check(rc, "nastar_bn_coef_fwd")
-                r = torch.empty_like(z)
-                L.affine(None, z, None, k2, k3, None, None, r, npix, cout, True, split)
                 zs.append(z)
                 coef.append((mean, invstd, k2, k3))
+                if fuse_act and l == D - 1:
+                    acts.append(None)  # relu(k2 z + k3) is formed inside the closing convolution's streams
+                    continue
+                r = torch.empty_like(z)
+                L.affine(None, z, None, k2, k3, None, None, r, npix, cout, True, split)
                 if cfg.get("debug") is not None:  # test probe: this block's ReLU mask is [k2 z + k3 > 0], its pool sees r
                     cfg["debug"][f"fwd:{l}"] = (z, k2, k3, r, (B, h, w, cout))
                 if pool:
@@ -454,13 +470,14 @@ class _CnnTrunk(torch.autograd.Function):
                                             L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None))
             scals.append(scal)
             # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros)
-            co1 = cfg.get("co1", True) and wl.shape[0] == 1 and L.co1_ok(_pad32(wl.shape[1]), wl.shape[1])
-            if co1:
+            if co1 and fuse_act:
+                zl = L.conv_co1(zs[D - 1], wl, bs[D], B, h, w, wl.shape[1], split, coef[D - 1][2], coef[D - 1][3])
+            elif co1:
                 zl = L.conv_co1(acts[-1], wl, bs[D], B, h, w, wl.shape[1], split)
             else:
                 zl = torch.empty((B, h, w), dtype=torch.float32, device=dev)
                 L.conv(acts[-1], wpackl, scalel, shiftl, B, h, w, _pad32(wl.shape[1]), 32, sflag | CONV_FINAL | CONV_RAW, out_f32=zl)
-            ctx.co1 = co1
+            ctx.co1, ctx.fuse_act = co1, fuse_act
             if tracked:
                 torch._foreach_add_(tracked, 1)
         ctx.cfg = cfg
@@ -499,7 +516,10 @@ class _CnnTrunk(torch.autograd.Function):
                 C = wl.shape[1]
                 rc = L.lib.nastar_grad_scale_f32(d.data_ptr(), npix, gscale.data_ptr(), amax.data_ptr(), L.stream)
                 _native.check(rc, "nastar_grad_scale_f32")
-                grads[4 * D] = L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
+                if ctx.fuse_act:
+                    grads[4 * D] = L.wgrad_co1(d, ctx.zs[D - 1], B, h, w, C, split, ctx.coef[D - 1][2], ctx.coef[D - 1][3])
+                else:
+                    grads[4 * D] = L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
                 grads[4 * D + 1] = torch.empty_like(params[4 * D + 1])
                 z = ctx.zs[D - 1]
                 mean, invstd, k2f, k3f = ctx.coef[D - 1]

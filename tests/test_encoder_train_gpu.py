@@ -744,3 +744,46 @@ def test_two_launch_batchnorm_pass_equals_the_three_launch_form(split, B, H, W, 
     assert float(S_in) == 4.0 and torch.equal(S_out, S_r) and torch.equal(s_out, sums_b)
     for a, b in ((dg, dgr), (db, dbr), (c1, c1r), (c2, c2r), (c3, c3r)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_closing_convolution_as_streams_equals_the_padded_matrix_form(precision):
+    """csrc/nastar_encoder_co1.hip.h: the 1-channel closing convolution of the CNN encoder as streams -- forward projection + shifted
+    sum (with the block in front's BatchNorm + ReLU applied while loading: its activation tensor is never written), streamed weight
+    gradient, input gradient formed on the fly inside the BatchNorm-backward passes -- against the same step with that layer padded to
+    32 channels on the MFMA (encoder_train.CO1_STREAMS = False): cost map and every gradient within the precision's own noise (the
+    third printed column pair is each form's distance to float64 autograd), f16x3 cost map within 1e-5 of float64."""
+    from neural_astar import encoder_train as ET
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    pr = syn.maze_maps(24, 32, seed=5)
+    m, s, g = (torch.from_numpy(x) for x in pr)
+    R = torch.randn((24, 1, 32, 32), generator=torch.Generator().manual_seed(2)) / (24 * 1024)
+    ref = _shipped_cnn_planner().double().train()
+    cost_ref = ref.encode(m.double(), s.double(), g.double())
+    (cost_ref * R.double()).sum().backward()
+    out = {}
+    keep = ET.CO1_STREAMS
+    try:
+        for mode in (True, False):
+            ET.CO1_STREAMS = mode
+            na = _shipped_cnn_planner().to(dev).train()
+            na.encoder_backend = "hip_" + precision
+            cost = na.encode(m.to(dev), s.to(dev), g.to(dev))
+            (cost * R.to(dev)).sum().backward()
+            out[mode] = (cost.detach(), {n: p.grad.clone() for n, p in na.encoder.named_parameters()})
+    finally:
+        ET.CO1_STREAMS = keep
+    tol_c, tol_g = (2e-6, 5e-5) if precision == "f16x3" else (5e-3, 2e-1)
+    assert float((out[True][0] - out[False][0]).abs().max()) <= tol_c
+    worst = {}
+    for (name, q) in ref.encoder.named_parameters():
+        a, b = out[True][1][name], out[False][1][name]
+        if float(q.grad.abs().max()) <= 1e-12:
+            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0
+            continue
+        worst[name] = (_rel(a, b), _rel(a, q.grad), _rel(b, q.grad))
+    print("CO1", precision, {k: tuple(f"{x:.1e}" for x in v) for k, v in worst.items()})
+    assert max(v[0] for v in worst.values()) <= tol_g, worst
+    if precision == "f16x3":  # (gradients against float64 are judged on the clear-margin batch of the test above: this batch has ReLU decisions inside fp32 noise)
+        assert float((out[True][0].cpu().double() - cost_ref.detach()).abs().max()) <= 1e-5
