@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nastar_device.hip.h"
 #include "nastar_encoder.hip.h"
 #include "nastar_encoder_co1.hip.h"
 
@@ -863,9 +864,21 @@ __global__ __launch_bounds__(256) void nastar_co1_proj_kernel(const uint16_t* __
             for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(x[e], wr[t][e], acc);
             s[t] = acc;
         }
-        for (int off = CG >> 1; off > 0; off >>= 1) {
+        if (CG == 32) {  // the 32 lanes of a pixel: four DPP steps inside each 16-lane row (no LDS crossbar), one exchange across the rows
 #pragma unroll
-            for (int t = 0; t < 9; ++t) s[t] += __shfl_xor(s[t], off);
+            for (int t = 0; t < 9; ++t) {
+                float v = s[t];
+                v += __uint_as_float(dpp_mov<DPP_QUAD_XOR1>(__float_as_uint(v)));
+                v += __uint_as_float(dpp_mov<DPP_QUAD_XOR2>(__float_as_uint(v)));
+                v += __uint_as_float(dpp_mov<DPP_ROW_HALF_MIRROR>(__float_as_uint(v)));
+                v += __uint_as_float(dpp_mov<DPP_ROW_MIRROR>(__float_as_uint(v)));
+                s[t] = v + __shfl_xor(v, 16);
+            }
+        } else {
+            for (int off = CG >> 1; off > 0; off >>= 1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s[t] += __shfl_xor(s[t], off);
+            }
         }
         if (ok) {
             if (CG >= 16) {
