@@ -275,6 +275,10 @@ def fresh_batches_pipelined(run, steps, warmup, dev):
 
 def timed_loop(run, steps, warmup, world, dev, collate=None):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds max over ranks, device ms)."""
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()   # (before the warm-up steps: a collection between warm-up and clock start would idle the GPU for tens of ms)
+    gc.disable()
     pending = None
     for _ in range(warmup):
         run.step()
@@ -285,7 +289,6 @@ def timed_loop(run, steps, warmup, world, dev, collate=None):
     # host hygiene of the timed region: the two events exist and have been recorded once BEFORE the clock starts (their first record after
     # a few thousand untimed launches was seen to take 40 ms in a process that had synthesised its problems itself -- 2.1 ms per step
     # instead of 0.12 over the driver's 20 steps, the GPU idle meanwhile), and the cyclic garbage collector does not run inside it
-    import gc
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -294,9 +297,6 @@ def timed_loop(run, steps, warmup, world, dev, collate=None):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    gc_was = gc.isenabled()
-    gc.collect()
-    gc.disable()
     pending = None
     t0 = time.perf_counter()
     e0.record()
