@@ -1105,6 +1105,9 @@ def train_main(args, real_stdout):
     while time.perf_counter() - t_pre < PREWARM_S:
         run(2)
         torch.cuda.synchronize(dev)
+    import gc
+    gc.collect()  # (before the warm-up steps; the cyclic collector then stays out of the timed region, as in timed_loop)
+    gc.disable()
     run(args.warmup)
     torch.cuda.synchronize(dev)
     if multi:
@@ -1117,6 +1120,7 @@ def train_main(args, real_stdout):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    gc.enable()
     planner.astar.raise_if_unsolvable()  # the deferred verdicts of every step above
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
