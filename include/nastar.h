@@ -430,6 +430,9 @@ int nastar_bn_stats_coef_bwd_u1_f16(const float* d, const float* wlast, int B, i
                                     const float* mt, int C, int split, const double* mean, const double* invstd, const float* gamma,
                                     const float* gscale_in, float* gscale_out, float* dgamma, float* dbeta, float* c1, float* c2,
                                     float* c3, double* sums_out, void* workspace, size_t workspace_bytes, void* stream);
+int nastar_chan_stats_u1_f16_ws(const float* d, const float* wlast, const float* gscale, int B, int H, int W, const uint16_t* v,
+                                const float* ms, const float* mt, double* sums, float* amax_out, int C, int split, void* workspace,
+                                size_t workspace_bytes, void* stream);  /* the same sums as a separate entry (sync-BN all-reduces them) */
 int nastar_chan_affine_u1_f16(const float* d, const float* wlast, const float* gscale, int B, int H, int W, const uint16_t* z,
                               const float* k1, const float* k2, const float* k3, const float* ms, const float* mt, uint16_t* out, int C,
                               int split, void* stream);

@@ -533,6 +533,32 @@ int nastar_grad_scale_f32(const float* d, long long npix, float* gscale, float* 
     return NASTAR_OK;
 }
 
+// nastar_chan_stats_f16_ws (backward form) with u = gscale * (the closing convolution's input gradient of d), formed on the fly: the sums a
+// data-parallel step all-reduces between the statistics and the coefficients
+int nastar_chan_stats_u1_f16_ws(const float* d, const float* wlast, const float* gscale, int B, int H, int W, const uint16_t* v, const float* ms,
+                                const float* mt, double* sums, float* amax_out, int C, int split, void* workspace, size_t workspace_bytes,
+                                void* stream)
+{
+    if (!d || !wlast || !gscale || !v || !ms || !mt || !sums || !workspace) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if (C % 8 || C > 2048 || 256 % (C / 8)) return NASTAR_ERR_UNSUPPORTED;
+    const long long npix = (long long)B * H * W;
+    if (workspace_bytes < nastar_chan_stats_workspace_bytes(npix, C)) return NASTAR_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long grid = chan_stats_grid(npix, C);
+    double* part = static_cast<double*>(workspace);
+    float* amax_part = reinterpret_cast<float*>(part + (size_t)grid * (size_t)(2 * C));
+    U1Src u1;
+    u1.d = d; u1.w = wlast; u1.gscale = gscale; u1.H = H; u1.W = W;
+    if (split) hipLaunchKernelGGL((nastar_chan_stats_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, v, ms, mt, sums, nullptr, npix, C, part, amax_part, u1);
+    else hipLaunchKernelGGL((nastar_chan_stats_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, s, nullptr, v, ms, mt, sums, nullptr, npix, C, part, amax_part, u1);
+    hipLaunchKernelGGL(nastar_chan_stats_finish_kernel, dim3((unsigned)((2 * C + 7) / 8)), dim3(256), 0, s, part, amax_part, (int)grid, 2 * C, sums,
+                       amax_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
+}
+
 // nastar_bn_stats_coef_bwd_f16 / nastar_chan_affine_f16 for the block in FRONT of the closing convolution: `da` is not read, it is
 // gscale_in * (the closing convolution's input gradient of d), formed on the fly
 int nastar_bn_stats_coef_bwd_u1_f16(const float* d, const float* wlast, int B, int H, int W, const uint16_t* z, const float* ms, const float* mt,

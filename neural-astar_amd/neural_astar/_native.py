@@ -92,6 +92,7 @@ EXPORTED_SYMBOLS = (
     "nastar_grad_scale_f32",
     "nastar_bn_stats_coef_bwd_u1_f16",
     "nastar_chan_affine_u1_f16",
+    "nastar_chan_stats_u1_f16_ws",
     "nastar_maxpool2x2_bwd_f16",
     "nastar_upcat_f16",
     "nastar_upcat_bwd_f16",
@@ -221,6 +222,8 @@ def load() -> ctypes.CDLL:
     lib.nastar_grad_scale_f32.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
     lib.nastar_bn_stats_coef_bwd_u1_f16.restype = ci
     lib.nastar_bn_stats_coef_bwd_u1_f16.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cz, vp]
+    lib.nastar_chan_stats_u1_f16_ws.restype = ci
+    lib.nastar_chan_stats_u1_f16_ws.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, cz, vp]
     lib.nastar_chan_affine_u1_f16.restype = ci
     lib.nastar_chan_affine_u1_f16.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
     lib.nastar_chan_affine_f16.restype = ci

@@ -339,6 +339,16 @@ class _Lib:
         _native.check(rc, "nastar_bn_stats_coef_bwd_u1_f16")
         return dgamma, dbeta, c1, c2, c3
 
+    def stats_u1(self, d, wlast, gscale, B, H, W, z, ms, mt, C, split, amax):
+        """``stats`` (backward form) with da formed on the fly: double sums [C,2] for the sync-BN all-reduce"""
+        sums = torch.empty((C, 2), dtype=torch.float64, device=self.dev)
+        nbytes = int(self.lib.nastar_chan_stats_workspace_bytes(B * H * W, C))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+        rc = self.lib.nastar_chan_stats_u1_f16_ws(d.data_ptr(), wlast.data_ptr(), gscale.data_ptr(), B, H, W, z.data_ptr(), ms.data_ptr(), mt.data_ptr(),
+                                                  sums.data_ptr(), amax.data_ptr(), C, int(split), ws.data_ptr(), nbytes, self.stream)
+        _native.check(rc, "nastar_chan_stats_u1_f16_ws")
+        return sums
+
     def affine_u1(self, d, wlast, gscale, B, H, W, z, k1, k2, k3, ms, mt, out, C, split):
         rc = self.lib.nastar_chan_affine_u1_f16(d.data_ptr(), wlast.data_ptr(), gscale.data_ptr(), B, H, W, z.data_ptr(), k1.data_ptr(), k2.data_ptr(),
                                                 k3.data_ptr(), ms.data_ptr(), mt.data_ptr(), out.data_ptr(), C, int(split), self.stream)
@@ -415,10 +425,10 @@ class _CnnTrunk(torch.autograd.Function):
             packs = L.pack_all([(ws[l], bs[l], False, l) for l in range(D + 1)] + [(ws[l], None, True, l) for l in range(1, D + 1)],
                                split, wmax)
             # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros); where nothing
-            # else reads the activations of the block in front of it (no pooling, no sync-BN fall-back in the backward, no test probe),
+            # else reads the activations of the block in front of it (no pooling, no test probe),
             # that block's BatchNorm + ReLU is applied while the stream loads its pre-activations and the activation tensor never exists
             co1 = cfg.get("co1", CO1_STREAMS) and ws[D].shape[0] == 1 and L.co1_ok(_pad32(ws[D].shape[1]), ws[D].shape[1])
-            fuse_act = co1 and D >= 1 and not pool and not sync and cfg.get("debug") is None
+            fuse_act = co1 and D >= 1 and not pool and cfg.get("debug") is None
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
@@ -509,23 +519,38 @@ class _CnnTrunk(torch.autograd.Function):
             gscale, amax = L.f32(1), L.f32(1)
             top = D
             # closing convolution as streams: its weight gradient from d itself, its input gradient never stored -- the BatchNorm backward
-            # of block D forms it on the fly (not for pooling stacks, whose gradient passes through the max-pool first, nor under sync-BN,
-            # whose sums take the separate entry points)
-            if getattr(ctx, "co1", False) and D >= 1 and not pool and not ctx.sync_state[0]:
+            # of block D forms it on the fly (not for pooling stacks, whose gradient passes through the max-pool first)
+            if getattr(ctx, "co1", False) and D >= 1 and not pool:
                 wl = ws[D]
                 C = wl.shape[1]
                 rc = L.lib.nastar_grad_scale_f32(d.data_ptr(), npix, gscale.data_ptr(), amax.data_ptr(), L.stream)
                 _native.check(rc, "nastar_grad_scale_f32")
-                if ctx.fuse_act:
-                    grads[4 * D] = L.wgrad_co1(d, ctx.zs[D - 1], B, h, w, C, split, ctx.coef[D - 1][2], ctx.coef[D - 1][3])
-                else:
-                    grads[4 * D] = L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
+                def closing_wgrad():
+                    if ctx.fuse_act:
+                        return L.wgrad_co1(d, ctx.zs[D - 1], B, h, w, C, split, ctx.coef[D - 1][2], ctx.coef[D - 1][3])
+                    return L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
+                if not ctx.sync_state[0]:
+                    grads[4 * D] = closing_wgrad()
                 grads[4 * D + 1] = torch.empty_like(params[4 * D + 1])
                 z = ctx.zs[D - 1]
                 mean, invstd, k2f, k3f = ctx.coef[D - 1]
                 wlc = _f32c(wl)
                 gs_new = L.f32(1)
-                dgamma, dbeta, c1, c2, c3 = L.bn_bwd_u1(d, wlc, B, h, w, z, k2f, k3f, C, split, mean, invstd, gammas[D - 1].detach(), gscale, gs_new)
+                if not ctx.sync_state[0]:
+                    dgamma, dbeta, c1, c2, c3 = L.bn_bwd_u1(d, wlc, B, h, w, z, k2f, k3f, C, split, mean, invstd, gammas[D - 1].detach(), gscale, gs_new)
+                else:  # data parallel: the sums of the GLOBAL batch (all-reduced between the statistics and the coefficients)
+                    sums = L.stats_u1(d, wlc, gscale, B, h, w, z, k2f, k3f, C, split, amax)
+                    work = _sync_sums_begin(sums, gscale, ctx.sync_state)
+                    grads[4 * D] = closing_wgrad()  # beside the collective, which it does not need
+                    world = _sync_sums_end(work, sums, gscale, ctx.sync_state)
+                    dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
+                    rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                     gammas[D - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), gs_new.data_ptr(),
+                                                     dgamma.data_ptr(), dbeta.data_ptr(), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
+                    _native.check(rc, "nastar_bn_coef_bwd_io")
+                    if world > 1:  # the flat gradient all-reduce AVERAGES over the ranks
+                        dgamma /= world
+                        dbeta /= world
                 grads[4 * (D - 1) + 2] = dgamma
                 grads[4 * (D - 1) + 3] = dbeta
                 dzb = torch.empty((npix * C * mult,), dtype=torch.int16, device=dev)
