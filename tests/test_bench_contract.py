@@ -44,6 +44,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0.0 < im["valu_busy_frac"] < 1.0 and 0.0 < im["lds_busy_frac"] < 1.0 and 0.0 < im["frac_of_serial_floor"] < 1.5
     assert im["instructions_per_step"] == 71 and im["serial_floor_us"] > 0
     assert rf["frac_counter_bytes"] is None or 0.0 < rf["frac_counter_bytes"] < rf["frac"]
+    # placement: the headline is the hinted figure and says so; the natural-order figure (a batch never searched before) and the pipelined
+    # predictor figure stand beside it, and the headline never loses to them by construction of the workload
+    assert j["config"]["placement"].startswith("hinted")
+    no = j["natural_order"]
+    assert no["value"] > 0 and j["value_natural_order"] == no["value"] and 0.0 < no["roofline_frac"] < rf["frac"] * 1.05
+    assert no["pipelined_with_predictor"] is None or no["pipelined_with_predictor"]["value"] > 0
     ce = j["contract_exact_no_prewarm"]  # the W + K protocol run first, before the untimed pre-warm launches
     assert ce["value"] > 0 and abs(ce["value"] - 4096 * 4 / (ce["ms_per_step"] * 4e-3)) < 1e-6 * ce["value"]
 
