@@ -35,6 +35,7 @@ B_PER_GPU = 4096
 G_RATIO = 0.5
 BYTES_PER_MAP = 28 * H * W  # reads cost+start+goal+passable (4x4 B/cell), writes fp32 hist + int64 paths
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MAX_FRESH_SETS = 512  # never-searched batches the headline loop may hold resident (50 MB of inputs each at 4096 x 32x32)
 N_ROTATE = 3  # distinct input/output batch sets cycled by the timed loop: 3 x 100 MB > the 256 MB MALL, so HBM is what is read
 
 
@@ -123,10 +124,11 @@ def make_problem_rows(kind: str, total: int, seed: int, rows: np.ndarray, rank: 
 
 
 class Runner:
-    """Device-resident inputs + preallocated outputs; step() = one nastar_forward launch on torch's current stream.
+    """Device-resident inputs + preallocated outputs; step() = one nastar_forward_ex launch on torch's current stream.
 
-    `prs` may be a list of problem sets (same shape): step i works on set i % len(prs), each with its own input AND output
-    buffers, so consecutive timed steps do not re-read a cache-resident batch (>256 MB in rotation)."""
+    `prs` may be a list of problem sets (same shape): step i works on set i % len(prs), each with its own input buffers and one of
+    N_ROTATE rotating output buffer sets, so consecutive timed steps do not re-read a cache-resident batch (>256 MB in rotation).
+    A set is a host `Problems` tuple or a device dict {"m", "s", "g"[, "order"]} (FreshBatches.batch)."""
 
     def __init__(self, prs, dev, g_ratio=G_RATIO, max_iters=None, flags=None, placement=None):
         from neural_astar import _native
@@ -136,26 +138,36 @@ class Runner:
         if not isinstance(prs, (list, tuple)) or hasattr(prs, "map_designs"):
             prs = [prs]
         self.sets = []
+        outs = []
         for pr in prs:
-            m = torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous()
-            st = torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous()
-            g = torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous()
-            B, Hh, Ww = m.shape
-            self.sets.append(dict(m=m, s=st, g=g,
-                                  hist=torch.empty((B, Hh, Ww), dtype=torch.float32, device=dev),
-                                  paths=torch.empty((B, Hh, Ww), dtype=torch.int64, device=dev),
-                                  iters=torch.empty((B,), dtype=torch.int32, device=dev),
-                                  status=torch.empty((B,), dtype=torch.int32, device=dev)))
+            if isinstance(pr, dict):
+                z = dict(m=pr["m"], s=pr["s"], g=pr["g"], order=pr.get("order"))
+            else:
+                z = dict(m=torch.from_numpy(pr.map_designs[:, 0]).to(dev).contiguous(), s=torch.from_numpy(pr.start_maps[:, 0]).to(dev).contiguous(),
+                         g=torch.from_numpy(pr.goal_maps[:, 0]).to(dev).contiguous(), order=None)
+            B, Hh, Ww = z["m"].shape
+            if len(outs) < max(N_ROTATE, 1):
+                outs.append(dict(hist=torch.empty((B, Hh, Ww), dtype=torch.float32, device=dev),
+                                 paths=torch.empty((B, Hh, Ww), dtype=torch.int64, device=dev),
+                                 iters=torch.empty((B,), dtype=torch.int32, device=dev),
+                                 status=torch.empty((B,), dtype=torch.int32, device=dev)))
+            z.update(outs[len(self.sets) % len(outs)])
+            self.sets.append(z)
         self.B, self.H, self.W = self.sets[0]["m"].shape
         self.g_ratio = float(g_ratio)
         self.max_iters = int(max_iters) if max_iters is not None else self.W * self.W  # eval mode: search to the goal
         # NASTAR_FLAG_* of include/nastar.h; default: the dev A/B switch NASTAR_FORWARD_FLAGS (0 = the general kernel)
         self.flags = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0")) if flags is None else int(flags)
         self.packed = None  # set by enable_packed(): the step then also emits the bit-packed masks (all-gather payload)
-        # placement "hinted": every batch set remembers the order its searches finished in at its previous visit and the next visit
-        # starts the longest first (nastar_forward_ordered, include/nastar.h): what a validation loop over a fixed set has every epoch
-        # after the first.  "natural": workgroup i searches map i (a batch never seen before).
+        # placement (which map workgroup i searches; outputs never depend on it):
+        #   "dataset": the order the batch was ASSEMBLED with -- counting sort of |opt_dist[start]|, data every sample of the reference's maze
+        #              files carries (utils/data.py:127-134,200-221); nothing measured in an earlier search is used (the headline);
+        #   "hinted":  every batch set remembers the order its searches finished in at its previous visit and the next visit starts the
+        #              longest first: what a validation loop over a fixed set has every epoch after the first;
+        #   "natural": workgroup i searches map i.
         self.placement = (PLACEMENT if placement is None else placement)
+        if self.placement == "dataset" and any(z["order"] is None for z in self.sets):
+            raise ValueError("placement 'dataset' needs sets assembled with an order (FreshBatches.batch)")
         if self.placement == "hinted":
             for z in self.sets:
                 z["ord"] = [torch.zeros((self.B + 1,), dtype=torch.int32, device=dev) for _ in range(2)]
@@ -174,42 +186,109 @@ class Runner:
         self._pk = 0
 
     def step(self):
+        z = self.sets[self._i % len(self.sets)]
         self._bind(self._i % len(self.sets))
         self._i += 1
+        order = order_out = None
         if self.placement == "hinted":
-            z = self.sets[(self._i - 1) % len(self.sets)]
-            cur = z["ord"][z["k"]] if z["seen"] else None
-            z["k"] ^= 1
-            z["seen"] = True
-            pk = None
-            if self.packed is not None:
-                self._pk ^= 1
-                pk = self.packed[self._pk].data_ptr()
-            rc = self.lib.nastar_forward_ordered(
-                self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
-                self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
-                self.status.data_ptr(), pk, None, 0, self.flags, cur.data_ptr() if cur is not None else None,
-                z["ord"][z["k"]].data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
-            self._check(rc, "nastar_forward_ordered")
-            return
+            order = z["ord"][z["k"]] if z["seen"] else None
+            order_out = z["ord"][z["k"] ^ 1]
+        elif self.placement == "dataset":
+            order = z["order"]
+        pk = None
         if self.packed is not None:
             self._pk ^= 1  # double buffer: the previous step's payload may still be in flight in the all-gather
-            rc = self.lib.nastar_forward_packed(
-                self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
-                self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
-                self.status.data_ptr(), self.packed[self._pk].data_ptr(), None, 0, self.flags,
-                torch.cuda.current_stream(self.dev).cuda_stream)
-            self._check(rc, "nastar_forward_packed")
-            return
-        rc = self.lib.nastar_forward(self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(),
-                                     self.B, self.H, self.W, self.g_ratio, self.max_iters, self.hist.data_ptr(),
-                                     self.paths.data_ptr(), None,
-                                     self.iters.data_ptr(), self.status.data_ptr(), None, 0, self.flags,
-                                     torch.cuda.current_stream(self.dev).cuda_stream)
-        self._check(rc, "nastar_forward")
+            pk = self.packed[self._pk].data_ptr()
+        rc = self.lib.nastar_forward_ex(
+            self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
+            self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
+            self.status.data_ptr(), pk, None, 0, self.flags, order.data_ptr() if order is not None else None,
+            order_out.data_ptr() if order_out is not None else None, None, torch.cuda.current_stream(self.dev).cuda_stream)
+        self._check(rc, "nastar_forward_ex")
+        if self.placement == "hinted":  # only now: a launch that failed must not leave a half-initialised order as the next hint
+            z["k"] ^= 1
+            z["seen"] = True
 
 
-PLACEMENT = "hinted"  # default of Runner(placement=None); main() sets it from --placement
+def _device_distances(m, g):
+    """[P,H,W] fp32 passable maps + goal one-hots on the device -> [P,H,W] int32 8-connected unit-cost distance to the goal (-1: obstacle
+    or unreachable): what a planning-datasets file stores as `opt_dists` (reference utils/data.py:127-134).  Bench-side data
+    preparation (one dilation per level with torch ops), not the product path."""
+    import torch.nn.functional as F
+    passable = m > 0
+    dist = torch.full(m.shape, -1, dtype=torch.int32, device=m.device)
+    front = (g > 0) & passable
+    seen = front.clone()
+    d = 0
+    while True:
+        dist[front] = d
+        grown = F.max_pool2d(front.float().unsqueeze(1), 3, 1, 1)[:, 0] > 0
+        front = grown & passable & ~seen
+        if d % 8 == 7 and not bool(front.any()):
+            break
+        seen |= front
+        d += 1
+        if d > m.shape[-1] * m.shape[-2]:
+            break
+    return dist
+
+
+class FreshBatches:
+    """Batches that have NEVER been searched, assembled the way the reference's loader assembles them: a resident pool of problems in
+    the layout of a planning-datasets split (map_designs, goal_maps, opt_dists; reference utils/data.py:127-134) and, per batch, a random
+    draw of maps with a random START per map -- for the maze workload from a random one of the 55-70 / 70-85 / 85-100 percentile bands
+    of the optimal distance (utils/data.py:200-221, `get_random_start_map`), for the random-obstacle workloads uniform over the cells that
+    reach the goal.  The sample's own `opt_dists[start]` gives the batch its placement (`order`: counting sort, longest route first;
+    ops.order_from_levels) AT ASSEMBLY -- no search of these inputs, and nothing any search has measured, goes into it."""
+
+    def __init__(self, kind, dev, prs, seed):
+        self.kind, self.dev = kind, dev
+        self.m = torch.cat([torch.from_numpy(pr.map_designs[:, 0]) for pr in prs]).to(dev).contiguous()
+        self.g = torch.cat([torch.from_numpy(pr.goal_maps[:, 0]) for pr in prs]).to(dev).contiguous()
+        self.s0 = torch.cat([torch.from_numpy(pr.start_maps[:, 0]) for pr in prs]).to(dev).contiguous()  # the generator's own starts (fixed())
+        self.P, self.H, self.W = self.m.shape
+        self.dist = _device_distances(self.m, self.g).reshape(self.P, -1)
+        d = self.dist.cpu().numpy()
+        self.th = None
+        if kind.startswith("maze"):
+            th = np.empty((self.P, 4), np.float64)
+            for n in range(self.P):
+                v = d[n]
+                th[n] = np.percentile(v[v > 0], 100.0 * np.array([0.55, 0.70, 0.85, 1.0]))
+            self.th = torch.from_numpy(th).to(dev)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+
+    def fixed(self, k, B):
+        """rows [k B, (k + 1) B) of the pool with the starts the generator drew (a recurring, seeded batch: the oracle / reference
+        checks and the strong-scaling global batch), placed by ITS starts' distances"""
+        from neural_astar import ops
+        sl = slice(k * B, (k + 1) * B)
+        s = self.s0[sl]
+        levels = (self.dist[sl] * (s.reshape(B, -1) > 0)).sum(1).to(torch.int32).contiguous()
+        return {"m": self.m[sl], "s": s, "g": self.g[sl], "order": ops.order_from_levels(levels), "levels": levels}
+
+    def batch(self, B):
+        from neural_astar import ops
+        idx = torch.randperm(self.P, device=self.dev, generator=self.gen)[:B]
+        d = self.dist[idx]
+        mask = d > 0
+        if self.th is not None:
+            band = torch.randint(0, 3, (B, 1), device=self.dev, generator=self.gen)
+            th = self.th[idx]
+            lo, hi = torch.gather(th, 1, band), torch.gather(th, 1, band + 1)
+            dd = d.double()
+            banded = (dd >= lo) & (dd <= hi) & mask
+            mask = torch.where(banded.any(1, keepdim=True), banded, mask)
+        sidx = torch.multinomial(mask.float(), 1, generator=self.gen)
+        s = torch.zeros((B, self.H * self.W), dtype=torch.float32, device=self.dev)
+        s.scatter_(1, sidx, 1.0)
+        levels = torch.gather(d, 1, sidx).reshape(-1).contiguous()
+        return {"m": self.m[idx].contiguous(), "s": s.reshape(B, self.H, self.W), "g": self.g[idx].contiguous(),
+                "order": ops.order_from_levels(levels), "levels": levels}
+
+
+PLACEMENT = "hinted"  # default of Runner(placement=None) for the secondary figures; the headline runner is built with placement="dataset"
 PREWARM_S = 0.3  # untimed launches before the W warm-up steps: the driver times 20 steps (~3 ms) after 5 warm-up steps, which on a GPU fresh out
                  # of problem synthesis measures the clock ramp, not the kernel (same process: 23.6 M maps/s first, 25.9 M a minute later)
 
@@ -941,28 +1020,78 @@ def cpu_baseline(pr, gpu_hist, gpu_paths):
     return port
 
 
-def through_module_ms(pr, dev, reps=30):
-    """End to end through the drop-in boundary: ms per VanillaAstar.forward() call on the bench batch -- torch custom-op
-    dispatch, output allocation, the launch, and the solvability policy: the default (True = "sync") waits for the kernel and raises in
-    the same call, "deferred" (opt-in) hands the verdict to a later call (no host sync; a device-side any() + an async copy), False skips
-    it."""
+def through_module_ms(pr, dev, reps=60):
+    """End to end through the drop-in boundary (north_star: "keeps the forward() API"): ms per VanillaAstar.forward() call on
+    the bench batch, wall clock -- output allocation, the launch, and the solvability policy: the default (True = "sync") waits for the
+    kernel and raises in the same call (one stream wait + one 64-byte read of the pinned status summary the launch wrote), "deferred"
+    (opt-in) hands the verdict to a later call (an event, no host wait), False skips it.  The batch carries the placement its loader
+    attached (start_maps.placement_order, by the optimal distance of the start cells); `no_placement_*` = the same calls without it."""
+    from neural_astar import ops
     from neural_astar.planner import VanillaAstar
     m, s_, g = (torch.from_numpy(x).to(dev) for x in (pr.map_designs, pr.start_maps, pr.goal_maps))
+    dist = _device_distances(m[:, 0], g[:, 0]).reshape(m.shape[0], -1)
+    levels = (dist * (s_.reshape(m.shape[0], -1) > 0)).sum(1).to(torch.int32).contiguous()
     out = {}
-    for label, chk in (("check_solvable_default_sync", True), ("check_solvable_deferred", "deferred"), ("check_solvable_false", False)):
+    for hinted in (True, False):
+        if hinted:
+            ops.attach_order(s_, levels)
+        elif hasattr(s_, "placement_order"):
+            del s_.placement_order
+        for label, chk in (("check_solvable_default_sync", True), ("check_solvable_deferred", "deferred"), ("check_solvable_false", False)):
+            va = VanillaAstar().to(dev).eval()
+            va.astar.check_solvable = chk
+            with torch.no_grad():
+                for _ in range(5):
+                    va(m, s_, g)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    va(m, s_, g)
+                torch.cuda.synchronize(dev)
+            out[("" if hinted else "no_placement_") + label] = (time.perf_counter() - t0) / reps * 1e3
+            va.astar.raise_if_unsolvable()
+    out["unit"] = "ms per VanillaAstar.forward() call, wall clock, same input batch each call"
+    out["note"] = ("default mode runs the unit-cost kernel (unit_cost='auto' needs the same-call verdict); deferred / false run the general kernel "
+                   "back to back without a host wait, i.e. at the kernel's own duration")
+    return out
+
+
+def in_flight_through_api(dev, steps, workloads=(("maze32", True), ("rand32", True), ("rand64", True), ("maze32", False)), ks=(3, 4, 6)):
+    """Batches in flight THROUGH THE PYTHON OBJECT (neural_astar.parallel.InFlightPlanner around a VanillaAstar): whole 4096-map batches
+    round-robin over k HIP streams, outputs allocated per batch, status summaries read once at collection, unit_cost="auto" without a
+    per-call wait.  maps/s over `n` batches incl. submission, collection and the final host wait; outputs checked equal to sequential
+    planner.forward() calls on the first batches."""
+    from neural_astar.parallel import InFlightPlanner
+    from neural_astar.planner import VanillaAstar
+    res = []
+    n = max(24, min(steps, 96))
+    for w, unit in workloads:
+        prs = [make_problem(w, B_PER_GPU, seed=1234 + 1000 * k) for k in range(N_ROTATE)]
+        batches = [tuple(torch.from_numpy(x).to(dev) for x in (pr.map_designs, pr.start_maps, pr.goal_maps)) for pr in prs]
         va = VanillaAstar().to(dev).eval()
-        va.astar.check_solvable = chk
         with torch.no_grad():
-            for _ in range(3):
-                va(m, s_, g)
+            seq = [va(*b) for b in batches]
+        sweep = {}
+        same = True
+        for k in ks:
+            fly = InFlightPlanner(va, streams=k, unit_cost="auto" if unit else False)
+            outs = fly.plan_many(batches * 2)  # warm-up (allocator, streams) + equality with the sequential calls
+            same = same and all(torch.equal(o.histories, seq[i % N_ROTATE].histories) and torch.equal(o.paths, seq[i % N_ROTATE].paths)
+                                for i, o in enumerate(outs))
+            del outs
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            for _ in range(reps):
-                va(m, s_, g)
-            torch.cuda.synchronize(dev)
-        out[label] = (time.perf_counter() - t0) / reps * 1e3
-    out["unit"] = "ms per VanillaAstar.forward() call, wall clock, same input batch each call"
-    return out
+            outs = fly.plan_many(batches[i % N_ROTATE] for i in range(n))
+            dt = time.perf_counter() - t0
+            del outs
+            sweep[str(k)] = n * B_PER_GPU / dt
+        best = max(sweep, key=sweep.get)
+        Hh, Ww = batches[0][0].shape[-2:]
+        res.append({"workload": f"{w}: {B_PER_GPU} maps per batch, {n} batches", "kernel": "unit_cost (auto)" if unit else "general",
+                    "streams_sweep_maps_per_s": sweep, "best_streams": int(best), "maps_per_s": sweep[best],
+                    "hbm_frac": sweep[best] * 24 * Hh * Ww / 1e9 / HBM_PEAK_GBS, "equal_to_sequential_forward": bool(same)})
+        del batches, seq
+    return res
 
 
 # ---- --mode train: BASELINE config 5 (and the maze configuration of scripts/train.py) as a driver-runnable training bench ---------------
@@ -1225,10 +1354,13 @@ def main():
                          "--global-batch 32768); default 0 = weak scaling, 4096 maps per GPU")
     ap.add_argument("--shard", default="contiguous", choices=["contiguous", "interleaved"],
                     help="strong scaling: which rows a rank owns (parallel.shard_rows)")
-    ap.add_argument("--placement", default="hinted", choices=["hinted", "natural"],
-                    help="hinted (default): every batch set is searched longest-first by the order its searches finished in at its previous "
-                         "visit (nastar_forward_ordered; the natural-order figures are reported beside it); natural: workgroup i = map i")
-    ap.add_argument("--no-natural", action="store_true", help="--placement hinted: skip the natural-order comparison passes (clean kernel profiles)")
+    ap.add_argument("--placement", default="dataset", choices=["dataset", "hinted", "natural"],
+                    help="dataset (default): every timed step searches a NEVER-SEARCHED batch, placed longest-first by the optimal distance of its "
+                         "start cells (data the sample carries; order computed at batch assembly); hinted: three recurring batch sets, each placed by the "
+                         "order its searches finished in at its previous visit (the round-4 headline; reported beside the headline anyway); natural: "
+                         "workgroup i = map i")
+    ap.add_argument("--no-natural", action="store_true", help="skip the natural-order and hinted comparison passes (clean kernel profiles)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed clock pre-warm launches (clean kernel profiles: every launch of the run is then a dataset-placed one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (clean kernel profiles)")
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
@@ -1248,7 +1380,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dev: every rank uses cuda:0 (only with --dist-backend gloo)")
     args = ap.parse_args()
     global PLACEMENT
-    PLACEMENT = args.placement
+    PLACEMENT = "hinted" if args.placement == "dataset" else args.placement  # (the secondary workloads run on recurring batch sets)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: re-launch one rank per GPU the way the driver does
@@ -1292,9 +1424,23 @@ def main():
         b_rank = B_PER_GPU
         prs = [make_problem(args.workload, B_PER_GPU, seed=1234 + rank + 1000 * k) for k in range(N_ROTATE)]
     pr = prs[0]
-    run = Runner(prs, dev)
+    # the resident pool (maps, goals, distance-to-goal maps: a planning-datasets split) the loader-style batches are drawn from
+    pool = FreshBatches(args.workload, dev, prs, seed=4321 + rank)
+    per_pass = args.steps + args.warmup
+    if args.placement == "dataset" and not strong:
+        # every step of the cold pass AND of the headline pass searches a batch that has never been searched: 2 (W + K) of them
+        # (+ 2: the collate trial step), capped at MAX_FRESH_SETS -- beyond the cap the loop revisits batches (same dataset order, nothing learned)
+        n_fresh = min(2 * per_pass + 2, MAX_FRESH_SETS)
+        sets = [pool.batch(b_rank) for _ in range(n_fresh)]
+    else:
+        sets = [pool.fixed(k, b_rank) for k in range(N_ROTATE)]
+        n_fresh = 0
+    torch.cuda.synchronize(dev)
+    run = Runner(sets, dev, placement=args.placement)
+    warm = Runner([pool.batch(b_rank) for _ in range(N_ROTATE)] if not strong else sets, dev, placement=args.placement if args.placement != "hinted" else "natural")
     Hh, Ww = run.H, run.W
-    bytes_per_map = 28 * Hh * Ww
+    bytes_per_map = 28 * Hh * Ww  # four input tensors
+    bytes_moved_per_map = 24 * Hh * Ww  # ... of which VanillaAstar's call passes ONE as cost and passable (reference astar.py:93-94): what really moves
 
     collate = None
     collate_note = "n/a (single GPU)"
@@ -1334,45 +1480,62 @@ def main():
         # them -- reported as `contract_exact_no_prewarm`; then PREWARM_S of untimed launches and the same W + K again = the headline
         # (`config.prewarm_s`; ADVICE r3: label which is which)
         dt_cold, _ = timed_loop(run, args.steps, args.warmup, world, dev, collate)
-        prewarm(run, dev)
+        if not args.no_prewarm:
+            prewarm(warm, dev)  # (on its OWN batches: the headline's batches stay unsearched)
+        first_fresh = run._i
         dt, dev_ms = timed_loop(run, args.steps, args.warmup, world, dev, collate)
-        dt_nat = None
-        if run.placement == "hinted" and not args.no_natural:  # the same W + K steps with workgroup i = map i: a batch that has never been searched before
-            run.placement = "natural"
-            dt_nat, _ = timed_loop(run, args.steps, args.warmup, world, dev, collate)
-            run.placement = "hinted"
+        all_first_visits = n_fresh > 0 and run._i <= len(run.sets)
+        dt_nat = dt_hint = None
+        run_h = None
+        if not args.no_natural and run.packed is None:
+            # the same W + K steps (a) in the natural order (workgroup i = map i) on the same kind of fresh batches, (b) "hinted": three
+            # recurring batch sets, each searched longest-first by the order its searches FINISHED in at its previous visit
+            run_n = Runner(sets[:per_pass] if n_fresh else sets, dev, placement="natural")
+            dt_nat, _ = timed_loop(run_n, args.steps, args.warmup, world, dev, None)
+            run_h = Runner([pool.fixed(k, b_rank) for k in range(N_ROTATE)], dev, placement="hinted")
+            prewarm(run_h, dev, 0.1)
+            dt_hint, _ = timed_loop(run_h, args.steps, args.warmup, world, dev, None)
     torch.cuda.synchronize(dev)
     _log(f"headline: {dt / args.steps * 1e3:.4f} ms/step")
     total_maps = n_gpus * b_rank * args.steps
     value = total_maps / dt
 
     if rank == 0:
-        run._bind(0)
-        hist = run.hist.cpu().numpy()
-        paths = run.paths.cpu().numpy()
-        iters = torch.cat([z["iters"] for z in run.sets]).cpu().numpy()
-        assert all(int(z["status"].abs().sum().item()) == 0 for z in run.sets), "unsolvable map in the synthetic batch"
+        # parity sample + iteration statistics on the pool's seeded batch 0 (the generator's own starts), through the SAME dataset placement
+        chk = Runner([pool.fixed(0, b_rank)], dev, placement="dataset")
+        chk.step()
+        torch.cuda.synchronize(dev)
+        hist = chk.hist.cpu().numpy()
+        paths = chk.paths.cpu().numpy()
+        outs3 = run.sets[:N_ROTATE]  # the rotating output sets hold the latest three batches
+        iters = torch.cat([z["iters"] for z in outs3]).cpu().numpy()
+        assert all(int(z["status"].abs().sum().item()) == 0 for z in outs3) and int(chk.status.abs().sum().item()) == 0, "unsolvable map in the synthetic batch"
         avg_ms, med_ms, min_ms = kernel_launch_ms(run, min(args.steps, 100), dev)
-        nat = None
+        nat = hinted = None
         dt_pipe = None
-        if dt_nat is not None and n_gpus == 1 and run.packed is None:
+        if run_h is not None and n_gpus == 1:
             try:
-                dt_pipe = fresh_batches_pipelined(run, max(args.steps, 60), max(args.warmup, 9), dev)
+                dt_pipe = fresh_batches_pipelined(run_h, max(args.steps, 60), max(args.warmup, 9), dev)
             except Exception as e:  # noqa: BLE001 - an extra figure never sinks the line
                 _log(f"fresh_batches_pipelined failed: {type(e).__name__}: {e}")
         if dt_nat is not None:
-            run.placement = "natural"
-            nat_ms = kernel_launch_ms(run, min(args.steps, 100), dev)[0]
-            run.placement = "hinted"
+            nat_ms = kernel_launch_ms(run_n, min(args.steps, 100), dev)[0]
             nat = {"value": total_maps / dt_nat, "ms_per_step": dt_nat / args.steps * 1e3, "launch_ms_avg": nat_ms,
-                   "roofline_frac": bytes_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "note": "same W + K steps, workgroup i searches map i: what a batch costs at its FIRST visit (nothing is known about its "
-                           "searches yet); identical outputs",
+                   "roofline_frac": bytes_moved_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "roofline_frac_28B_per_cell": bytes_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "same W + K steps on never-searched batches, workgroup i searches map i: a batch whose assembler passed no placement; identical outputs",
                    "pipelined_with_predictor": ({"value": b_rank * max(args.steps, 60) / dt_pipe, "ms_per_step": dt_pipe / max(args.steps, 60) * 1e3,
                                                  "note": "never-searched batches in a pipeline: a side stream computes the NEXT batch's placement from "
                                                          "its maps alone (nastar_placement_predict) while this batch is searched; nothing from an "
                                                          "earlier visit is used"} if dt_pipe else None)}
-        achieved = bytes_per_map * b_rank / (avg_ms * 1e-3) / 1e9
+        if dt_hint is not None:
+            hint_ms = kernel_launch_ms(run_h, min(args.steps, 100), dev)[0]
+            hinted = {"value": total_maps / dt_hint, "ms_per_step": dt_hint / args.steps * 1e3, "launch_ms_avg": hint_ms,
+                      "roofline_frac": bytes_moved_per_map * b_rank / (hint_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "RECURRING batches (three sets in rotation, each visited many times before the clock): every visit is searched longest-first by the "
+                              "order its searches finished in at the previous visit (nastar_forward_ex order_out -> order; planner.Placement) -- what a "
+                              "validation loop over a fixed set has from its second epoch on; this was the round-4 headline"}
+        achieved = bytes_moved_per_map * b_rank / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
@@ -1384,44 +1547,61 @@ def main():
         if os.path.exists(kp):
             with open(kp) as f:
                 kprof = json.load(f).get(args.workload)
+        placement_note = {
+            "dataset": ("dataset: workgroup i searches map order[i], order = counting sort (longest first) of |opt_dist[start]| -- the optimal distance of each "
+                        "sample's start cell, which the reference's maze files carry and its loader reads to draw that start (utils/data.py:127-134,"
+                        "200-221) -- computed when the batch is ASSEMBLED (ops.order_from_levels: one small launch, outside the timed region like the "
+                        "assembly itself); nothing any search has measured is used; identical outputs"),
+            "hinted": "hinted: every recurring batch set is searched longest-first by the order its searches finished in at its previous visit",
+            "natural": "natural: workgroup i searches map i"}[run.placement]
         out = {
             "metric": f"map-instances/s (forward A*) {Hh}x{Ww} Moore-8 @batch {b_rank * n_gpus if strong else B_PER_GPU}",
             "value": value, "unit": "maps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {b_rank} maps/GPU of {Hh}x{Ww} Moore-8, cost=map (VanillaAstar), "
-                                   f"g_ratio={G_RATIO}, eval mode (search to goal), {N_ROTATE} distinct batch sets in rotation "
-                                   f"({N_ROTATE * 25 * Hh * Ww * b_rank / 1e6:.0f} MB of inputs+outputs per GPU), "
+                                   f"g_ratio={G_RATIO}, eval mode (search to goal), "
+                                   + (f"{n_fresh} never-searched batches assembled loader-style from a resident pool of {pool.P} problems "
+                                      f"(random maps + a random start per map from the optimal-distance bands, reference utils/data.py:200-221), "
+                                      f"{n_fresh * 12 * Hh * Ww * b_rank / 1e6:.0f} MB of inputs per GPU, {N_ROTATE} rotating output sets, " if n_fresh else
+                                      f"{N_ROTATE} recurring batch sets in rotation, ")
                                    + (f"global batch {args.global_batch} seeded 1234+1000k, {args.shard} shards"
-                                      if strong else "seeds 1234+rank+1000k"),
+                                      if strong else "pool seeds 1234+rank+1000k"),
                        "batch_per_gpu": b_rank, "global_batch": n_gpus * b_rank, "H": Hh, "W": Ww,
                        "parallelism": f"shard{n_gpus}" if n_gpus > 1 else "single", "collate": collate_note,
-                       "prewarm_s": PREWARM_S,
-                       "placement": ("hinted: every batch set is searched longest-first by the order its searches FINISHED in at its previous visit "
-                                     "(nastar_forward_ordered writes that order itself: no extra launch, no host sync, identical outputs) -- what a "
-                                     "validation / evaluation loop over a fixed set has from its second epoch on; the first visit is `natural_order`"
-                                     if run.placement == "hinted" else "natural: workgroup i searches map i")},
+                       "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S,
+                       "prewarm_note": "untimed launches on batches of their OWN (never the headline's)",
+                       "placement": placement_note,
+                       "every_timed_step_is_a_first_visit": bool(all_first_visits),
+                       "first_visit_note": (f"headline pass = batches #{first_fresh}..#{first_fresh + per_pass - 1} of {n_fresh} assembled; none was searched before its step"
+                                            if all_first_visits else "batches recur (see workload)")},
             "natural_order": nat,
-            "value_natural_order": nat["value"] if nat else None,  # (the same figure at top level: maps/s when nothing is known about the batch)
+            "value_natural_order": nat["value"] if nat else None,  # (the same figure at top level: maps/s when the batch comes with no placement)
+            "hinted": hinted,
+            "value_hinted": hinted["value"] if hinted else None,  # (recurring batches placed by their previous visit: the round-4 headline)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # the same fraction on the bytes the PMC counters saw instead of SURVEY 8(d)'s 28 B/cell (VanillaAstar hands ONE
-                         # tensor over as cost and passable map and the kernel loads it once: 24 B/cell really move)
-                         "frac_counter_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop, round-4 instruction stream: nastar_search_asm4.hip.h)",
-                         "algorithmic_bytes_per_launch": bytes_per_map * b_rank,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_note": "achieved / frac on the bytes this call MUST move: 24 B/cell (VanillaAstar hands ONE tensor over as cost and passable "
+                                       "map, reference astar.py:93-94; reads 3 x 4 B, writes fp32 histories + int64 paths); SURVEY 8(d)'s 28 B/cell "
+                                       "(DifferentiableAstar boundary, four distinct inputs) beside it",
+                         "algorithmic_bytes_per_launch": bytes_moved_per_map * b_rank,
+                         "frac_28B_per_cell": bytes_per_map * b_rank / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "traffic_source": "committed constant: profiles/hbm_traffic.json (rocprofv3 PMC passes of an earlier round, same kernel and batch shape), NOT measured in this run",
+                         "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop: nastar_search_asm4.hip.h)",
                          "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms,
-                         "kernel_profile_us": kprof["avg_us"] if kprof else None,
-                         "kernel_profile_source": kprof["source"] if kprof else None,
-                         "frac_from_kernel_profile": (bytes_per_map * b_rank / (kprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kprof else None},
+                         "launch_ms_note": "HIP events around single launches on the launch stream, measured in THIS run, placement as the headline",
+                         "committed_kernel_profile_us": kprof["avg_us"] if kprof else None,
+                         "committed_kernel_profile_source": kprof["source"] if kprof else None,
+                         "committed_frac_from_kernel_profile": (bytes_moved_per_map * b_rank / (kprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kprof else None},
             # the search is a serial chain of select + update steps with all state on-chip, so next to the HBM fraction the line
             # carries what the launch costs the CU's pipes and what its longest chain alone costs (pipe_model above)
-            "issue_model": (pipe_model(float(iters.sum()) / len(run.sets), avg_ms * 1e3, int(iters.max()), LONE_STEP_NS, FIXED_US)
+            "issue_model": (pipe_model(float(iters.sum()) / N_ROTATE, avg_ms * 1e3, int(iters.max()), LONE_STEP_NS, FIXED_US)
                             if (Hh, Ww) == (32, 32) and not strong else None),
             "contract_exact_no_prewarm": {"value": total_maps / dt_cold, "ms_per_step": dt_cold / args.steps * 1e3,
-                                          "note": "the same W warm-up + K timed steps run FIRST, without the untimed pre-warm launches: "
-                                                  "the headline `value` is the second pass (clocks out of their idle state)"},
-            "expansions_per_s": float(iters.sum()) / len(run.sets) * n_gpus * args.steps / dt,
+                                          "note": "the same W warm-up + K timed steps run FIRST (on never-searched batches of their own), without the untimed "
+                                                  "pre-warm launches: the headline `value` is the second pass (clocks out of their idle state)"},
+            "expansions_per_s": float(iters.sum()) / N_ROTATE * n_gpus * args.steps / dt,
             "mean_iters_per_map": float(iters.mean()), "max_iters_per_map": int(iters.max()),
             "device_ms_per_step": dev_ms / args.steps,
         }
@@ -1494,6 +1674,12 @@ def main():
                     ex[name] = fn()
                 except Exception as e:  # noqa: BLE001 - an extra never sinks the headline line
                     ex[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            _log("batches in flight through the Python API (InFlightPlanner)")
+            try:
+                out["in_flight_through_api"] = in_flight_through_api(dev, args.steps)
+                out["value_in_flight"] = out["in_flight_through_api"][0]["maps_per_s"]  # maze32, VanillaAstar, through the Python object
+            except Exception as e:  # noqa: BLE001 - never sinks the headline line
+                out["in_flight_through_api"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             _log("throughput regime (all workloads, general + unit-cost kernels)")
             try:
                 out["throughput_regime"] = throughput_regime(dev, max(args.steps, 240))

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 401 /* 0.4.1: nastar_forward_ordered (placement); 0.4.0: round-4 search instruction stream, unit-cost LDS layout */
+#define NASTAR_VERSION 500 /* 0.5.0: nastar_forward_ex (status summary, checked placement), nastar_placement_from_levels; 0.4.1: nastar_forward_ordered (placement); 0.4.0: round-4 search instruction stream, unit-cost LDS layout */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0
@@ -63,6 +63,18 @@ extern "C" {
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
+#define NASTAR_FLAG_CHECK_ORDER 256 /* nastar_forward_ex / nastar_forward_ordered / nastar_backward_replay_ordered: verify on the device that `order` is a
+                                     * permutation of 0..B-1 (one small launch before the search) and IGNORE it when it is not -- every map is then
+                                     * searched in the natural order and status_summary[NASTAR_SUMMARY_BAD_ORDER] is set.  Needs the workspace that
+                                     * nastar_workspace_bytes(B,H,W,flags) / nastar_backward_workspace_bytes() report (16 bytes for LDS-resident
+                                     * forward searches).  Without the flag `order` is TRUSTED: a map it never names is never searched and its
+                                     * output rows are left as the caller allocated them. */
+/* status_summary of nastar_forward_ex: NASTAR_SUMMARY_WORDS int32 cells, device or host-mapped memory, zeroed by the caller.  Cell c (a per-map
+ * status code, 1..14) becomes 1 when SOME map of the launch ends with that status; cell NASTAR_SUMMARY_BAD_ORDER when a checked `order` was
+ * rejected.  Plain idempotent stores, no atomics: a pinned host buffer works and turns "did any map fail?" into one 64-byte host read after the
+ * stream (or an event) has been waited for -- no reduction launch, no device-to-host copy. */
+#define NASTAR_SUMMARY_WORDS 16
+#define NASTAR_SUMMARY_BAD_ORDER 15
 
 int nastar_version(void);
 
@@ -97,12 +109,13 @@ int nastar_forward(const float* cost, const float* start, const float* goal, con
  * launch, 64x64 random maps 277 -> 234 us; profiles/r04/order_*.jsonl).  Nothing cheap predicts a search's length from its map, but
  * a data set is searched once per epoch (reference scripts/train.py:43-50 validates after every epoch on a fixed, unshuffled
  * loader, utils/data.py:40-47): the previous visit of the same batch is the predictor.
- *   order      [B] int32 device, a permutation of 0..B-1, or NULL (identity)
+ *   order      [B] int32 device, a permutation of 0..B-1, or NULL (identity).  TRUSTED unless flags has NASTAR_FLAG_CHECK_ORDER.
  *   order_out  [B+1] int32 device or NULL: receives the `order` to pass at the next visit of the same batch -- the maps in REVERSE
  *              order of search completion in THIS launch when all B maps are resident at once (one atomic per map inside the
  *              kernel), sorted by their step counts (one more small launch on the same stream) when the launch takes several
- *              rounds of workgroups.  order_out[B] is the launch's counter: it must be 0 on entry and is 0 again when the launch
- *              has finished (zero the buffer once, then reuse it; one buffer per launch in flight).
+ *              rounds of workgroups.  order_out[B] is the launch's counter: zero the buffer once, then reuse it (one buffer per launch in
+ *              flight).  The counter wraps at B: it is back at its entry value when the launch has finished, and every rank is handed
+ *              out exactly once whatever it held -- a buffer that was not zeroed gets a rotated, still complete order.
  *   packed_out NULL, or the bit-packed masks of nastar_forward_packed.
  * Maps whose search state lives in HBM (nastar_workspace_bytes > 0) take no placement: NASTAR_ERR_UNSUPPORTED if either is given.
  */
@@ -111,6 +124,27 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
                            int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out,
                            void* workspace, size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out,
                            void* stream);
+
+/*
+ * nastar_forward with every option of the search launch (0.5.0): placement (`order` / `order_out`, see nastar_forward_ordered), the bit-packed
+ * masks (`packed_out`, see nastar_forward_packed) and the per-launch STATUS SUMMARY (`status_summary`, NASTAR_SUMMARY_WORDS int32 cells, see
+ * above).  Every optional pointer may be NULL; with all of them NULL this is nastar_forward.  flags: NASTAR_FLAG_*; with
+ * NASTAR_FLAG_CHECK_ORDER the order is verified on the device first (workspace: nastar_workspace_bytes(B,H,W,flags) bytes).
+ * Replaces the same reference code as nastar_forward (differentiable_astar.py:150-267).
+ */
+int nastar_forward_ex(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W,
+                      double g_ratio, int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out,
+                      int32_t* iters_out, int32_t* status_out, uint8_t* packed_out, void* workspace, size_t workspace_bytes,
+                      int flags, const int32_t* order, int32_t* order_out, int32_t* status_summary, void* stream);
+
+/*
+ * A placement from data the CALLER already has: `levels[b]` = any non-negative integer that grows with the expected length of map b's
+ * search -- for the reference's maze data sets the optimal distance of the sampled start cell, |opt_dists[start]|, which every sample
+ * carries (utils/data.py:127-134, :200-221).  order_out [B] = the maps sorted by level, largest first (one counting-sort launch, one
+ * workgroup; levels are clamped to 4095; maps of equal level in arbitrary order).  A permutation by construction: pass it to
+ * nastar_forward_ex without NASTAR_FLAG_CHECK_ORDER.
+ */
+int nastar_placement_from_levels(const int32_t* levels, int B, int32_t* order_out, void* stream);
 
 /*
  * A placement (the `order` of nastar_forward_ordered) for a batch that has never been searched: maps sorted, longest first, by the

@@ -37,6 +37,7 @@ struct BwdRArgs {
     const int* iters;     // [B]
     const int* t_batch;   // device scalar or nullptr
     const int* order;     // optional placement (workgroup i replays map order[i]); nullptr = identity
+    const int* order_bad; // optional verdict of nastar_order_check_kernel (NASTAR_FLAG_CHECK_ORDER): != 0 = ignore `order`
     int B_total;          // maps in the batch (bounds the placement)
     float* grad_cost;     // [B,H,W], fully written by this kernel
     double* hist;         // workspace: [B][hist_len][2]  (A, B) after each step; entry 0 = (0, 0)
@@ -107,7 +108,7 @@ template <bool kGlobal, bool kHistLds, bool kFastDiv>
 __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const int b = (a.order == nullptr || (a.order_bad != nullptr && *a.order_bad != 0)) ? (int)blockIdx.x : a.order[blockIdx.x];
     if ((unsigned)b >= (unsigned)a.B_total) return;  // not a permutation: never touch memory outside the batch
     const int lane = threadIdx.x;
     const CompactDims d = a.d;

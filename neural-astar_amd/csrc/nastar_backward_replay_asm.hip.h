@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_asm_kernel(const Bw
 {
     using L = BwdAsmLayout<LOGW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const int b = (a.order == nullptr || (a.order_bad != nullptr && *a.order_bad != 0)) ? (int)blockIdx.x : a.order[blockIdx.x];
     if ((unsigned)b >= (unsigned)a.B_total) return;  // not a permutation: never touch memory outside the batch
     const int lane = threadIdx.x;
     CompactDims d = a.d;

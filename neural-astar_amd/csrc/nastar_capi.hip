@@ -35,11 +35,55 @@ struct FwdCArgs {
     uint8_t* packed;
     const int* order;  // optional placement: workgroup i runs map order[i] (a permutation of 0..B-1), nullptr = identity
     int* order_out;    // optional [B + 1]: the maps in REVERSE order of search completion (the placement for the next visit); [B] = counter
+    int* summary;      // optional [NASTAR_SUMMARY_WORDS]: summary[c] = 1 when some map of this launch ends with per-map status c != 0 (device or host-mapped)
+    const int* order_bad;  // optional: *order_bad != 0 (written by nastar_order_check_kernel earlier on the stream) = `order` is not a permutation, ignore it
     int max_iters;
     int B;
     int flags;
     CompactDims d;
 };
+
+// which map this workgroup searches: `order[blockIdx.x]`, unless the launch was asked to check `order` (NASTAR_FLAG_CHECK_ORDER) and the
+// check kernel, earlier on the same stream, found that it is not a permutation of 0..B-1 -- then the natural order (every map is searched)
+__device__ __forceinline__ int placed_map(const int* order, const int* order_bad, int B)
+{
+    if (order == nullptr || (order_bad != nullptr && *order_bad != 0)) return (int)blockIdx.x;
+    return order[blockIdx.x];
+}
+
+// order_out: this search's rank by completion time, counted from the end -- the longest searches come first next time.  The counter cell
+// order_out[B] wraps at B (atomicInc): B completions bring it back to where it started (0 for a zeroed buffer) and every rank in [0, B) is
+// handed out exactly once WHATEVER the cell held on entry -- a buffer that was not zeroed gets a rotated, still complete order.
+__device__ __forceinline__ void note_completion(int* order_out, int B, int b)
+{
+    unsigned pos = atomicInc(reinterpret_cast<unsigned*>(order_out + B), (unsigned)B - 1u);
+    if (pos >= (unsigned)B) pos = (unsigned)B - 1u;  // a cell that held garbage >= B: only the first increment sees it, and rank B-1 is the one nobody else gets
+    order_out[B - 1 - (int)pos] = b;
+}
+
+// NASTAR_FLAG_CHECK_ORDER: is `order` a permutation of 0..B-1?  ONE workgroup, a bitmap of B bits in LDS; writes *bad = 0 / 1 (always)
+// and, when it is not, summary[NASTAR_SUMMARY_BAD_ORDER] = 1.  The search / replay kernels that follow on the stream read *bad.
+__global__ __launch_bounds__(1024) void nastar_order_check_kernel(const int* __restrict__ order, int B, int* __restrict__ bad, int* summary)
+{
+    extern __shared__ unsigned bitmap[];
+    __shared__ int any_bad;
+    const int tid = threadIdx.x, nw = (B + 31) >> 5;
+    if (tid == 0) any_bad = 0;
+    for (int i = tid; i < nw; i += 1024) bitmap[i] = 0u;
+    __syncthreads();
+    bool mine = false;
+    for (int i = tid; i < B; i += 1024) {
+        const int v = order[i];
+        if ((unsigned)v >= (unsigned)B) mine = true;
+        else if (atomicOr(&bitmap[v >> 5], 1u << (v & 31)) & (1u << (v & 31))) mine = true;  // named twice: some other map is never named
+    }
+    if (mine) any_bad = 1;
+    __syncthreads();
+    if (tid == 0) {
+        *bad = any_bad;
+        if (any_bad && summary) summary[NASTAR_SUMMARY_BAD_ORDER] = 1;
+    }
+}
 
 // LOGH > 0 && LOGW > 0: the map is exactly (1<<LOGH) x (1<<LOGW) (compile-time sizes, immediate ds offsets).
 // CPL_T: chunk minima per lane (1 or 4) when known at compile time, 0 = runtime.
@@ -48,8 +92,8 @@ template <bool kVec4, int LOGW, int LOGH, int CPL_T, bool kFastDiv, bool kLog, b
 __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCArgs a, const float rcp_sqrtW)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation: never read or write outside the batch
+    const int b = placed_map(a.order, a.order_bad, a.B);
+    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation (and not checked: NASTAR_FLAG_CHECK_ORDER): never read or write outside the batch
     const int lane = threadIdx.x;
     CompactDims d = a.d;
     if constexpr (LOGH > 0 && LOGW > 0) {
@@ -141,11 +185,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
-        if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
-            const int pos = atomicAdd(a.order_out + a.B, 1);
-            if ((unsigned)pos < (unsigned)a.B) a.order_out[a.B - 1 - pos] = b;  // (a counter that did not start at 0 must not write outside)
-            if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
-        }
+        if (status != NASTAR_OK && a.summary) a.summary[status] = 1;  // plain idempotent store: the word may be host-mapped (no atomics over PCIe)
+        if (a.order_out) note_completion(a.order_out, a.B, b);
     }
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
@@ -159,8 +200,8 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int W = 1 << LOGW, HW = W * W;
-    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation: never read or write outside the batch
+    const int b = placed_map(a.order, a.order_bad, a.B);
+    if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation (and not checked: NASTAR_FLAG_CHECK_ORDER): never read or write outside the batch
     const int lane = threadIdx.x;
     const CompactDims& d = a.d;
     const UnitLds l = carve_unit_lds<LOGW>(smem);
@@ -201,11 +242,8 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
-        if (a.order_out) {  // this search's rank by completion time, counted from the end: the longest searches come first next time
-            const int pos = atomicAdd(a.order_out + a.B, 1);
-            if ((unsigned)pos < (unsigned)a.B) a.order_out[a.B - 1 - pos] = b;  // (a counter that did not start at 0 must not write outside)
-            if (pos == a.B - 1) a.order_out[a.B] = 0;  // every other workgroup has counted already: the cell is left as it was found
-        }
+        if (status != NASTAR_OK && a.summary) a.summary[status] = 1;  // plain idempotent store: the word may be host-mapped (no atomics over PCIe)
+        if (a.order_out) note_completion(a.order_out, a.B, b);
     }
     if (goal_idx >= 0 && !bad) {
         CompactLds cl;  // the backtrack reads and marks parents only
@@ -277,6 +315,7 @@ __global__ __launch_bounds__(256) void nastar_unpack_kernel(const uint8_t* __res
 thread_local char g_last_error[256] = "";
 
 constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
+constexpr size_t kOrderCheckBytes = 16;                // NASTAR_FLAG_CHECK_ORDER: verdict word at the end of the workspace
 
 // maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
 static long long resident_capacity(size_t lds_per_map)
@@ -346,10 +385,30 @@ const char* nastar_last_error(void) { return g_last_error; }
 
 size_t nastar_workspace_bytes(int B, int H, int W, int flags)
 {
-    (void)flags;
     if (B <= 0 || H <= 0 || W <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
-    if (!needs_global_state(H, W)) return 0;  // the whole search state lives in LDS
-    return (size_t)B * global_slab_bytes(H * W);
+    const size_t chk = (flags & NASTAR_FLAG_CHECK_ORDER) ? kOrderCheckBytes : 0;  // the verdict word of nastar_order_check_kernel
+    if (!needs_global_state(H, W)) return chk;  // the whole search state lives in LDS
+    return (size_t)B * global_slab_bytes(H * W) + chk;
+}
+
+// NASTAR_FLAG_CHECK_ORDER: one small launch that decides whether `order` is a permutation of 0..B-1; its verdict word is the LAST
+// kOrderCheckBytes of the workspace and is read by the search / replay launch that follows on the same stream
+static int check_order(const int32_t* order, int B, void* workspace, size_t workspace_bytes, size_t need, int32_t* summary, hipStream_t s,
+                       const int** order_bad)
+{
+    *order_bad = nullptr;
+    if (!workspace) return NASTAR_ERR_NULL;
+    if (need < kOrderCheckBytes || workspace_bytes < need) return NASTAR_ERR_WORKSPACE;
+    const size_t lds = (size_t)((B + 31) / 32) * 4;
+    if (lds > kMaxLdsBytes - 64) return NASTAR_ERR_UNSUPPORTED;  // > 1.3 M maps in one launch: check the order on the caller's side
+    int* bad = reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + need - kOrderCheckBytes);
+    int rc = ensure_lds(nastar_order_check_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nastar_order_check_kernel, dim3(1), dim3(1024), lds, s, order, B, bad, summary);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    *order_bad = bad;
+    return NASTAR_OK;
 }
 
 // order_out for a multi-round launch: maps sorted by their step counts, longest first (nastar_placement.hip.h: counting sort, one
@@ -366,7 +425,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
                         int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                         int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                         size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done,
-                        const int32_t* order = nullptr, int32_t* order_out = nullptr)
+                        const int32_t* order = nullptr, int32_t* order_out = nullptr, int32_t* summary = nullptr)
 {
     *packed_done = false;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
@@ -379,7 +438,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         FwdGlobalArgs ga;
         ga.cost = cost; ga.start = start; ga.goal = goal; ga.passable = passable;
         ga.hist = histories_out; ga.paths = reinterpret_cast<long long*>(paths_out);
-        ga.sel_log = sel_log_out; ga.iters = iters_out; ga.status = status_out;
+        ga.sel_log = sel_log_out; ga.iters = iters_out; ga.status = status_out; ga.summary = summary;
         ga.workspace = static_cast<unsigned char*>(workspace); ga.slab_bytes = slab; ga.max_iters = max_iters;
         GlobalDims& gd = ga.d;
         gd.H = H; gd.W = W; gd.HW = H * W;
@@ -404,6 +463,12 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.packed = nullptr;
         c.order = order;
         c.order_out = order_out;  // (decided below: in-kernel completion order, or a rank of the step counts after the launch)
+        c.summary = summary;
+        c.order_bad = nullptr;
+        if (order && (flags & NASTAR_FLAG_CHECK_ORDER)) {
+            rc = check_order(order, B, workspace, workspace_bytes, nastar_workspace_bytes(B, H, W, flags), summary, s, &c.order_bad);
+            if (rc) return rc;
+        }
         c.flags = flags;
         const bool vec4 = (W % 4 == 0) && aligned16(cost) && aligned16(start) && aligned16(goal) && aligned16(passable) &&
                           aligned16(histories_out) && aligned16(paths_out);
@@ -472,12 +537,31 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
                            int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, uint8_t* packed_out, void* workspace,
                            size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out, void* stream)
 {
+    return nastar_forward_ex(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out, iters_out,
+                             status_out, packed_out, workspace, workspace_bytes, flags, order, order_out, nullptr, stream);
+}
+
+int nastar_forward_ex(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
+                      int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out,
+                      uint8_t* packed_out, void* workspace, size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out,
+                      int32_t* status_summary, void* stream)
+{
     if ((order || order_out) && B > 0 && H > 0 && W > 0 && needs_global_state(H, W)) return NASTAR_ERR_UNSUPPORTED;  // LDS-resident searches only
     bool done = false;
     int rc = forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
-                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out);
+                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out, status_summary);
     if (rc != NASTAR_OK || done || !packed_out) return rc;
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);
+}
+
+int nastar_placement_from_levels(const int32_t* levels, int B, int32_t* order_out, void* stream)
+{
+    if (!levels || !order_out) return NASTAR_ERR_NULL;
+    if (B <= 0) return NASTAR_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(nastar_rank_levels_kernel, dim3(1), dim3(PLC_RANK_THREADS), 0, reinterpret_cast<hipStream_t>(stream), levels, B, order_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return NASTAR_OK;
 }
 
 int nastar_placement_predict(const float* passable, const float* start, const float* goal, int B, int H, int W, int32_t* order_out,
@@ -521,7 +605,7 @@ size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters)
     const int HW = H * W, HWp = ((HW + 63) / 64) * 64;
     size_t n = (size_t)B * (size_t)bwdr_hist_len(HW, max_iters) * 16;
     if (!bwdr_fits_lds(HW)) n += (size_t)B * ((bwdr_state_bytes(HWp) + 255) & ~(size_t)255);
-    return n;
+    return n + kOrderCheckBytes;  // + the verdict word of NASTAR_FLAG_CHECK_ORDER (nastar_backward_replay_ordered)
 }
 
 static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* start, const float* goal, const float* passable,
@@ -580,6 +664,7 @@ int nastar_backward_replay(const float* grad_histories, const float* cost, const
     BwdRArgs a;
     a.grad_hist = grad_histories; a.l1_hist = nullptr; a.l1_traj = nullptr; a.l1_up = nullptr; a.l1_scale = 0.f;
     a.order = nullptr;
+    a.order_bad = nullptr;
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
                                 grad_cost_out, workspace, workspace_bytes, stream, flags);
 }
@@ -595,6 +680,7 @@ int nastar_backward_l1_replay(const float* histories, const float* opt_trajs, co
     a.grad_hist = nullptr; a.l1_hist = histories; a.l1_traj = opt_trajs; a.l1_up = grad_loss_dev;
     a.l1_scale = (float)(1.0 / ((double)B * H * W));
     a.order = nullptr;
+    a.order_bad = nullptr;
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
                                 grad_cost_out, workspace, workspace_bytes, stream);
 }
@@ -612,6 +698,14 @@ int nastar_backward_replay_ordered(const float* grad_histories, const float* his
     a.l1_up = grad_histories ? nullptr : grad_loss_dev;
     a.l1_scale = grad_histories ? 0.f : (float)(1.0 / ((double)B * H * W));
     a.order = order;
+    a.order_bad = nullptr;
+    if (order && (flags & NASTAR_FLAG_CHECK_ORDER)) {
+        // the verdict word sits behind the replay's own workspace (nastar_backward_workspace_bytes already includes it)
+        const size_t need = nastar_backward_workspace_bytes(B, H, W, max_iters);
+        if (need == 0) return NASTAR_ERR_UNSUPPORTED;
+        int rc = check_order(order, B, workspace, workspace_bytes, need, nullptr, reinterpret_cast<hipStream_t>(stream), &a.order_bad);
+        if (rc) return rc;
+    }
     return backward_replay_impl(a, cost, start, goal, passable, sel_log, B, H, W, g_ratio, max_iters, iters, t_batch_dev,
                                 grad_cost_out, workspace, workspace_bytes, stream, flags);
 }

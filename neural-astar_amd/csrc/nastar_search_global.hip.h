@@ -84,6 +84,7 @@ struct FwdGlobalArgs {
     int* sel_log;
     int* iters;
     int* status;
+    int* summary;  // optional [NASTAR_SUMMARY_WORDS]: summary[c] = 1 when some map ends with status c != 0
     unsigned char* workspace;
     size_t slab_bytes;
     int max_iters;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(64) void nastar_forward_global_kernel(const FwdGlob
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
+        if (status != NASTAR_OK && a.summary) a.summary[status] = 1;
     }
 }
 

@@ -41,6 +41,8 @@ EXPORTED_SYMBOLS = (
     "nastar_forward",
     "nastar_forward_packed",
     "nastar_forward_ordered",
+    "nastar_forward_ex",
+    "nastar_placement_from_levels",
     "nastar_placement_predict",
     "nastar_backward_workspace_bytes",
     "nastar_backward_replay",
@@ -134,6 +136,10 @@ def load() -> ctypes.CDLL:
     lib.nastar_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, ci, vp]
     lib.nastar_forward_ordered.restype = ci
     lib.nastar_forward_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp]
+    lib.nastar_forward_ex.restype = ci
+    lib.nastar_forward_ex.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp, vp]
+    lib.nastar_placement_from_levels.restype = ci
+    lib.nastar_placement_from_levels.argtypes = [vp, ci, vp, vp]
     lib.nastar_placement_predict.restype = ci
     lib.nastar_placement_predict.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, cz, vp]
     lib.nastar_forward_packed.restype = ci

@@ -13,7 +13,8 @@ import torch
 
 from . import _native
 
-__all__ = ["astar_forward", "astar_backward_replay", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for"]
+__all__ = ["astar_forward", "astar_backward_replay", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for", "search_nograd", "order_from_levels", "OrderHint", "attach_order",
+           "StatusBoard"]
 
 
 def max_iters_for(W: int, Tmax: float, training: bool) -> int:
@@ -33,10 +34,15 @@ def _require_device(*tensors: torch.Tensor) -> None:
 
 
 FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
+FLAG_CHECK_ORDER = 256  # NASTAR_FLAG_CHECK_ORDER: the launch verifies `order` on the device and ignores it when it is not a permutation
+STATUS_UNSOLVABLE = 3  # NASTAR_ERR_UNSOLVABLE (per-map status)
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
-# development knob: NASTAR_FORWARD_FLAGS=1 forces the LDS-resident kernel, =2 the register-resident one (include/nastar.h)
+SUMMARY_WORDS = 16  # NASTAR_SUMMARY_WORDS
+SUMMARY_BAD_ORDER = 15  # NASTAR_SUMMARY_BAD_ORDER
+# development knob: NASTAR_FLAG_* of include/nastar.h OR-ed into every forward launch (A/B switches: NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
-CHECK_ORDER = os.environ.get("NASTAR_CHECK_ORDER", "0") not in ("", "0")  # verify every placement handed to astar_forward_ordered (debug)
+if FORWARD_FLAGS & ~(8 | 16 | 32 | 64 | 128):
+    raise ValueError(f"NASTAR_FORWARD_FLAGS={FORWARD_FLAGS}: unknown flag bits (include/nastar.h NASTAR_FLAG_*)")
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -44,9 +50,50 @@ def _stream_ptr(device: torch.device) -> int:
 
 
 def _order_ptr(order: torch.Tensor, B: int, dev: torch.device) -> int:
-    if order.dtype != torch.int32 or order.numel() < B or order.device != dev or not order.is_contiguous():
-        raise ValueError(f"order must be a contiguous int32 tensor of at least {B} elements on {dev}")
+    if order.dtype != torch.int32 or order.numel() != B or order.device != dev or not order.is_contiguous():
+        raise ValueError(f"order must be a contiguous int32 tensor of exactly {B} elements on {dev} (got {tuple(order.shape)} {order.dtype} on {order.device})")
     return order.data_ptr()
+
+
+class StatusBoard:
+    """Pinned host memory the search launches write their STATUS SUMMARY into (include/nastar.h: status_summary of nastar_forward_ex): one
+    row of NASTAR_SUMMARY_WORDS int32 per launch in flight; cell c becomes 1 when some map of that launch ended with per-map status c.
+    "Did any map of this batch fail?" is then one 64-byte host read after the stream (or an event) has been waited for -- no reduction
+    launch, no device-to-host copy, nothing on a side stream.  One board per device, rows handed out and returned by the callers."""
+
+    _boards: dict = {}
+
+    def __init__(self, device: torch.device, rows: int = 256):
+        with torch.cuda.device(device):
+            self.t = torch.zeros((rows, SUMMARY_WORDS), dtype=torch.int32).pin_memory()
+        self.np = self.t.numpy()
+        self.base = self.t.data_ptr()
+        self.free = list(range(rows - 1, -1, -1))
+
+    @classmethod
+    def of(cls, device: torch.device) -> "StatusBoard":
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        b = cls._boards.get(key)
+        if b is None:
+            b = cls._boards[key] = cls(device)
+        return b
+
+    def acquire(self) -> int:
+        if not self.free:
+            raise RuntimeError("more than 256 search launches with an unread status: call raise_if_unsolvable() / finish() on the planners that issued them")
+        return self.free.pop()
+
+    def ptr(self, row: int) -> int:
+        return self.base + 4 * SUMMARY_WORDS * row
+
+    def read(self, row: int):
+        """the row as a numpy view if any cell is set, else None (the launch that was handed the row must have finished)"""
+        r = self.np[row]
+        return r if r.any() else None
+
+    def release(self, row: int) -> None:
+        self.np[row] = 0
+        self.free.append(row)
 
 
 # batches from this size on replay their backward longest-first, by the order the forward's searches finished in (one 4 x (B + 1)-byte
@@ -61,37 +108,57 @@ def _maps3(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order, summary_ptr, dev,
+                   one_meta=False, stream_ptr=None):
+    """allocate the five outputs and issue ONE nastar_forward_ex launch on torch's current stream (shared by the custom ops and the
+    no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape)."""
+    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    if one_meta:  # iters, status: one allocation (not for the custom ops, whose outputs must not alias each other)
+        meta = torch.empty((2, B), dtype=torch.int32, device=dev)
+        iters, status = meta[0], meta[1]
+    else:
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
+    # entries at positions >= iters[b] are never read (the backward replays iters[b] steps, _intermediate_results masks by iters)
+    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
+    flags = int(flags) | FORWARD_FLAGS
+    op = oo = 0
+    if order is not None:
+        op = _order_ptr(order, B, dev)
+        if check_order:
+            flags |= FLAG_CHECK_ORDER
+    if order_out is not None:
+        if order_out.dtype != torch.int32 or order_out.numel() != B + 1 or order_out.device != dev or not order_out.is_contiguous():
+            raise ValueError(f"order_out must be a contiguous int32 tensor of exactly {B + 1} elements on {dev} (ops.new_placement_buffer)")
+        oo = order_out.data_ptr()
+    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, flags))  # > 0 for maps too large for LDS and for a checked order
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+    with torch.cuda.device(dev):
+        rc = lib.nastar_forward_ex(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
+                                   float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
+                                   sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
+                                   workspace.data_ptr() if workspace is not None else None, ws_bytes, flags,
+                                   op or None, oo or None, summary_ptr or None, _stream_ptr(dev) if stream_ptr is None else stream_ptr)
+    _native.check(rc, "nastar_forward_ex")
+    return hist, paths, iters, status, sel_log
+
+
 @torch.library.custom_op("nastar::astar_forward", mutates_args=())
 def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
-                  g_ratio: float, max_iters: int, want_log: bool, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                  g_ratio: float, max_iters: int, want_log: bool, flags: int = 0, summary_ptr: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Returns (histories [B,H,W] f32, paths [B,H,W] i64, iters [B] i32, status [B] i32, sel_log [B,T] i32 or [0]).
-    ``flags``: NASTAR_FLAG_* of include/nastar.h (e.g. ``FLAG_UNIT_COST`` when cost and passable are ONE binary tensor)."""
+    ``flags``: NASTAR_FLAG_* of include/nastar.h (e.g. ``FLAG_UNIT_COST`` when cost and passable are ONE binary tensor);
+    ``summary_ptr``: address of a ``StatusBoard`` row (0 = none) that receives the launch's status summary."""
     _require_device(cost, start, goal, passable)
     lib = _native.load()
     cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
     B, H, W = cost.shape
-    dev = cost.device
-    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-    iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.empty((B,), dtype=torch.int32, device=dev)
-    # entries at positions >= iters[b] are never read (the backward replays iters[b] steps, _intermediate_results masks by iters)
-    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
-    flags = int(flags) | FORWARD_FLAGS
-    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, flags))  # > 0 only for maps too large for LDS
-    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-    with torch.cuda.device(dev):
-        rc = lib.nastar_forward(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
-                                float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
-                                sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
-                                workspace.data_ptr() if workspace is not None else None, ws_bytes, flags,
-                                _stream_ptr(dev))
-    _native.check(rc, "nastar_forward")
-    return hist, paths, iters, status, sel_log
+    return _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, None, None, False, summary_ptr, cost.device)
 
 
 @astar_forward.register_fake
-def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0):
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0, summary_ptr=0):
     B, H, W = cost.shape
     return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
             cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
@@ -101,45 +168,88 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0):
 @torch.library.custom_op("nastar::astar_forward_ordered", mutates_args=("order_out",))
 def astar_forward_ordered(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor, g_ratio: float,
                           max_iters: int, want_log: bool, flags: int, order: Optional[torch.Tensor],
-                          order_out: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``astar_forward`` with a placement (include/nastar.h: nastar_forward_ordered): workgroup i searches map ``order[i]`` (int32
+                          order_out: Optional[torch.Tensor], check_order: bool = True, summary_ptr: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``astar_forward`` with a placement (include/nastar.h: nastar_forward_ex): workgroup i searches map ``order[i]`` (int32 [B], a
     permutation of 0..B-1, or None = identity).  Same five outputs as ``astar_forward``.  ``order_out`` (int32 [B + 1] from
     ``new_placement_buffer``, or None) receives in [:B] the maps in reverse order of search completion in this launch -- the ``order``
-    for the next visit of the same batch; its last cell is the launch's counter (0 before and after).  No autograd."""
+    for the next visit of the same batch; its last cell is the launch's counter (0 before and after).  ``check_order`` (default): the
+    launch verifies ``order`` on the device (one small launch) and searches in the natural order when it is not a permutation -- every
+    map is searched whatever the caller passed; False only for orders that are permutations by construction (an earlier launch's
+    ``order_out``, ``order_from_levels``, ``placement_predict``, an argsort).  No autograd."""
     _require_device(cost, start, goal, passable)
     lib = _native.load()
     cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
     B, H, W = cost.shape
-    dev = cost.device
-    for name, t, n in (("order", order, B), ("order_out", order_out, B + 1)):
-        if t is not None and (t.dtype != torch.int32 or t.numel() < n or t.device != dev or not t.is_contiguous()):
-            raise ValueError(f"{name} must be a contiguous int32 tensor of at least {n} elements on {dev}")
-    if CHECK_ORDER and order is not None and not torch.cuda.is_current_stream_capturing():
-        # debugging aid (NASTAR_CHECK_ORDER=1; one host synchronisation): a map that `order` never names is never searched
-        if not torch.equal(torch.sort(order[:B].long()).values, torch.arange(B, device=dev)):
-            raise ValueError("order is not a permutation of 0..B-1")
-    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
-    iters = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.empty((B,), dtype=torch.int32, device=dev)
-    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
-    flags = int(flags) | FORWARD_FLAGS
-    with torch.cuda.device(dev):
-        rc = lib.nastar_forward_ordered(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
-                                        float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
-                                        sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None, None, 0,
-                                        flags, order.data_ptr() if order is not None else None,
-                                        order_out.data_ptr() if order_out is not None else None, _stream_ptr(dev))
-    _native.check(rc, "nastar_forward_ordered")
-    return hist, paths, iters, status, sel_log
+    return _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order,
+                          summary_ptr, cost.device)
 
 
 @astar_forward_ordered.register_fake
-def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out):
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out, check_order=True, summary_ptr=0):
     B, H, W = cost.shape
     return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
             cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
             cost.new_empty((B, max_iters) if want_log else (0,), dtype=torch.int32))
+
+
+def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, obstacles_maps: torch.Tensor, g_ratio: float,
+                  max_iters: int, want_log: bool = False, flags: int = 0, order: Optional[torch.Tensor] = None,
+                  order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None):
+    """The search launch WITHOUT the torch.library dispatch: what ``DifferentiableAstar.forward`` calls when no gradient can flow
+    (``torch.no_grad()`` / inputs that do not require one) and nothing is being traced -- the custom-op machinery costs more host time
+    than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs.
+    ``stream_ptr``: a hipStream_t to launch on instead of torch's current stream (``parallel.InFlightPlanner``; the outputs are
+    allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them)."""
+    for t in (cost_maps, start_maps, goal_maps, obstacles_maps):
+        if not t.is_cuda or t.dtype != torch.float32:
+            _require_device(t)
+    if cost_maps.ndim == 4:
+        if cost_maps.shape[1] != 1 or start_maps.shape[1] != 1 or goal_maps.shape[1] != 1 or obstacles_maps.shape[1] != 1:
+            cost_maps, start_maps, goal_maps, obstacles_maps = (x[:, 0] for x in (cost_maps, start_maps, goal_maps, obstacles_maps))
+    B, H, W = cost_maps.shape[0], cost_maps.shape[-2], cost_maps.shape[-1]
+    if not (start_maps.shape[0] == B and goal_maps.shape[0] == B and obstacles_maps.shape[0] == B
+            and start_maps.shape[-2:] == cost_maps.shape[-2:] == goal_maps.shape[-2:] == obstacles_maps.shape[-2:]):
+        raise ValueError("cost / start / goal / obstacle maps must have one shape")
+    same = obstacles_maps is cost_maps
+    cost_maps = cost_maps if cost_maps.is_contiguous() else cost_maps.contiguous()
+    obstacles_maps = cost_maps if same else (obstacles_maps if obstacles_maps.is_contiguous() else obstacles_maps.contiguous())
+    start_maps = start_maps if start_maps.is_contiguous() else start_maps.contiguous()
+    goal_maps = goal_maps if goal_maps.is_contiguous() else goal_maps.contiguous()
+    return _launch_search(_native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters, want_log, flags,
+                          order, order_out, check_order, summary_ptr, cost_maps.device, one_meta=True, stream_ptr=stream_ptr)
+
+
+def order_from_levels(levels: torch.Tensor) -> torch.Tensor:
+    """``order`` ([B] int32) for ``astar_forward_ordered`` from data the caller already HAS: ``levels[b]`` = any non-negative number that
+    grows with the expected length of map b's search -- for the reference's maze data sets the optimal distance of the sampled start
+    cell, ``|opt_dists[start]|``, which every sample carries (reference utils/data.py:127-134, :200-221).  Largest first; one
+    counting-sort launch (include/nastar.h: nastar_placement_from_levels).  A permutation by construction (``check_order=False``)."""
+    if not levels.is_cuda:
+        raise RuntimeError("order_from_levels: levels must live on a HIP device")
+    lv = levels.reshape(-1).abs().to(torch.int32).contiguous() if levels.dtype != torch.int32 else levels.reshape(-1).contiguous()
+    B = lv.numel()
+    order = torch.empty((B,), dtype=torch.int32, device=lv.device)
+    with torch.cuda.device(lv.device):
+        rc = _native.load().nastar_placement_from_levels(lv.data_ptr(), B, order.data_ptr(), _stream_ptr(lv.device))
+    _native.check(rc, "nastar_placement_from_levels")
+    return order
+
+
+class OrderHint:
+    """A placement for ONE batch, attached to its ``start_maps`` tensor as ``start_maps.placement_order`` by whoever assembled the batch
+    (``DeviceMazeBatches``, ``order_hint_from_distances``): the reference's 4-tuple batches keep their shape, ``PlannerModule`` and
+    ``DifferentiableAstar.forward`` pick the hint up from the tensor.  ``trusted`` = a permutation by construction."""
+
+    __slots__ = ("order", "trusted")
+
+    def __init__(self, order: torch.Tensor, trusted: bool = False):
+        self.order, self.trusted = order, trusted
+
+
+def attach_order(start_maps: torch.Tensor, levels: torch.Tensor) -> torch.Tensor:
+    """tag ``start_maps`` with the placement ``order_from_levels(levels)``; returns ``start_maps``"""
+    start_maps.placement_order = OrderHint(order_from_levels(levels), trusted=True)
+    return start_maps
 
 
 def workspace_bytes(shape) -> int:
@@ -230,7 +340,7 @@ def _setup_context(ctx, inputs, output):
 def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
     cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
     if g_hist is None:
-        return None, None, None, None, None, None, None, None
+        return (None,) * 9
     # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
     # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
     t_batch = BatchCoupling.t_batch(iters)
@@ -239,7 +349,7 @@ def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
                            "(DifferentiableAstar.forward does whenever cost_maps.requires_grad)")
     grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
                                                        ctx.g_ratio, ctx.max_iters, iters, t_batch)
-    return grad_cost, None, None, None, None, None, None, None
+    return (grad_cost,) + (None,) * 8
 
 
 astar_forward.register_autograd(_backward, setup_context=_setup_context)
@@ -328,20 +438,21 @@ def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, sel_log, g_r
 
 
 class _AstarL1Loss(torch.autograd.Function):
-    """search + L1 loss as ONE autograd node: forward = nastar_forward + nastar_l1_loss, backward = nastar_backward_l1_replay."""
+    """search + L1 loss as ONE autograd node: forward = nastar_forward_ex + nastar_l1_loss, backward = nastar_backward_l1_replay."""
 
     @staticmethod
-    def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters):
+    def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters, order_in, check_order, summary_ptr):
+        B = cost.shape[0]
         with torch.no_grad():
             order = None
-            if cost.shape[0] >= PLACEMENT_MIN_BATCH and workspace_bytes(cost.shape) == 0:
-                order = new_placement_buffer(cost.shape[0], cost.device)  # the forward writes the order its searches finish in
+            if (order_in is not None or B >= PLACEMENT_MIN_BATCH) and workspace_bytes(cost.shape) == 0:
+                order = new_placement_buffer(B, cost.device)  # the forward writes the order its searches finish in
                 hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters,
-                                                                                             True, 0, None, order)
+                                                                                             True, 0, order_in, order, check_order, summary_ptr)
             else:
-                hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, True)
+                hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, True, 0, summary_ptr)
             loss = torch.ops.nastar.l1_loss(hist, opt_trajs)
-        ctx.order = order
+        ctx.order = order[:B] if order is not None else None
         ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(hist, paths, iters, status)
@@ -352,25 +463,26 @@ class _AstarL1Loss(torch.autograd.Function):
     def backward(ctx, g_loss, g_hist, g_paths, g_iters, g_status):
         cost, start, goal, passable, opt_trajs, hist, iters, sel_log = ctx.saved_tensors
         if g_loss is None:
-            return None, None, None, None, None, None, None
+            return (None,) * 10
         grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
                                                               ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters), ctx.order)
-        return grad_cost, None, None, None, None, None, None
+        return (grad_cost,) + (None,) * 9
 
 
 class _AstarForwardPlaced(torch.autograd.Function):
     """``astar_forward`` for large batches under autograd: the forward launch writes the order its searches finish in and the replay
     backward starts its workgroups in that order (same values as the registered autograd of ``astar_forward``; outputs other than
-    ``histories`` carry no gradient).  ``order_in`` / ``order_out``: the forward's own placement (planner.Placement) or None."""
+    ``histories`` carry no gradient).  ``order_in`` / ``order_out``: the forward's own placement (planner.Placement / OrderHint) or None."""
 
     @staticmethod
-    def forward(ctx, cost, start, goal, passable, g_ratio, max_iters, flags, order_in, order_out):
+    def forward(ctx, cost, start, goal, passable, g_ratio, max_iters, flags, order_in, order_out, check_order, summary_ptr):
+        B = cost.shape[0]
         with torch.no_grad():
             if order_out is None:
-                order_out = new_placement_buffer(cost.shape[0], cost.device)
+                order_out = new_placement_buffer(B, cost.device)
             hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters, True,
-                                                                                         flags, order_in, order_out)
-        ctx.order = order_out
+                                                                                         flags, order_in, order_out, check_order, summary_ptr)
+        ctx.order = order_out[:B]
         ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(paths, iters, status, sel_log)
@@ -380,22 +492,26 @@ class _AstarForwardPlaced(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
         if g_hist is None:
-            return (None,) * 9
+            return (None,) * 11
         cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
         grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log, ctx.g_ratio, ctx.max_iters,
                                                            iters, BatchCoupling.t_batch(iters), ctx.order)
-        return (grad_cost,) + (None,) * 8
+        return (grad_cost,) + (None,) * 10
 
 
-def astar_forward_placed(cost, start, goal, passable, g_ratio: float, max_iters: int, flags: int = 0, order_in=None, order_out=None):
+def astar_forward_placed(cost, start, goal, passable, g_ratio: float, max_iters: int, flags: int = 0, order_in=None, order_out=None,
+                         check_order: bool = True, summary_ptr: int = 0):
     """differentiable ``astar_forward`` (selection log kept) whose backward replays longest-first; see ``_AstarForwardPlaced``"""
-    return _AstarForwardPlaced.apply(cost, start, goal, passable, float(g_ratio), int(max_iters), int(flags), order_in, order_out)
+    return _AstarForwardPlaced.apply(cost, start, goal, passable, float(g_ratio), int(max_iters), int(flags), order_in, order_out,
+                                     bool(check_order), int(summary_ptr))
 
 
 def astar_l1_loss(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
-                  opt_trajs: torch.Tensor, g_ratio: float, max_iters: int):
-    """[B,H,W] maps -> (loss scalar, histories, paths, iters, status); only ``loss`` carries gradient (to ``cost``)."""
-    return _AstarL1Loss.apply(cost, start, goal, passable, opt_trajs, float(g_ratio), int(max_iters))
+                  opt_trajs: torch.Tensor, g_ratio: float, max_iters: int, order_in: Optional[torch.Tensor] = None,
+                  check_order: bool = True, summary_ptr: int = 0):
+    """[B,H,W] maps -> (loss scalar, histories, paths, iters, status); only ``loss`` carries gradient (to ``cost``).
+    ``order_in``: a placement for the forward launch (``OrderHint.order``); the backward replays by the forward's completion order."""
+    return _AstarL1Loss.apply(cost, start, goal, passable, opt_trajs, float(g_ratio), int(max_iters), order_in, bool(check_order), int(summary_ptr))
 
 
 def heuristic(goal_maps: torch.Tensor) -> torch.Tensor:

@@ -12,12 +12,13 @@ batch-coupled gradient terms match a single-device run 
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Iterable, Iterator, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .planner.differentiable_astar import AstarOutput
+from . import ops
+from .planner.differentiable_astar import AstarOutput, UnsolvableMapError, _raise_unsolvable
 
 _BIT_WEIGHTS = None
 _SEARCH_STREAMS: dict = {}
@@ -202,6 +203,162 @@ def global_t_batch(group: Optional[dist.ProcessGroup] = None):
     return fn
 
 
+class InFlightPlanner:
+    """Batches IN FLIGHT behind the planner API: whole batches go round-robin to ``streams`` HIP streams, so the tail of one launch (its
+    longest search, a serial chain that leaves most of the chip idle) overlaps the bulk of the next ones.  One launch at a time is bound
+    by its longest search (4096 mazes: ~12 % of the HBM roofline); with 3-4 batches in flight the same kernels sustain 2-3x the maps/s
+    (DESIGN.md section 4.1).  This is what an evaluation loop over a data set wants (reference utils/training.py:63-87,
+    scripts/train.py:43-50: a validation pass is a sequence of independent ``planner(map, start, goal)`` calls).
+
+    ``planner``: a ``VanillaAstar`` / ``NeuralAstar`` (eval-mode budget, no gradients: this is an inference path).  Outputs are identical
+    to sequential ``planner.forward()`` calls.
+
+        fly = InFlightPlanner(planner, streams=4)
+        outs = fly.plan_many(loader)                 # list of AstarOutput, one per batch, in order
+        for out in fly.plan_iter(loader, window=8):  # or lazily, at most `window` batches in flight
+            ...
+
+    Status policy: no host wait per batch -- every launch writes its status summary into a pinned ``ops.StatusBoard`` row and the rows
+    are read ONCE when the results are collected.  ``unit_cost="auto"`` (default) therefore needs no per-call wait either: a
+    ``VanillaAstar`` batch goes to the unit-cost kernel optimistically and is re-run on the general kernel at collection time in the
+    rare case that one of its maps is not binary.  An unsolvable map raises ``UnsolvableMapError`` at collection (naming the batch)
+    unless ``check_solvable=False``."""
+
+    def __init__(self, planner: torch.nn.Module, streams: int = 4, check_solvable: bool = True, unit_cost="auto"):
+        if streams < 1:
+            raise ValueError("streams must be >= 1")
+        self.planner = planner
+        self.n_streams = int(streams)
+        self.check_solvable = check_solvable
+        self.unit_cost = unit_cost
+        self._streams: List[torch.cuda.Stream] = []
+        self._ptrs: List[int] = []
+        self._device = None
+        self._inflight: List[tuple] = []  # (ticket, stream index, row, inputs, outputs, flags, order, check)
+        self._k = 0
+        self.reruns = 0  # batches that were re-run on the general kernel (a non-binary map under unit_cost="auto")
+
+    def _setup(self, device: torch.device) -> None:
+        if self._device != device:
+            if self._inflight:
+                raise RuntimeError("InFlightPlanner: collect the batches in flight before switching devices")
+            self._device = device
+            self._streams = [torch.cuda.Stream(device) for _ in range(self.n_streams)]
+            self._ptrs = [s.cuda_stream for s in self._streams]
+
+    def submit(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, inputs_ready: bool = False) -> int:
+        """Queue one batch (the reference's [B,1,H,W] tensors); returns its ticket (0, 1, 2, ... since the last collection).
+        ``inputs_ready=True``: the caller guarantees the three tensors are complete (e.g. resident data-set tensors) -- the launch stream
+        then does not wait for the current stream."""
+        if not map_designs.is_cuda:
+            raise RuntimeError("InFlightPlanner needs tensors on a HIP device (no CPU path)")
+        dev = map_designs.device
+        self._setup(dev)
+        planner, astar = self.planner, self.planner.astar
+        k = self._k % self.n_streams
+        st = self._streams[k]
+        if not inputs_ready:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        W = map_designs.shape[-1]
+        encode = getattr(planner, "encode", None)
+        with torch.no_grad():
+            if encode is not None:  # NeuralAstar: the encoder's launches go to the same stream as the search
+                with torch.cuda.stream(st):
+                    cost = encode(map_designs, start_maps, goal_maps)
+                    passable = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
+                cost.record_stream(torch.cuda.current_stream(dev))
+                same = False
+            else:
+                cost = passable = map_designs
+                same = True
+            max_iters = ops.max_iters_for(start_maps.shape[-1], 1.0, False)
+            unit = same and self.unit_cost in (True, "auto")
+            flags = ops.FLAG_UNIT_COST if unit else 0
+            order = check = None
+            hint = getattr(start_maps, "placement_order", None)
+            if hint is not None and ops.workspace_bytes(start_maps.shape) == 0:
+                o = hint.order if isinstance(hint, ops.OrderHint) else hint
+                if torch.is_tensor(o) and o.numel() == start_maps.shape[0] and o.dtype == torch.int32 and o.device == dev:
+                    order, check = o.reshape(-1), not getattr(hint, "trusted", False)
+            board = ops.StatusBoard.of(dev)
+            row = board.acquire() if (self.check_solvable or (unit and self.unit_cost == "auto")) else -1
+            try:
+                out = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio, max_iters, False, flags, order, None, bool(check),
+                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k])
+            except BaseException:
+                if row >= 0:
+                    board.release(row)
+                raise
+        ticket = len(self._inflight)
+        self._inflight.append((ticket, k, row, (cost, start_maps, goal_maps, passable), out, flags, order, check))
+        self._k += 1
+        return ticket
+
+    def collect(self) -> List[AstarOutput]:
+        """Wait for every batch in flight and return their outputs in submission order (re-running / raising as the class docstring says)."""
+        if not self._inflight:
+            return []
+        dev = self._device
+        board = ops.StatusBoard.of(dev)
+        for st in self._streams:
+            st.synchronize()
+        outs: List[AstarOutput] = []
+        failed = None
+        astar = self.planner.astar
+        for ticket, k, row, ins, out, flags, order, check in self._inflight:
+            hist, paths, iters, status, _ = out
+            summ = None
+            if row >= 0:
+                r = board.read(row)
+                summ = None if r is None else r.copy()
+                board.release(row)
+            if summ is not None and summ[ops.STATUS_NOT_UNIT_COST] and self.unit_cost == "auto":
+                # a non-binary map in a batch that went to the unit-cost kernel optimistically: the batch again on the general kernel
+                self.reruns += 1
+                cost, start_maps, goal_maps, passable = ins
+                r2 = board.acquire()
+                try:
+                    hist, paths, iters, status, _ = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio,
+                                                                      ops.max_iters_for(start_maps.shape[-1], 1.0, False), False, 0, order, None,
+                                                                      bool(check), board.ptr(r2))
+                    torch.cuda.current_stream(dev).synchronize()
+                    r = board.read(r2)
+                    summ = None if r is None else r.copy()
+                finally:
+                    board.release(r2)
+            if summ is not None and summ[1:ops.SUMMARY_BAD_ORDER].any() and self.check_solvable and failed is None:
+                failed = (ticket, status)
+            outs.append(AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), []))
+            astar.last_status, astar.last_iters = status, iters
+        self._inflight = []
+        self._k = 0
+        if failed is not None:
+            try:
+                _raise_unsolvable(failed[1], failed[0])
+            except UnsolvableMapError as e:
+                raise UnsolvableMapError(f"InFlightPlanner, batch #{failed[0]} since the last collection: {e}") from None
+        return outs
+
+    def plan_many(self, batches: Iterable) -> List[AstarOutput]:
+        """``[planner(*b[:3]) for b in batches]`` with the batches in flight; each item is ``(map_designs, start_maps, goal_maps, ...)``."""
+        for b in batches:
+            self.submit(b[0], b[1], b[2])
+        return self.collect()
+
+    def plan_iter(self, batches: Iterable, window: Optional[int] = None) -> Iterator[AstarOutput]:
+        """Lazy form: yields the outputs in order while keeping at most ``window`` (default 2 x streams) batches in flight; a window is
+        collected as a whole, so the consumer's work on window i overlaps nothing -- size it to the memory you want held."""
+        window = int(window or 2 * self.n_streams)
+        n = 0
+        for b in batches:
+            self.submit(b[0], b[1], b[2])
+            n += 1
+            if n == window:
+                yield from self.collect()
+                n = 0
+        yield from self.collect()
+
+
 class ShardedPlanner(torch.nn.Module):
     """Wraps a planner (``VanillaAstar`` / ``NeuralAstar``): each rank plans ITS rows of the batch; in eval mode the full-batch
     output is collated on every rank with one all-gather.
@@ -231,3 +388,19 @@ class ShardedPlanner(torch.nn.Module):
         if self.sharding != "contiguous":
             order = collated_order(world * out.histories.shape[0], world, self.sharding)
         return all_gather_output(out, self.group, order=order)
+
+    def plan_many(self, batches: Iterable, streams: int = 4) -> List[AstarOutput]:
+        """An evaluation sweep: every rank plans ITS shard of each batch with the batches in flight (``InFlightPlanner``), then each
+        batch is collated with its one all-gather (eval-mode semantics of ``forward``)."""
+        fly = InFlightPlanner(self.planner, streams=streams)
+        outs = fly.plan_many(batches)
+        if self.gather is False or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return outs
+        world = dist.get_world_size(self.group)
+        res = []
+        for out in outs:
+            order = None
+            if self.sharding != "contiguous":
+                order = collated_order(world * out.histories.shape[0], world, self.sharding)
+            res.append(all_gather_output(out, self.group, order=order))
+        return res

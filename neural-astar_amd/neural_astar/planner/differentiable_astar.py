@@ -31,39 +31,26 @@ class UnsolvableMapError(RuntimeError):
     (SURVEY.md section 0.4); here the kernel reports a per-map status instead."""
 
 
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-    key = (device.type, device.index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
-    return _SIDE_STREAMS[key]
-
-
 class _PendingStatus:
-    """status of an earlier call on its way to the host: a device-side any() + a non-blocking copy into pinned memory + an event, all on
-    a SIDE stream that waits for the search launch -- the stream the caller keeps launching on never sees these three small ops"""
+    """status of an earlier launch on its way to the host: the launch itself writes its summary into a pinned ``ops.StatusBoard`` row;
+    an event recorded behind it on the SAME stream says when the row may be read -- no reduction launch, no copy, no side stream"""
 
-    def __init__(self, status: torch.Tensor, seq: int = 0):
+    def __init__(self, status: torch.Tensor, row: int, seq: int = 0):
         self.status = status
         self.seq = seq
-        self.flag = torch.empty((1,), dtype=torch.bool, pin_memory=True)
-        main = torch.cuda.current_stream(status.device)
-        side = _side_stream(status.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.flag.copy_((status != 0).any().reshape(1), non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record(side)
-        status.record_stream(side)
+        self.row = row
+        self.board = ops.StatusBoard.of(status.device)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(status.device))
 
     def done(self) -> bool:
         return self.event.query()
 
     def raise_if_unsolvable(self) -> None:
         self.event.synchronize()
-        if bool(self.flag[0]):
+        bad = self.board.read(self.row) is not None
+        self.board.release(self.row)
+        if bad:
             _raise_unsolvable(self.status, self.seq, deferred=True)
 
 
@@ -110,13 +97,6 @@ class Placement:
 
     def __getstate__(self):  # device scratch is not state (deepcopy / pickle of a planner that holds one)
         return {"bufs": None, "k": 0, "valid": False}
-
-
-def _search(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order=None, order_out=None):
-    """the one launch (csrc/nastar_capi.hip::nastar_forward / nastar_forward_ordered) behind DifferentiableAstar.forward"""
-    if order is None and order_out is None:
-        return torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, want_log, flags)
-    return torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out)
 
 
 class DifferentiableAstar(nn.Module):
@@ -187,22 +167,79 @@ class DifferentiableAstar(nn.Module):
         while self._pending and (wait or self._pending[0].done()):
             self._pending.pop(0).raise_if_unsolvable()
 
-    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None) -> None:
+    # ---- status protocol of ONE search launch: row = begin_launch(); launch(..., summary_ptr=summary_ptr(row)); note_status(..., row=row) ----
+    def begin_launch(self, like: torch.Tensor) -> int:
+        """Reserve the pinned status-summary row the next search launch of this module writes into (``ops.StatusBoard``); -1 when
+        nothing will be checked (``check_solvable`` False, or a hipGraph capture is underway: nothing may synchronise there)."""
+        if not self.check_solvable or not like.is_cuda or _capturing(like):
+            return -1
+        return ops.StatusBoard.of(like.device).acquire()
+
+    @staticmethod
+    def summary_ptr(row: int, like: torch.Tensor) -> int:
+        return ops.StatusBoard.of(like.device).ptr(row) if row >= 0 else 0
+
+    def _collect_sync(self, row: int, device: torch.device):
+        """wait for the stream the launch went to and return a COPY of its summary row (None = every map ended with status 0)"""
+        board = ops.StatusBoard.of(device)
+        torch.cuda.current_stream(device).synchronize()  # the ONE device->host wait of a checked call
+        r = board.read(row)
+        r = None if r is None else r.copy()
+        board.release(row)
+        return r
+
+    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1) -> None:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
-        step and the validation pair, which launch the search themselves).  ``clean``: the caller has already read ``status`` on the
-        host (True = all zero, False = some map failed) -- the "sync" policy then does not wait a second time."""
+        step and the validation pair, which launch the search themselves).  ``row``: the ``begin_launch()`` row whose address the
+        launch was given as ``summary_ptr`` -- the verdict is then one host read after the stream wait ("sync") or after an event
+        ("deferred"); without a row the status tensor is reduced on the device (one more launch + a blocking copy).  ``clean``: the
+        caller has already read the verdict on the host (True = all zero) -- the "sync" policy then does not wait a second time."""
         self.last_status, self.last_iters = status, iters
         self._calls += 1
         mode = self.check_solvable
         if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
+            if row >= 0:
+                ops.StatusBoard.of(status.device).release(row)
             return
         if mode != "deferred":  # True / "sync": the verdict belongs to THIS call
+            if clean is None and row >= 0:
+                summ = self._collect_sync(row, status.device)
+                row = -1
+                clean = summ is None or not (summ[1:ops.SUMMARY_BAD_ORDER].any())
+                if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
+                    _warn_bad_order()
+            if row >= 0:
+                ops.StatusBoard.of(status.device).release(row)
             if (not clean) if clean is not None else bool((status != 0).any()):
                 _raise_unsolvable(status, self._calls)
             return
-        self._pending.append(_PendingStatus(status, self._calls))
+        if row < 0:  # a launch that carried no summary: reduce on the device into a fresh row's worth of pinned memory
+            row = ops.StatusBoard.of(status.device).acquire()
+            ops.StatusBoard.of(status.device).t[row, ops.STATUS_UNSOLVABLE:ops.STATUS_UNSOLVABLE + 1].copy_((status != 0).any().reshape(1), non_blocking=True)
+        self._pending.append(_PendingStatus(status, row, self._calls))
         if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
             self._pending.pop(0).raise_if_unsolvable()
+
+    def resolve_placement(self, B: int, start_maps: torch.Tensor, in_lds: bool):
+        """(order, order_out, check_order, placement) for the next launch: the module's ``placement`` (a recurring batch: the order its
+        searches finished in last time) or, for a batch seen for the first time, the ``OrderHint`` its loader attached to
+        ``start_maps`` (``start_maps.placement_order``: by the optimal distance of the start cells, data the sample carries)."""
+        pl, self.placement = self.placement, None
+        if not in_lds:
+            return None, None, False, None
+        order = order_out = None
+        check = False
+        if pl is not None:
+            order, order_out = pl.buffers(B, start_maps.device)
+            if order is not None:
+                order = order[:B]
+        if order is None:
+            hint = getattr(start_maps, "placement_order", None)
+            if hint is not None:
+                o = hint.order if isinstance(hint, ops.OrderHint) else hint
+                if torch.is_tensor(o) and o.numel() == B and o.device == start_maps.device and o.dtype == torch.int32:
+                    order, check = o.reshape(-1), not getattr(hint, "trusted", False)
+        return order, order_out, check, pl
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
                 obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
@@ -211,55 +248,83 @@ class DifferentiableAstar(nn.Module):
         assert goal_maps.ndim == 4
         assert obstacles_maps.ndim == 4
 
-        cost = cost_maps[:, 0]
-        start = start_maps[:, 0]
-        goal = goal_maps[:, 0]
-        passable = obstacles_maps[:, 0]
-        W = cost.shape[-1]
+        W = cost_maps.shape[-1]
+        B = cost_maps.shape[0]
         max_iters = ops.max_iters_for(W, self.Tmax, self.training)
-
+        needs_grad = torch.is_grad_enabled() and cost_maps.requires_grad
         # the selection log doubles as the tape of the backward (replayed by nastar_backward_replay): keep it whenever
         # autograd will need it
-        want_log = bool(store_intermediate_results) or (
-            torch.is_grad_enabled() and cost_maps.requires_grad)
-        if not _capturing(cost_maps):
+        want_log = bool(store_intermediate_results) or needs_grad
+        capturing = _capturing(cost_maps)
+        if not capturing and self._pending:
             self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
         # VanillaAstar hands ONE tensor over as cost and obstacle map: the unit-cost kernel (see __init__) applies when it is binary,
         # which the kernel itself checks; in "auto" mode only when this call reads the status anyway and can fall back
-        same = (cost.data_ptr() == passable.data_ptr() and cost.shape == passable.shape and cost.stride() == passable.stride())
-        sync_check = self.check_solvable in (True, "sync") and not _capturing(cost_maps)
-        unit = (same and not want_log and not (torch.is_grad_enabled() and cost_maps.requires_grad)
-                and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
-        # a recurring batch starts its longest searches first (Placement); gradients need the autograd-registered op, and maps whose
-        # state lives in HBM take no placement
-        order = order_out = None
-        pl, self.placement = self.placement, None
-        in_lds = ops.workspace_bytes(cost.shape) == 0
-        needs_grad = torch.is_grad_enabled() and cost_maps.requires_grad
-        if pl is not None and in_lds:
-            order, order_out = pl.buffers(cost.shape[0], cost.device)
-        if needs_grad and in_lds and (order_out is not None or cost.shape[0] >= ops.PLACEMENT_MIN_BATCH):
-            # large batches under autograd: the replay backward starts longest-first, by the order THIS forward's searches finish in
-            hist, paths, iters, status, sel_log = ops.astar_forward_placed(cost, start, goal, passable, self.g_ratio, max_iters, 0, order, order_out)
-        else:
-            hist, paths, iters, status, sel_log = _search(
-                cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, ops.FLAG_UNIT_COST if unit else 0, order, order_out)
+        same = obstacles_maps is cost_maps or (cost_maps.data_ptr() == obstacles_maps.data_ptr() and cost_maps.shape == obstacles_maps.shape
+                                               and cost_maps.stride() == obstacles_maps.stride())
+        sync_check = self.check_solvable in (True, "sync") and not capturing
+        unit = (same and not want_log and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
+        in_lds = ops.workspace_bytes(cost_maps.shape) == 0
+        # a recurring batch starts its longest searches first (Placement), a fresh one by its loader's hint; maps whose state lives in HBM take no placement
+        order, order_out, check_order, pl = self.resolve_placement(B, start_maps, in_lds)
+        row = self.begin_launch(cost_maps)
+        sptr = self.summary_ptr(row, cost_maps)
+        flags = ops.FLAG_UNIT_COST if unit else 0
+        traced = needs_grad or type(cost_maps) is not torch.Tensor or torch.compiler.is_compiling()
+        try:
+            if not traced:
+                # no gradient can flow and nothing is tracing: straight to the C ABI (no torch.library dispatch)
+                hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
+                                                                        self.g_ratio, max_iters, want_log, flags, order, order_out, check_order, sptr)
+            else:
+                cost, start, goal, passable = cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles_maps[:, 0]
+                if needs_grad and in_lds and (order is not None or order_out is not None or B >= ops.PLACEMENT_MIN_BATCH):
+                    # large batches under autograd: the replay backward starts longest-first, by the order THIS forward's searches finish in
+                    hist, paths, iters, status, sel_log = ops.astar_forward_placed(cost, start, goal, passable, self.g_ratio, max_iters, 0, order, order_out,
+                                                                                   check_order, sptr)
+                elif order is None and order_out is None:
+                    hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, float(self.g_ratio), max_iters,
+                                                                                         want_log, flags, sptr)
+                else:
+                    hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, float(self.g_ratio), max_iters,
+                                                                                                 want_log, flags, order, order_out, check_order, sptr)
+        except BaseException:
+            if row >= 0:
+                ops.StatusBoard.of(cost_maps.device).release(row)
+            raise
         clean = None
-        if unit and self.unit_cost == "auto":
-            clean = not bool((status != 0).any())  # the ONE device->host wait of this call (note_status does not wait again)
-            if not clean and bool((status == ops.STATUS_NOT_UNIT_COST).any()):
+        if unit and self.unit_cost == "auto" and row >= 0:
+            summ = self._collect_sync(row, cost_maps.device)  # the ONE device->host wait of this call (note_status does not wait again)
+            row = -1
+            clean = summ is None or not summ[1:ops.SUMMARY_BAD_ORDER].any()
+            if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
+                _warn_bad_order()
+            if summ is not None and summ[ops.STATUS_NOT_UNIT_COST]:
                 # a map with values other than 0 / 1: the whole batch again on the general kernel (same call, same outputs contract)
-                hist, paths, iters, status, sel_log = _search(
-                    cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, 0, order, order_out)
+                row = self.begin_launch(cost_maps)
+                hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps, self.g_ratio, max_iters, want_log, 0,
+                                                                        order, order_out, check_order, self.summary_ptr(row, cost_maps))
                 clean = None
         if pl is not None and order_out is not None:
             pl.commit()
-        self.note_status(status, iters, clean)
+        self.note_status(status, iters, clean, row)
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:
-            intermediate_results = _intermediate_results(hist, paths, goal, iters, sel_log)
+            intermediate_results = _intermediate_results(hist, paths, goal_maps[:, 0], iters, sel_log)
         return AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), intermediate_results)
+
+
+_BAD_ORDER_WARNED = False
+
+
+def _warn_bad_order() -> None:
+    global _BAD_ORDER_WARNED
+    if not _BAD_ORDER_WARNED:
+        _BAD_ORDER_WARNED = True
+        import warnings
+        warnings.warn("a placement order handed to the search was not a permutation of 0..B-1: it was ignored (natural order, identical "
+                      "outputs); build orders with ops.order_from_levels / Placement", RuntimeWarning, stacklevel=3)
 
 
 def _intermediate_results(hist, paths, goal, iters, sel_log) -> List[dict]:

@@ -178,6 +178,7 @@ class DeviceMazeBatches:
         self.opt_dists = torch.from_numpy(ds.opt_dists).to(dev).reshape(N, -1).contiguous()           # [N,HW]
         self.thresholds = torch.from_numpy(ds.thresholds).to(dev)   # [N,4] float64: compared in double, exactly as numpy does
         self.last_status: Optional[torch.Tensor] = None
+        self.emit_placement = True  # tag every batch's start_maps with a longest-first placement (see sample())
 
     def __len__(self) -> int:
         return (self.N + self.batch_size - 1) // self.batch_size
@@ -211,7 +212,14 @@ class DeviceMazeBatches:
         self.last_status = status
         if check and bool((status != 0).any()):
             raise RuntimeError("optimal policy does not lead to the goal for roll-outs " + str(torch.nonzero(status).flatten().tolist()[:16]))
-        return self.map_designs[idx], start_maps.reshape(B, S, self.H, self.W), self.goal_maps[idx], trajs
+        start_maps = start_maps.reshape(B, S, self.H, self.W)
+        if self.emit_placement:
+            # a placement for the batch's FIRST search, from data every sample carries: the optimal distance of its start cell
+            # (|opt_dists[start]|, reference :127-134,:200-221) -- the longest searches start first (planner/differentiable_astar.py:
+            # resolve_placement reads start_maps.placement_order); one gather + one counting-sort launch at batch assembly
+            from .. import ops
+            ops.attach_order(start_maps, torch.gather(self.opt_dists[idx], 1, start_idx[:, :1]))
+        return self.map_designs[idx], start_maps, self.goal_maps[idx], trajs
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]]:
         order = (torch.randperm(self.N, device=self.device, generator=self.generator) if self.shuffle

@@ -133,7 +133,15 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
         astar.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier steps that have reached the host
     W = cost_maps.shape[-1]
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)
-    loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
-                                                         opt_trajs[:, 0], astar.g_ratio, max_iters)
-    astar.note_status(status, iters)  # same contract as DifferentiableAstar.forward (default: raises in THIS call, before any backward)
+    # a batch assembled by DeviceMazeBatches carries a placement (start_maps.placement_order: by the optimal distance of its start cells)
+    order, _, check, _ = astar.resolve_placement(cost_maps.shape[0], start_maps, ops.workspace_bytes(cost_maps.shape) == 0)
+    row = astar.begin_launch(cost_maps)
+    try:
+        loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
+                                                             opt_trajs[:, 0], astar.g_ratio, max_iters, order, check, astar.summary_ptr(row, cost_maps))
+    except BaseException:
+        if row >= 0:
+            ops.StatusBoard.of(cost_maps.device).release(row)
+        raise
+    astar.note_status(status, iters, row=row)  # same contract as DifferentiableAstar.forward (default: raises in THIS call, before any backward)
     return loss, AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), [])

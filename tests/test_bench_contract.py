@@ -43,12 +43,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     im = j["issue_model"]  # pipe model: what the launch costs the VALU / LDS pipes, and what its longest chain alone costs
     assert 0.0 < im["valu_busy_frac"] < 1.0 and 0.0 < im["lds_busy_frac"] < 1.0 and 0.0 < im["frac_of_serial_floor"] < 1.5
     assert im["instructions_per_step"] == 71 and im["serial_floor_us"] > 0
-    assert rf["frac_counter_bytes"] is None or 0.0 < rf["frac_counter_bytes"] < rf["frac"]
-    # placement: the headline is the hinted figure and says so; the natural-order figure (a batch never searched before) and the pipelined
-    # predictor figure stand beside it, and the headline never loses to them by construction of the workload
-    assert j["config"]["placement"].startswith("hinted")
-    no = j["natural_order"]
+    # the fraction is quoted on the bytes the VanillaAstar call must move (24 B/cell), the 28 B/cell figure of SURVEY 8(d) beside it; fields read
+    # from committed profile files say so in their names
+    assert rf["algorithmic_bytes_per_launch"] == 24 * 32 * 32 * 4096 and abs(rf["frac_28B_per_cell"] - rf["frac"] * 28 / 24) < 1e-9
+    assert "committed_kernel_profile_us" in rf and "traffic_source" in rf
+    # placement: the headline is the FIRST-VISIT figure -- never-searched batches placed by the data set's own start distances -- and says so;
+    # the natural-order figure (no placement) and the recurring-batch figure (placed by the previous visit: the round-4 headline) stand beside it
+    assert j["config"]["placement"].startswith("dataset") and j["config"]["every_timed_step_is_a_first_visit"] is True
+    no, hi = j["natural_order"], j["hinted"]
     assert no["value"] > 0 and j["value_natural_order"] == no["value"] and 0.0 < no["roofline_frac"] < rf["frac"] * 1.05
+    assert hi["value"] > 0 and j["value_hinted"] == hi["value"]
     assert no["pipelined_with_predictor"] is None or no["pipelined_with_predictor"]["value"] > 0
     ce = j["contract_exact_no_prewarm"]  # the W + K protocol run first, before the untimed pre-warm launches
     assert ce["value"] > 0 and abs(ce["value"] - 4096 * 4 / (ce["ms_per_step"] * 4e-3)) < 1e-6 * ce["value"]

@@ -51,6 +51,14 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward_ordered(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, one, None, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, None, one, None) == _native.NASTAR_ERR_UNSUPPORTED
+    # nastar_forward_ex (0.5.0): the same checks; a CHECKED order needs its 16-byte verdict word in the workspace
+    assert lib.nastar_forward_ex(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, None, None, None, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_ex(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_workspace_bytes(4096, 32, 32, 256) == 16 and lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
+    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, None, 0, 256, one, None, None, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, one, 8, 256, one, None, None, None) == _native.NASTAR_ERR_WORKSPACE
+    assert lib.nastar_placement_from_levels(None, 4, one, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_placement_from_levels(one, 0, one, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_backward_replay(None, one, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, one, 64, 0, None) == _native.NASTAR_ERR_NULL
     for sym in ("nastar_backward", "nastar_backward_l1", "nastar_has_dev_kernels"):  # rounds 1-3 legacy entry points: gone in 0.4.0
         assert not hasattr(lib, sym), sym
