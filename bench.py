@@ -1075,7 +1075,7 @@ def in_flight_through_api(dev, steps, workloads=(("maze32", True), ("rand32", Tr
         same = True
         for k in ks:
             fly = InFlightPlanner(va, streams=k, unit_cost="auto" if unit else False)
-            outs = fly.plan_many(batches * 2)  # warm-up (allocator, streams) + equality with the sequential calls
+            outs = fly.plan_many(batches[i % N_ROTATE] for i in range(n))  # warm-up (the allocator then holds n output sets) + equality with the sequential calls
             same = same and all(torch.equal(o.histories, seq[i % N_ROTATE].histories) and torch.equal(o.paths, seq[i % N_ROTATE].paths)
                                 for i, o in enumerate(outs))
             del outs

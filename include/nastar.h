@@ -63,6 +63,7 @@ extern "C" {
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
+#define NASTAR_FLAG_GLOBAL_V1 512 /* forward, maps larger than LDS: the round-4 kernel with all three open-list levels in HBM (A/B; needs its own, larger workspace) */
 #define NASTAR_FLAG_CHECK_ORDER 256 /* nastar_forward_ex / nastar_forward_ordered / nastar_backward_replay_ordered: verify on the device that `order` is a
                                      * permutation of 0..B-1 (one small launch before the search) and IGNORE it when it is not -- every map is then
                                      * searched in the natural order and status_summary[NASTAR_SUMMARY_BAD_ORDER] is set.  Needs the workspace that

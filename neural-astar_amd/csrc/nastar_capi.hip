@@ -9,6 +9,7 @@
 #include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
 #include "nastar_search_global.hip.h"
+#include "nastar_search_hybrid.hip.h"
 #include "nastar_search_compact.hip.h"
 #include "nastar_search_asm.hip.h"
 #include "nastar_search_asm3.hip.h"
@@ -388,7 +389,7 @@ size_t nastar_workspace_bytes(int B, int H, int W, int flags)
     if (B <= 0 || H <= 0 || W <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
     const size_t chk = (flags & NASTAR_FLAG_CHECK_ORDER) ? kOrderCheckBytes : 0;  // the verdict word of nastar_order_check_kernel
     if (!needs_global_state(H, W)) return chk;  // the whole search state lives in LDS
-    return (size_t)B * global_slab_bytes(H * W) + chk;
+    return (size_t)B * ((flags & NASTAR_FLAG_GLOBAL_V1) ? global_slab_bytes(H * W) : hybrid_slab_bytes(H * W)) + chk;
 }
 
 // NASTAR_FLAG_CHECK_ORDER: one small launch that decides whether `order` is a permutation of 0..B-1; its verdict word is the LAST
@@ -431,9 +432,25 @@ static int forward_impl(const float* cost, const float* start, const float* goal
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
     if (B > 0 && H > 0 && W > 0 && max_iters > 0 && (long long)H * W <= kMaxGlobalCells && needs_global_state(H, W)) {
-        // large map: state in the caller's HBM workspace (nastar_search_global.hip.h)
-        const size_t slab = global_slab_bytes(H * W);
+        // large map: cells in the caller's HBM workspace, open list in LDS (nastar_search_hybrid.hip.h)
         if (!workspace) return NASTAR_ERR_NULL;
+        if (!(flags & NASTAR_FLAG_GLOBAL_V1)) {
+            const size_t slab = hybrid_slab_bytes(H * W);
+            if (workspace_bytes < (size_t)B * slab) return NASTAR_ERR_WORKSPACE;
+            FwdHybridArgs ha;
+            ha.cost = cost; ha.start = start; ha.goal = goal; ha.passable = passable;
+            ha.hist = histories_out; ha.paths = reinterpret_cast<long long*>(paths_out);
+            ha.sel_log = sel_log_out; ha.iters = iters_out; ha.status = status_out; ha.summary = summary;
+            ha.workspace = static_cast<unsigned char*>(workspace); ha.slab_bytes = slab; ha.max_iters = max_iters;
+            HybridDims& hd = ha.d;
+            hd.H = H; hd.W = W; hd.HW = H * W;
+            hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
+            hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
+            hd.inv_W = 1.0f / (float)W;
+            return launch(nastar_forward_hybrid_kernel, B, hybrid_lds_bytes(hd.HW), reinterpret_cast<hipStream_t>(stream), ha);
+        }
+        // round-4 kernel (all three open-list levels in HBM), kept for the A/B of profiles/r05 only
+        const size_t slab = global_slab_bytes(H * W);
         if (workspace_bytes < (size_t)B * slab) return NASTAR_ERR_WORKSPACE;
         FwdGlobalArgs ga;
         ga.cost = cost; ga.start = start; ga.goal = goal; ga.passable = passable;

@@ -1,0 +1,242 @@
+// nastar_search_hybrid.hip.h -- forward search for maps too large for LDS (129x129 ... 512x512): the OPEN LIST lives in LDS, the cells in HBM.
+//
+// The reference's answer to large maps is "use the CPU pq_astar" (astar.py:36-37) because its loop touches every cell of every map
+// per step (differentiable_astar.py:203-252).  Here a step touches 64 + 8 + 1 cells.  State of one map (one 64-lane wavefront):
+//
+//   HBM slab (5 B/cell, caller's workspace; L2-resident in practice)
+//     g[]     fp32, the node state in the sign of infinity exactly as in the LDS kernels (nastar_search.hip.h): +inf passable & never
+//             opened, -inf closed or obstacle, finite = open.  "relax neighbour n" (:229,:235) is the one comparison g[n] > g2.
+//     pdir[]  parent direction | passable | on-path bits (1 B)
+//     cost is NOT copied: it is read from the caller's tensor when a cell is touched; h0 is recomputed from the coordinates.
+//   LDS (8 B per 64 cells + 512 B: 33 KB at 512x512)
+//     cmin[c] per 64-cell chunk: (key << 32 | cell) of its first minimal open cell, ~0 when it holds none   (u64 order = first-index tie-break)
+//     smin[s] per 64 chunks: the minimum of their cmin entries
+//
+// A step (round 4's kernel, nastar_search_global.hip.h, kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
+//   select   ONE ds_read_b64 per lane of smin + a wave minimum: the entry itself names s*                               (LDS only)
+//   load     g / cost of s*, of its 8 neighbours and of the 64 cells of its chunk: issued together, ONE round trip       (HBM)
+//   update   g / pdir stores of the relaxed neighbours (drain overlapped with the LDS work below); chunk minimum without s*
+//            recomputed from the loaded cells; ds_min_u64 inserts the neighbours; the super-chunk of s* is re-minimised     (LDS)
+// Keys are never stored: q = fl(f / fl32(sqrt(W))) is re-derived from (g, cost, coordinates), with the IEEE division (no reciprocal).
+#pragma once
+#include "nastar_search.hip.h"
+#include "nastar_search_global.hip.h"  // gld / gst / global_step_fence: agent-scope accesses served by L2
+
+namespace nastar {
+
+struct HybridDims {
+    int H, W, HW;
+    int nchunks;   // ceil(HW / 64)
+    int nsuper;    // ceil(nchunks / 64) <= 64
+    float gr, omg, sqrtW;
+    float inv_W;   // 1 / W: row of a flat index by one multiply (exact for HW <= 2^18, W <= 512: see hybrid_row)
+};
+
+__host__ __device__ inline size_t hybrid_slab_bytes(int HW)
+{
+    const size_t HWp = (((size_t)HW + 63) / 64) * 64;
+    return (HWp * 5 + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t hybrid_lds_bytes(int HW)
+{
+    const size_t nchunks = ((size_t)HW + 63) / 64;
+    const size_t nsuper = (nchunks + 63) / 64;
+    return nsuper * 64 * 8 + 64 * 8;
+}
+
+struct FwdHybridArgs {
+    const float* cost;
+    const float* start;
+    const float* goal;
+    const float* passable;
+    float* hist;
+    long long* paths;
+    int* sel_log;
+    int* iters;
+    int* status;
+    int* summary;
+    unsigned char* workspace;
+    size_t slab_bytes;
+    int max_iters;
+    HybridDims d;
+};
+
+// row of flat index i (< 2^18) for W <= 512: (i + 0.5) / W is at least 0.5 / W away from an integer and the fp32 product is within
+// 2^-23 * 512 of it; one correction step keeps it exact even so
+__device__ __forceinline__ int hybrid_row(int i, const HybridDims& d, int& c)
+{
+    int r = (int)(((float)i + 0.5f) * d.inv_W);
+    c = i - r * d.W;
+    if (c < 0) { --r; c += d.W; }
+    else if (c >= d.W) { ++r; c -= d.W; }
+    return r;
+}
+
+// minimum of a u64 per lane over the wavefront, in every lane (high word first, then the low word among the lanes that hold it)
+__device__ __forceinline__ unsigned long long wave_min_all_u64(unsigned long long v)
+{
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = wave_min_all_u32(hi);
+    const uint32_t ml = wave_min_all_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
+__device__ __forceinline__ uint32_t hybrid_key(const HybridDims& d, float g, float h)
+{
+    const float f = d.gr * g + d.omg * h;   // :206  f = g_ratio * g + (1 - g_ratio) * h
+    return f32_to_ord(f / d.sqrtW);        // :207  the quotient the reference's softmax orders by (IEEE division)
+}
+
+__global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const HybridDims d = a.d;
+    const int HWp = d.nchunks * 64;
+    unsigned long long* const cmin = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* const smin = cmin + d.nsuper * 64;
+    unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
+    float* const g = reinterpret_cast<float*>(slab);
+    uint8_t* const pdir = reinterpret_cast<uint8_t*>(g + HWp);
+    const size_t off = (size_t)b * (size_t)d.HW;
+    const float* cost = a.cost + off;
+    const float* start = a.start + off;
+    const float* goal = a.goal + off;
+    const float* passable = a.passable + off;
+
+    // ---- load: start / goal, node states; empty open list -------------------------------------------------------------
+    int sidx = -1, gidx = -1;
+    for (int i = lane; i < HWp; i += 64) {
+        const bool valid = i < d.HW;
+        if (valid && start[i] != 0.f) sidx = i;
+        if (valid && goal[i] != 0.f) gidx = i;
+        const bool pass = valid && passable[i] != 0.f;
+        gst(&g[i], pass ? NASTAR_POS_INF : NASTAR_NEG_INF);
+        gst(&pdir[i], (uint8_t)(PARENT_UNSET | (pass ? P_PASS : 0u)));
+    }
+    sidx = wave_max_i32(sidx);
+    gidx = wave_max_i32(gidx);
+    for (int c = lane; c < d.nsuper * 64; c += 64) cmin[c] = ~0ull;
+    smin[lane] = ~0ull;
+    const int gi = gidx < 0 ? 0 : gidx;
+    int goal_c;
+    const int goal_r = hybrid_row(gi, d, goal_c);
+    global_step_fence();
+    if (lane == 0 && sidx >= 0) {  // open list = {start} (:187), g[start] = 0 (:193); the start is expanded even on an obstacle
+        int sc;
+        const int sr = hybrid_row(sidx, d, sc);
+        const uint32_t k0 = hybrid_key(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
+        const unsigned long long e = ((unsigned long long)k0 << 32) | (uint32_t)sidx;
+        gst(&g[sidx], 0.0f);
+        gst(&pdir[sidx], (uint8_t)(PARENT_UNSET | P_PASS));
+        cmin[sidx >> 6] = e;
+        smin[sidx >> 12] = e;
+    }
+    __syncthreads();
+
+    int dr, dc;
+    neighbour_delta(lane & 7, dr, dc);
+    int status = NASTAR_OK;
+    int iters = 0;
+    bool solved = false;
+    if (sidx < 0 || gidx < 0) {
+        status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start / goal map
+    } else {
+        while (iters < a.max_iters) {  // :203
+            // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
+            const unsigned long long M = wave_min_all_u64(smin[lane]);
+            if (M == ~0ull) {  // open list empty (:68 would divide by zero)
+                status = NASTAR_ERR_UNSOLVABLE;
+                break;
+            }
+            const int s = (int)(uint32_t)M;
+            if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            ++iters;
+            if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point
+                if (lane == 0) gst(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
+                solved = true;
+                break;
+            }
+            const int C = s >> 6, S = s >> 12;
+            int c;
+            const int r = hybrid_row(s, d, c);
+            const int nr = r + dr, nc = c + dc;
+            const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+            const int n = inb ? s + dr * d.W + dc : s;
+            const int ic = C * 64 + lane;
+            const bool icv = ic < d.HW;
+            global_step_fence();  // the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+            // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
+            const float gs = gld(&g[s]);
+            const float gn = gld(&g[n]);
+            const float gc = gld(&g[ic]);
+            const float cs = cost[s];
+            const float cn = cost[n];
+            const float cc = icv ? cost[ic] : 0.f;
+            int icc;
+            const int icr = hybrid_row(icv ? ic : 0, d, icc);
+            const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
+            const bool upd = inb & (gn > g2);                                      // :229,:235
+            const uint32_t kn = hybrid_key(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+            // chunk minimum without s*: open <=> finite g
+            const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
+            const uint32_t kc = hybrid_key(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc);
+            const unsigned long long ec = open_c ? (((unsigned long long)kc << 32) | (uint32_t)ic) : ~0ull;
+            const unsigned long long newC = wave_min_all_u64(ec);
+            // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
+            if (lane == 0) gst(&g[s], NASTAR_NEG_INF);
+            if (upd) {
+                gst(&g[n], g2);
+                gst(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
+            }
+            // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
+            const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
+            if (lane == 0) cmin[C] = newC;
+            wave_order();
+            if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
+            wave_order();
+            const unsigned long long newS = wave_min_all_u64(cmin[S * 64 + lane]);  // the super-chunk of s*, exactly
+            if (lane == 0) smin[S] = newS;
+            wave_order();
+            if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
+            wave_order();
+        }
+    }
+    global_step_fence();
+    if (lane == 0) {
+        a.iters[b] = iters;
+        a.status[b] = status;
+        if (status != NASTAR_OK && a.summary) a.summary[status] = 1;
+    }
+
+    // ---- backtrack (:96-125): walk to the start, cap = this map's own step count in the budget-truncated case ----------
+    if (gidx >= 0 && lane == 0) {
+        const int cap = solved ? d.HW : iters - 1;
+        uint32_t m = gld(&pdir[gidx]);
+        gst(&pdir[gidx], (uint8_t)(m | P_PATH));
+        uint32_t code = m & P_DIRMASK;
+        if (code != PARENT_UNSET) {
+            int pdr, pdc;
+            neighbour_delta((int)code, pdr, pdc);
+            int loc = gidx - (pdr * d.W + pdc);
+            for (int k2 = 0; k2 < cap; ++k2) {
+                const uint32_t ml = gld(&pdir[loc]);
+                gst(&pdir[loc], (uint8_t)(ml | P_PATH));
+                if (loc == sidx) break;
+                const uint32_t cd = ml & P_DIRMASK;
+                if (cd == PARENT_UNSET) break;
+                neighbour_delta((int)cd, pdr, pdc);
+                loc -= pdr * d.W + pdc;
+            }
+        }
+    }
+    global_step_fence();
+    for (int i = lane; i < d.HW; i += 64) {
+        const uint32_t m = gld(&pdir[i]);
+        a.hist[off + i] = ((m & P_PASS) && gld(&g[i]) == NASTAR_NEG_INF) ? 1.0f : 0.0f;
+        a.paths[off + i] = (m & P_PATH) ? 1 : 0;
+    }
+}
+
+}  // namespace nastar

@@ -49,8 +49,10 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _order_ptr(order: torch.Tensor, B: int, dev: torch.device) -> int:
-    if order.dtype != torch.int32 or order.numel() != B or order.device != dev or not order.is_contiguous():
+def _order_ptr(order: torch.Tensor, B: int, dev: torch.device, buffer_ok: bool = False) -> int:
+    """``buffer_ok``: also accept the [B + 1] ``order_out`` buffer of the forward launch as it is (the replay backward reads its first B cells)"""
+    if (order.dtype != torch.int32 or (order.numel() != B and not (buffer_ok and order.numel() == B + 1)) or order.device != dev
+            or not order.is_contiguous()):
         raise ValueError(f"order must be a contiguous int32 tensor of exactly {B} elements on {dev} (got {tuple(order.shape)} {order.dtype} on {order.device})")
     return order.data_ptr()
 
@@ -108,12 +110,24 @@ def _maps3(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_IN_LDS: dict = {}
+
+
+def in_lds(H: int, W: int) -> bool:
+    """does the search state of an H x W map live in LDS (no HBM workspace; placements apply)?  Cached per size."""
+    v = _IN_LDS.get((H, W))
+    if v is None:
+        v = _IN_LDS[(H, W)] = int(_native.load().nastar_workspace_bytes(1, H, W, 0)) == 0
+    return v
+
+
 def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order, summary_ptr, dev,
-                   one_meta=False, stream_ptr=None):
+                   one_meta=False, stream_ptr=None, out_4d=False):
     """allocate the five outputs and issue ONE nastar_forward_ex launch on torch's current stream (shared by the custom ops and the
     no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape)."""
-    hist = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    paths = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    shape = (B, 1, H, W) if out_4d else (B, H, W)
+    hist = torch.empty(shape, dtype=torch.float32, device=dev)
+    paths = torch.empty(shape, dtype=torch.int64, device=dev)
     if one_meta:  # iters, status: one allocation (not for the custom ops, whose outputs must not alias each other)
         meta = torch.empty((2, B), dtype=torch.int32, device=dev)
         iters, status = meta[0], meta[1]
@@ -121,7 +135,7 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)
     # entries at positions >= iters[b] are never read (the backward replays iters[b] steps, _intermediate_results masks by iters)
-    sel_log = torch.empty((B, max_iters) if want_log else (0,), dtype=torch.int32, device=dev)
+    sel_log = torch.empty((B, max_iters), dtype=torch.int32, device=dev) if want_log else (None if out_4d else torch.empty((0,), dtype=torch.int32, device=dev))
     flags = int(flags) | FORWARD_FLAGS
     op = oo = 0
     if order is not None:
@@ -132,15 +146,20 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
         if order_out.dtype != torch.int32 or order_out.numel() != B + 1 or order_out.device != dev or not order_out.is_contiguous():
             raise ValueError(f"order_out must be a contiguous int32 tensor of exactly {B + 1} elements on {dev} (ops.new_placement_buffer)")
         oo = order_out.data_ptr()
-    ws_bytes = int(lib.nastar_workspace_bytes(B, H, W, flags))  # > 0 for maps too large for LDS and for a checked order
+    # workspace: > 0 for maps too large for LDS and for a checked order
+    ws_bytes = (16 if flags & FLAG_CHECK_ORDER else 0) if in_lds(H, W) else int(lib.nastar_workspace_bytes(B, H, W, flags))
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-    with torch.cuda.device(dev):
-        rc = lib.nastar_forward_ex(cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W,
-                                   float(g_ratio), int(max_iters), hist.data_ptr(), paths.data_ptr(),
-                                   sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
-                                   workspace.data_ptr() if workspace is not None else None, ws_bytes, flags,
-                                   op or None, oo or None, summary_ptr or None, _stream_ptr(dev) if stream_ptr is None else stream_ptr)
-    _native.check(rc, "nastar_forward_ex")
+    sp = stream_ptr if stream_ptr is not None else torch.cuda.current_stream(dev).cuda_stream
+    args = (cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W, float(g_ratio), int(max_iters), hist.data_ptr(),
+            paths.data_ptr(), sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
+            workspace.data_ptr() if workspace is not None else None, ws_bytes, flags, op or None, oo or None, summary_ptr or None, sp)
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        rc = lib.nastar_forward_ex(*args)
+    else:
+        with torch.cuda.device(dev):
+            rc = lib.nastar_forward_ex(*args)
+    if rc:
+        _native.check(rc, "nastar_forward_ex")
     return hist, paths, iters, status, sel_log
 
 
@@ -194,29 +213,37 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, o
 
 def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, obstacles_maps: torch.Tensor, g_ratio: float,
                   max_iters: int, want_log: bool = False, flags: int = 0, order: Optional[torch.Tensor] = None,
-                  order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None):
+                  order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None,
+                  out_4d: bool = False):
     """The search launch WITHOUT the torch.library dispatch: what ``DifferentiableAstar.forward`` calls when no gradient can flow
     (``torch.no_grad()`` / inputs that do not require one) and nothing is being traced -- the custom-op machinery costs more host time
-    than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs.
+    than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs
+    (``out_4d``: histories / paths as [B,1,H,W], the AstarOutput layout, and None instead of an empty selection log).
     ``stream_ptr``: a hipStream_t to launch on instead of torch's current stream (``parallel.InFlightPlanner``; the outputs are
     allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them)."""
-    for t in (cost_maps, start_maps, goal_maps, obstacles_maps):
-        if not t.is_cuda or t.dtype != torch.float32:
-            _require_device(t)
-    if cost_maps.ndim == 4:
-        if cost_maps.shape[1] != 1 or start_maps.shape[1] != 1 or goal_maps.shape[1] != 1 or obstacles_maps.shape[1] != 1:
-            cost_maps, start_maps, goal_maps, obstacles_maps = (x[:, 0] for x in (cost_maps, start_maps, goal_maps, obstacles_maps))
+    if not (cost_maps.is_cuda and start_maps.is_cuda and goal_maps.is_cuda and obstacles_maps.is_cuda
+            and cost_maps.dtype == start_maps.dtype == goal_maps.dtype == obstacles_maps.dtype == torch.float32):
+        _require_device(cost_maps, start_maps, goal_maps, obstacles_maps)
+    same = obstacles_maps is cost_maps
+    if cost_maps.ndim == 4 and not (cost_maps.shape[1] == start_maps.shape[1] == goal_maps.shape[1] == obstacles_maps.shape[1] == 1):
+        cost_maps, start_maps, goal_maps, obstacles_maps = (x[:, 0] for x in (cost_maps, start_maps, goal_maps, obstacles_maps))
     B, H, W = cost_maps.shape[0], cost_maps.shape[-2], cost_maps.shape[-1]
-    if not (start_maps.shape[0] == B and goal_maps.shape[0] == B and obstacles_maps.shape[0] == B
+    n = B * H * W
+    if not (start_maps.numel() == n and goal_maps.numel() == n and obstacles_maps.numel() == n
             and start_maps.shape[-2:] == cost_maps.shape[-2:] == goal_maps.shape[-2:] == obstacles_maps.shape[-2:]):
         raise ValueError("cost / start / goal / obstacle maps must have one shape")
-    same = obstacles_maps is cost_maps
-    cost_maps = cost_maps if cost_maps.is_contiguous() else cost_maps.contiguous()
-    obstacles_maps = cost_maps if same else (obstacles_maps if obstacles_maps.is_contiguous() else obstacles_maps.contiguous())
-    start_maps = start_maps if start_maps.is_contiguous() else start_maps.contiguous()
-    goal_maps = goal_maps if goal_maps.is_contiguous() else goal_maps.contiguous()
+    if not cost_maps.is_contiguous():
+        cost_maps = cost_maps.contiguous()
+    if same:
+        obstacles_maps = cost_maps
+    elif not obstacles_maps.is_contiguous():
+        obstacles_maps = obstacles_maps.contiguous()
+    if not start_maps.is_contiguous():
+        start_maps = start_maps.contiguous()
+    if not goal_maps.is_contiguous():
+        goal_maps = goal_maps.contiguous()
     return _launch_search(_native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters, want_log, flags,
-                          order, order_out, check_order, summary_ptr, cost_maps.device, one_meta=True, stream_ptr=stream_ptr)
+                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d)
 
 
 def order_from_levels(levels: torch.Tensor) -> torch.Tensor:
@@ -255,6 +282,8 @@ def attach_order(start_maps: torch.Tensor, levels: torch.Tensor) -> torch.Tensor
 def workspace_bytes(shape) -> int:
     """bytes of HBM workspace a [B, H, W] search needs (0: the state of every map lives in LDS)"""
     B, H, W = (int(x) for x in shape[-3:])
+    if in_lds(H, W):
+        return 0
     return int(_native.load().nastar_workspace_bytes(B, H, W, 0))
 
 
@@ -318,7 +347,7 @@ def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: to
             rc = lib.nastar_backward_replay_ordered(grad_hist.data_ptr(), None, None, None, cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
                                                     passable.data_ptr(), sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters),
                                                     iters.data_ptr(), t_batch.data_ptr() if t_batch is not None else None,
-                                                    grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev), _stream_ptr(dev))
+                                                    grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev, True), _stream_ptr(dev))
     _native.check(rc, "nastar_backward_replay")
     return grad_cost
 
@@ -427,7 +456,7 @@ def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, g
                                                     cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(),
                                                     sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
                                                     t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(),
-                                                    ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev), _stream_ptr(dev))
+                                                    ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev, True), _stream_ptr(dev))
     _native.check(rc, "nastar_backward_l1_replay")
     return grad_cost
 

@@ -232,6 +232,7 @@ class InFlightPlanner:
         self.check_solvable = check_solvable
         self.unit_cost = unit_cost
         self._streams: List[torch.cuda.Stream] = []
+        self._events: List[torch.cuda.Event] = []
         self._ptrs: List[int] = []
         self._device = None
         self._inflight: List[tuple] = []  # (ticket, stream index, row, inputs, outputs, flags, order, check)
@@ -245,6 +246,7 @@ class InFlightPlanner:
             self._device = device
             self._streams = [torch.cuda.Stream(device) for _ in range(self.n_streams)]
             self._ptrs = [s.cuda_stream for s in self._streams]
+            self._events = [torch.cuda.Event() for _ in range(self.n_streams)]  # "the inputs of the batch going to stream k are complete"
 
     def submit(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, inputs_ready: bool = False) -> int:
         """Queue one batch (the reference's [B,1,H,W] tensors); returns its ticket (0, 1, 2, ... since the last collection).
@@ -257,20 +259,23 @@ class InFlightPlanner:
         planner, astar = self.planner, self.planner.astar
         k = self._k % self.n_streams
         st = self._streams[k]
-        if not inputs_ready:
-            st.wait_stream(torch.cuda.current_stream(dev))
-        W = map_designs.shape[-1]
         encode = getattr(planner, "encode", None)
         with torch.no_grad():
-            if encode is not None:  # NeuralAstar: the encoder's launches go to the same stream as the search
-                with torch.cuda.stream(st):
-                    cost = encode(map_designs, start_maps, goal_maps)
-                    passable = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
-                cost.record_stream(torch.cuda.current_stream(dev))
+            if encode is not None:
+                # NeuralAstar: the ENCODER stays on the current stream, one batch after the other -- its kernels fill the chip on their own and
+                # share one activation workspace per module (encoder_hip.py) -- and only the search, the serial chain worth overlapping, goes to
+                # the batch's stream, behind the encoder
+                cost = encode(map_designs, start_maps, goal_maps)
+                passable = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
                 same = False
+                inputs_ready = False
             else:
                 cost = passable = map_designs
                 same = True
+            if not inputs_ready:  # (st.wait_stream() with a reused event: this runs once per batch)
+                ev = self._events[k]
+                ev.record(torch.cuda.current_stream(dev))
+                st.wait_event(ev)
             max_iters = ops.max_iters_for(start_maps.shape[-1], 1.0, False)
             unit = same and self.unit_cost in (True, "auto")
             flags = ops.FLAG_UNIT_COST if unit else 0
@@ -284,7 +289,7 @@ class InFlightPlanner:
             row = board.acquire() if (self.check_solvable or (unit and self.unit_cost == "auto")) else -1
             try:
                 out = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio, max_iters, False, flags, order, None, bool(check),
-                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k])
+                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k], True)
             except BaseException:
                 if row >= 0:
                     board.release(row)
@@ -320,7 +325,7 @@ class InFlightPlanner:
                 try:
                     hist, paths, iters, status, _ = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio,
                                                                       ops.max_iters_for(start_maps.shape[-1], 1.0, False), False, 0, order, None,
-                                                                      bool(check), board.ptr(r2))
+                                                                      bool(check), board.ptr(r2), None, True)
                     torch.cuda.current_stream(dev).synchronize()
                     r = board.read(r2)
                     summ = None if r is None else r.copy()
@@ -328,7 +333,7 @@ class InFlightPlanner:
                     board.release(r2)
             if summ is not None and summ[1:ops.SUMMARY_BAD_ORDER].any() and self.check_solvable and failed is None:
                 failed = (ticket, status)
-            outs.append(AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), []))
+            outs.append(AstarOutput(hist, paths, []))
             astar.last_status, astar.last_iters = status, iters
         self._inflight = []
         self._k = 0

@@ -88,14 +88,25 @@ class NeuralAstar(VanillaAstar):
         # = the training kernels of neural_astar/encoder_train.py (forward, input and weight gradients, batch-statistics BatchNorm,
         # max-pool, upsample-concat) for CNN of any depth / map size, CNNDownSize and the VggUnet definition of Unet; shapes those
         # kernels do not take, and eval mode with gradients, stay on torch.nn.  Not part of the reference's constructor.
+        # "hip_strict" = "hip_f16x3" that RAISES instead of falling back to torch.nn for a shape / mode the kernels do not take.
         self.encoder_backend = "auto"
         self._hip_encoder = None
+        # which code predicted the latest cost map: "hip:<kernel family>/<precision>" or "torch.nn" (+ why); a fall-back to torch.nn on a HIP
+        # device under a hip_* backend also warns once per reason (a shape that misses must not train on MIOpen without a word)
+        self.last_encoder_route: str = ""
+        self._route_warned: set = set()
 
     def effective_encoder_backend(self, like: torch.Tensor) -> str:
         """``encoder_backend`` with "auto" resolved for a tensor on ``like``'s device."""
         if self.encoder_backend == "auto":
             return "hip_f16x3" if like.is_cuda else "torch"
+        if self.encoder_backend == "hip_strict":
+            return "hip_f16x3"
         return self.encoder_backend
+
+    def _routed(self, route: str, cost: torch.Tensor) -> torch.Tensor:
+        self.last_encoder_route = route
+        return cost
 
     def encode(self, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor) -> torch.Tensor:
         """Predict cost maps (reference astar.py:154-180)."""
@@ -111,7 +122,7 @@ class NeuralAstar(VanillaAstar):
                     and map_designs.shape[-2] % (1 << depth) == 0 and map_designs.shape[-1] % (1 << depth) == 0):
                 if not isinstance(self._hip_encoder, _downsize_cls()):
                     self._hip_encoder = _downsize_cls()(self.encoder)
-                return self._hip_encoder(map_designs, start_maps, goal_maps, plus)
+                return self._routed("hip:CNNDownSize-infer/f32", self._hip_encoder(map_designs, start_maps, goal_maps, plus))
         if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and isinstance(self.encoder, encoder.Unet) and isinstance(self.encoder.model, encoder.VggUnet)
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
@@ -122,7 +133,7 @@ class NeuralAstar(VanillaAstar):
             from ..encoder_hip import HipUnetEncoder
             if type(self._hip_encoder) is not HipUnetEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
-            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
+            return self._routed(f"hip:Unet-infer/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
         if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
                 and map_designs.shape[-2:] == start_maps.shape[-2:]):
@@ -130,8 +141,9 @@ class NeuralAstar(VanillaAstar):
             first = next(m for m in self.encoder.model.modules() if isinstance(m, nn.Conv2d))
             if (unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
                     and first.in_channels == 1 + int("+" in self.encoder_input)):
-                return unet_train_forward(self.encoder, map_designs, start_maps, goal_maps, "+" in self.encoder_input,
-                                          "f16" if backend == "hip_f16" else "f16x3")
+                prec = "f16" if backend == "hip_f16" else "f16x3"
+                return self._routed(f"hip:Unet-train/{prec}", unet_train_forward(self.encoder, map_designs, start_maps, goal_maps,
+                                                                                 "+" in self.encoder_input, prec))
         if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.CNN)):
             # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
@@ -144,8 +156,9 @@ class NeuralAstar(VanillaAstar):
             if (supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
                     and map_designs.shape[1] + int(plus) == convs[0].in_channels
                     and (pool or map_designs.shape[-2:] == start_maps.shape[-2:])):
-                return cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus,
-                                         "f16" if backend == "hip_f16" else "f16x3")
+                prec = "f16" if backend == "hip_f16" else "f16x3"
+                return self._routed(f"hip:{'CNNDownSize' if pool else 'CNN'}-train/{prec}",
+                                    cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus, prec))
         tile = 32 if backend in ("hip_f16", "hip_f16x3") else 16
         if (backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
@@ -156,7 +169,7 @@ class NeuralAstar(VanillaAstar):
             from ..encoder_hip import HipCnnEncoder
             if type(self._hip_encoder) is not HipCnnEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipCnnEncoder(self.encoder, precision)
-            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
+            return self._routed(f"hip:CNN-infer-img32/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
         if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and type(self.encoder) is encoder.CNN and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-1] <= 126 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
@@ -165,7 +178,22 @@ class NeuralAstar(VanillaAstar):
             from ..encoder_hip import HipFlatCnnEncoder
             if type(self._hip_encoder) is not HipFlatCnnEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipFlatCnnEncoder(self.encoder, precision)
-            return self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input)
+            return self._routed(f"hip:CNN-infer-flat/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
+        # torch.nn (MIOpen on a HIP device): the CPU path, the "torch" backend -- or a shape / mode the kernels do not take
+        route = "torch.nn"
+        if backend.startswith("hip"):
+            why = (f"{type(self.encoder).__name__} on {tuple(map_designs.shape)} maps, training={self.encoder.training}, "
+                   f"grad={torch.is_grad_enabled()}, device={map_designs.device.type}")
+            route = f"torch.nn (fell through from {backend}: {why})"
+            if self.encoder_backend == "hip_strict":
+                raise RuntimeError(f"encoder_backend='hip_strict': no MI355X encoder kernel takes {why}; it would run on torch.nn")
+            if map_designs.is_cuda and why not in self._route_warned:
+                self._route_warned.add(why)
+                import warnings
+                warnings.warn(f"NeuralAstar.encode: {why} is not covered by the MI355X encoder kernels -- this call runs on torch.nn (MIOpen); "
+                              "planner.last_encoder_route records the route, encoder_backend='hip_strict' turns this into an error, "
+                              "'torch' silences it", RuntimeWarning, stacklevel=2)
+        self.last_encoder_route = route
         inputs = map_designs
         if "+" in self.encoder_input:
             sg = start_maps + goal_maps

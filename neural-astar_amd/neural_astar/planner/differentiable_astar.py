@@ -183,8 +183,11 @@ class DifferentiableAstar(nn.Module):
         """wait for the stream the launch went to and return a COPY of its summary row (None = every map ended with status 0)"""
         board = ops.StatusBoard.of(device)
         torch.cuda.current_stream(device).synchronize()  # the ONE device->host wait of a checked call
-        r = board.read(row)
-        r = None if r is None else r.copy()
+        r = board.np[row]
+        if not r.any():  # (the row is still all zero: nothing to clear)
+            board.free.append(row)
+            return None
+        r = r.copy()
         board.release(row)
         return r
 
@@ -197,6 +200,8 @@ class DifferentiableAstar(nn.Module):
         self.last_status, self.last_iters = status, iters
         self._calls += 1
         mode = self.check_solvable
+        if clean is True and row < 0 and mode is not False and mode != "deferred":
+            return  # the caller has read a clean verdict for THIS call already
         if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
             if row >= 0:
                 ops.StatusBoard.of(status.device).release(row)
@@ -248,34 +253,41 @@ class DifferentiableAstar(nn.Module):
         assert goal_maps.ndim == 4
         assert obstacles_maps.ndim == 4
 
-        W = cost_maps.shape[-1]
-        B = cost_maps.shape[0]
+        B, _, H, W = cost_maps.shape
         max_iters = ops.max_iters_for(W, self.Tmax, self.training)
-        needs_grad = torch.is_grad_enabled() and cost_maps.requires_grad
+        needs_grad = cost_maps.requires_grad and torch.is_grad_enabled()
         # the selection log doubles as the tape of the backward (replayed by nastar_backward_replay): keep it whenever
         # autograd will need it
         want_log = bool(store_intermediate_results) or needs_grad
-        capturing = _capturing(cost_maps)
-        if not capturing and self._pending:
+        capturing = cost_maps.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self._pending and not capturing:
             self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
         # VanillaAstar hands ONE tensor over as cost and obstacle map: the unit-cost kernel (see __init__) applies when it is binary,
         # which the kernel itself checks; in "auto" mode only when this call reads the status anyway and can fall back
         same = obstacles_maps is cost_maps or (cost_maps.data_ptr() == obstacles_maps.data_ptr() and cost_maps.shape == obstacles_maps.shape
                                                and cost_maps.stride() == obstacles_maps.stride())
-        sync_check = self.check_solvable in (True, "sync") and not capturing
+        mode = self.check_solvable
+        sync_check = (mode is True or mode == "sync") and not capturing
         unit = (same and not want_log and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
-        in_lds = ops.workspace_bytes(cost_maps.shape) == 0
+        in_lds = ops.in_lds(H, W)
         # a recurring batch starts its longest searches first (Placement), a fresh one by its loader's hint; maps whose state lives in HBM take no placement
-        order, order_out, check_order, pl = self.resolve_placement(B, start_maps, in_lds)
-        row = self.begin_launch(cost_maps)
-        sptr = self.summary_ptr(row, cost_maps)
+        if self.placement is None and not hasattr(start_maps, "placement_order"):
+            order = order_out = pl = None
+            check_order = False
+        else:
+            order, order_out, check_order, pl = self.resolve_placement(B, start_maps, in_lds)
+        dev = cost_maps.device
+        board = ops.StatusBoard.of(dev) if (mode and cost_maps.is_cuda and not capturing) else None
+        row = board.acquire() if board is not None else -1
+        sptr = board.ptr(row) if board is not None else 0
         flags = ops.FLAG_UNIT_COST if unit else 0
         traced = needs_grad or type(cost_maps) is not torch.Tensor or torch.compiler.is_compiling()
         try:
             if not traced:
                 # no gradient can flow and nothing is tracing: straight to the C ABI (no torch.library dispatch)
                 hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
-                                                                        self.g_ratio, max_iters, want_log, flags, order, order_out, check_order, sptr)
+                                                                        self.g_ratio, max_iters, want_log, flags, order, order_out, check_order, sptr,
+                                                                        None, True)
             else:
                 cost, start, goal, passable = cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles_maps[:, 0]
                 if needs_grad and in_lds and (order is not None or order_out is not None or B >= ops.PLACEMENT_MIN_BATCH):
@@ -288,13 +300,14 @@ class DifferentiableAstar(nn.Module):
                 else:
                     hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, float(self.g_ratio), max_iters,
                                                                                                  want_log, flags, order, order_out, check_order, sptr)
+                hist, paths = hist.unsqueeze(1), paths.unsqueeze(1)
         except BaseException:
             if row >= 0:
-                ops.StatusBoard.of(cost_maps.device).release(row)
+                board.release(row)
             raise
         clean = None
         if unit and self.unit_cost == "auto" and row >= 0:
-            summ = self._collect_sync(row, cost_maps.device)  # the ONE device->host wait of this call (note_status does not wait again)
+            summ = self._collect_sync(row, dev)  # the ONE device->host wait of this call (note_status does not wait again)
             row = -1
             clean = summ is None or not summ[1:ops.SUMMARY_BAD_ORDER].any()
             if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
@@ -303,7 +316,7 @@ class DifferentiableAstar(nn.Module):
                 # a map with values other than 0 / 1: the whole batch again on the general kernel (same call, same outputs contract)
                 row = self.begin_launch(cost_maps)
                 hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps, self.g_ratio, max_iters, want_log, 0,
-                                                                        order, order_out, check_order, self.summary_ptr(row, cost_maps))
+                                                                        order, order_out, check_order, self.summary_ptr(row, cost_maps), None, True)
                 clean = None
         if pl is not None and order_out is not None:
             pl.commit()
@@ -311,8 +324,8 @@ class DifferentiableAstar(nn.Module):
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:
-            intermediate_results = _intermediate_results(hist, paths, goal_maps[:, 0], iters, sel_log)
-        return AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), intermediate_results)
+            intermediate_results = _intermediate_results(hist[:, 0], paths[:, 0], goal_maps[:, 0], iters, sel_log)
+        return AstarOutput(hist, paths, intermediate_results)
 
 
 _BAD_ORDER_WARNED = False

@@ -226,6 +226,50 @@ r04_final2)
   python bench.py --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench.err; echo "bench rc=$?"
   bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1; tail -c 600 $O/profile_round.log
   ;;
+r05_a)
+  # 0.5.0 boundary: new tests first (pinned status summary, checked orders, fast path, data-set placement, InFlightPlanner), then the
+  # bench line (driver's command shape, short) and a clean first-visit kernel profile, then the whole GPU suite
+  O=gpurun_out/r05/a; mkdir -p $O
+  python -m pytest tests/test_boundary_gpu.py -q -x -m gpu > $O/boundary.log 2>&1; echo "boundary rc=$?"
+  tail -30 $O/boundary.log
+  python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $O/bench_short.json 2> $O/bench_short.err; echo "bench rc=$?"
+  tail -5 $O/bench_short.err
+  python - <<'P'
+import json
+j=json.load(open("gpurun_out/r05/a/bench_short.json"))
+print("value", round(j["value"]/1e6,2), "M maps/s  ms/step", round(j["ms_per_step"],4), "natural", j["value_natural_order"] and round(j["value_natural_order"]/1e6,2), "hinted", j["value_hinted"] and round(j["value_hinted"]/1e6,2))
+print("roofline", {k: j["roofline"][k] for k in ("frac","frac_28B_per_cell","launch_ms_avg","launch_ms_median","launch_ms_min")})
+print("first visits:", j["config"]["every_timed_step_is_a_first_visit"], j["config"]["first_visit_note"])
+P
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --no-secondary --no-natural --no-prewarm --steps 200 --warmup 20 > $R/$O/bench_under_rocprof.json 2> $R/$O/bench_under_rocprof.err)
+  find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/first_visit_kernel_stats.csv \;
+  head -5 $O/first_visit_kernel_stats.csv
+  python -m pytest tests -q -m gpu -x > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"
+  tail -15 $O/all_gpu_tests.log
+  ;;
+r05_b)
+  # boundary tests again, the whole GPU suite (no -x), then the driver's bench command in full (through_module, in-flight through the API, secondaries)
+  O=gpurun_out/r05/b; mkdir -p $O
+  python -m pytest tests/test_boundary_gpu.py -q -m gpu > $O/boundary.log 2>&1; echo "boundary rc=$?"; tail -5 $O/boundary.log
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -8 $O/all_gpu_tests.log
+  python bench.py --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
+  python - <<'P'
+import json
+j=json.load(open("gpurun_out/r05/b/bench_driver_command.json"))
+print("value", round(j["value"]/1e6,2), "M maps/s  ms/step", round(j["ms_per_step"],4), "natural", j["value_natural_order"] and round(j["value_natural_order"]/1e6,2), "hinted", j["value_hinted"] and round(j["value_hinted"]/1e6,2), "in flight", j.get("value_in_flight"))
+print("roofline", {k: j["roofline"][k] for k in ("frac","frac_28B_per_cell","launch_ms_avg","launch_ms_median","launch_ms_min")})
+print("through_module", j.get("through_module"))
+print("in_flight", json.dumps(j.get("in_flight_through_api"), indent=0))
+print("cpu_baseline", {k: v for k, v in j.get("cpu_baseline", {}).items() if k in ("value","unit","cores","kind","sample")})
+P
+  ;;
+r05_c)
+  # host-time breakdown of the boundary (forward() vs raw launch; InFlightPlanner vs raw round-robin), then the tests that failed in r05_b
+  O=gpurun_out/r05/c; mkdir -p $O
+  python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err; echo "probe rc=$?"; tail -3 $O/probe_boundary.err; cat $O/probe_boundary.jsonl
+  python -m pytest tests/test_boundary_gpu.py tests/test_tie_class.py -q -m gpu > $O/boundary.log 2>&1; echo "boundary rc=$?"; tail -5 $O/boundary.log
+  python -m pytest tests/test_gpu_parity.py -q -m gpu -k "unit_cost or placement or unsolvable or hipgraph or planner_modules" > $O/parity_subset.log 2>&1; echo "parity rc=$?"; tail -5 $O/parity_subset.log
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
