@@ -203,7 +203,7 @@ class Runner:
             self.m.data_ptr(), self.s.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.B, self.H, self.W,
             self.g_ratio, self.max_iters, self.hist.data_ptr(), self.paths.data_ptr(), None, self.iters.data_ptr(),
             self.status.data_ptr(), pk, None, 0, self.flags, order.data_ptr() if order is not None else None,
-            order_out.data_ptr() if order_out is not None else None, None, torch.cuda.current_stream(self.dev).cuda_stream)
+            order_out.data_ptr() if order_out is not None else None, None, None, torch.cuda.current_stream(self.dev).cuda_stream)
         self._check(rc, "nastar_forward_ex")
         if self.placement == "hinted":  # only now: a launch that failed must not leave a half-initialised order as the next hint
             z["k"] ^= 1

@@ -136,7 +136,21 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
 int nastar_forward_ex(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W,
                       double g_ratio, int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out,
                       int32_t* iters_out, int32_t* status_out, uint8_t* packed_out, void* workspace, size_t workspace_bytes,
-                      int flags, const int32_t* order, int32_t* order_out, int32_t* status_summary, void* stream);
+                      int flags, const int32_t* order, int32_t* order_out, int32_t* status_summary, int32_t* completion_counter,
+                      void* stream);
+
+/*
+ * completion_counter of nastar_forward_ex (optional, with status_summary): ONE int32 in DEVICE memory, 0 on entry and 0 again when the
+ * launch has finished (it wraps at B; one cell per launch in flight).  Every search counts itself when it ENDS; the workgroup that
+ * counts last sets status_summary[0] = 1, ordered behind every other summary cell of the launch (system-scope release / acquire).  With
+ * status_summary in pinned host memory the host learns "every search is over, and this is the verdict" by POLLING one word
+ * (nastar_host_wait_nonzero) -- no stream wait, no driver wake-up; the output tensors themselves are complete only in stream order
+ * (the backtrack and the output stores of the last maps follow the flag).  LDS-resident map sizes only (nastar_completion_supported);
+ * ignored for larger maps, whose status_summary[0] is never set.
+ */
+int nastar_completion_supported(int H, int W);
+/* Spin (pause loop, at most timeout_us) until *word_host != 0; returns 1 when it is, 0 on timeout.  HOST pointer (pinned memory). */
+int nastar_host_wait_nonzero(const volatile int32_t* word_host, int timeout_us);
 
 /*
  * A placement from data the CALLER already has: `levels[b]` = any non-negative integer that grows with the expected length of map b's

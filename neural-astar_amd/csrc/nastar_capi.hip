@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
@@ -38,6 +39,7 @@ struct FwdCArgs {
     int* order_out;    // optional [B + 1]: the maps in REVERSE order of search completion (the placement for the next visit); [B] = counter
     int* summary;      // optional [NASTAR_SUMMARY_WORDS]: summary[c] = 1 when some map of this launch ends with per-map status c != 0 (device or host-mapped)
     const int* order_bad;  // optional: *order_bad != 0 (written by nastar_order_check_kernel earlier on the stream) = `order` is not a permutation, ignore it
+    int* done_counter;     // optional device cell (0 on entry, 0 again at the end): the workgroup whose search finishes LAST sets summary[0] = 1
     int max_iters;
     int B;
     int flags;
@@ -60,6 +62,19 @@ __device__ __forceinline__ void note_completion(int* order_out, int B, int b)
     unsigned pos = atomicInc(reinterpret_cast<unsigned*>(order_out + B), (unsigned)B - 1u);
     if (pos >= (unsigned)B) pos = (unsigned)B - 1u;  // a cell that held garbage >= B: only the first increment sees it, and rank B-1 is the one nobody else gets
     order_out[B - 1 - (int)pos] = b;
+}
+
+// completion_counter of nastar_forward_ex: every search counts itself when it ENDS (before its backtrack and output stores); the last one
+// publishes summary[0] = 1.  A workgroup that wrote a summary cell makes it visible system-wide BEFORE it counts (release), the last one
+// orders its flag store behind the count it observed (acquire): a host that sees summary[0] != 0 in pinned memory sees every cell of the launch.
+__device__ __forceinline__ void note_done(int* counter, int* summary, int B, bool wrote_summary)
+{
+    if (wrote_summary) __threadfence_system();
+    const unsigned pos = atomicInc(reinterpret_cast<unsigned*>(counter), (unsigned)B - 1u);
+    if (pos == (unsigned)B - 1u && summary) {
+        __threadfence_system();
+        __hip_atomic_store(summary, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // NASTAR_FLAG_CHECK_ORDER: is `order` a permutation of 0..B-1?  ONE workgroup, a bitmap of B bits in LDS; writes *bad = 0 / 1 (always)
@@ -188,6 +203,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         a.status[b] = status;
         if (status != NASTAR_OK && a.summary) a.summary[status] = 1;  // plain idempotent store: the word may be host-mapped (no atomics over PCIe)
         if (a.order_out) note_completion(a.order_out, a.B, b);
+        if (a.done_counter) note_done(a.done_counter, a.summary, a.B, status != NASTAR_OK);
     }
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
@@ -245,6 +261,7 @@ __global__ __launch_bounds__(64) void nastar_forward_unit_kernel(const FwdCArgs 
         a.status[b] = status;
         if (status != NASTAR_OK && a.summary) a.summary[status] = 1;  // plain idempotent store: the word may be host-mapped (no atomics over PCIe)
         if (a.order_out) note_completion(a.order_out, a.B, b);
+        if (a.done_counter) note_done(a.done_counter, a.summary, a.B, status != NASTAR_OK);
     }
     if (goal_idx >= 0 && !bad) {
         CompactLds cl;  // the backtrack reads and marks parents only
@@ -321,11 +338,16 @@ constexpr size_t kOrderCheckBytes = 16;                // NASTAR_FLAG_CHECK_ORDE
 // maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
 static long long resident_capacity(size_t lds_per_map)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
+    // CU count of the CURRENT device, looked up once per device (a launch on device 3 must not size itself by device 0's answer)
+    static int cus_of[64] = {0};
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        int n = __atomic_load_n(&cus_of[dev], __ATOMIC_RELAXED);
+        if (n == 0) {
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            __atomic_store_n(&cus_of[dev], n, __ATOMIC_RELAXED);  // (racing threads store the same value)
+        }
+        cus = n;
     }
     long long per_cu = (long long)(kMaxLdsBytes / (lds_per_map ? lds_per_map : 1));
     if (per_cu > 32) per_cu = 32;
@@ -426,7 +448,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
                         int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                         int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                         size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done,
-                        const int32_t* order = nullptr, int32_t* order_out = nullptr, int32_t* summary = nullptr)
+                        const int32_t* order = nullptr, int32_t* order_out = nullptr, int32_t* summary = nullptr, int32_t* done_counter = nullptr)
 {
     *packed_done = false;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
@@ -447,7 +469,26 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
             hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
             hd.inv_W = 1.0f / (float)W;
-            return launch(nastar_forward_hybrid_kernel, B, hybrid_lds_bytes(hd.HW), reinterpret_cast<hipStream_t>(stream), ha);
+            hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+            // headers (start / goal cell per map) to -1: the fill launch raises them with atomicMax
+            for (int bb = 0; bb < B; ++bb) {
+                hipError_t me = hipMemsetAsync(ha.workspace + (size_t)bb * slab + hybrid_header_offset(hd.HW), 0xFF, 8, hs);
+                if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync");
+                if (B > 64) break;  // (many maps: one strided fill kernel below instead of B memsets)
+            }
+            if (B > 64) {
+                hipLaunchKernelGGL(nastar_hybrid_header_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs, ha.workspace, slab,
+                                   hybrid_header_offset(hd.HW), B);
+            }
+            const unsigned per_map = (unsigned)((hd.nchunks * 64 + 255) / 256);
+            const dim3 grid2(per_map < 64u ? per_map : 64u, (unsigned)B);
+            hipLaunchKernelGGL(nastar_hybrid_fill_kernel, grid2, dim3(256), 0, hs, ha);
+            int rc2 = launch(nastar_forward_hybrid_kernel, B, hybrid_lds_bytes(hd.HW), hs, ha);
+            if (rc2) return rc2;
+            hipLaunchKernelGGL(nastar_hybrid_store_kernel, grid2, dim3(256), 0, hs, ha);
+            hipError_t he = hipGetLastError();
+            if (he != hipSuccess) return hip_fail(he, "kernel launch");
+            return NASTAR_OK;
         }
         // round-4 kernel (all three open-list levels in HBM), kept for the A/B of profiles/r05 only
         const size_t slab = global_slab_bytes(H * W);
@@ -481,6 +522,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.order = order;
         c.order_out = order_out;  // (decided below: in-kernel completion order, or a rank of the step counts after the launch)
         c.summary = summary;
+        c.done_counter = summary ? done_counter : nullptr;
         c.order_bad = nullptr;
         if (order && (flags & NASTAR_FLAG_CHECK_ORDER)) {
             rc = check_order(order, B, workspace, workspace_bytes, nastar_workspace_bytes(B, H, W, flags), summary, s, &c.order_bad);
@@ -555,20 +597,43 @@ int nastar_forward_ordered(const float* cost, const float* start, const float* g
                            size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out, void* stream)
 {
     return nastar_forward_ex(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out, iters_out,
-                             status_out, packed_out, workspace, workspace_bytes, flags, order, order_out, nullptr, stream);
+                             status_out, packed_out, workspace, workspace_bytes, flags, order, order_out, nullptr, nullptr, stream);
 }
 
 int nastar_forward_ex(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W, double g_ratio,
                       int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out,
                       uint8_t* packed_out, void* workspace, size_t workspace_bytes, int flags, const int32_t* order, int32_t* order_out,
-                      int32_t* status_summary, void* stream)
+                      int32_t* status_summary, int32_t* completion_counter, void* stream)
 {
     if ((order || order_out) && B > 0 && H > 0 && W > 0 && needs_global_state(H, W)) return NASTAR_ERR_UNSUPPORTED;  // LDS-resident searches only
     bool done = false;
     int rc = forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out,
-                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out, status_summary);
+                          iters_out, status_out, workspace, workspace_bytes, flags, stream, packed_out, &done, order, order_out, status_summary,
+                          completion_counter);
     if (rc != NASTAR_OK || done || !packed_out) return rc;
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);
+}
+
+int nastar_completion_supported(int H, int W)
+{
+    return (H > 0 && W > 0 && (long long)H * W <= kMaxGlobalCells && !needs_global_state(H, W)) ? 1 : 0;
+}
+
+int nastar_host_wait_nonzero(const volatile int32_t* word_host, int timeout_us)
+{
+    if (!word_host) return 0;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spin = 0;; ++spin) {
+        if (*word_host != 0) return 1;
+        __builtin_ia32_pause();
+        if ((spin & 255u) == 255u) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const long long us = (long long)(t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            if (us >= timeout_us) return *word_host != 0 ? 1 : 0;
+        }
+    }
 }
 
 int nastar_placement_from_levels(const int32_t* levels, int B, int32_t* order_out, void* stream)

@@ -16,7 +16,9 @@
 //   nastar_bfs_level_kernel   one wavefront per map (32x32: lanes 0-31 = rows, 32-bit masks; 64x64: 64 lanes, 64-bit masks)
 //   nastar_rank_levels_kernel ONE workgroup: counting sort of the B levels, longest first (ties in arbitrary order) -> order[B]
 //
-// Both are a few microseconds on 4096 maps; NeuralAstar runs them on a side stream under its encoder (planner/astar.py).
+// 17-44 us on 4096 maps -- worth it only hidden under other work (bench.py: fresh_batches_pipelined runs them on a side stream beside the
+// previous batch's search).  A batch whose samples carry their optimal distance needs neither: nastar_placement_from_levels ranks
+// |opt_dist[start]| with nastar_rank_levels_kernel alone (ops.order_from_levels; what DeviceMazeBatches attaches to every batch).
 #pragma once
 #include "nastar_device.hip.h"
 

@@ -12,7 +12,7 @@
 //     cmin[c] per 64-cell chunk: (key << 32 | cell) of its first minimal open cell, ~0 when it holds none   (u64 order = first-index tie-break)
 //     smin[s] per 64 chunks: the minimum of their cmin entries
 //
-// A step (round 4's kernel, nastar_search_global.hip.h, kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
+// Three launches per call (fill / search / store, see below).  A step of the search (round 4's kernel, nastar_search_global.hip.h, kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
 //   select   ONE ds_read_b64 per lane of smin + a wave minimum: the entry itself names s*                               (LDS only)
 //   load     g / cost of s*, of its 8 neighbours and of the 64 cells of its chunk: issued together, ONE round trip       (HBM)
 //   update   g / pdir stores of the relaxed neighbours (drain overlapped with the LDS work below); chunk minimum without s*
@@ -32,11 +32,13 @@ struct HybridDims {
     float inv_W;   // 1 / W: row of a flat index by one multiply (exact for HW <= 2^18, W <= 512: see hybrid_row)
 };
 
-__host__ __device__ inline size_t hybrid_slab_bytes(int HW)
+// per map: g[HWp] fp32 | pdir[HWp] u8 | (256-byte aligned) header {start cell, goal cell} written by the fill kernel
+__host__ __device__ inline size_t hybrid_header_offset(int HW)
 {
     const size_t HWp = (((size_t)HW + 63) / 64) * 64;
     return (HWp * 5 + 255) & ~(size_t)255;
 }
+__host__ __device__ inline size_t hybrid_slab_bytes(int HW) { return hybrid_header_offset(HW) + 256; }
 __host__ __device__ inline size_t hybrid_lds_bytes(int HW)
 {
     const size_t nchunks = ((size_t)HW + 63) / 64;
@@ -87,6 +89,58 @@ __device__ __forceinline__ uint32_t hybrid_key(const HybridDims& d, float g, flo
     return f32_to_ord(f / d.sqrtW);        // :207  the quotient the reference's softmax orders by (IEEE division)
 }
 
+// Three launches on the caller's stream: FILL (all CUs: node states from the passable map, start / goal cells into the slab header), SEARCH
+// (one wavefront per map: as many maps resident per CU as wave slots allow -- a step is an L2 round trip, residency is what hides it), STORE
+// (all CUs: histories / paths from the slab).  One wavefront filling and storing 262144 cells took 5 ms per map.
+__global__ __launch_bounds__(256) void nastar_hybrid_fill_kernel(const FwdHybridArgs a)
+{
+    const int b = blockIdx.y;
+    const HybridDims d = a.d;
+    const int HWp = d.nchunks * 64;
+    unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
+    float* const g = reinterpret_cast<float*>(slab);
+    uint8_t* const pdir = reinterpret_cast<uint8_t*>(g + HWp);
+    int* const hdr = reinterpret_cast<int*>(slab + hybrid_header_offset(d.HW));  // {-1, -1} on entry (hipMemsetAsync 0xFF)
+    const size_t off = (size_t)b * (size_t)d.HW;
+    int sidx = -1, gidx = -1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HWp; i += gridDim.x * 256) {
+        const bool valid = i < d.HW;
+        if (valid && a.start[off + i] != 0.f) sidx = i;
+        if (valid && a.goal[off + i] != 0.f) gidx = i;
+        const bool pass = valid && a.passable[off + i] != 0.f;
+        g[i] = pass ? NASTAR_POS_INF : NASTAR_NEG_INF;
+        pdir[i] = (uint8_t)(PARENT_UNSET | (pass ? P_PASS : 0u));
+    }
+    if (sidx >= 0) atomicMax(&hdr[0], sidx);  // (the LAST non-zero cell, like the LDS kernels)
+    if (gidx >= 0) atomicMax(&hdr[1], gidx);
+}
+
+__global__ __launch_bounds__(256) void nastar_hybrid_header_kernel(unsigned char* workspace, size_t slab_bytes, size_t header_off, int B)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) {
+        int* hdr = reinterpret_cast<int*>(workspace + (size_t)b * slab_bytes + header_off);
+        hdr[0] = -1;
+        hdr[1] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybridArgs a)
+{
+    const int b = blockIdx.y;
+    const HybridDims d = a.d;
+    const int HWp = d.nchunks * 64;
+    const unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
+    const float* const g = reinterpret_cast<const float*>(slab);
+    const uint8_t* const pdir = reinterpret_cast<const uint8_t*>(g + HWp);
+    const size_t off = (size_t)b * (size_t)d.HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.HW; i += gridDim.x * 256) {
+        const uint32_t m = pdir[i];
+        a.hist[off + i] = ((m & P_PASS) && g[i] == NASTAR_NEG_INF) ? 1.0f : 0.0f;  // closed list (:222-223)
+        a.paths[off + i] = (m & P_PATH) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,30 +153,18 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
     float* const g = reinterpret_cast<float*>(slab);
     uint8_t* const pdir = reinterpret_cast<uint8_t*>(g + HWp);
+    const int* const hdr = reinterpret_cast<const int*>(slab + hybrid_header_offset(d.HW));
     const size_t off = (size_t)b * (size_t)d.HW;
     const float* cost = a.cost + off;
-    const float* start = a.start + off;
-    const float* goal = a.goal + off;
-    const float* passable = a.passable + off;
 
-    // ---- load: start / goal, node states; empty open list -------------------------------------------------------------
-    int sidx = -1, gidx = -1;
-    for (int i = lane; i < HWp; i += 64) {
-        const bool valid = i < d.HW;
-        if (valid && start[i] != 0.f) sidx = i;
-        if (valid && goal[i] != 0.f) gidx = i;
-        const bool pass = valid && passable[i] != 0.f;
-        gst(&g[i], pass ? NASTAR_POS_INF : NASTAR_NEG_INF);
-        gst(&pdir[i], (uint8_t)(PARENT_UNSET | (pass ? P_PASS : 0u)));
-    }
-    sidx = wave_max_i32(sidx);
-    gidx = wave_max_i32(gidx);
+    // ---- start / goal from the fill launch; empty open list -------------------------------------------------------------
+    const int sidx = hdr[0], gidx = hdr[1];
     for (int c = lane; c < d.nsuper * 64; c += 64) cmin[c] = ~0ull;
     smin[lane] = ~0ull;
     const int gi = gidx < 0 ? 0 : gidx;
     int goal_c;
     const int goal_r = hybrid_row(gi, d, goal_c);
-    global_step_fence();
+    __syncthreads();
     if (lane == 0 && sidx >= 0) {  // open list = {start} (:187), g[start] = 0 (:193); the start is expanded even on an obstacle
         int sc;
         const int sr = hybrid_row(sidx, d, sc);
@@ -232,11 +274,6 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
         }
     }
     global_step_fence();
-    for (int i = lane; i < d.HW; i += 64) {
-        const uint32_t m = gld(&pdir[i]);
-        a.hist[off + i] = ((m & P_PASS) && gld(&g[i]) == NASTAR_NEG_INF) ? 1.0f : 0.0f;
-        a.paths[off + i] = (m & P_PATH) ? 1 : 0;
-    }
 }
 
 }  // namespace nastar

@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = (
     "nastar_forward_packed",
     "nastar_forward_ordered",
     "nastar_forward_ex",
+    "nastar_completion_supported",
+    "nastar_host_wait_nonzero",
     "nastar_placement_from_levels",
     "nastar_placement_predict",
     "nastar_backward_workspace_bytes",
@@ -137,7 +139,11 @@ def load() -> ctypes.CDLL:
     lib.nastar_forward_ordered.restype = ci
     lib.nastar_forward_ordered.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp]
     lib.nastar_forward_ex.restype = ci
-    lib.nastar_forward_ex.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp, vp]
+    lib.nastar_forward_ex.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp, vp, vp]
+    lib.nastar_completion_supported.restype = ci
+    lib.nastar_completion_supported.argtypes = [ci, ci]
+    lib.nastar_host_wait_nonzero.restype = ci
+    lib.nastar_host_wait_nonzero.argtypes = [vp, ci]
     lib.nastar_placement_from_levels.restype = ci
     lib.nastar_placement_from_levels.argtypes = [vp, ci, vp, vp]
     lib.nastar_placement_predict.restype = ci

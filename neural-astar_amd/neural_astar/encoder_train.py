@@ -421,14 +421,21 @@ class _CnnTrunk(torch.autograd.Function):
             sync = ctx.sync_state[0]
             h, w = H, W
             wmax = L.weight_maxima(ws) if split else None  # one launch for all D + 1 weight maxima
-            # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs
-            packs = L.pack_all([(ws[l], bs[l], False, l) for l in range(D + 1)] + [(ws[l], None, True, l) for l in range(1, D + 1)],
-                               split, wmax)
             # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros); where nothing
             # else reads the activations of the block in front of it (no pooling, no test probe),
             # that block's BatchNorm + ReLU is applied while the stream loads its pre-activations and the activation tensor never exists
             co1 = cfg.get("co1", CO1_STREAMS) and ws[D].shape[0] == 1 and L.co1_ok(_pad32(ws[D].shape[1]), ws[D].shape[1])
             fuse_act = co1 and D >= 1 and not pool and cfg.get("debug") is None
+            # ... and one for every weight pack of the step: the D + 1 forward forms, then the D input-gradient forms the backward needs --
+            # minus the ones the streams make unnecessary: the padded forward pack of the closing convolution, and its input-gradient pack
+            # where the BatchNorm backward of the block in front forms that gradient on the fly (no pooling)
+            specs = [(ws[l], bs[l], False, l) for l in range(D + 1)] + [(ws[l], None, True, l) for l in range(1, D + 1)]
+            unused = ({D} if co1 else set()) | ({2 * D} if (co1 and D >= 1 and not pool) else set())
+            got = L.pack_all([sp for i, sp in enumerate(specs) if i not in unused], split, wmax)
+            packs = None
+            if got is not None:
+                it = iter(got)
+                packs = [None if i in unused else next(it) for i in range(len(specs))]
             for l in range(D):
                 wt = ws[l]
                 cout, cin_p = wt.shape[0], _pad32(wt.shape[1])
@@ -476,8 +483,12 @@ class _CnnTrunk(torch.autograd.Function):
                 else:
                     acts.append(r)
             wl = ws[D]
-            wpackl, scalel, shiftl, scal = (packs[D] if packs is not None else  # cout 1 -> 32 (padded channels: zero weights, zero shift)
-                                            L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None))
+            if co1:  # streams: no padded pack of the closing convolution
+                wpackl = scalel = shiftl = None
+                scal = wmax[D] if wmax is not None else None
+            else:
+                wpackl, scalel, shiftl, scal = (packs[D] if packs is not None else  # cout 1 -> 32 (padded channels: zero weights, zero shift)
+                                                L.pack(wl, False, split, bs[D], scal=wmax[D] if wmax is not None else None))
             scals.append(scal)
             # the 1-channel closing convolution: a stream over its input (31/32 of a padded matrix product would be zeros)
             if co1 and fuse_act:
@@ -577,7 +588,7 @@ class _CnnTrunk(torch.autograd.Function):
                 if l == 0:
                     break
                 # input gradient: the same convolution with W^T flipped (cin <-> cout; cout 1 of the last block padded to 32 inputs)
-                wpack, scale, shift, _ = ctx.tpacks[l - 1] if ctx.tpacks is not None else L.pack(wt, True, split, scal=ctx.scals[l])
+                wpack, scale, shift, _ = ctx.tpacks[l - 1] if (ctx.tpacks is not None and ctx.tpacks[l - 1] is not None) else L.pack(wt, True, split, scal=ctx.scals[l])
                 da = torch.empty((npix * cin_p * mult,), dtype=torch.int16, device=dev)
                 L.conv(dzb, wpack, scale, shift, B, h, w, cur_co, cin_p, sflag, out=da)
                 C = cin_p

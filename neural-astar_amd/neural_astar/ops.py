@@ -57,47 +57,6 @@ def _order_ptr(order: torch.Tensor, B: int, dev: torch.device, buffer_ok: bool =
     return order.data_ptr()
 
 
-class StatusBoard:
-    """Pinned host memory the search launches write their STATUS SUMMARY into (include/nastar.h: status_summary of nastar_forward_ex): one
-    row of NASTAR_SUMMARY_WORDS int32 per launch in flight; cell c becomes 1 when some map of that launch ended with per-map status c.
-    "Did any map of this batch fail?" is then one 64-byte host read after the stream (or an event) has been waited for -- no reduction
-    launch, no device-to-host copy, nothing on a side stream.  One board per device, rows handed out and returned by the callers."""
-
-    _boards: dict = {}
-
-    def __init__(self, device: torch.device, rows: int = 256):
-        with torch.cuda.device(device):
-            self.t = torch.zeros((rows, SUMMARY_WORDS), dtype=torch.int32).pin_memory()
-        self.np = self.t.numpy()
-        self.base = self.t.data_ptr()
-        self.free = list(range(rows - 1, -1, -1))
-
-    @classmethod
-    def of(cls, device: torch.device) -> "StatusBoard":
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        b = cls._boards.get(key)
-        if b is None:
-            b = cls._boards[key] = cls(device)
-        return b
-
-    def acquire(self) -> int:
-        if not self.free:
-            raise RuntimeError("more than 256 search launches with an unread status: call raise_if_unsolvable() / finish() on the planners that issued them")
-        return self.free.pop()
-
-    def ptr(self, row: int) -> int:
-        return self.base + 4 * SUMMARY_WORDS * row
-
-    def read(self, row: int):
-        """the row as a numpy view if any cell is set, else None (the launch that was handed the row must have finished)"""
-        r = self.np[row]
-        return r if r.any() else None
-
-    def release(self, row: int) -> None:
-        self.np[row] = 0
-        self.free.append(row)
-
-
 # batches from this size on replay their backward longest-first, by the order the forward's searches finished in (one 4 x (B + 1)-byte
 # fill per step buys it; 4096 mazes at Tmax 0.25: 187 -> 133 us for the replay; below ~1000 maps every search has a SIMD to itself)
 PLACEMENT_MIN_BATCH = 1024
@@ -108,6 +67,72 @@ def _maps3(t: torch.Tensor) -> torch.Tensor:
     if t.ndim == 4:
         t = t[:, 0]
     return t.contiguous()
+
+
+class StatusBoard:
+    """Pinned host memory the search launches write their STATUS SUMMARY into (include/nastar.h: status_summary of nastar_forward_ex): one
+    row of NASTAR_SUMMARY_WORDS int32 per launch in flight; cell c (1..15) becomes 1 when some map of that launch ended with per-map status
+    c, cell 0 when every search of the launch is over (completion_counter: one device cell per row).  "Did any map of this batch fail?" is
+    then a poll of one host word and a 64-byte read -- no reduction launch, no device-to-host copy, no stream wait, nothing on a side
+    stream.  One board per device; rows are handed out and returned by the callers."""
+
+    _boards: dict = {}
+
+    def __init__(self, device: torch.device, rows: int = 256):
+        with torch.cuda.device(device):
+            self.t = torch.zeros((rows, SUMMARY_WORDS), dtype=torch.int32).pin_memory()
+            self.counters = torch.zeros((rows,), dtype=torch.int32, device=device)
+        self.np = self.t.numpy()
+        self.base = self.t.data_ptr()
+        self.cbase = self.counters.data_ptr()
+        self.device = device
+        self.free = list(range(rows - 1, -1, -1))
+        self.lib = _native.load()
+
+    @classmethod
+    def of(cls, device: torch.device) -> "StatusBoard":
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        b = cls._boards.get(key)
+        if b is None:
+            b = cls._boards[key] = cls(torch.device("cuda", key))
+        return b
+
+    def acquire(self) -> int:
+        if not self.free:
+            raise RuntimeError("more than 256 search launches with an unread status: call raise_if_unsolvable() / collect() on the planners that issued them")
+        return self.free.pop()
+
+    def ptr(self, row: int) -> int:
+        return self.base + 4 * SUMMARY_WORDS * row
+
+    def counter_ptr(self, row: int) -> int:
+        return self.cbase + 4 * row
+
+    def done(self, row: int) -> bool:
+        """has the launch that was handed ``ptr(row)`` AND ``counter_ptr(row)`` finished every search?  (one host read)"""
+        return bool(self.np[row, 0])
+
+    def wait(self, row: int, stream: Optional["torch.cuda.Stream"] = None, spin_us: int = 2000) -> None:
+        """return once the verdict of the launch that owns ``row`` is complete: poll the completion flag for at most ``spin_us``, then fall
+        back to waiting for ``stream`` (default: the device) -- a launch that carried no completion counter (maps larger than LDS) or one
+        that takes longer than the spin budget ends up there"""
+        if self.np[row, 0] or (spin_us > 0 and self.lib.nastar_host_wait_nonzero(self.ptr(row), spin_us)):
+            return
+        if stream is not None:
+            stream.synchronize()
+        else:
+            torch.cuda.synchronize(self.device)
+        if not self.np[row, 0]:
+            self.counters[row] = 0  # no flag although the launch is over: no counter was passed, or an aborted launch left the cell out of phase
+
+    def read(self, row: int):
+        """the row as a numpy view if any STATUS cell (1..15) is set, else None (the launch that was handed the row must be over: wait())"""
+        r = self.np[row]
+        return r if r[1:].any() else None
+
+    def release(self, row: int) -> None:
+        self.np[row] = 0
+        self.free.append(row)
 
 
 _IN_LDS: dict = {}
@@ -122,7 +147,7 @@ def in_lds(H: int, W: int) -> bool:
 
 
 def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order, summary_ptr, dev,
-                   one_meta=False, stream_ptr=None, out_4d=False):
+                   one_meta=False, stream_ptr=None, out_4d=False, counter_ptr=0):
     """allocate the five outputs and issue ONE nastar_forward_ex launch on torch's current stream (shared by the custom ops and the
     no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape)."""
     shape = (B, 1, H, W) if out_4d else (B, H, W)
@@ -152,7 +177,8 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
     sp = stream_ptr if stream_ptr is not None else torch.cuda.current_stream(dev).cuda_stream
     args = (cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W, float(g_ratio), int(max_iters), hist.data_ptr(),
             paths.data_ptr(), sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
-            workspace.data_ptr() if workspace is not None else None, ws_bytes, flags, op or None, oo or None, summary_ptr or None, sp)
+            workspace.data_ptr() if workspace is not None else None, ws_bytes, flags, op or None, oo or None, summary_ptr or None,
+            (counter_ptr or None) if summary_ptr else None, sp)
     if dev.index is None or torch.cuda.current_device() == dev.index:
         rc = lib.nastar_forward_ex(*args)
     else:
@@ -214,11 +240,12 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, o
 def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, obstacles_maps: torch.Tensor, g_ratio: float,
                   max_iters: int, want_log: bool = False, flags: int = 0, order: Optional[torch.Tensor] = None,
                   order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None,
-                  out_4d: bool = False):
+                  out_4d: bool = False, counter_ptr: int = 0):
     """The search launch WITHOUT the torch.library dispatch: what ``DifferentiableAstar.forward`` calls when no gradient can flow
     (``torch.no_grad()`` / inputs that do not require one) and nothing is being traced -- the custom-op machinery costs more host time
     than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs
     (``out_4d``: histories / paths as [B,1,H,W], the AstarOutput layout, and None instead of an empty selection log).
+    ``summary_ptr`` / ``counter_ptr``: a ``StatusBoard`` row (status summary in pinned memory + its completion counter on the device).
     ``stream_ptr``: a hipStream_t to launch on instead of torch's current stream (``parallel.InFlightPlanner``; the outputs are
     allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them)."""
     if not (cost_maps.is_cuda and start_maps.is_cuda and goal_maps.is_cuda and obstacles_maps.is_cuda
@@ -243,7 +270,7 @@ def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: 
     if not goal_maps.is_contiguous():
         goal_maps = goal_maps.contiguous()
     return _launch_search(_native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters, want_log, flags,
-                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d)
+                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d, counter_ptr)
 
 
 def order_from_levels(levels: torch.Tensor) -> torch.Tensor:

@@ -254,11 +254,7 @@ class InFlightPlanner:
         then does not wait for the current stream."""
         if not map_designs.is_cuda:
             raise RuntimeError("InFlightPlanner needs tensors on a HIP device (no CPU path)")
-        dev = map_designs.device
-        self._setup(dev)
-        planner, astar = self.planner, self.planner.astar
-        k = self._k % self.n_streams
-        st = self._streams[k]
+        planner = self.planner
         encode = getattr(planner, "encode", None)
         with torch.no_grad():
             if encode is not None:
@@ -267,21 +263,37 @@ class InFlightPlanner:
                 # the batch's stream, behind the encoder
                 cost = encode(map_designs, start_maps, goal_maps)
                 passable = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
-                same = False
-                inputs_ready = False
-            else:
-                cost = passable = map_designs
-                same = True
-            if not inputs_ready:  # (st.wait_stream() with a reused event: this runs once per batch)
-                ev = self._events[k]
-                ev.record(torch.cuda.current_stream(dev))
-                st.wait_event(ev)
+                return self.submit_search(cost, start_maps, goal_maps, passable, False)
+            return self.submit_search(map_designs, start_maps, goal_maps, map_designs, inputs_ready)
+
+    def submit_search(self, cost: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, passable: torch.Tensor,
+                      inputs_ready: bool = False) -> int:
+        """Queue ONE search launch on the next stream: ``planner.astar``'s g_ratio, eval-mode budget, no gradients (the validation pair of
+        ``utils.training.PlannerModule.validate`` stacks the planner's and the VanillaAstar problem into one such launch).  ``passable is
+        cost`` (one binary tensor) is what the unit-cost kernel needs."""
+        dev = cost.device
+        self._setup(dev)
+        astar = self.planner.astar
+        k = self._k % self.n_streams
+        st = self._streams[k]
+        same = passable is cost
+        with torch.no_grad():
+            if not inputs_ready:
+                cur = torch.cuda.current_stream(dev)
+                # the batch's inputs (and the memory the allocator hands out for its outputs) belong to the CURRENT stream: the launch stream
+                # must come after whatever is still pending there.  An idle current stream -- resident inputs, the usual case of an
+                # evaluation sweep -- needs no dependency, and it matters: a cross-stream event costs ~20 us of GPU time per batch
+                # (probe_boundary: 45 M instead of 66 M maps/s on 4096-map maze batches)
+                if not cur.query():
+                    ev = self._events[k]
+                    ev.record(cur)
+                    st.wait_event(ev)
             max_iters = ops.max_iters_for(start_maps.shape[-1], 1.0, False)
             unit = same and self.unit_cost in (True, "auto")
             flags = ops.FLAG_UNIT_COST if unit else 0
             order = check = None
             hint = getattr(start_maps, "placement_order", None)
-            if hint is not None and ops.workspace_bytes(start_maps.shape) == 0:
+            if hint is not None and ops.in_lds(start_maps.shape[-2], start_maps.shape[-1]):
                 o = hint.order if isinstance(hint, ops.OrderHint) else hint
                 if torch.is_tensor(o) and o.numel() == start_maps.shape[0] and o.dtype == torch.int32 and o.device == dev:
                     order, check = o.reshape(-1), not getattr(hint, "trusted", False)

@@ -32,22 +32,29 @@ class UnsolvableMapError(RuntimeError):
 
 
 class _PendingStatus:
-    """status of an earlier launch on its way to the host: the launch itself writes its summary into a pinned ``ops.StatusBoard`` row;
-    an event recorded behind it on the SAME stream says when the row may be read -- no reduction launch, no copy, no side stream"""
+    """status of an earlier launch on its way to the host: the launch itself writes its summary -- and, when every search is over, its
+    completion flag -- into a pinned ``ops.StatusBoard`` row.  Nothing is recorded, copied or launched for it: ``done()`` is one host
+    read; ``stream`` is only the fall-back for launches that carry no completion counter (maps larger than LDS)."""
 
-    def __init__(self, status: torch.Tensor, row: int, seq: int = 0):
+    def __init__(self, status: torch.Tensor, row: int, seq: int = 0, flagged: bool = True):
         self.status = status
         self.seq = seq
         self.row = row
         self.board = ops.StatusBoard.of(status.device)
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(status.device))
+        self.stream = torch.cuda.current_stream(status.device)
+        self.event = None
+        if not flagged:
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
 
     def done(self) -> bool:
-        return self.event.query()
+        return self.board.done(self.row) if self.event is None else self.event.query()
 
     def raise_if_unsolvable(self) -> None:
-        self.event.synchronize()
+        if self.event is None:
+            self.board.wait(self.row, self.stream)
+        else:
+            self.event.synchronize()
         bad = self.board.read(self.row) is not None
         self.board.release(self.row)
         if bad:
@@ -121,11 +128,11 @@ class DifferentiableAstar(nn.Module):
                 the cost map and the obstacle map are ONE tensor -- ``VanillaAstar.forward`` (reference astar.py:93-94) -- and no
                 gradient or selection log is wanted.  On binary maps every cell the search can touch then costs 1.0, the LDS state
                 needs no cost word, and 29 instead of 16 maps of 32x32 are resident per CU: same outputs, ~1.5x the maps/s with
-                several batches in flight.  The kernel CHECKS the promise per map.  ``"auto"`` (default): taken whenever this call
-                reads the status itself (``check_solvable`` True / "sync", no graph capture) -- a batch with a non-binary map is then
-                re-run on the general kernel inside the same call, so the result never depends on the promise; ``True``: always
-                (a map that breaks the promise raises ``ValueError``, with "deferred" checking possibly from a later call);
-                ``False``: never.
+                SEVERAL batches in flight.  One launch at a time is a serial chain that gains nothing from the layout, so
+                ``forward()`` takes it only with ``True`` (the kernel CHECKS the promise per map; a map that breaks it raises
+                ``ValueError``, with "deferred" checking possibly from a later call); ``"auto"`` (default) and ``False`` run the
+                general kernel here.  ``parallel.InFlightPlanner`` is where "auto" means unit-cost first (with a re-run of the
+                rare non-binary batch at collection).
         """
         super().__init__()
         nf = torch.ones(1, 1, 3, 3)
@@ -179,23 +186,29 @@ class DifferentiableAstar(nn.Module):
     def summary_ptr(row: int, like: torch.Tensor) -> int:
         return ops.StatusBoard.of(like.device).ptr(row) if row >= 0 else 0
 
-    def _collect_sync(self, row: int, device: torch.device):
-        """wait for the stream the launch went to and return a COPY of its summary row (None = every map ended with status 0)"""
+    @staticmethod
+    def counter_ptr(row: int, like: torch.Tensor) -> int:
+        """the completion counter of the row (device cell), for launches of LDS-resident sizes; 0 otherwise"""
+        return ops.StatusBoard.of(like.device).counter_ptr(row) if (row >= 0 and ops.in_lds(like.shape[-2], like.shape[-1])) else 0
+
+    def _collect_sync(self, row: int, device: torch.device, flagged: bool = False):
+        """wait for the launch that owns ``row`` and return a COPY of its summary row (None = every map ended with status 0);
+        ``flagged``: the launch was given the row's completion counter"""
         board = ops.StatusBoard.of(device)
-        torch.cuda.current_stream(device).synchronize()  # the ONE device->host wait of a checked call
+        # the ONE device->host wait of a checked call: a poll of the launch's completion flag in pinned memory (no stream wait, no driver
+        # wake-up; the outputs themselves stay stream-ordered), falling back to the stream for launches without a completion counter
+        board.wait(row, torch.cuda.current_stream(device), 2000 if flagged else 0)
         r = board.np[row]
-        if not r.any():  # (the row is still all zero: nothing to clear)
-            board.free.append(row)
-            return None
-        r = r.copy()
+        r = r.copy() if r[1:].any() else None
         board.release(row)
         return r
 
-    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1) -> None:
+    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1, flagged: bool = False) -> None:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
         step and the validation pair, which launch the search themselves).  ``row``: the ``begin_launch()`` row whose address the
-        launch was given as ``summary_ptr`` -- the verdict is then one host read after the stream wait ("sync") or after an event
-        ("deferred"); without a row the status tensor is reduced on the device (one more launch + a blocking copy).  ``clean``: the
+        launch was given as ``summary_ptr`` (``flagged``: and its ``counter_ptr``) -- the verdict is then a poll of the row's completion flag
+        (unflagged: a stream wait / an event) and one 64-byte host read; without a row the status tensor is reduced on the device (one
+        more launch + a blocking copy).  ``clean``: the
         caller has already read the verdict on the host (True = all zero) -- the "sync" policy then does not wait a second time."""
         self.last_status, self.last_iters = status, iters
         self._calls += 1
@@ -208,7 +221,7 @@ class DifferentiableAstar(nn.Module):
             return
         if mode != "deferred":  # True / "sync": the verdict belongs to THIS call
             if clean is None and row >= 0:
-                summ = self._collect_sync(row, status.device)
+                summ = self._collect_sync(row, status.device, flagged)
                 row = -1
                 clean = summ is None or not (summ[1:ops.SUMMARY_BAD_ORDER].any())
                 if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
@@ -221,7 +234,8 @@ class DifferentiableAstar(nn.Module):
         if row < 0:  # a launch that carried no summary: reduce on the device into a fresh row's worth of pinned memory
             row = ops.StatusBoard.of(status.device).acquire()
             ops.StatusBoard.of(status.device).t[row, ops.STATUS_UNSOLVABLE:ops.STATUS_UNSOLVABLE + 1].copy_((status != 0).any().reshape(1), non_blocking=True)
-        self._pending.append(_PendingStatus(status, row, self._calls))
+            flagged = False
+        self._pending.append(_PendingStatus(status, row, self._calls, flagged))
         if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
             self._pending.pop(0).raise_if_unsolvable()
 
@@ -267,8 +281,10 @@ class DifferentiableAstar(nn.Module):
         same = obstacles_maps is cost_maps or (cost_maps.data_ptr() == obstacles_maps.data_ptr() and cost_maps.shape == obstacles_maps.shape
                                                and cost_maps.stride() == obstacles_maps.stride())
         mode = self.check_solvable
-        sync_check = (mode is True or mode == "sync") and not capturing
-        unit = (same and not want_log and (self.unit_cost is True or (self.unit_cost == "auto" and sync_check)))
+        # the unit-cost layout pays with SEVERAL launches in flight (more maps resident per CU); one launch at a time is a serial chain whose
+        # length does not depend on the layout (probe_boundary: 117 us unit vs 114 us general per placed 4096-map launch), so forward()
+        # takes it only on request -- parallel.InFlightPlanner is where "auto" means "unit-cost first"
+        unit = same and not want_log and self.unit_cost is True
         in_lds = ops.in_lds(H, W)
         # a recurring batch starts its longest searches first (Placement), a fresh one by its loader's hint; maps whose state lives in HBM take no placement
         if self.placement is None and not hasattr(start_maps, "placement_order"):
@@ -280,6 +296,7 @@ class DifferentiableAstar(nn.Module):
         board = ops.StatusBoard.of(dev) if (mode and cost_maps.is_cuda and not capturing) else None
         row = board.acquire() if board is not None else -1
         sptr = board.ptr(row) if board is not None else 0
+        cptr = board.counter_ptr(row) if (board is not None and in_lds) else 0
         flags = ops.FLAG_UNIT_COST if unit else 0
         traced = needs_grad or type(cost_maps) is not torch.Tensor or torch.compiler.is_compiling()
         try:
@@ -287,7 +304,7 @@ class DifferentiableAstar(nn.Module):
                 # no gradient can flow and nothing is tracing: straight to the C ABI (no torch.library dispatch)
                 hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
                                                                         self.g_ratio, max_iters, want_log, flags, order, order_out, check_order, sptr,
-                                                                        None, True)
+                                                                        None, True, cptr)
             else:
                 cost, start, goal, passable = cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles_maps[:, 0]
                 if needs_grad and in_lds and (order is not None or order_out is not None or B >= ops.PLACEMENT_MIN_BATCH):
@@ -306,21 +323,9 @@ class DifferentiableAstar(nn.Module):
                 board.release(row)
             raise
         clean = None
-        if unit and self.unit_cost == "auto" and row >= 0:
-            summ = self._collect_sync(row, dev)  # the ONE device->host wait of this call (note_status does not wait again)
-            row = -1
-            clean = summ is None or not summ[1:ops.SUMMARY_BAD_ORDER].any()
-            if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
-                _warn_bad_order()
-            if summ is not None and summ[ops.STATUS_NOT_UNIT_COST]:
-                # a map with values other than 0 / 1: the whole batch again on the general kernel (same call, same outputs contract)
-                row = self.begin_launch(cost_maps)
-                hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps, self.g_ratio, max_iters, want_log, 0,
-                                                                        order, order_out, check_order, self.summary_ptr(row, cost_maps), None, True)
-                clean = None
         if pl is not None and order_out is not None:
             pl.commit()
-        self.note_status(status, iters, clean, row)
+        self.note_status(status, iters, clean, row, flagged=bool(cptr) and not traced)  # (the custom ops carry the summary, not the counter)
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:

@@ -33,7 +33,7 @@ except ImportError:  # pragma: no cover - depends on the environment
     pl = None
     _ModuleBase = nn.Module
 
-__all__ = ["load_from_ptl_checkpoint", "PlannerModule", "set_global_seeds", "fused_l1_step"]
+__all__ = ["load_from_ptl_checkpoint", "PlannerModule", "set_global_seeds", "fused_l1_step", "validate_in_flight"]
 
 
 def load_from_ptl_checkpoint(checkpoint_path: str) -> dict:
@@ -91,6 +91,10 @@ class PlannerModule(_ModuleBase):
         self.log("metrics/train_loss", loss)
         return loss
 
+    def validate(self, loader, streams: int = 4) -> dict:
+        """a whole validation pass with the searches in flight: see ``validate_in_flight``"""
+        return validate_in_flight(self, loader, streams)
+
     def validation_step(self, val_batch, batch_idx):
         map_designs, start_maps, goal_maps, opt_trajs = val_batch
         astar = getattr(self.planner, "astar", None)
@@ -109,6 +113,56 @@ class PlannerModule(_ModuleBase):
         loss = nn.L1Loss()(outputs.histories, opt_trajs)
         self.log("metrics/val_loss", loss)
         return loss
+
+
+def validate_in_flight(module: "PlannerModule", loader, streams: int = 4) -> dict:
+    """One validation pass over ``loader`` with the searches IN FLIGHT (``parallel.InFlightPlanner``): the mean, over the batches, of what
+    ``PlannerModule.validation_step`` logs per batch (``metrics/val_loss`` and, for shortest-path problems, ``p_opt`` / ``p_exp`` /
+    ``h_mean``; reference utils/training.py:63-87 -- Lightning averages the per-batch values the same way).  Per batch the planner's
+    and the VanillaAstar search are ONE launch, as in ``validation_step``; the launches of consecutive batches overlap (a 4096-map
+    launch is as long as its longest search: 3-4 in flight sustain 2-3x the maps/s), the encoder runs batch after batch on the current
+    stream, the metrics are reduced on the device when everything has been collected.  Falls back to ``validation_step`` per batch for
+    planners the pair launch does not cover."""
+    from ..parallel import InFlightPlanner
+    planner = module.planner
+    pair_ok = (hasattr(planner, "encode") and not planner.training and float(planner.g_ratio) == 0.5)
+    sums: dict = {}
+    n = 0
+    if not pair_ok:
+        for i, batch in enumerate(loader):
+            module.logged = {}
+            module.validation_step(batch, i)
+            for k, v in module.logged.items():
+                sums[k] = sums.get(k, 0.0) + v.detach().double()
+            n += 1
+        return {k: v / max(n, 1) for k, v in sums.items()}
+    fly = InFlightPlanner(planner, streams=streams, unit_cost=False)
+    kept = []
+    with torch.no_grad():
+        for map_designs, start_maps, goal_maps, opt_trajs in loader:
+            shortest = map_designs.shape[1] == 1
+            cost = planner.encode(map_designs, start_maps, goal_maps)
+            passable = map_designs if not planner.learn_obstacles else torch.ones_like(start_maps)
+            if shortest:  # the planner's problem and the VanillaAstar problem stacked along the batch dimension (maps are independent)
+                fly.submit_search(torch.cat((cost, map_designs), 0), torch.cat((start_maps, start_maps), 0), torch.cat((goal_maps, goal_maps), 0),
+                                  torch.cat((passable, map_designs), 0))
+            else:
+                fly.submit_search(cost, start_maps, goal_maps, passable)
+            kept.append((opt_trajs, shortest, map_designs.shape[0]))
+        outs = fly.collect()
+        for out, (opt_trajs, shortest, B) in zip(outs, kept):
+            o = AstarOutput(out.histories[:B], out.paths[:B], [])
+            vals = {"metrics/val_loss": nn.L1Loss()(o.histories, opt_trajs)}
+            if shortest:
+                m = validation_metrics(o, AstarOutput(out.histories[B:], out.paths[B:], []))
+                vals.update({"metrics/p_opt": m.p_opt, "metrics/p_exp": m.p_exp, "metrics/h_mean": m.h_mean})
+            for k, v in vals.items():
+                sums[k] = sums.get(k, 0.0) + v.double()
+            n += 1
+    res = {k: v / max(n, 1) for k, v in sums.items()}
+    for k, v in res.items():
+        module.log(k, v)
+    return res
 
 
 def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,

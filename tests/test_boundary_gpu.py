@@ -73,7 +73,7 @@ def test_status_summary_is_written_by_the_launch_into_pinned_host_memory():
     it = torch.empty(3, dtype=torch.int32, device=dev)
     stt = torch.empty(3, dtype=torch.int32, device=dev)
     rc = lib.nastar_forward_ex(c.data_ptr(), st[:, 0].contiguous().data_ptr(), gt[:, 0].contiguous().data_ptr(), c.data_ptr(), 3, 16, 16, 0.5, 256,
-                               hist.data_ptr(), paths.data_ptr(), None, it.data_ptr(), stt.data_ptr(), None, None, 0, 0, None, None, summ.data_ptr(),
+                               hist.data_ptr(), paths.data_ptr(), None, it.data_ptr(), stt.data_ptr(), None, None, 0, 0, None, None, summ.data_ptr(), None,
                                torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert summ.tolist() == [0, 0, 0, 1] + [0] * 12
@@ -421,3 +421,35 @@ def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
         na.encoder_backend = "torch"
         na(wide, sw, gw)
         assert na.last_encoder_route == "torch.nn"
+
+
+def test_validation_pass_in_flight_equals_the_per_batch_steps(tmp_path):
+    """PlannerModule.validate(loader): planner + VanillaAstar pair per batch in one launch, launches of consecutive batches in flight ==
+    the mean of what validation_step logs batch by batch (reference utils/training.py:63-87)."""
+    from types import SimpleNamespace
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    from neural_astar.utils.data import create_device_loader
+    from neural_astar.utils.training import PlannerModule
+    f = str(tmp_path / "mazes.npz")
+    syn.write_maze_npz(f, n_train=8, n_valid=96, n_test=8, size=32, seed=5)
+    gen = torch.Generator(device=_dev())
+    gen.manual_seed(3)
+    batches = list(create_device_loader(f, "valid", 32, _dev(), generator=gen))
+    assert len(batches) == 3
+    torch.manual_seed(0)
+    mod = PlannerModule(NeuralAstar(encoder_arch="CNN").to(_dev()), SimpleNamespace(params=SimpleNamespace(lr=1e-3))).to(_dev())
+    mod.planner.eval()
+    mod.vanilla_astar.eval()
+    acc = {}
+    with torch.no_grad():
+        for i, b in enumerate(batches):
+            mod.logged = {}
+            mod.validation_step(b, i)
+            for k, v in mod.logged.items():
+                acc[k] = acc.get(k, 0.0) + float(v)
+    ref = {k: v / len(batches) for k, v in acc.items()}
+    got = mod.validate(batches, streams=3)
+    assert set(got) == set(ref) == {"metrics/val_loss", "metrics/p_opt", "metrics/p_exp", "metrics/h_mean"}
+    for k in ref:
+        assert abs(float(got[k]) - ref[k]) < 1e-6, (k, float(got[k]), ref[k])

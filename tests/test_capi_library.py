@@ -30,7 +30,10 @@ def test_library_builds_loads_and_exports_everything():
     assert lib.nastar_version() == int(re.search(r"#define NASTAR_VERSION (\d+)", hdr).group(1)) >= 300  # the library matches the header
     assert lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
     assert lib.nastar_workspace_bytes(2, 128, 128, 0) == 0  # 9 B/cell compact state: 128x128 still fits one CU's LDS
-    assert lib.nastar_workspace_bytes(2, 200, 150, 0) >= 2 * 200 * 150 * 17  # larger maps keep their state in the workspace
+    assert 2 * 200 * 150 * 5 <= lib.nastar_workspace_bytes(2, 200, 150, 0) < 2 * 200 * 150 * 6  # larger maps: 5 B/cell in the workspace (open list in LDS)
+    assert lib.nastar_workspace_bytes(2, 200, 150, 512) >= 2 * 200 * 150 * 17  # ... 17 B/cell for the round-4 kernel (NASTAR_FLAG_GLOBAL_V1, A/B)
+    assert lib.nastar_completion_supported(32, 32) == 1 and lib.nastar_completion_supported(200, 150) == 0
+    assert lib.nastar_host_wait_nonzero(None, 10) == 0
     assert lib.nastar_backward_workspace_bytes(4, 32, 32, 256) >= 4 * 258 * 16  # replay backward: 16 B of history per step
     assert lib.nastar_last_error() == b""
 
@@ -52,11 +55,11 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_forward_ordered(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, None, one, None) == _native.NASTAR_ERR_UNSUPPORTED
     # nastar_forward_ex (0.5.0): the same checks; a CHECKED order needs its 16-byte verdict word in the workspace
-    assert lib.nastar_forward_ex(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, None, None, None, None) == _native.NASTAR_ERR_NULL
-    assert lib.nastar_forward_ex(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward_ex(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, None, 0, 0, None, None, None, None, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_ex(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, one, 1 << 30, 0, one, None, None, None, None) == _native.NASTAR_ERR_UNSUPPORTED
     assert lib.nastar_workspace_bytes(4096, 32, 32, 256) == 16 and lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
-    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, None, 0, 256, one, None, None, None) == _native.NASTAR_ERR_NULL
-    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, one, 8, 256, one, None, None, None) == _native.NASTAR_ERR_WORKSPACE
+    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, None, 0, 256, one, None, None, None, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_ex(one, one, one, one, 4, 32, 32, 0.5, 64, one, one, None, one, one, None, one, 8, 256, one, None, None, None, None) == _native.NASTAR_ERR_WORKSPACE
     assert lib.nastar_placement_from_levels(None, 4, one, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_placement_from_levels(one, 0, one, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_backward_replay(None, one, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, one, 64, 0, None) == _native.NASTAR_ERR_NULL

@@ -849,8 +849,8 @@ def test_unit_cost_kernel_edge_cases_and_the_promise_check():
     finally:
         ops.FORWARD_FLAGS = prev
     assert np.array_equal(sep[0], gen[0]) and np.array_equal(sep[1], gen[1]) and (sep[3] == 0).all()
-    va = VanillaAstar().to(_dev()).eval()           # (e)
-    seen = []
+    va = VanillaAstar().to(_dev()).eval()           # (e) forward(): the general kernel unless unit_cost=True (one launch at a time gains nothing
+    seen = []                                       #     from the layout; InFlightPlanner is where "auto" means unit-cost first, test_boundary_gpu.py)
     orig = ops.search_nograd
 
     def spy(*a, **k):
@@ -861,9 +861,14 @@ def test_unit_cost_kernel_edge_cases_and_the_promise_check():
         with torch.no_grad():
             out = va(_t(pr.map_designs), _t(pr.start_maps), _t(pr.goal_maps))
             out2 = va(_t(m2), _t(pr.start_maps), _t(pr.goal_maps))
+            va.astar.unit_cost = True
+            out3 = va(_t(pr.map_designs), _t(pr.start_maps), _t(pr.goal_maps))
+            with pytest.raises(ValueError, match="unit_cost=True"):
+                va(_t(m2), _t(pr.start_maps), _t(pr.goal_maps))
     finally:
         ops.search_nograd = orig
-    assert seen == [64, 64, 0], seen                # binary batch: unit kernel; non-binary batch: unit kernel, then the general one
+    assert seen == [0, 0, 64, 64], seen
+    assert torch.equal(out3.histories, out.histories) and torch.equal(out3.paths, out.paths)
     full = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 0)
     assert np.array_equal(out.histories[:, 0].cpu().numpy(), full[0]) and np.array_equal(out.paths[:, 0].cpu().numpy(), full[1])
     assert np.array_equal(out2.histories[:, 0].cpu().numpy(), gen[0]) and np.array_equal(out2.paths[:, 0].cpu().numpy(), gen[1])

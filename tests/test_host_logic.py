@@ -431,3 +431,38 @@ def test_placement_memory_alternates_its_buffers_and_is_not_module_state():
         assert clone.astar.placement is None
     q = pickle.loads(pickle.dumps(p))
     assert q.bufs is None and not q.valid
+
+
+def test_no_name_is_used_that_no_scope_of_its_module_defines():
+    """A cheap static net under the GPU-only code paths (nothing on this box executes them): every name LOADED anywhere in a product module
+    must be bound somewhere in that module (any scope), imported, or a builtin.  Catches a helper or constant lost in an edit before
+    the GPU box does."""
+    import ast
+    import builtins
+    import glob
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-astar_amd", "neural_astar")
+    files = glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True) + [os.path.join(os.path.dirname(pkg), "..", "bench.py")]
+    bad = []
+    for f in files:
+        tree = ast.parse(open(f).read())
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                bound.add(node.name)
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                a = node.args
+                for x in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []):
+                    bound.add(x.arg)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                bound.add(node.id)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                for al in node.names:
+                    bound.add((al.asname or al.name).split(".")[0])
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                bound.add(node.name)
+            elif isinstance(node, (ast.Global, ast.Nonlocal)):
+                bound.update(node.names)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in bound:
+                bad.append(f"{os.path.relpath(f, pkg)}:{node.lineno}: {node.id}")
+    assert not bad, bad

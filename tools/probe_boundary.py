@@ -36,7 +36,7 @@ def raw_sync_floor(m, s, g, order, flags, reps=100):
 
     def one():
         lib.nastar_forward_ex(m.data_ptr(), s.data_ptr(), g.data_ptr(), m.data_ptr(), B, H, W, 0.5, W * W, hist.data_ptr(), paths.data_ptr(), None,
-                              it.data_ptr(), st.data_ptr(), None, None, 0, flags, order.data_ptr() if order is not None else None, None, None,
+                              it.data_ptr(), st.data_ptr(), None, None, 0, flags, order.data_ptr() if order is not None else None, None, None, None,
                               stream.cuda_stream)
     for _ in range(10):
         one()

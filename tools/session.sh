@@ -270,6 +270,14 @@ r05_c)
   python -m pytest tests/test_boundary_gpu.py tests/test_tie_class.py -q -m gpu > $O/boundary.log 2>&1; echo "boundary rc=$?"; tail -5 $O/boundary.log
   python -m pytest tests/test_gpu_parity.py -q -m gpu -k "unit_cost or placement or unsolvable or hipgraph or planner_modules" > $O/parity_subset.log 2>&1; echo "parity rc=$?"; tail -5 $O/parity_subset.log
   ;;
+r05_d)
+  # completion flag + lean boundary: probe again; large maps: parity (oracle at 256^2 / 512^2, hybrid vs round-4 kernel), ns per step; then the suite
+  O=gpurun_out/r05/d; mkdir -p $O
+  python -m pytest tests/test_large_maps_gpu.py tests/test_boundary_gpu.py tests/test_tie_class.py -q -m gpu > $O/new_tests.log 2>&1; echo "new tests rc=$?"; tail -8 $O/new_tests.log
+  python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; tail -2 $O/probe_large.err; cat $O/probe_large.jsonl
+  python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err; echo "probe rc=$?"; tail -3 $O/probe_boundary.err; cat $O/probe_boundary.jsonl
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -8 $O/all_gpu_tests.log
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
