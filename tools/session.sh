@@ -278,6 +278,14 @@ r05_d)
   python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err; echo "probe rc=$?"; tail -3 $O/probe_boundary.err; cat $O/probe_boundary.jsonl
   python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -8 $O/all_gpu_tests.log
   ;;
+r05_e)
+  # after the fixes: whole GPU suite, large-map probe (fill / search / store launches), 8 gloo ranks sharing the GPU (every world > 1 branch of bench.py)
+  O=gpurun_out/r05/e; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/all_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -12 $O/all_gpu_tests.log | cut -c1-300
+  python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; cat $O/probe_large.jsonl
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 10 --warmup 3 --dist-backend gloo --share-gpu --no-secondary --no-cpu-baseline > $O/world8_maze32_weak.json 2> $O/world8_maze32_weak.err; echo "world8 weak rc=$?"; tail -2 $O/world8_maze32_weak.err; cut -c1-600 $O/world8_maze32_weak.json
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 8 --steps 10 --warmup 3 --dist-backend gloo --share-gpu --no-secondary --no-cpu-baseline --workload rand64 --global-batch 32768 --shard interleaved > $O/world8_rand64_interleaved.json 2> $O/world8_rand64_interleaved.err; echo "world8 rand64 rc=$?"; tail -2 $O/world8_rand64_interleaved.err; cut -c1-600 $O/world8_rand64_interleaved.json
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
