@@ -468,6 +468,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             hd.H = H; hd.W = W; hd.HW = H * W;
             hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
             hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
+            hd.rcp_sqrtW = 1.0f / hd.sqrtW;
             hd.inv_W = 1.0f / (float)W;
             hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
             // headers (start / goal cell per map) to -1: the fill launch raises them with atomicMax
@@ -483,7 +484,8 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             const unsigned per_map = (unsigned)((hd.nchunks * 64 + 255) / 256);
             const dim3 grid2(per_map < 64u ? per_map : 64u, (unsigned)B);
             hipLaunchKernelGGL(nastar_hybrid_fill_kernel, grid2, dim3(256), 0, hs, ha);
-            int rc2 = launch(nastar_forward_hybrid_kernel, B, hybrid_lds_bytes(hd.HW), hs, ha);
+            int rc2 = fastdiv_verified(W) ? launch(nastar_forward_hybrid_kernel<true>, B, hybrid_lds_bytes(hd.HW), hs, ha)
+                                          : launch(nastar_forward_hybrid_kernel<false>, B, hybrid_lds_bytes(hd.HW), hs, ha);
             if (rc2) return rc2;
             hipLaunchKernelGGL(nastar_hybrid_store_kernel, grid2, dim3(256), 0, hs, ha);
             hipError_t he = hipGetLastError();

@@ -28,7 +28,7 @@ struct HybridDims {
     int H, W, HW;
     int nchunks;   // ceil(HW / 64)
     int nsuper;    // ceil(nchunks / 64) <= 64
-    float gr, omg, sqrtW;
+    float gr, omg, sqrtW, rcp_sqrtW;
     float inv_W;   // 1 / W: row of a flat index by one multiply (exact for HW <= 2^18, W <= 512: see hybrid_row)
 };
 
@@ -74,19 +74,31 @@ __device__ __forceinline__ int hybrid_row(int i, const HybridDims& d, int& c)
     return r;
 }
 
-// minimum of a u64 per lane over the wavefront, in every lane (high word first, then the low word among the lanes that hold it)
-__device__ __forceinline__ unsigned long long wave_min_all_u64(unsigned long long v)
+// first-index minimum of per-lane (key, cell) entries = the u64 minimum of (key << 32 | cell), in every lane and without leaving the vector
+// registers: the key minimum, then the cell minimum among the lanes that hold it.  (A scalar form -- v_readlane of the minimum, ballot, s_ff1,
+// v_readlane of the cell -- is three instructions shorter and was 28 % SLOWER per step: each VALU -> SALU -> VALU hop costs a lone wavefront
+// ~25 cycles, profiles/r05/probe_large_scalar_reductions.jsonl.)
+__device__ __forceinline__ unsigned long long first_min_entry(uint32_t key, uint32_t cell)
 {
-    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-    const uint32_t mh = wave_min_all_u32(hi);
-    const uint32_t ml = wave_min_all_u32(hi == mh ? lo : 0xFFFFFFFFu);
-    return ((unsigned long long)mh << 32) | ml;
+    const uint32_t m = wave_min_all_u32(key);
+    const uint32_t c = wave_min_all_u32(key == m ? cell : 0xFFFFFFFFu);
+    return m == KEY_INF ? ~0ull : (((unsigned long long)m << 32) | c);
 }
 
+template <bool kFastDiv>
 __device__ __forceinline__ uint32_t hybrid_key(const HybridDims& d, float g, float h)
 {
     const float f = d.gr * g + d.omg * h;   // :206  f = g_ratio * g + (1 - g_ratio) * h
-    return f32_to_ord(f / d.sqrtW);        // :207  the quotient the reference's softmax orders by (IEEE division)
+    float q;
+    if constexpr (kFastDiv) {
+        // correctly rounded f / sqrt(W) (exhaustively verified per W, tools/fastdiv_check.c; the LDS kernels use the same three instructions)
+        const float q0 = f * d.rcp_sqrtW;
+        const float rem = __builtin_fmaf(-q0, d.sqrtW, f);
+        q = __builtin_fmaf(rem, d.rcp_sqrtW, q0);
+    } else {
+        q = f / d.sqrtW;                    // :207  the quotient the reference's softmax orders by (IEEE division)
+    }
+    return f32_to_ord(q);
 }
 
 // Three launches on the caller's stream: FILL (all CUs: node states from the passable map, start / goal cells into the slab header), SEARCH
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybri
     }
 }
 
+template <bool kFastDiv>
 __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     if (lane == 0 && sidx >= 0) {  // open list = {start} (:187), g[start] = 0 (:193); the start is expanded even on an obstacle
         int sc;
         const int sr = hybrid_row(sidx, d, sc);
-        const uint32_t k0 = hybrid_key(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
+        const uint32_t k0 = hybrid_key<kFastDiv>(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
         const unsigned long long e = ((unsigned long long)k0 << 32) | (uint32_t)sidx;
         gst(&g[sidx], 0.0f);
         gst(&pdir[sidx], (uint8_t)(PARENT_UNSET | P_PASS));
@@ -187,7 +200,8 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     } else {
         while (iters < a.max_iters) {  // :203
             // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-            const unsigned long long M = wave_min_all_u64(smin[lane]);
+            const unsigned long long e0 = smin[lane];
+            const unsigned long long M = first_min_entry((uint32_t)(e0 >> 32), (uint32_t)e0);
             if (M == ~0ull) {  // open list empty (:68 would divide by zero)
                 status = NASTAR_ERR_UNSOLVABLE;
                 break;
@@ -220,12 +234,11 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             const int icr = hybrid_row(icv ? ic : 0, d, icc);
             const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
             const bool upd = inb & (gn > g2);                                      // :229,:235
-            const uint32_t kn = hybrid_key(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+            const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
             // chunk minimum without s*: open <=> finite g
             const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
-            const uint32_t kc = hybrid_key(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc);
-            const unsigned long long ec = open_c ? (((unsigned long long)kc << 32) | (uint32_t)ic) : ~0ull;
-            const unsigned long long newC = wave_min_all_u64(ec);
+            const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
+            const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
             // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
             if (lane == 0) gst(&g[s], NASTAR_NEG_INF);
             if (upd) {
@@ -238,7 +251,8 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             wave_order();
             if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
             wave_order();
-            const unsigned long long newS = wave_min_all_u64(cmin[S * 64 + lane]);  // the super-chunk of s*, exactly
+            const unsigned long long ev = cmin[S * 64 + lane];
+            const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
             if (lane == 0) smin[S] = newS;
             wave_order();
             if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)

@@ -224,10 +224,13 @@ class InFlightPlanner:
     rare case that one of its maps is not binary.  An unsolvable map raises ``UnsolvableMapError`` at collection (naming the batch)
     unless ``check_solvable=False``."""
 
-    def __init__(self, planner: torch.nn.Module, streams: int = 4, check_solvable: bool = True, unit_cost="auto"):
+    def __init__(self, planner: torch.nn.Module, streams: int = 4, check_solvable: bool = True, unit_cost="auto", use_placement: bool = False):
         if streams < 1:
             raise ValueError("streams must be >= 1")
         self.planner = planner
+        # a batch's placement hint (start_maps.placement_order) is for ONE launch on an otherwise empty chip: with batches in flight it front-loads
+        # every launch's long searches and starves the short ones of overlap (rand32: 188 -> 151 M maps/s, DESIGN.md 4.1) -- ignored unless asked for
+        self.use_placement = use_placement
         self.n_streams = int(streams)
         self.check_solvable = check_solvable
         self.unit_cost = unit_cost
@@ -292,7 +295,7 @@ class InFlightPlanner:
             unit = same and self.unit_cost in (True, "auto")
             flags = ops.FLAG_UNIT_COST if unit else 0
             order = check = None
-            hint = getattr(start_maps, "placement_order", None)
+            hint = getattr(start_maps, "placement_order", None) if self.use_placement else None
             if hint is not None and ops.in_lds(start_maps.shape[-2], start_maps.shape[-1]):
                 o = hint.order if isinstance(hint, ops.OrderHint) else hint
                 if torch.is_tensor(o) and o.numel() == start_maps.shape[0] and o.dtype == torch.int32 and o.device == dev:

@@ -286,6 +286,50 @@ r05_e)
   HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 10 --warmup 3 --dist-backend gloo --share-gpu --no-secondary --no-cpu-baseline > $O/world8_maze32_weak.json 2> $O/world8_maze32_weak.err; echo "world8 weak rc=$?"; tail -2 $O/world8_maze32_weak.err; cut -c1-600 $O/world8_maze32_weak.json
   HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 8 --steps 10 --warmup 3 --dist-backend gloo --share-gpu --no-secondary --no-cpu-baseline --workload rand64 --global-batch 32768 --shard interleaved > $O/world8_rand64_interleaved.json 2> $O/world8_rand64_interleaved.err; echo "world8 rand64 rc=$?"; tail -2 $O/world8_rand64_interleaved.err; cut -c1-600 $O/world8_rand64_interleaved.json
   ;;
+r05_prof)
+  # the record of round 5 on the final tree: GPU suite + smoke, the driver's bench command, a clean FIRST-VISIT kernel profile (every launch of the
+  # run is a dataset-placed search of a never-searched batch), natural-order profile, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes),
+  # large-map and boundary probes
+  O=gpurun_out/r05/prof; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/gpu_tests_final.log 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_tests_final.log | cut -c1-200
+  python __graft_entry__.py smoke 2>&1 | tail -1
+  python bench.py --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err
+  B="python $R/bench.py --no-cpu-baseline --no-secondary --no-natural --no-prewarm"
+  (cd /tmp && export TMPDIR=/tmp
+   timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o bench --output-format csv -- $B --steps 200 --warmup 20 > $R/$O/bench_under_rocprof.json 2> $R/$O/bench_under_rocprof.err
+   timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/trace_natural -o bench --output-format csv -- $B --placement natural --steps 200 --warmup 20 > $R/$O/bench_natural_under_rocprof.json 2> $R/$O/bench_natural_under_rocprof.err
+   for C in FETCH_SIZE WRITE_SIZE; do
+     timeout 300 rocprofv3 --pmc $C --kernel-trace -d $R/$O/pmc_$C -o bench --output-format csv -- $B --steps 20 --warmup 2 > $R/$O/pmc_$C.log 2>&1
+   done)
+  find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/bench_first_visit_kernel_stats.csv \;
+  find $O/trace_natural -name "*kernel_stats.csv" -exec cp {} $O/bench_natural_order_kernel_stats.csv \;
+  python - <<'P'
+import csv, glob, json, collections
+O = "gpurun_out/r05/prof"
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/pmc_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "nastar_forward_compact" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[c] = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items()}
+json.dump(out, open(f"{O}/pmc_summary.json", "w"), indent=1)
+print(json.dumps(out))
+for name in ("bench_first_visit_kernel_stats.csv", "bench_natural_order_kernel_stats.csv"):
+    try:
+        print(name, open(f"{O}/{name}").read().splitlines()[1][:200])
+    except Exception as e:
+        print(name, "ERR", e)
+j = json.load(open(f"{O}/bench_driver_command.json"))
+print("value", round(j["value"] / 1e6, 2), "M maps/s  ms/step", round(j["ms_per_step"], 4), "natural", round(j["value_natural_order"] / 1e6, 2), "hinted", round(j["value_hinted"] / 1e6, 2), "in flight", j.get("value_in_flight"))
+print("roofline", {k: j["roofline"][k] for k in ("frac", "frac_28B_per_cell", "launch_ms_avg")}, "through_module", j.get("through_module"))
+for r in j.get("in_flight_through_api", []):
+    print(r["workload"], r["kernel"], {k: round(v / 1e6, 1) for k, v in r["streams_sweep_maps_per_s"].items()}, r["equal_to_sequential_forward"])
+P
+  python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; grep '"B": 256' $O/probe_large.jsonl | cut -c1-260
+  python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err; echo "probe rc=$?"; head -1 $O/probe_boundary.jsonl | cut -c1-1200
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
