@@ -447,7 +447,7 @@ def throughput_regime(dev, steps, workloads=("maze32", "rand32", "rand64"), ks=(
             # launch's long searches and starves the HBM-bound short ones of overlap (rand32: 151 instead of 188 M maps/s)
             runs = [Runner(pr, dev, flags=flags, placement="natural") for _ in range(max(ks))]
             prewarm(runs[0], dev, 0.1)
-            nbytes = 28 * runs[0].H * runs[0].W
+            nbytes = 24 * runs[0].H * runs[0].W  # cost == passable (one tensor): the bytes that move (28 B/cell figure = x 7/6)
             sweep = {str(k): multi_stream_throughput(pr, steps, dev, k, runs=runs[:k]) for k in ks}
             best_k = max(sweep, key=sweep.get)
             ok = all(int(r.status.abs().sum().item()) == 0 for r in runs)
@@ -474,7 +474,7 @@ def throughput_regime(dev, steps, workloads=("maze32", "rand32", "rand64"), ks=(
             del rb, big
             out.append({"workload": f"{w}: {B_PER_GPU} maps per launch", "kernel": label,
                         "streams_sweep_maps_per_s": sweep, "best_streams": int(best_k), "maps_per_s": sweep[best_k],
-                        "hbm_frac": sweep[best_k] * nbytes / 1e9 / HBM_PEAK_GBS,
+                        "hbm_frac": sweep[best_k] * nbytes / 1e9 / HBM_PEAK_GBS, "hbm_frac_bytes_per_cell": 24,
                         "one_launch_32768_maps": {"ms": ms_big, "maps_per_s": 8 * B_PER_GPU / (ms_big * 1e-3),
                                                   "hbm_frac": 8 * B_PER_GPU * nbytes / (ms_big * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                   "placement": PLACEMENT + (" (maps sorted by the step counts of the previous visit, longest first)" if ms_big_nat else ""),
@@ -1587,7 +1587,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_moved_per_map * b_rank,
                          "frac_28B_per_cell": bytes_per_map * b_rank / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_source": "committed constant: profiles/hbm_traffic.json (rocprofv3 PMC passes of an earlier round, same kernel and batch shape), NOT measured in this run",
+                         "traffic_source": "committed constant: profiles/hbm_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of the same command, same kernel and batch shape; see its note), NOT measured in this run",
                          "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop: nastar_search_asm4.hip.h)",
                          "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms,
                          "launch_ms_note": "HIP events around single launches on the launch stream, measured in THIS run, placement as the headline",
@@ -1627,14 +1627,14 @@ def main():
                 prewarm(run2, dev, 0.1)
                 dt2, _ = timed_loop(run2, max(50, args.steps // 4), max(2, args.warmup // 4), 1, dev)
                 a2, _, _ = kernel_launch_ms(run2, 50, dev)
-                nbytes = 28 * run2.H * run2.W * B_PER_GPU
+                nbytes = 24 * run2.H * run2.W * B_PER_GPU  # cost == passable: the bytes that move
                 a2n = None
                 if run2.placement == "hinted" and not args.no_natural:
                     run2.placement = "natural"
                     a2n = kernel_launch_ms(run2, 50, dev)[0]
                     run2.placement = "hinted"
                 sec.append({"workload": f"{other}: {B_PER_GPU} maps of {run2.H}x{run2.W}", "value": B_PER_GPU * max(50, args.steps // 4) / dt2,
-                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": nbytes / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "hbm_frac_bytes_per_cell": 24,
                             "placement": run2.placement, "launch_ms_avg_natural_order": a2n,
                             "hbm_frac_natural_order": (nbytes / (a2n * 1e-3) / 1e9 / HBM_PEAK_GBS) if a2n else None,
                             "mean_iters_per_map": float(run2.iters.float().mean().item()),
@@ -1650,8 +1650,8 @@ def main():
                 dt2, _ = timed_loop(run2, max(10, args.steps // 4), max(2, args.warmup // 4), 1, dev)
                 a2, _, _ = kernel_launch_ms(run2, max(10, min(args.steps // 4, 50)), dev)
                 sec.append({"workload": f"{label}: {B_PER_GPU} maps of 32x32", "value": B_PER_GPU * max(10, args.steps // 4) / dt2,
-                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": bytes_per_map * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "mean_iters_per_map": float(run2.iters.float().mean().item()),
+                            "unit": "maps/s", "launch_ms_avg": a2, "hbm_frac": bytes_moved_per_map * B_PER_GPU / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "hbm_frac_bytes_per_cell": 24, "mean_iters_per_map": float(run2.iters.float().mean().item()),
                             "max_iters_per_map": int(run2.iters.max().item())})
                 del run2
             out["secondary"] = sec

@@ -87,6 +87,7 @@ class StatusBoard:
         self.cbase = self.counters.data_ptr()
         self.device = device
         self.free = list(range(rows - 1, -1, -1))
+        self.zombies: list = []  # rows whose owner went away before its launch was known to be over (retire()): reaped by acquire()
         self.lib = _native.load()
 
     @classmethod
@@ -98,9 +99,33 @@ class StatusBoard:
         return b
 
     def acquire(self) -> int:
+        if self.zombies:
+            self._reap(False)
+        if not self.free and self.zombies:
+            self._reap(True)
         if not self.free:
             raise RuntimeError("more than 256 search launches with an unread status: call raise_if_unsolvable() / collect() on the planners that issued them")
         return self.free.pop()
+
+    def retire(self, row: int, event: Optional["torch.cuda.Event"]) -> None:
+        """give a row back although nobody read it (its planner was dropped with verdicts pending): it is reused only once its launch is over
+        -- the completion flag is up, or ``event`` (recorded behind the launch) has passed"""
+        self.zombies.append((row, event))
+
+    def _reap(self, wait: bool) -> None:
+        keep = []
+        for row, ev in self.zombies:
+            if self.np[row, 0] or (ev is not None and ev.query()):
+                self.release(row)
+            elif wait:
+                if ev is not None:
+                    ev.synchronize()
+                else:
+                    torch.cuda.synchronize(self.device)
+                self.release(row)
+            else:
+                keep.append((row, ev))
+        self.zombies = keep
 
     def ptr(self, row: int) -> int:
         return self.base + 4 * SUMMARY_WORDS * row

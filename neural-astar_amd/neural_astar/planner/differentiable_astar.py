@@ -43,6 +43,7 @@ class _PendingStatus:
         self.board = ops.StatusBoard.of(status.device)
         self.stream = torch.cuda.current_stream(status.device)
         self.event = None
+        self.released = False
         if not flagged:
             self.event = torch.cuda.Event()
             self.event.record(self.stream)
@@ -57,8 +58,17 @@ class _PendingStatus:
             self.event.synchronize()
         bad = self.board.read(self.row) is not None
         self.board.release(self.row)
+        self.released = True
         if bad:
             _raise_unsolvable(self.status, self.seq, deferred=True)
+
+    def __del__(self):  # a planner dropped with verdicts pending: the row goes back once its launch is over (never while it may still be written)
+        try:
+            if not self.released:
+                self.released = True
+                self.board.retire(self.row, self.event)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def _capturing(t: torch.Tensor) -> bool:
@@ -215,7 +225,7 @@ class DifferentiableAstar(nn.Module):
         mode = self.check_solvable
         if clean is True and row < 0 and mode is not False and mode != "deferred":
             return  # the caller has read a clean verdict for THIS call already
-        if not mode or _capturing(status):  # nothing may synchronise inside a hipGraph capture
+        if not mode or _capturing(status) or torch.compiler.is_compiling():  # nothing may synchronise inside a hipGraph capture / a trace
             if row >= 0:
                 ops.StatusBoard.of(status.device).release(row)
             return
@@ -276,8 +286,7 @@ class DifferentiableAstar(nn.Module):
         capturing = cost_maps.is_cuda and torch.cuda.is_current_stream_capturing()
         if self._pending and not capturing:
             self.raise_if_unsolvable(wait=False)  # deferred verdicts of earlier calls that have reached the host
-        # VanillaAstar hands ONE tensor over as cost and obstacle map: the unit-cost kernel (see __init__) applies when it is binary,
-        # which the kernel itself checks; in "auto" mode only when this call reads the status anyway and can fall back
+        # VanillaAstar hands ONE tensor over as cost and obstacle map (reference astar.py:93-94): the kernel then loads it once
         same = obstacles_maps is cost_maps or (cost_maps.data_ptr() == obstacles_maps.data_ptr() and cost_maps.shape == obstacles_maps.shape
                                                and cost_maps.stride() == obstacles_maps.stride())
         mode = self.check_solvable
@@ -293,12 +302,14 @@ class DifferentiableAstar(nn.Module):
         else:
             order, order_out, check_order, pl = self.resolve_placement(B, start_maps, in_lds)
         dev = cost_maps.device
-        board = ops.StatusBoard.of(dev) if (mode and cost_maps.is_cuda and not capturing) else None
+        compiling = torch.compiler.is_compiling()
+        # (no status protocol while a hipGraph is captured or torch.compile traces: its host side would run once, at capture / trace time)
+        board = ops.StatusBoard.of(dev) if (mode and cost_maps.is_cuda and not capturing and not compiling) else None
         row = board.acquire() if board is not None else -1
         sptr = board.ptr(row) if board is not None else 0
         cptr = board.counter_ptr(row) if (board is not None and in_lds) else 0
         flags = ops.FLAG_UNIT_COST if unit else 0
-        traced = needs_grad or type(cost_maps) is not torch.Tensor or torch.compiler.is_compiling()
+        traced = needs_grad or type(cost_maps) is not torch.Tensor or compiling
         try:
             if not traced:
                 # no gradient can flow and nothing is tracing: straight to the C ABI (no torch.library dispatch)

@@ -330,6 +330,12 @@ P
   python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; grep '"B": 256' $O/probe_large.jsonl | cut -c1-260
   python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err; echo "probe rc=$?"; head -1 $O/probe_boundary.jsonl | cut -c1-1200
   ;;
+r05_f)
+  # the shipped hybrid kernel (VGPR reductions + FMA division): parity and step time once more
+  O=gpurun_out/r05/f; mkdir -p $O
+  python -m pytest tests/test_large_maps_gpu.py tests/test_boundary_gpu.py -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
+  python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; grep -v '"B": 1,' $O/probe_large.jsonl | cut -c1-260
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
