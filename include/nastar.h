@@ -8,6 +8,11 @@
  *   nastar_forward          <- DifferentiableAstar.forward   differentiable_astar.py:150-267
  *                              (get_heuristic :26-52, _st_softmax_noexp :55-74, expand :77-93,
  *                               backtrack :96-125 all fused into one launch)
+ *   nastar_forward_ex       <- the same code; every option of the launch in one call (0.5.0): placement (order / order_out, optionally
+ *                              checked on the device), bit-packed masks, and the launch's STATUS SUMMARY + completion flag in (pinned host)
+ *                              memory -- what the Python layer calls.  nastar_forward / _ordered / _packed are its subsets.
+ *   nastar_placement_from_levels <- (new) a placement from per-map levels the caller has: |opt_dists[start]| of the reference's maze
+ *                              files (utils/data.py:127-134, 200-221)
  *   nastar_backward_replay  <- the autograd graph PyTorch records for that forward
  *                              (what loss.backward() runs in utils/training.py:55-61)
  *   nastar_heuristic        <- get_heuristic                 differentiable_astar.py:26-52 (debug/parity)

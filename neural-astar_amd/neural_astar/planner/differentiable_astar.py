@@ -250,24 +250,26 @@ class DifferentiableAstar(nn.Module):
             self._pending.pop(0).raise_if_unsolvable()
 
     def resolve_placement(self, B: int, start_maps: torch.Tensor, in_lds: bool):
-        """(order, order_out, check_order, placement) for the next launch: the module's ``placement`` (a recurring batch: the order its
-        searches finished in last time) or, for a batch seen for the first time, the ``OrderHint`` its loader attached to
-        ``start_maps`` (``start_maps.placement_order``: by the optimal distance of the start cells, data the sample carries)."""
+        """(order, order_out, check_order, placement) for the next launch.  The ``OrderHint`` the batch's loader attached to ``start_maps``
+        (``start_maps.placement_order``: by the optimal distance of THIS batch's start cells, data the sample carries) comes first -- the
+        reference's loaders draw new start cells at every visit of a map (utils/data.py:152-166), so only a hint describes the batch at
+        hand; without one, the module's ``placement`` (a batch that really recurs: the order its searches finished in last time).  A
+        ``placement`` still records this launch's completion order either way."""
         pl, self.placement = self.placement, None
         if not in_lds:
             return None, None, False, None
         order = order_out = None
         check = False
+        prev = None
         if pl is not None:
-            order, order_out = pl.buffers(B, start_maps.device)
-            if order is not None:
-                order = order[:B]
-        if order is None:
-            hint = getattr(start_maps, "placement_order", None)
-            if hint is not None:
-                o = hint.order if isinstance(hint, ops.OrderHint) else hint
-                if torch.is_tensor(o) and o.numel() == B and o.device == start_maps.device and o.dtype == torch.int32:
-                    order, check = o.reshape(-1), not getattr(hint, "trusted", False)
+            prev, order_out = pl.buffers(B, start_maps.device)
+        hint = getattr(start_maps, "placement_order", None)
+        if hint is not None:
+            o = hint.order if isinstance(hint, ops.OrderHint) else hint
+            if torch.is_tensor(o) and o.numel() == B and o.device == start_maps.device and o.dtype == torch.int32:
+                order, check = o.reshape(-1), not getattr(hint, "trusted", False)
+        if order is None and prev is not None:
+            order = prev[:B]
         return order, order_out, check, pl
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,

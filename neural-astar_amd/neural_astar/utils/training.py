@@ -70,8 +70,9 @@ class PlannerModule(_ModuleBase):
         self.vanilla_astar = VanillaAstar()
         self.config = config
         self.logged = {}
-        # validation batches recur every epoch in the same order (reference scripts/train.py:43-50: unshuffled loader, utils/data.py:40-47):
-        # each keeps the order its searches finished in, and the next epoch starts the longest first (planner/differentiable_astar.py: Placement)
+        # validation MAPS recur every epoch in the same order (reference scripts/train.py:43-50: unshuffled loader, utils/data.py:40-47) but the
+        # loaders re-draw every start cell (utils/data.py:152-166): a batch that carries its loader's placement hint (DeviceMazeBatches) is
+        # placed by that; one without a hint by the order the same batch index finished in last epoch (planner/differentiable_astar.py: Placement)
         self._val_placements = {}
 
     if pl is None:

@@ -453,3 +453,63 @@ def test_validation_pass_in_flight_equals_the_per_batch_steps(tmp_path):
     assert set(got) == set(ref) == {"metrics/val_loss", "metrics/p_opt", "metrics/p_exp", "metrics/h_mean"}
     for k in ref:
         assert abs(float(got[k]) - ref[k]) < 1e-6, (k, float(got[k]), ref[k])
+
+
+def test_status_verdicts_under_stress_are_never_lost_or_misattributed():
+    """The completion flag is raised by the LAST search to end, ordered behind every status cell of its launch by a system-scope release /
+    acquire pair; rows and counters are reused by the very next call.  400 calls in a row, a random third of them with ONE unsolvable map at
+    a random row (early or late finisher), sync and deferred checking: every bad call must raise exactly once, no good call may."""
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.planner.differentiable_astar import UnsolvableMapError
+    rng = np.random.default_rng(7)
+    pr, (m, s, g) = _problems(1024, 32, seed=21)
+    dev = _dev()
+    bad_maps = []
+    for _ in range(8):
+        mb = m.clone()
+        b = int(rng.integers(0, 1024))
+        gi = int(g[b].reshape(-1).argmax())
+        gy, gx = divmod(gi, 32)
+        mb[b, 0, max(gy - 1, 0):gy + 2, max(gx - 1, 0):gx + 2] = 0  # wall the goal in
+        mb[b, 0, gy, gx] = 1
+        if int(s[b].reshape(-1).argmax()) != gi and abs(int(s[b].reshape(-1).argmax()) // 32 - gy) + abs(int(s[b].reshape(-1).argmax()) % 32 - gx) > 2:
+            bad_maps.append((mb, b))
+    assert bad_maps
+    va = VanillaAstar().to(dev).eval()
+    with torch.no_grad():
+        ref = va(m, s, g)
+        raised = expected = 0
+        for i in range(400):
+            if rng.random() < 0.33:
+                mb, b = bad_maps[int(rng.integers(len(bad_maps)))]
+                expected += 1
+                with pytest.raises(UnsolvableMapError):
+                    va(mb, s, g)
+                raised += 1
+                assert int(va.astar.last_status[b]) == 3 and int((va.astar.last_status != 0).sum()) == 1
+            else:
+                out = va(m, s, g)
+                if i % 50 == 0:
+                    assert torch.equal(out.paths, ref.paths)
+        assert raised == expected > 50
+        # deferred: verdicts arrive with later calls, each exactly once, naming its own call
+        va2 = VanillaAstar().to(dev).eval()
+        va2.astar.check_solvable = "deferred"
+        want, got = [], []
+        for i in range(300):
+            bad = rng.random() < 0.2
+            launched = True
+            try:
+                va2(bad_maps[0][0] if bad else m, s, g)
+            except UnsolvableMapError as e:  # the verdict of an EARLIER call, delivered before this call launched anything
+                got.append(int(str(e).split("call #")[1].split(" ")[0]))
+                launched = False
+            if bad and launched:
+                want.append(va2.astar._calls)
+        while True:
+            try:
+                va2.astar.raise_if_unsolvable()
+                break
+            except UnsolvableMapError as e:
+                got.append(int(str(e).split("call #")[1].split(" ")[0]))
+        assert sorted(got) == want, (want[:10], sorted(got)[:10])

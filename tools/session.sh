@@ -336,6 +336,15 @@ r05_f)
   python -m pytest tests/test_large_maps_gpu.py tests/test_boundary_gpu.py -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
   python tools/probe_large.py > $O/probe_large.jsonl 2> $O/probe_large.err; echo "large rc=$?"; grep -v '"B": 1,' $O/probe_large.jsonl | cut -c1-260
   ;;
+r05_g)
+  # final tree: whole GPU suite (incl. the status-verdict stress test), the collated path in a 1-rank RCCL group, both training benches
+  O=gpurun_out/r05/g; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/gpu_tests_final.log 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_tests_final.log | cut -c1-200
+  python bench.py --force-collate --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $O/bench_force_collate.json 2> $O/bench_force_collate.err; echo "collate rc=$?"; tail -2 $O/bench_force_collate.err; cut -c1-300 $O/bench_force_collate.json
+  for c in maze warcraft; do
+    python bench.py --mode train --config $c --steps 20 --warmup 5 --no-cpu-baseline > $O/train_$c.json 2> $O/train_$c.err; echo "train $c rc=$?"; cut -c1-260 $O/train_$c.json
+  done
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
