@@ -1056,7 +1056,7 @@ def through_module_ms(pr, dev, reps=60):
     return out
 
 
-def in_flight_through_api(dev, steps, workloads=(("maze32", True), ("rand32", True), ("rand64", True), ("maze32", False)), ks=(3, 4, 6, 8)):
+def in_flight_through_api(dev, steps, workloads=(("maze32", True), ("rand32", True), ("rand64", True), ("maze32", False)), ks=(3, 4, 6, 8, 12)):
     """Batches in flight THROUGH THE PYTHON OBJECT (neural_astar.parallel.InFlightPlanner around a VanillaAstar): whole 4096-map batches
     round-robin over k HIP streams, outputs allocated per batch, status summaries read once at collection, unit_cost="auto" without a
     per-call wait.  maps/s over `n` batches incl. submission, collection and the final host wait; outputs checked equal to sequential
@@ -1064,7 +1064,7 @@ def in_flight_through_api(dev, steps, workloads=(("maze32", True), ("rand32", Tr
     from neural_astar.parallel import InFlightPlanner
     from neural_astar.planner import VanillaAstar
     res = []
-    n = max(48, min(steps, 192))
+    n = max(144, min(steps, 288))  # (not the K timed steps of the contract: 20 batches are a pipeline that never fills)
     for w, unit in workloads:
         prs = [make_problem(w, B_PER_GPU, seed=1234 + 1000 * k) for k in range(N_ROTATE)]
         batches = [tuple(torch.from_numpy(x).to(dev) for x in (pr.map_designs, pr.start_maps, pr.goal_maps)) for pr in prs]
