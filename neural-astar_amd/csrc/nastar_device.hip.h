@@ -124,16 +124,35 @@ __device__ __forceinline__ float ord_to_f32(uint32_t k)
 // exact n / d for n, d < 2^16 with magic = floor(2^32 / d) + 1
 __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
 
+// ---- correctly rounded square root of an exactly representable integer >= 0 ------------------------------------------------------------
+// v_sqrt_f32 is a 1-ulp instruction: NOT correctly rounded for ~15 % of the integers (first miss at 6; tools/ubench/sqrt_check.hip,
+// profiles/r05/sqrt_check.txt) -- and neither is __fsqrt_rn, which compiles to it.  get_heuristic's h0 = cheb + 0.001 * sqrt(dr^2 + dc^2)
+// absorbs the error while max(|dr|, |dc|) < 140 (exhaustive: h0 bit-identical to the host for every pair below that) -- the
+// hand-scheduled 16 / 32 / 64 streams may keep the bare instruction -- but 16 pairs differ in [128, 256), 62 in [256, 512): on maps with a
+// side above 140 a search could leave the reference's (found by tools/fuzz_parity.py: 12 of 1067 large-map cases, rounds 1-4 latent).
+// One FMA residual test against each neighbour (LLVM's own IEEE lowering of sqrt) fixes every integer below 2^24.
+__device__ __forceinline__ float sqrt_rn_int(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    if (x > 0.f) {
+        const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+        const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+        if (vp <= 0.f) s = sd;
+        if (vs > 0.f) s = su;
+    }
+    return s;
+}
+
 // ---- get_heuristic (differentiable_astar.py:26-52), one cell ------------------------------------------
 // h0 = fl( fl(|dr|+|dc| - min(|dr|,|dc|)) + fl( fl32(0.001) * fl(sqrt(dr^2+dc^2)) ) ); every op one fp32
-// rounding (the TU is compiled with -ffp-contract=off), sqrt correctly rounded.
+// rounding (the TU is compiled with -ffp-contract=off), sqrt correctly rounded (sqrt_rn_int).
 __device__ __forceinline__ float heuristic0(int r, int c, int goal_r, int goal_c)
 {
     float a = (float)r - (float)goal_r;
     float b = (float)c - (float)goal_c;
     float dr = fabsf(a), dc = fabsf(b);
     float cheb = (dr + dc) - fminf(dr, dc);
-    float euc = __fsqrt_rn(a * a + b * b);
+    float euc = sqrt_rn_int(a * a + b * b);
     return cheb + 0.001f * euc;
 }
 

@@ -79,15 +79,15 @@ __device__ __forceinline__ uint32_t compact_key(const CompactDims& d, float G, f
     return f32_to_ord(q);
 }
 
-// get_heuristic (:26-52) for one cell; sqrt on an exactly representable integer >= 0: v_sqrt_f32 is correctly rounded on
-// gfx950 for normal inputs (it is what __fsqrt_rn compiles to, minus the denormal pre-scaling that cannot trigger here)
+// get_heuristic (:26-52) for one cell of the COMPILED step loops (any H x W that fits LDS, e.g. a 5 x 200 strip): the square root is the
+// corrected one (nastar_device.hip.h: sqrt_rn_int; the bare v_sqrt_f32 of the hand-scheduled 16 / 32 / 64 streams is exact for sides < 140)
 __device__ __forceinline__ float heuristic0_fast(int r, int c, int goal_r, int goal_c)
 {
     const float a = (float)(r - goal_r);
     const float b = (float)(c - goal_c);
     const float dr = fabsf(a), dc = fabsf(b);
     const float cheb = (dr + dc) - fminf(dr, dc);
-    const float euc = __builtin_amdgcn_sqrtf(a * a + b * b);
+    const float euc = sqrt_rn_int(a * a + b * b);
     return cheb + 0.001f * euc;
 }
 

@@ -89,10 +89,13 @@ def _raise_unsolvable(status: torch.Tensor, seq: int = 0, deferred: bool = False
 
 
 class Placement:
-    """Memory of ONE recurring batch (a validation batch, an evaluation set searched every epoch): the order in which its searches
-    finished at the previous visit.  ``planner.astar.placement = p`` before a call makes that call start the longest searches first
-    (``nastar_forward_ordered``, include/nastar.h) and leaves the order for the next visit in ``p`` -- no extra launch, no host
-    synchronisation, identical outputs.  The first visit (or a visit with another batch size) runs in the natural order."""
+    """Memory of ONE batch that truly recurs (a fixed evaluation set held in memory -- same maps AND same start cells at every visit): the
+    order in which its searches finished at the previous visit.  ``planner.astar.placement = p`` before a call makes that call start the
+    longest searches first (``order`` / ``order_out`` of ``nastar_forward_ex``, include/nastar.h) and leaves the order for the next visit
+    in ``p`` -- no extra launch, no host synchronisation, identical outputs.  The first visit (or a visit with another batch size) runs in
+    the natural order -- unless the batch carries its loader's hint (``start_maps.placement_order``, ``ops.OrderHint``), which always takes
+    precedence: the reference's loaders re-draw every start cell at every visit (utils/data.py:152-166), so for THEIR batches only the
+    hint describes the searches at hand."""
 
     def __init__(self):
         self.bufs: Optional[List[torch.Tensor]] = None

@@ -36,7 +36,9 @@ def test_native_library_loaded_and_heuristic_bit_exact():
     from neural_astar import _native, ops
     from oracle import oracle as O
     assert _native.load().nastar_version() >= 100
-    for (H, W, gr, gc) in [(64, 64, 63, 63), (32, 32, 5, 17), (20, 45, 19, 0), (64, 128, 0, 127)]:
+    # (the two large ones reach |dr|, |dc| >= 140, where the bare v_sqrt_f32 -- not a correctly rounded instruction -- starts to show in h0:
+    #  tools/ubench/sqrt_check.hip, profiles/r05/sqrt_check.txt; the generic heuristic corrects it with one FMA residual test per neighbour)
+    for (H, W, gr, gc) in [(64, 64, 63, 63), (32, 32, 5, 17), (20, 45, 19, 0), (64, 128, 0, 127), (200, 300, 0, 0), (255, 257, 254, 3)]:
         goal = np.zeros((1, 1, H, W), np.float32)
         goal[0, 0, gr, gc] = 1
         h = ops.heuristic(_t(goal)).cpu().numpy()[0, 0]

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (run on the GPU box): the search through the C ABI against the oracle's state-machine restatement on random map
+sizes (LDS-resident, compiled and hand-scheduled instantiations, and the hybrid large-map kernel just above the LDS limit), obstacle
+densities, cost kinds (map / U(0,1) / U(0,10)), g_ratio and budgets, with and without a selection log and a random placement.  Prints one
+JSON line per failing case and a summary; exit code 1 on any mismatch."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from neural_astar import ops  # noqa: E402
+from neural_astar.utils import synthetic as syn  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+dev = torch.device("cuda:0")
+sizes = [(16, 16), (32, 32), (64, 64), (12, 12), (7, 5), (20, 45), (64, 128), (100, 100), (128, 128), (130, 131), (135, 150), (140, 140), (150, 200), (33, 31),
+         (96, 96), (48, 80), (5, 200), (200, 5), (1, 40), (40, 1), (129, 129), (131, 127)]
+
+
+def run(seed=20260926, N=160, big_frac=0.15, verbose=True):
+  """-> (cases per kernel family, list of failing case descriptions)"""
+  rng = np.random.default_rng(seed)
+  bad = []
+  stats = {}
+  for case in range(N):
+    if case < 2 * len(sizes):
+        H, W = sizes[case % len(sizes)]
+    elif rng.random() < big_frac:  # above the LDS limit: the hybrid kernel (fill / search / store launches)
+        H, W = int(rng.integers(120, 260)), int(rng.integers(120, 260))
+    else:
+        H, W = int(rng.integers(3, 160)), int(rng.integers(3, 160))
+    B = int(rng.integers(1, 9))
+    p = float(rng.choice([0.0, 0.1, 0.2, 0.3]))
+    try:
+        pr = syn.random_obstacle_maps(B, H, W, p, seed=int(rng.integers(1 << 30)))
+    except Exception:
+        continue
+    kind = str(rng.choice(["map", "u01", "u10"]))
+    cost = pr.map_designs if kind == "map" else syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
+    gr = float(rng.choice([0.5, 0.5, 0.5, 0.2, 0.8, 0.0, 1.0]))
+    T = W * W if rng.random() < 0.7 else max(1, int(rng.choice([0.05, 0.25, 0.5]) * W * W))
+    log = bool(rng.random() < 0.5)
+    in_lds = ops.in_lds(H, W)
+    order = None
+    if in_lds and rng.random() < 0.4:
+        order = torch.from_numpy(rng.permutation(B).astype(np.int32)).to(dev)
+    c, s, g, m = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (cost, pr.start_maps, pr.goal_maps, pr.map_designs))
+    try:
+        hist, paths, iters, status, sel = ops.search_nograd(c, s, g, c if kind == "map" else m, gr, T, want_log=log, order=order, check_order=False)
+        torch.cuda.synchronize()
+        o = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T, mode="sm", want_log=log)
+        ok = (np.array_equal(hist.cpu().numpy(), o.histories) and np.array_equal(paths.cpu().numpy(), o.paths) and np.array_equal(iters.cpu().numpy(), o.iters)
+              and bool((status == 0).all()))
+        if ok and log:
+            lg, it = sel.cpu().numpy(), o.iters
+            ok = all(np.array_equal(lg[b, :it[b]], o.sel_log[b, :it[b]]) for b in range(B))
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        if verbose:
+            print(json.dumps({"case": case, "error": f"{type(e).__name__}: {e}"[:300]}), flush=True)
+    key = "lds" if in_lds else "hybrid"
+    stats[key] = stats.get(key, 0) + 1
+    if not ok:
+        d = {"case": case, "H": H, "W": W, "B": B, "p": p, "cost": kind, "g_ratio": gr, "max_iters": T, "log": log, "placed": order is not None, "in_lds": in_lds}
+        bad.append(d)
+        if verbose:
+            print(json.dumps(d), flush=True)
+  return stats, bad
+
+
+def run_backward(seed=11, N=40, verbose=True):
+    """dL/dcost of the replay backward (through DifferentiableAstar under autograd) against the oracle's literal reverse-mode restatement on
+    random small maps, training and eval budgets, random upstream gradients; tolerance 1e-5 (north_star).  -> (cases, failures)"""
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    rng = np.random.default_rng(seed)
+    small = [(16, 16), (32, 32), (12, 12), (7, 5), (20, 45), (33, 31), (24, 40), (48, 48), (9, 30)]
+    bad, n = [], 0
+    for case in range(N):
+        H, W = small[case % len(small)] if case < 2 * len(small) else (int(rng.integers(4, 50)), int(rng.integers(4, 50)))
+        B = int(rng.integers(1, 5))
+        pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.15, 0.3])), seed=int(rng.integers(1 << 30)))
+        cost_np = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)))
+        gr = float(rng.choice([0.5, 0.5, 0.2, 0.8]))
+        train = bool(rng.random() < 0.5)
+        Tmax = float(rng.choice([0.25, 0.5, 1.0])) if train else 1.0
+        T = int((Tmax if train else 1.0) * W * W)
+        if T < 1:
+            continue
+        up = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+        da = DifferentiableAstar(gr, Tmax).to(dev).train(train)
+        cost = torch.from_numpy(cost_np).to(dev).requires_grad_(True)
+        s, g, m = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (pr.start_maps, pr.goal_maps, pr.map_designs))
+        out = da(cost, s, g, m)
+        (out.histories * torch.from_numpy(up).to(dev)).sum().backward()
+        ref = O.backward(up, cost_np, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T)
+        err = float(np.abs(cost.grad[:, 0].cpu().numpy() - ref).max())
+        n += 1
+        if not err <= 1e-5 * max(1.0, float(np.abs(ref).max())):
+            d = {"case": case, "H": H, "W": W, "B": B, "g_ratio": gr, "train": train, "Tmax": Tmax, "err": err}
+            bad.append(d)
+            if verbose:
+                print(json.dumps(d), flush=True)
+    return n, bad
+
+
+if __name__ == "__main__":
+    st, bad_cases = run(int(sys.argv[1]) if len(sys.argv) > 1 else 20260926, int(sys.argv[2]) if len(sys.argv) > 2 else 160,
+                        float(sys.argv[3]) if len(sys.argv) > 3 else 0.15)
+    print(json.dumps({"cases": sum(st.values()), "by_kernel": st, "mismatches": len(bad_cases)}))
+    nb, bad_b = run_backward(N=max(20, (int(sys.argv[2]) if len(sys.argv) > 2 else 160) // 10))
+    print(json.dumps({"backward_cases": nb, "backward_failures": len(bad_b)}))
+    sys.exit(1 if (bad_cases or bad_b) else 0)

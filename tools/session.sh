@@ -345,6 +345,14 @@ r05_g)
     python bench.py --mode train --config $c --steps 20 --warmup 5 --no-cpu-baseline > $O/train_$c.json 2> $O/train_$c.err; echo "train $c rc=$?"; cut -c1-260 $O/train_$c.json
   done
   ;;
+r05_fuzz)
+  # randomised parity sweep of the search against the oracle (sizes around every kernel boundary, costs, budgets, logs, placements)
+  O=gpurun_out/r05/fuzz; mkdir -p $O
+  for seed in 20260926 7 8; do
+    python tools/fuzz_parity.py $seed ${2:-1500} 0.2 > $O/fuzz_parity_$seed.jsonl 2> $O/fuzz_parity_$seed.err; echo "fuzz $seed rc=$?"; tail -1 $O/fuzz_parity_$seed.err; tail -6 $O/fuzz_parity_$seed.jsonl
+  done
+  python -m pytest tests/test_fuzz_parity_gpu.py -q -m gpu 2>&1 | tail -2
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
