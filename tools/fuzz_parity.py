@@ -31,6 +31,8 @@ def run(seed=20260926, N=160, big_frac=0.15, verbose=True):
         H, W = sizes[case % len(sizes)]
     elif rng.random() < big_frac:  # above the LDS limit: the hybrid kernel (fill / search / store launches)
         H, W = int(rng.integers(120, 260)), int(rng.integers(120, 260))
+    elif rng.random() < 0.3:       # the hand-scheduled instruction streams (general and unit-cost layouts)
+        H = W = int(rng.choice([16, 32, 64]))
     else:
         H, W = int(rng.integers(3, 160)), int(rng.integers(3, 160))
     B = int(rng.integers(1, 9))
@@ -39,18 +41,37 @@ def run(seed=20260926, N=160, big_frac=0.15, verbose=True):
         pr = syn.random_obstacle_maps(B, H, W, p, seed=int(rng.integers(1 << 30)))
     except Exception:
         continue
-    kind = str(rng.choice(["map", "u01", "u10"]))
-    cost = pr.map_designs if kind == "map" else syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
+    kind = str(rng.choice(["map", "u01", "u10", "signed", "zeros"]))
+    if kind == "map":
+        cost = pr.map_designs
+    elif kind == "signed":  # negative costs: the round-2 instruction stream with its order-preserving key transform (16 / 32 / 64), generic paths elsewhere
+        cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), lo=-0.5, hi=1.0)
+    elif kind == "zeros":   # many exactly-zero costs: ties in g as well as in h
+        cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30))) * (rng.random((B, 1, H, W)) < 0.5).astype(np.float32)
+    else:
+        cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
+    maps = pr.map_designs.copy()
+    starts = pr.start_maps
+    variant = str(rng.choice(["plain", "plain", "plain", "start_on_obstacle", "start_is_goal"]))
+    if variant == "start_on_obstacle":  # the start is expanded even on an obstacle (reference :187: open = start)
+        maps.reshape(B, -1)[np.arange(B), pr.start_maps.reshape(B, -1).argmax(1)] = 0.0
+        if kind == "map":
+            cost = maps
+    elif variant == "start_is_goal":
+        starts = pr.goal_maps.copy()
+    pr = syn.Problems(maps, starts, pr.goal_maps)
+    unit = kind == "map" and H == W and W in (32, 64) and rng.random() < 0.5  # the unit-cost LDS layout (NASTAR_FLAG_UNIT_COST)
     gr = float(rng.choice([0.5, 0.5, 0.5, 0.2, 0.8, 0.0, 1.0]))
     T = W * W if rng.random() < 0.7 else max(1, int(rng.choice([0.05, 0.25, 0.5]) * W * W))
-    log = bool(rng.random() < 0.5)
+    log = bool(rng.random() < 0.5) and not unit
     in_lds = ops.in_lds(H, W)
     order = None
     if in_lds and rng.random() < 0.4:
         order = torch.from_numpy(rng.permutation(B).astype(np.int32)).to(dev)
     c, s, g, m = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (cost, pr.start_maps, pr.goal_maps, pr.map_designs))
     try:
-        hist, paths, iters, status, sel = ops.search_nograd(c, s, g, c if kind == "map" else m, gr, T, want_log=log, order=order, check_order=False)
+        hist, paths, iters, status, sel = ops.search_nograd(c, s, g, c if kind == "map" else m, gr, T, want_log=log, order=order, check_order=False,
+                                                            flags=ops.FLAG_UNIT_COST if unit else 0)
         torch.cuda.synchronize()
         o = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T, mode="sm", want_log=log)
         ok = (np.array_equal(hist.cpu().numpy(), o.histories) and np.array_equal(paths.cpu().numpy(), o.paths) and np.array_equal(iters.cpu().numpy(), o.iters)
@@ -62,10 +83,11 @@ def run(seed=20260926, N=160, big_frac=0.15, verbose=True):
         ok = False
         if verbose:
             print(json.dumps({"case": case, "error": f"{type(e).__name__}: {e}"[:300]}), flush=True)
-    key = "lds" if in_lds else "hybrid"
+    key = ("unit" if unit else "lds") if in_lds else "hybrid"
     stats[key] = stats.get(key, 0) + 1
     if not ok:
-        d = {"case": case, "H": H, "W": W, "B": B, "p": p, "cost": kind, "g_ratio": gr, "max_iters": T, "log": log, "placed": order is not None, "in_lds": in_lds}
+        d = {"case": case, "H": H, "W": W, "B": B, "p": p, "cost": kind, "variant": variant, "unit": bool(unit), "g_ratio": gr, "max_iters": T, "log": log,
+             "placed": order is not None, "in_lds": in_lds}
         bad.append(d)
         if verbose:
             print(json.dumps(d), flush=True)
