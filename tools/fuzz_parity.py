@@ -94,21 +94,25 @@ def run(seed=20260926, N=160, big_frac=0.15, verbose=True):
   return stats, bad
 
 
-def run_backward(seed=11, N=40, verbose=True):
+def run_backward(seed=11, N=40, verbose=True, large=False):
     """dL/dcost of the replay backward (through DifferentiableAstar under autograd) against the oracle's literal reverse-mode restatement on
-    random small maps, training and eval budgets, random upstream gradients; tolerance 1e-5 (north_star).  -> (cases, failures)"""
+    random small maps (``large``: 64 .. 140 cells per side -- the generic LDS replay and the one with its state in the HBM workspace; the
+    oracle needs seconds per map there), training and eval budgets, random upstream gradients; tolerance 1e-5 (north_star).
+    -> (cases, failures)"""
     from neural_astar.planner.differentiable_astar import DifferentiableAstar
     rng = np.random.default_rng(seed)
     small = [(16, 16), (32, 32), (12, 12), (7, 5), (20, 45), (33, 31), (24, 40), (48, 48), (9, 30)]
+    if large:
+        small = [(64, 64), (96, 96), (100, 100), (110, 130), (140, 90), (128, 128)]
     bad, n = [], 0
     for case in range(N):
-        H, W = small[case % len(small)] if case < 2 * len(small) else (int(rng.integers(4, 50)), int(rng.integers(4, 50)))
-        B = int(rng.integers(1, 5))
+        H, W = small[case % len(small)] if (large or case < 2 * len(small)) else (int(rng.integers(4, 50)), int(rng.integers(4, 50)))
+        B = int(rng.integers(1, 3 if large else 5))
         pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.15, 0.3])), seed=int(rng.integers(1 << 30)))
         cost_np = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)))
         gr = float(rng.choice([0.5, 0.5, 0.2, 0.8]))
         train = bool(rng.random() < 0.5)
-        Tmax = float(rng.choice([0.25, 0.5, 1.0])) if train else 1.0
+        Tmax = float(rng.choice([0.05, 0.1] if large else [0.25, 0.5, 1.0])) if train else 1.0
         T = int((Tmax if train else 1.0) * W * W)
         if T < 1:
             continue
@@ -135,4 +139,8 @@ if __name__ == "__main__":
     print(json.dumps({"cases": sum(st.values()), "by_kernel": st, "mismatches": len(bad_cases)}))
     nb, bad_b = run_backward(N=max(20, (int(sys.argv[2]) if len(sys.argv) > 2 else 160) // 10))
     print(json.dumps({"backward_cases": nb, "backward_failures": len(bad_b)}))
-    sys.exit(1 if (bad_cases or bad_b) else 0)
+    bad_l = []
+    if len(sys.argv) > 4:  # a few LARGE backward cases (seconds of oracle time each)
+        nl, bad_l = run_backward(seed=5, N=int(sys.argv[4]), large=True)
+        print(json.dumps({"backward_large_cases": nl, "backward_large_failures": len(bad_l)}))
+    sys.exit(1 if (bad_cases or bad_b or bad_l) else 0)
