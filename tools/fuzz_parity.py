@@ -133,6 +133,65 @@ def run_backward(seed=11, N=40, verbose=True, large=False):
     return n, bad
 
 
+def run_encoder(seed=21, N=30, verbose=True):
+    """cost maps of the MI355X inference encoders (f16x3: the default backend) against the SAME module on torch.nn fp32, random depths / map
+    sizes / inputs / const, BatchNorm statistics and weights randomised; tolerance 1e-5 (north_star) on the cost map.  -> (cases, failures)"""
+    from neural_astar.planner import NeuralAstar
+    rng = np.random.default_rng(seed)
+    bad, n = [], 0
+    routes = {}
+    for case in range(N):
+        arch = "CNNDownSize" if rng.random() < 0.3 else "CNN"
+        depth = int(rng.integers(1, 5))
+        if arch == "CNN":
+            H, W = (32, 32) if rng.random() < 0.25 else (int(rng.integers(4, 100)), int(rng.integers(4, 120)))
+            gh, gw = H, W
+        else:
+            f = 1 << depth
+            gh, gw = int(rng.integers(2, 9)), int(rng.integers(2, 9))
+            H, W = gh * f, gw * f
+        inp = str(rng.choice(["m+", "m"])) if arch == "CNN" else "m+"
+        const = None if rng.random() < 0.5 else float(rng.choice([2.0, 10.0]))
+        B = int(rng.integers(1, 6))
+        torch.manual_seed(int(rng.integers(1 << 30)))
+        na = NeuralAstar(encoder_input=inp, encoder_arch=arch, encoder_depth=depth, const=const, learn_obstacles=(arch == "CNNDownSize")).to(dev).eval()
+        with torch.no_grad():
+            for mod in na.encoder.modules():  # non-trivial BatchNorm statistics
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.normal_(0, 0.3)
+                    mod.running_var.uniform_(0.5, 2.0)
+                    mod.weight.uniform_(0.5, 1.5)
+                    mod.bias.normal_(0, 0.2)
+            m = (torch.rand(B, 1, H, W, device=dev) > 0.2).float()
+            s = torch.zeros(B, 1, gh, gw, device=dev)
+            g = torch.zeros(B, 1, gh, gw, device=dev)
+            s[:, 0, 0, 0] = 1
+            g[:, 0, -1, -1] = 1
+            na.encoder_backend = "auto"
+            try:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    c_hip = na.encode(m, s, g)
+                route = na.last_encoder_route
+                na.encoder_backend = "torch"
+                c_ref = na.encode(m, s, g)
+                scale = float(const or 1.0)
+                err = float((c_hip - c_ref).abs().max()) / scale
+                ok = err <= 1e-5 or not route.startswith("hip")
+            except Exception as e:  # noqa: BLE001
+                ok, err, route = False, -1.0, f"{type(e).__name__}: {e}"[:200]
+        n += 1
+        routes[route.split(" ")[0]] = routes.get(route.split(" ")[0], 0) + 1
+        if not ok:
+            d = {"case": case, "arch": arch, "depth": depth, "H": H, "W": W, "B": B, "input": inp, "const": const, "err": err, "route": route}
+            bad.append(d)
+            if verbose:
+                print(json.dumps(d), flush=True)
+    run_encoder.routes = routes
+    return n, bad
+
+
 if __name__ == "__main__":
     st, bad_cases = run(int(sys.argv[1]) if len(sys.argv) > 1 else 20260926, int(sys.argv[2]) if len(sys.argv) > 2 else 160,
                         float(sys.argv[3]) if len(sys.argv) > 3 else 0.15)
@@ -143,4 +202,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 4:  # a few LARGE backward cases (seconds of oracle time each)
         nl, bad_l = run_backward(seed=5, N=int(sys.argv[4]), large=True)
         print(json.dumps({"backward_large_cases": nl, "backward_large_failures": len(bad_l)}))
-    sys.exit(1 if (bad_cases or bad_b or bad_l) else 0)
+    ne, bad_e = run_encoder(N=int(sys.argv[5]) if len(sys.argv) > 5 else 40)
+    print(json.dumps({"encoder_cases": ne, "encoder_failures": len(bad_e), "routes": run_encoder.routes}))
+    sys.exit(1 if (bad_cases or bad_b or bad_l or bad_e) else 0)
