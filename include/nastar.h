@@ -81,6 +81,13 @@ extern "C" {
  * stream (or an event) has been waited for -- no reduction launch, no device-to-host copy. */
 #define NASTAR_SUMMARY_WORDS 16
 #define NASTAR_SUMMARY_BAD_ORDER 15
+/* cell 14, a NOTE, not an error: some map that reached its goal is not at a fixed point of the reference's batch loop.  The reference steps a
+ * finished map until EVERY map of its batch selects its goal in the same step (differentiable_astar.py:224, :251); the kernels stop each map
+ * at its own goal.  The outputs agree iff the goal's own expansion would open nothing that beats the goal -- always true for g_ratio in
+ * [0.5, 1) with costs >= 0 (every shipped configuration), not for g_ratio < 0.5 with an expensive goal cell, g_ratio = 1 with a zero-cost one,
+ * or negative costs: there the reference's histories of that map depend on the rest of its batch, and the kernels return what the reference
+ * returns for the map searched alone.  (The unit-cost layout never sets it: cost = 1 everywhere.) */
+#define NASTAR_SUMMARY_COUPLED 14
 
 int nastar_version(void);
 

@@ -191,6 +191,23 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
                 }
                 ++iters;
                 solved = true;
+                if (a.summary) {
+                    // Is this map now at a FIXED POINT of the reference's batch loop?  The reference keeps stepping a finished map until every
+                    // map of the batch selects its goal in the same step (:224 the goal stays open, :251); this kernel stops here.  The two
+                    // agree iff the goal's own expansion opens nothing that beats the goal: true for every g_ratio in [0.5, 1) with costs >= 0
+                    // (f(n) - f(goal) = (2 g_ratio - 1) c_goal + (1 - g_ratio)(h0(n) + c_n) > 0), not for g_ratio < 0.5 with an expensive goal
+                    // cell, g_ratio = 1 with a zero-cost one, or negative costs.  Detected here, reported as summary[NASTAR_SUMMARY_COUPLED].
+                    const int nr = goal_r + lc.dr, nc = goal_c + lc.dc;
+                    const bool inb = lc.is_nb & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+                    const int n = inb ? s + lc.off : s;
+                    const float2 gg = l.gc[s], gn = l.gc[n];
+                    const float g2 = gg.x + gg.y;
+                    const uint32_t kn = compact_key<kFastDiv>(d, g2, d.omg * (heuristic0_fast(nr, nc, goal_r, goal_c) + gn.y), rcp_sqrtW);
+                    const uint32_t kg = compact_key<kFastDiv>(d, gg.x, d.omg * (heuristic0_fast(goal_r, goal_c, goal_r, goal_c) + gg.y), rcp_sqrtW);
+                    const bool beats = inb & (gn.x > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
+                    if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+                    wave_order();
+                }
                 if (lane == 0) l.gc[s].x = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
             }
         }

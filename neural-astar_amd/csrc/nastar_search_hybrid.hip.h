@@ -209,7 +209,22 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             const int s = (int)(uint32_t)M;
             if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
             ++iters;
-            if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point
+            if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
+                if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
+                    int gc0;
+                    const int gr0 = hybrid_row(s, d, gc0);
+                    const int nr = gr0 + dr, nc = gc0 + dc;
+                    const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+                    const int n = inb ? s + dr * d.W + dc : s;
+                    global_step_fence();
+                    const float gs = gld(&g[s]), gn = gld(&g[n]);
+                    const float cs = cost[s], cn = cost[n];
+                    const float g2 = gs + cs;
+                    const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+                    const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
+                    const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
+                    if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+                }
                 if (lane == 0) gst(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
                 solved = true;
                 break;

@@ -39,6 +39,8 @@ STATUS_UNSOLVABLE = 3  # NASTAR_ERR_UNSOLVABLE (per-map status)
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
 SUMMARY_WORDS = 16  # NASTAR_SUMMARY_WORDS
 SUMMARY_BAD_ORDER = 15  # NASTAR_SUMMARY_BAD_ORDER
+SUMMARY_COUPLED = 14  # NASTAR_SUMMARY_COUPLED: a NOTE (a finished map is not at a fixed point of the reference's batch loop), cells 1..13 are errors
+SUMMARY_ERRORS = slice(1, 14)
 # development knob: NASTAR_FLAG_* of include/nastar.h OR-ed into every forward launch (A/B switches: NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
 if FORWARD_FLAGS & ~(8 | 16 | 32 | 64 | 128):
@@ -153,7 +155,7 @@ class StatusBoard:
     def read(self, row: int):
         """the row as a numpy view if any STATUS cell (1..15) is set, else None (the launch that was handed the row must be over: wait())"""
         r = self.np[row]
-        return r if r[1:].any() else None
+        return r if r[1:].any() else None  # (incl. the notes in cells 14 / 15: the caller tells errors -- SUMMARY_ERRORS -- from notes)
 
     def release(self, row: int) -> None:
         self.np[row] = 0

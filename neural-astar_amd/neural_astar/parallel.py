@@ -346,7 +346,7 @@ class InFlightPlanner:
                     summ = None if r is None else r.copy()
                 finally:
                     board.release(r2)
-            if summ is not None and summ[1:ops.SUMMARY_BAD_ORDER].any() and self.check_solvable and failed is None:
+            if summ is not None and summ[ops.SUMMARY_ERRORS].any() and self.check_solvable and failed is None:
                 failed = (ticket, status)
             outs.append(AstarOutput(hist, paths, []))
             astar.last_status, astar.last_iters = status, iters

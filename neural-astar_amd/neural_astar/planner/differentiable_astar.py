@@ -56,7 +56,12 @@ class _PendingStatus:
             self.board.wait(self.row, self.stream)
         else:
             self.event.synchronize()
-        bad = self.board.read(self.row) is not None
+        r = self.board.read(self.row)
+        bad = r is not None and bool(r[ops.SUMMARY_ERRORS].any())
+        if r is not None and r[ops.SUMMARY_COUPLED] and self.status.numel() > 1:
+            _warn_coupled(None)
+        if r is not None and r[ops.SUMMARY_BAD_ORDER]:
+            _warn_bad_order()
         self.board.release(self.row)
         self.released = True
         if bad:
@@ -236,9 +241,11 @@ class DifferentiableAstar(nn.Module):
             if clean is None and row >= 0:
                 summ = self._collect_sync(row, status.device, flagged)
                 row = -1
-                clean = summ is None or not (summ[1:ops.SUMMARY_BAD_ORDER].any())
+                clean = summ is None or not (summ[ops.SUMMARY_ERRORS].any())
                 if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
                     _warn_bad_order()
+                if summ is not None and summ[ops.SUMMARY_COUPLED] and status.numel() > 1:
+                    _warn_coupled(self.g_ratio)
             if row >= 0:
                 ops.StatusBoard.of(status.device).release(row)
             if (not clean) if clean is not None else bool((status != 0).any()):
@@ -350,6 +357,21 @@ class DifferentiableAstar(nn.Module):
 
 
 _BAD_ORDER_WARNED = False
+_COUPLED_WARNED = False
+
+
+def _warn_coupled(g_ratio) -> None:
+    """summary[NASTAR_SUMMARY_COUPLED]: see include/nastar.h"""
+    global _COUPLED_WARNED
+    if not _COUPLED_WARNED:
+        _COUPLED_WARNED = True
+        import warnings
+        warnings.warn("a map of this batch reached its goal but is not at a fixed point of the reference's batch loop (possible only for g_ratio < 0.5 "
+                      "with an expensive goal cell, g_ratio = 1 with a zero-cost one, or negative costs"
+                      + (f"; g_ratio = {g_ratio}" if g_ratio is not None else "") + "): the reference would keep expanding cells of that map until "
+                      "every map of the batch selects its goal in the same step, so its histories there depend on the rest of the batch; this "
+                      "implementation returns what the reference returns for each map searched alone (DESIGN.md section 2.3)", RuntimeWarning, stacklevel=3)
+
 
 
 def _warn_bad_order() -> None:

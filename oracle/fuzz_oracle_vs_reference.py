@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""The oracle against the LIVE reference on random inputs (authoring container only: runs the reference; test infrastructure).
+
+tests/golden/ pins the oracle on fixed vectors; this sweep widens the net: random map sizes (small, and some with sides above 140 cells where
+get_heuristic's square root starts to matter), obstacle densities, cost kinds (map / U(0,1) / U(0,10) / zeros), g_ratio, eval and training
+budgets.  The literal restatement (dense) must reproduce the reference's histories and paths bit for bit, the dense backward its autograd gradient to
+1e-5 (north_star).  The state-machine restatement (sm: per-map early exit, what the kernels implement) must do so too EXCEPT in the
+batch-coupled class (a finished map whose goal's expansion opens a cell that beats the goal keeps closing cells while
+the rest of the batch searches) -- possible only for g_ratio < 0.5, g_ratio = 1 with zero costs, or negative costs; there sm must equal the
+reference run on each map ALONE, which is checked as well.
+
+Usage: python oracle/fuzz_oracle_vs_reference.py [n_cases] [seed]   (writes profiles/r05/oracle_vs_reference_fuzz.json)"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.join(ROOT, "oracle")]
+sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
+from neural_astar.utils import synthetic as syn  # noqa: E402
+from oracle import gen_golden as GG  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ref = GG.load_reference()
+    torch.set_num_threads(os.cpu_count() or 1)
+    bad, stats = [], {"forward": 0, "backward": 0, "large": 0}
+    for case in range(n_cases):
+        large = rng.random() < 0.08
+        H, W = (int(rng.integers(141, 230)), int(rng.integers(141, 230))) if large else (int(rng.integers(3, 48)), int(rng.integers(3, 48)))
+        B = 1 if large else int(rng.integers(1, 5))
+        pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.1, 0.25])), seed=int(rng.integers(1 << 30)))
+        kind = str(rng.choice(["map", "u01", "u10", "zeros"]))
+        if kind == "map":
+            cost = pr.map_designs
+        elif kind == "zeros":
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30))) * (rng.random((B, 1, H, W)) < 0.5).astype(np.float32)
+        else:
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
+        gr = float(rng.choice([0.5, 0.5, 0.2, 0.8, 0.0, 1.0]))
+        train = bool(rng.random() < 0.3)
+        Tmax = float(rng.choice([0.1, 0.25, 0.5])) if train else 1.0
+        T = int((Tmax if train else 1.0) * W * W)
+        if T < 1:
+            continue
+        want_grad = (not large) and rng.random() < 0.3
+        up = rng.standard_normal((B, 1, H, W)).astype(np.float32) if want_grad else None
+        out, grad = GG.run_ref(ref, cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, Tmax, train, up)
+        hist, paths = out.histories[:, 0].detach().numpy(), out.paths[:, 0].numpy()
+        od = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T, mode="dense")
+        osm = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T, mode="sm")
+        ok = np.array_equal(od.histories, hist) and np.array_equal(od.paths, paths)
+        stats["forward"] += 1
+        stats["large"] += int(large)
+        if not (np.array_equal(osm.histories, hist) and np.array_equal(osm.paths, paths)):
+            # allowed only in the coupled class, and then sm == the reference on each map alone
+            stats["coupled"] = stats.get("coupled", 0) + 1
+            in_class = gr < 0.5 or (gr == 1.0 and kind == "zeros")
+            alone_ok = True
+            for b in range(B):
+                o1, _ = GG.run_ref(ref, cost[b:b + 1], pr.start_maps[b:b + 1], pr.goal_maps[b:b + 1], pr.map_designs[b:b + 1], gr, Tmax, train)
+                alone_ok = alone_ok and np.array_equal(o1.histories[0, 0].numpy(), osm.histories[b]) and np.array_equal(o1.paths[0, 0].numpy(), osm.paths[b])
+            ok = ok and in_class and alone_ok
+        if want_grad:
+            g = O.backward(up, cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T)
+            err = float(np.abs(g - grad[:, 0]).max()) / max(1.0, float(np.abs(grad).max()))
+            ok = ok and err <= 1e-5
+            stats["backward"] += 1
+        if not ok:
+            d = {"case": case, "H": H, "W": W, "B": B, "cost": kind, "g_ratio": gr, "train": train, "Tmax": Tmax}
+            bad.append(d)
+            print(json.dumps(d), flush=True)
+    res = {"cases": stats, "mismatches": len(bad), "failing": bad, "torch": torch.__version__}
+    print(json.dumps(res))
+    out_path = os.path.join(ROOT, "profiles", "r05", "oracle_vs_reference_fuzz.json")
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

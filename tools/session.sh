@@ -353,6 +353,22 @@ r05_fuzz)
   done
   python -m pytest tests/test_fuzz_parity_gpu.py -q -m gpu 2>&1 | tail -2
   ;;
+r05_final)
+  # the final tree: GPU suite, smoke, the driver's bench command
+  O=gpurun_out/r05/final; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/gpu_tests_final.log 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_tests_final.log | cut -c1-200
+  python __graft_entry__.py smoke 2>&1 | tail -1
+  python bench.py --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err
+  python - <<'P'
+import json
+j = json.load(open("gpurun_out/r05/final/bench_driver_command.json"))
+print("value", round(j["value"] / 1e6, 2), "M maps/s  ms/step", round(j["ms_per_step"], 4), "natural", round(j["value_natural_order"] / 1e6, 2), "hinted", round(j["value_hinted"] / 1e6, 2), "in flight", j.get("value_in_flight"))
+print("roofline", {k: j["roofline"][k] for k in ("frac", "frac_28B_per_cell", "launch_ms_avg")}, "through_module", {k: round(v, 4) for k, v in j.get("through_module", {}).items() if isinstance(v, float)})
+for r in j.get("in_flight_through_api", []):
+    print(r["workload"], r["kernel"], {k: round(v / 1e6, 1) for k, v in r["streams_sweep_maps_per_s"].items()}, r["equal_to_sequential_forward"])
+print("cpu", j["cpu_baseline"]["value"], j["cpu_baseline"]["cores"])
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
