@@ -68,6 +68,11 @@ extern "C" {
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
 #define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
+#define NASTAR_FLAG_LOCKSTEP 1024 /* forward: the reference's batch loop TO THE LETTER for every map -- no exit at the goal: a selected goal is expanded like any cell, stays
+                                   * on the open list (differentiable_astar.py:224) and the map is stepped on until exactly max_iters steps have been executed (or its
+                                   * open list is empty).  What the Python layer uses, with max_iters = the step at which every map of the batch selects its goal, when a
+                                   * launch reports NASTAR_SUMMARY_COUPLED.  Compiled step loops, LDS-resident sizes (NASTAR_ERR_UNSUPPORTED beyond); sel_log_out then
+                                   * records every step, goal selections included */
 #define NASTAR_FLAG_GLOBAL_V1 512 /* forward, maps larger than LDS: the round-4 kernel with all three open-list levels in HBM (A/B; needs its own, larger workspace) */
 #define NASTAR_FLAG_CHECK_ORDER 256 /* nastar_forward_ex / nastar_forward_ordered / nastar_backward_replay_ordered: verify on the device that `order` is a
                                      * permutation of 0..B-1 (one small launch before the search) and IGNORE it when it is not -- every map is then

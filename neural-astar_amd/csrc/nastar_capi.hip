@@ -140,6 +140,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     int status = NASTAR_OK;
     int iters = 0;
     bool solved = false;
+    const bool lockstep = !kAsm && (a.flags & NASTAR_FLAG_LOCKSTEP);  // (forward_impl picks a compiled instantiation for it)
+    bool goal_hit = false;
     if (start_idx < 0 || goal_idx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
     } else {
@@ -175,13 +177,17 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
         while (iters < a.max_iters) {  // :203 for t in range(Tmax)
             uint2 mine;
             s = compact_select<CPL_T>(d, l, lane, mine);
-            if (s < 0 || s == goal_idx) break;  // single exit test: open list empty (:68 would divide by zero) or goal
+            if (s < 0 || (s == goal_idx && !lockstep)) break;  // single exit test: open list empty (:68 would divide by zero) or goal
             if constexpr (kLog) {
                 if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
             }
             ++iters;
-            compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine);
+            // lock-step mode: the reference's loop to the letter -- a selected goal is expanded like any cell, stays open, and the map is stepped
+            // on (it may wander: NASTAR_SUMMARY_COUPLED) until the caller's step count is reached
+            goal_hit |= s == goal_idx;
+            compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine, s == goal_idx);
         }
+        if (lockstep && goal_hit && lane == 0) l.gc[goal_idx].x = NASTAR_NEG_INF;  // histories holds the goal (:222-223); nothing reads its g any more
         if (kAsm ? (s != -2) : (iters < a.max_iters)) {
             if (s < 0) {
                 status = NASTAR_ERR_UNSOLVABLE;
@@ -471,6 +477,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
     if (B > 0 && H > 0 && W > 0 && max_iters > 0 && (long long)H * W <= kMaxGlobalCells && needs_global_state(H, W)) {
+        if (flags & NASTAR_FLAG_LOCKSTEP) return NASTAR_ERR_UNSUPPORTED;  // LDS-resident sizes only
         // large map: cells in the caller's HBM workspace, open list in LDS (nastar_search_hybrid.hip.h)
         if (!workspace) return NASTAR_ERR_NULL;
         if (!(flags & NASTAR_FLAG_GLOBAL_V1)) {
@@ -561,7 +568,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.B = B;
 #define NASTAR_CPICK(V4, LW, LH, CPL, FD) \
     kern = lg ? &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, true> : &nastar_forward_compact_kernel<V4, LW, LH, CPL, FD, false>
-        const bool use_asm = !(flags & NASTAR_FLAG_NO_ASM);
+        const bool use_asm = !(flags & (NASTAR_FLAG_NO_ASM | NASTAR_FLAG_LOCKSTEP));  // (lock-step mode lives in the compiled step loops)
         // unit-cost layout: the caller promises cost == passable with values in {0, 1} (checked per map by the kernel); taken when the
         // promise can hold at all (ONE tensor), no selection log is wanted and the hand-scheduled stream exists for the size
         if ((flags & NASTAR_FLAG_UNIT_COST) && cost == passable && use_asm && !(flags & (NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3)) && !lg && vec4 && fast &&

@@ -257,9 +257,11 @@ __device__ __forceinline__ CompactLane make_compact_lane(const CompactDims& d, i
 
 // ---- close s (:222-225) and relax its <= 8 Moore neighbours (:228-249); re-minimise the chunk of s without it ----------
 // CPL_T == 1: `mine` is this lane's own cmin entry as read by compact_select (nothing has touched it since).
+// keep_open (lock-step mode, NASTAR_FLAG_LOCKSTEP): s* is the goal -- the reference expands it like any cell but leaves it on the open list
+// (:224 open_maps - is_unsolved * selected) while histories records it (:222-223); the caller keeps that flag
 template <int LOGW, bool kFastDiv, int CPL_T>
 __device__ __forceinline__ void compact_expand(const CompactDims& d, const CompactLds& l, const CompactLane& lc, int lane, int s,
-                                               int goal_r, int goal_c, float rcp_sqrtW, const uint2 mine)
+                                               int goal_r, int goal_c, float rcp_sqrtW, const uint2 mine, const bool keep_open = false)
 {
     int r, c;
     if constexpr (LOGW) {
@@ -295,7 +297,7 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
     // neighbour lanes: key of the relaxed neighbour (g2); chunk lanes: current key of their cell (its own g)
     const uint32_t k = compact_key<kFastDiv>(d, lc.is_nb ? g2 : gl.x, hh, rcp_sqrtW);
     // chunk minimum without s*: open <=> finite g
-    const bool open_l = lc.is_chk & (fabsf(gl.x) < NASTAR_POS_INF) & (il != s);
+    const bool open_l = lc.is_chk & (fabsf(gl.x) < NASTAR_POS_INF) & ((il != s) | keep_open);
     const uint32_t kk = open_l ? k : KEY_INF;
     const uint32_t mc = row_min16_u32(kk);
     const unsigned long long firstm = __ballot(lc.is_chk & (kk == mc));  // bits 16..31; never empty
@@ -303,7 +305,7 @@ __device__ __forceinline__ void compact_expand(const CompactDims& d, const Compa
     const uint32_t ci = (uint32_t)(cbase + __builtin_ctzll(firstm) - 16);
     // All stores are unconditional: a lane with nothing to write targets its private dump word / a no-op atomic.
     uint32_t* const dmp = l.dump + lane;
-    float* const g_dst = upd ? &l.gc[il].x : ((lane == 8) ? &l.gc[s].x : reinterpret_cast<float*>(dmp));
+    float* const g_dst = upd ? &l.gc[il].x : ((lane == 8 && !keep_open) ? &l.gc[s].x : reinterpret_cast<float*>(dmp));
     uint8_t* const p_dst = upd ? &l.pdir[il] : reinterpret_cast<uint8_t*>(dmp);
     *g_dst = upd ? g2 : NASTAR_NEG_INF;  // :238 g update          | :222-225 s* joins the closed list, leaves the open list
     *p_dst = (uint8_t)lc.pcode;          // :246-249 parent = s*

@@ -34,6 +34,7 @@ def _require_device(*tensors: torch.Tensor) -> None:
 
 
 FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
+FLAG_LOCKSTEP = 1024  # NASTAR_FLAG_LOCKSTEP: the reference's batch loop to the letter (no exit at the goal; exactly max_iters steps)
 FLAG_CHECK_ORDER = 256  # NASTAR_FLAG_CHECK_ORDER: the launch verifies `order` on the device and ignores it when it is not a permutation
 STATUS_UNSOLVABLE = 3  # NASTAR_ERR_UNSOLVABLE (per-map status)
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)

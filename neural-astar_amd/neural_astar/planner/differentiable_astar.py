@@ -221,22 +221,25 @@ class DifferentiableAstar(nn.Module):
         board.release(row)
         return r
 
-    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1, flagged: bool = False) -> None:
+    def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1, flagged: bool = False,
+                    warn_coupled: bool = True) -> bool:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
         step and the validation pair, which launch the search themselves).  ``row``: the ``begin_launch()`` row whose address the
         launch was given as ``summary_ptr`` (``flagged``: and its ``counter_ptr``) -- the verdict is then a poll of the row's completion flag
         (unflagged: a stream wait / an event) and one 64-byte host read; without a row the status tensor is reduced on the device (one
         more launch + a blocking copy).  ``clean``: the
-        caller has already read the verdict on the host (True = all zero) -- the "sync" policy then does not wait a second time."""
+        caller has already read the verdict on the host (True = all zero) -- the "sync" policy then does not wait a second time.
+        Returns True when the launch reported NASTAR_SUMMARY_COUPLED and the verdict was read in this call (``warn_coupled`` False: the
+        caller deals with it -- ``forward`` re-runs the batch in lock-step mode -- instead of the warning)."""
         self.last_status, self.last_iters = status, iters
         self._calls += 1
         mode = self.check_solvable
         if clean is True and row < 0 and mode is not False and mode != "deferred":
-            return  # the caller has read a clean verdict for THIS call already
+            return False  # the caller has read a clean verdict for THIS call already
         if not mode or _capturing(status) or torch.compiler.is_compiling():  # nothing may synchronise inside a hipGraph capture / a trace
             if row >= 0:
                 ops.StatusBoard.of(status.device).release(row)
-            return
+            return False
         if mode != "deferred":  # True / "sync": the verdict belongs to THIS call
             if clean is None and row >= 0:
                 summ = self._collect_sync(row, status.device, flagged)
@@ -244,13 +247,16 @@ class DifferentiableAstar(nn.Module):
                 clean = summ is None or not (summ[ops.SUMMARY_ERRORS].any())
                 if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
                     _warn_bad_order()
-                if summ is not None and summ[ops.SUMMARY_COUPLED] and status.numel() > 1:
+                coupled = summ is not None and bool(summ[ops.SUMMARY_COUPLED]) and status.numel() > 1
+                if coupled and warn_coupled:
                     _warn_coupled(self.g_ratio)
+            else:
+                coupled = False
             if row >= 0:
                 ops.StatusBoard.of(status.device).release(row)
             if (not clean) if clean is not None else bool((status != 0).any()):
                 _raise_unsolvable(status, self._calls)
-            return
+            return coupled
         if row < 0:  # a launch that carried no summary: reduce on the device into a fresh row's worth of pinned memory
             row = ops.StatusBoard.of(status.device).acquire()
             ops.StatusBoard.of(status.device).t[row, ops.STATUS_UNSOLVABLE:ops.STATUS_UNSOLVABLE + 1].copy_((status != 0).any().reshape(1), non_blocking=True)
@@ -258,6 +264,21 @@ class DifferentiableAstar(nn.Module):
         self._pending.append(_PendingStatus(status, row, self._calls, flagged))
         if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
             self._pending.pop(0).raise_if_unsolvable()
+        return False
+
+    def _lockstep(self, cost_maps, start_maps, goal_maps, passable, max_iters):
+        """The reference's batch loop to the letter for a batch in which a finished map is NOT at a fixed point (NASTAR_SUMMARY_COUPLED;
+        DESIGN.md section 2.3): every map is stepped, goal selections included, until the first step at which ALL maps select their goal
+        (reference :219-225, :251) or the budget ends.  Two launches of the lock-step mode (NASTAR_FLAG_LOCKSTEP, compiled step loops):
+        one with the selection log over the whole budget to find that step, one that stops exactly there."""
+        B = cost_maps.shape[0]
+        log = ops.search_nograd(cost_maps, start_maps, goal_maps, passable, self.g_ratio, max_iters, True, ops.FLAG_LOCKSTEP)[4]
+        goal_idx = goal_maps.reshape(B, -1).argmax(1).to(torch.int32)
+        hit = (log == goal_idx[:, None]).all(0)  # [max_iters]: every map selects its goal at step t
+        first = torch.nonzero(hit)
+        t_end = int(first[0]) if first.numel() else max_iters - 1  # (one host read; the budget ends the loop otherwise, :203)
+        return ops.search_nograd(cost_maps, start_maps, goal_maps, passable, self.g_ratio, t_end + 1, False, ops.FLAG_LOCKSTEP, None, None, False, 0,
+                                 None, True)
 
     def resolve_placement(self, B: int, start_maps: torch.Tensor, in_lds: bool):
         """(order, order_out, check_order, placement) for the next launch.  The ``OrderHint`` the batch's loader attached to ``start_maps``
@@ -348,7 +369,11 @@ class DifferentiableAstar(nn.Module):
         clean = None
         if pl is not None and order_out is not None:
             pl.commit()
-        self.note_status(status, iters, clean, row, flagged=bool(cptr) and not traced)  # (the custom ops carry the summary, not the counter)
+        exact = (not traced) and in_lds and not want_log  # (this call can re-run the batch in lock-step mode when a finished map is not at a fixed point)
+        coupled = self.note_status(status, iters, clean, row, flagged=bool(cptr) and not traced, warn_coupled=not exact)
+        if coupled and exact:
+            hist, paths, iters, status, sel_log = self._lockstep(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps, max_iters)
+            self.last_status, self.last_iters = status, iters
 
         intermediate_results: List[dict] = []
         if store_intermediate_results:

@@ -133,6 +133,44 @@ def run_backward(seed=11, N=40, verbose=True, large=False):
     return n, bad
 
 
+def run_module(seed=31, N=60, verbose=True):
+    """DifferentiableAstar.forward() (default checking: the same-call verdict, and with it the lock-step re-run of batches in which a finished
+    map is not at a fixed point) against the oracle's LITERAL restatement of the reference's batch loop, on small random batches incl. the
+    cost kinds / g_ratio values of the batch-coupled class.  -> (cases, coupled re-runs seen, failures)"""
+    import warnings
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    rng = np.random.default_rng(seed)
+    bad, n, reruns = [], 0, 0
+    for case in range(N):
+        H, W = int(rng.integers(4, 40)), int(rng.integers(4, 40))
+        B = int(rng.integers(2, 6))
+        pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.1, 0.25])), seed=int(rng.integers(1 << 30)))
+        kind = str(rng.choice(["map", "u01", "u10", "u10", "zeros"]))
+        if kind == "map":
+            cost = pr.map_designs
+        elif kind == "zeros":
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30))) * (rng.random((B, 1, H, W)) < 0.5).astype(np.float32)
+        else:
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
+        gr = float(rng.choice([0.5, 0.2, 0.0, 0.8, 1.0, 0.3]))
+        o = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, W * W, mode="dense")
+        osm = O.forward(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, W * W, mode="sm")
+        reruns += int(not np.array_equal(o.histories, osm.histories))
+        da = DifferentiableAstar(gr, 1.0).to(dev).eval()
+        c, s, g, m = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (cost, pr.start_maps, pr.goal_maps, pr.map_designs))
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = da(c, s, g, c if kind == "map" else m)
+        ok = np.array_equal(out.histories[:, 0].cpu().numpy(), o.histories) and np.array_equal(out.paths[:, 0].cpu().numpy(), o.paths)
+        n += 1
+        if not ok:
+            d = {"case": case, "H": H, "W": W, "B": B, "cost": kind, "g_ratio": gr}
+            bad.append(d)
+            if verbose:
+                print(json.dumps(d), flush=True)
+    return n, reruns, bad
+
+
 def run_encoder(seed=21, N=30, verbose=True):
     """cost maps of the MI355X inference encoders (f16x3: the default backend) against the SAME module on torch.nn fp32, random depths / map
     sizes / inputs / const, BatchNorm statistics and weights randomised; tolerance 1e-5 (north_star) on the cost map.  -> (cases, failures)"""
@@ -202,6 +240,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 4:  # a few LARGE backward cases (seconds of oracle time each)
         nl, bad_l = run_backward(seed=5, N=int(sys.argv[4]), large=True)
         print(json.dumps({"backward_large_cases": nl, "backward_large_failures": len(bad_l)}))
+    nm, rr, bad_m = run_module(N=int(sys.argv[6]) if len(sys.argv) > 6 else 60)
+    print(json.dumps({"module_vs_literal_batch_loop_cases": nm, "batches_in_the_coupled_class": rr, "module_failures": len(bad_m)}))
+    if bad_m:
+        sys.exit(1)
     ne, bad_e = run_encoder(N=int(sys.argv[5]) if len(sys.argv) > 5 else 40)
     print(json.dumps({"encoder_cases": ne, "encoder_failures": len(bad_e), "routes": run_encoder.routes}))
     sys.exit(1 if (bad_cases or bad_b or bad_l or bad_e) else 0)
