@@ -346,6 +346,13 @@ class InFlightPlanner:
                     summ = None if r is None else r.copy()
                 finally:
                     board.release(r2)
+            if (summ is not None and summ[ops.SUMMARY_COUPLED] and not summ[ops.SUMMARY_ERRORS].any() and status.numel() > 1
+                    and ops.in_lds(ins[1].shape[-2], ins[1].shape[-1])):
+                # a finished map of this batch is not at a fixed point of the reference's batch loop (g_ratio < 0.5 with an expensive goal cell;
+                # DESIGN.md section 2.3): the batch again in lock-step mode, exactly as planner.forward() does
+                self.reruns += 1
+                cost, start_maps, goal_maps, passable = ins
+                hist, paths, iters, status, _ = astar._lockstep(cost, start_maps, goal_maps, passable, ops.max_iters_for(start_maps.shape[-1], 1.0, False))
             if summ is not None and summ[ops.SUMMARY_ERRORS].any() and self.check_solvable and failed is None:
                 failed = (ticket, status)
             outs.append(AstarOutput(hist, paths, []))

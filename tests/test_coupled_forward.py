@@ -92,6 +92,16 @@ def test_kernels_return_each_map_alone_and_report_the_coupling():
             out = da(c, s, go, p)
         da.raise_if_unsolvable()
     assert np.array_equal(out.histories[:, 0].cpu().numpy(), h_alone) and any("fixed point" in str(w.message) for w in rec)
+    # batches in flight: the flagged batch is re-run in lock-step mode when the results are collected
+    from neural_astar.parallel import InFlightPlanner
+
+    class _P:  # the planner surface InFlightPlanner needs
+        astar = DA.DifferentiableAstar(g.g_ratio, 1.0).to(c.device).eval()
+    fly = InFlightPlanner(_P(), streams=2, unit_cost=False)
+    fly.submit_search(c, s, go, p)
+    fly.submit_search(c, s, go, p)
+    outs = fly.collect()
+    assert fly.reruns == 2 and all(np.array_equal(o.histories[:, 0].cpu().numpy(), g.histories[:, 0]) for o in outs)
     # lock-step mode itself: on a batch of fixed points (g_ratio 0.5) it returns exactly what the early-exit kernels return
     ref5 = ops.search_nograd(c, s, go, p, 0.5, g.max_iters)
     t_end = int(ref5[2].max())
