@@ -175,9 +175,11 @@ def in_lds(H: int, W: int) -> bool:
 
 
 def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order, summary_ptr, dev,
-                   one_meta=False, stream_ptr=None, out_4d=False, counter_ptr=0):
+                   one_meta=False, stream_ptr=None, out_4d=False, counter_ptr=0, keep=None):
     """allocate the five outputs and issue ONE nastar_forward_ex launch on torch's current stream (shared by the custom ops and the
-    no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape)."""
+    no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape).
+    ``keep``: a list that receives the launch's temporaries (its workspace) when the launch goes to ANOTHER stream than the one the
+    caching allocator hands the memory out for -- the caller holds them until that stream is done."""
     shape = (B, 1, H, W) if out_4d else (B, H, W)
     hist = torch.empty(shape, dtype=torch.float32, device=dev)
     paths = torch.empty(shape, dtype=torch.int64, device=dev)
@@ -202,6 +204,11 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
     # workspace: > 0 for maps too large for LDS and for a checked order
     ws_bytes = (16 if flags & FLAG_CHECK_ORDER else 0) if in_lds(H, W) else int(lib.nastar_workspace_bytes(B, H, W, flags))
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+    if stream_ptr is not None and workspace is not None:
+        if keep is None:
+            raise ValueError("a launch on a foreign stream that needs a workspace must be given a `keep` list (the allocator would hand the "
+                             "workspace to the next launch on the current stream while this one still runs)")
+        keep.append(workspace)
     sp = stream_ptr if stream_ptr is not None else torch.cuda.current_stream(dev).cuda_stream
     args = (cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(), B, H, W, float(g_ratio), int(max_iters), hist.data_ptr(),
             paths.data_ptr(), sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
@@ -268,14 +275,19 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, o
 def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, obstacles_maps: torch.Tensor, g_ratio: float,
                   max_iters: int, want_log: bool = False, flags: int = 0, order: Optional[torch.Tensor] = None,
                   order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None,
-                  out_4d: bool = False, counter_ptr: int = 0):
+                  out_4d: bool = False, counter_ptr: int = 0, keep: Optional[list] = None):
     """The search launch WITHOUT the torch.library dispatch: what ``DifferentiableAstar.forward`` calls when no gradient can flow
     (``torch.no_grad()`` / inputs that do not require one) and nothing is being traced -- the custom-op machinery costs more host time
     than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs
     (``out_4d``: histories / paths as [B,1,H,W], the AstarOutput layout, and None instead of an empty selection log).
     ``summary_ptr`` / ``counter_ptr``: a ``StatusBoard`` row (status summary in pinned memory + its completion counter on the device).
     ``stream_ptr``: a hipStream_t to launch on instead of torch's current stream (``parallel.InFlightPlanner``; the outputs are
-    allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them)."""
+    allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them, passes contiguous inputs --
+    a copy made here would be made on the current stream, after the caller ordered the streams -- and holds ``keep``, the list that
+    receives the launch's workspace, until that stream is done)."""
+    if stream_ptr is not None and not (cost_maps.is_contiguous() and start_maps.is_contiguous() and goal_maps.is_contiguous()
+                                       and obstacles_maps.is_contiguous()):
+        raise ValueError("search_nograd(stream_ptr=...): the maps must be contiguous (make the copies before ordering the streams)")
     if not (cost_maps.is_cuda and start_maps.is_cuda and goal_maps.is_cuda and obstacles_maps.is_cuda
             and cost_maps.dtype == start_maps.dtype == goal_maps.dtype == obstacles_maps.dtype == torch.float32):
         _require_device(cost_maps, start_maps, goal_maps, obstacles_maps)
@@ -298,7 +310,7 @@ def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: 
     if not goal_maps.is_contiguous():
         goal_maps = goal_maps.contiguous()
     return _launch_search(_native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters, want_log, flags,
-                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d, counter_ptr)
+                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d, counter_ptr, keep)
 
 
 def order_from_levels(levels: torch.Tensor) -> torch.Tensor:

@@ -238,7 +238,7 @@ class InFlightPlanner:
         self._events: List[torch.cuda.Event] = []
         self._ptrs: List[int] = []
         self._device = None
-        self._inflight: List[tuple] = []  # (ticket, stream index, row, inputs, outputs, flags, order, check)
+        self._inflight: List[tuple] = []  # (ticket, stream index, row, inputs, outputs, flags, order, check, workspace)
         self._k = 0
         self.reruns = 0  # batches that were re-run on the general kernel (a non-binary map under unit_cost="auto")
 
@@ -281,6 +281,12 @@ class InFlightPlanner:
         st = self._streams[k]
         same = passable is cost
         with torch.no_grad():
+            # copies of strided inputs are made HERE, on the current stream and before the two streams are ordered, and are held with the batch
+            cost, start_maps_c, goal_maps = cost.contiguous(), start_maps.contiguous(), goal_maps.contiguous()
+            passable = cost if same else passable.contiguous()
+            if start_maps_c is not start_maps and hasattr(start_maps, "placement_order"):
+                start_maps_c.placement_order = start_maps.placement_order
+            start_maps = start_maps_c
             if not inputs_ready:
                 cur = torch.cuda.current_stream(dev)
                 # the batch's inputs (and the memory the allocator hands out for its outputs) belong to the CURRENT stream: the launch stream
@@ -302,15 +308,16 @@ class InFlightPlanner:
                     order, check = o.reshape(-1), not getattr(hint, "trusted", False)
             board = ops.StatusBoard.of(dev)
             row = board.acquire() if (self.check_solvable or (unit and self.unit_cost == "auto")) else -1
+            keep: list = []  # the launch's workspace (maps larger than LDS, a checked order): allocated for the current stream, used on stream k
             try:
                 out = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio, max_iters, False, flags, order, None, bool(check),
-                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k], True)
+                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k], True, 0, keep)
             except BaseException:
                 if row >= 0:
                     board.release(row)
                 raise
         ticket = len(self._inflight)
-        self._inflight.append((ticket, k, row, (cost, start_maps, goal_maps, passable), out, flags, order, check))
+        self._inflight.append((ticket, k, row, (cost, start_maps, goal_maps, passable), out, flags, order, check, keep))
         self._k += 1
         return ticket
 
@@ -325,7 +332,7 @@ class InFlightPlanner:
         outs: List[AstarOutput] = []
         failed = None
         astar = self.planner.astar
-        for ticket, k, row, ins, out, flags, order, check in self._inflight:
+        for ticket, k, row, ins, out, flags, order, check, _keep in self._inflight:
             hist, paths, iters, status, _ = out
             summ = None
             if row >= 0:

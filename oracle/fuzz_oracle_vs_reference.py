@@ -9,7 +9,7 @@ batch-coupled class (a finished map whose goal's expansio
 the rest of the batch searches) -- possible only for g_ratio < 0.5, g_ratio = 1 with zero costs, or negative costs; there sm must equal the
 reference run on each map ALONE, which is checked as well.
 
-Usage: python oracle/fuzz_oracle_vs_reference.py [n_cases] [seed]   (writes profiles/r05/oracle_vs_reference_fuzz.json)"""
+Usage: python oracle/fuzz_oracle_vs_reference.py [n_cases] [seed] [out.json]   (default: profiles/r05/oracle_vs_reference_fuzz.json)"""
 from __future__ import annotations
 
 import json
@@ -38,11 +38,13 @@ def main():
         H, W = (int(rng.integers(141, 230)), int(rng.integers(141, 230))) if large else (int(rng.integers(3, 48)), int(rng.integers(3, 48)))
         B = 1 if large else int(rng.integers(1, 5))
         pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.1, 0.25])), seed=int(rng.integers(1 << 30)))
-        kind = str(rng.choice(["map", "u01", "u10", "zeros"]))
+        kind = str(rng.choice(["map", "u01", "u10", "zeros", "signed"], p=[0.23, 0.23, 0.23, 0.23, 0.08]))
         if kind == "map":
             cost = pr.map_designs
         elif kind == "zeros":
             cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30))) * (rng.random((B, 1, H, W)) < 0.5).astype(np.float32)
+        elif kind == "signed":  # (the kernels' order-preserving key transform; a negative cost puts any g_ratio into the coupled class)
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), lo=-0.5, hi=1.0)
         else:
             cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
         gr = float(rng.choice([0.5, 0.5, 0.2, 0.8, 0.0, 1.0]))
@@ -63,7 +65,7 @@ def main():
         if not (np.array_equal(osm.histories, hist) and np.array_equal(osm.paths, paths)):
             # allowed only in the coupled class, and then sm == the reference on each map alone
             stats["coupled"] = stats.get("coupled", 0) + 1
-            in_class = gr < 0.5 or (gr == 1.0 and kind == "zeros")
+            in_class = gr < 0.5 or (gr == 1.0 and kind == "zeros") or kind == "signed"
             alone_ok = True
             for b in range(B):
                 o1, _ = GG.run_ref(ref, cost[b:b + 1], pr.start_maps[b:b + 1], pr.goal_maps[b:b + 1], pr.map_designs[b:b + 1], gr, Tmax, train)
@@ -78,9 +80,9 @@ def main():
             d = {"case": case, "H": H, "W": W, "B": B, "cost": kind, "g_ratio": gr, "train": train, "Tmax": Tmax}
             bad.append(d)
             print(json.dumps(d), flush=True)
-    res = {"cases": stats, "mismatches": len(bad), "failing": bad, "torch": torch.__version__}
+    res = {"cases": stats, "mismatches": len(bad), "failing": bad, "torch": torch.__version__, "argv": sys.argv[1:3]}
     print(json.dumps(res))
-    out_path = os.path.join(ROOT, "profiles", "r05", "oracle_vs_reference_fuzz.json")
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05", "oracle_vs_reference_fuzz.json")
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
     sys.exit(1 if bad else 0)

@@ -325,6 +325,52 @@ def test_in_flight_planner_equals_sequential_forward():
         assert torch.equal(a.histories, b.histories) and torch.equal(a.paths, b.paths)
 
 
+def test_in_flight_planner_holds_what_a_foreign_stream_uses():
+    """Memory the caching allocator hands out for the CURRENT stream but a launch uses on ANOTHER one must outlive that launch: the HBM
+    slab of maps larger than LDS (every batch in flight needs its own -- a freed slab would be handed to the next submit while the first
+    search still runs in it), the 16-byte workspace of a checked order, and the contiguous copies of strided inputs (made before the
+    streams are ordered, held with the batch).  6 batches of 150x150 maps over 3 streams, strided inputs with a hand-made (checked)
+    order == the sequential forward() calls."""
+    from neural_astar import ops
+    from neural_astar.parallel import InFlightPlanner
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    dev = _dev()
+    va = VanillaAstar().to(dev).eval()
+    big = [tuple(_t(x) for x in syn.random_obstacle_maps(24, 150, 150, 0.2, seed=900 + k)) for k in range(6)]
+    assert not ops.in_lds(150, 150)
+    with torch.no_grad():
+        seq = [va(*b) for b in big]
+    fly = InFlightPlanner(va, streams=3)
+    for rep in range(2):
+        outs = fly.plan_many(big)
+        for a, b in zip(seq, outs):
+            assert torch.equal(a.histories, b.histories) and torch.equal(a.paths, b.paths)
+    # a launch on a foreign stream that needs a workspace refuses to run without a holder for it; strided maps are refused too
+    m, s, g = big[0]
+    st = torch.cuda.Stream(dev)
+    with pytest.raises(ValueError, match="keep"):
+        ops.search_nograd(m, s, g, m, 0.5, 150 * 150, stream_ptr=st.cuda_stream)
+    wide = torch.zeros((24, 1, 150, 300), device=dev)
+    with pytest.raises(ValueError, match="contiguous"):
+        ops.search_nograd(wide[..., ::2], s, g, wide[..., ::2], 0.5, 150 * 150, stream_ptr=st.cuda_stream, keep=[])
+    # strided inputs + a checked order through the planner: copies and the order-check workspace are held until collection
+    small = []
+    for k in range(6):
+        mm, ss, gg = (_t(x) for x in syn.maze_maps(512, 32, seed=950 + k))
+        pad = torch.zeros((512, 1, 32, 64), device=dev)
+        pad[..., ::2] = mm
+        ss.placement_order = torch.randperm(512, device=dev).to(torch.int32)  # (a bare tensor: not trusted, checked on the device)
+        small.append((pad[..., ::2], ss, gg))
+    with torch.no_grad():
+        seq = [va(b[0].contiguous(), b[1], b[2]) for b in small]
+    fly = InFlightPlanner(va, streams=3, use_placement=True)
+    for rep in range(2):
+        outs = fly.plan_many(small)
+        for a, b in zip(seq, outs):
+            assert torch.equal(a.histories, b.histories) and torch.equal(a.paths, b.paths)
+
+
 def test_forward_host_overhead_is_bounded():
     """The module boundary must not dominate a 4096-map call (+70 %).  Deferred checking never waits for the device: 48 calls
     (fewer than the 64 verdicts the module lets queue up before it waits for the oldest) are ISSUED in far less time than they take to

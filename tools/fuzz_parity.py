@@ -142,14 +142,16 @@ def run_module(seed=31, N=60, verbose=True):
     rng = np.random.default_rng(seed)
     bad, n, reruns = [], 0, 0
     for case in range(N):
-        H, W = int(rng.integers(4, 40)), int(rng.integers(4, 40))
+        H, W = (int(rng.integers(4, 40)), int(rng.integers(4, 40))) if rng.random() < 0.8 else (int(rng.choice([16, 32])),) * 2
         B = int(rng.integers(2, 6))
         pr = syn.random_obstacle_maps(B, H, W, float(rng.choice([0.0, 0.1, 0.25])), seed=int(rng.integers(1 << 30)))
-        kind = str(rng.choice(["map", "u01", "u10", "u10", "zeros"]))
+        kind = str(rng.choice(["map", "u01", "u10", "u10", "zeros", "signed"]))
         if kind == "map":
             cost = pr.map_designs
         elif kind == "zeros":
             cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30))) * (rng.random((B, 1, H, W)) < 0.5).astype(np.float32)
+        elif kind == "signed":  # negative costs put any g_ratio into the batch-coupled class (and the 16 / 32 / 64 streams onto the key transform)
+            cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), lo=-0.5, hi=1.0)
         else:
             cost = syn.random_costs(B, H, W, seed=int(rng.integers(1 << 30)), hi=1.0 if kind == "u01" else 10.0)
         gr = float(rng.choice([0.5, 0.2, 0.0, 0.8, 1.0, 0.3]))

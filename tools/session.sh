@@ -369,6 +369,20 @@ for r in j.get("in_flight_through_api", []):
 print("cpu", j["cpu_baseline"]["value"], j["cpu_baseline"]["cores"])
 P
   ;;
+r05_h)
+  # foreign-stream lifetimes of InFlightPlanner + forward() against the literal batch loop incl. signed costs
+  O=gpurun_out/r05/h; mkdir -p $O
+  python -m pytest tests/test_boundary_gpu.py -q -x -k "in_flight" > $O/in_flight.log 2>&1; echo "in_flight rc=$?"; tail -15 $O/in_flight.log | cut -c1-220
+  python - > $O/module_signed.jsonl 2>&1 <<'P'
+import json, sys
+sys.path.insert(0, "tools")
+import fuzz_parity
+for seed in (9, 31, 77):
+    n, rr, bad = fuzz_parity.run_module(seed=seed, N=150, verbose=True)
+    print(json.dumps({"seed": seed, "module_vs_literal_batch_loop_cases": n, "batches_in_the_coupled_class": rr, "module_failures": len(bad)}))
+P
+  echo "module rc=$?"; tail -12 $O/module_signed.jsonl | cut -c1-220
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
