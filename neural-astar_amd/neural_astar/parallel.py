@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .planner.differentiable_astar import AstarOutput, UnsolvableMapError, _raise_unsolvable
+from .planner.differentiable_astar import AstarOutput, UnsolvableMapError, _raise_unsolvable, _warn_coupled
 
 _BIT_WEIGHTS = None
 _SEARCH_STREAMS: dict = {}
@@ -242,6 +242,17 @@ class InFlightPlanner:
         self._k = 0
         self.reruns = 0  # batches that were re-run on the general kernel (a non-binary map under unit_cost="auto")
 
+    def __del__(self):  # dropped with batches in flight: their status rows go back once the device has caught up (StatusBoard.retire)
+        try:
+            if self._inflight and self._device is not None:
+                board = ops.StatusBoard.of(self._device)
+                for item in self._inflight:
+                    if item[2] >= 0:
+                        board.retire(item[2], None)
+                self._inflight = []
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _setup(self, device: torch.device) -> None:
         if self._device != device:
             if self._inflight:
@@ -332,13 +343,18 @@ class InFlightPlanner:
         outs: List[AstarOutput] = []
         failed = None
         astar = self.planner.astar
-        for ticket, k, row, ins, out, flags, order, check, _keep in self._inflight:
-            hist, paths, iters, status, _ = out
-            summ = None
+        # every launch is over: read all the rows and hand them back first, so that an exception further down (a re-run that fails) leaves
+        # neither rows nor batches behind
+        inflight, self._inflight, self._k = self._inflight, [], 0
+        summaries = []
+        for item in inflight:
+            row = item[2]
+            r = board.read(row) if row >= 0 else None
+            summaries.append(None if r is None else r.copy())
             if row >= 0:
-                r = board.read(row)
-                summ = None if r is None else r.copy()
                 board.release(row)
+        for (ticket, k, row, ins, out, flags, order, check, _keep), summ in zip(inflight, summaries):
+            hist, paths, iters, status, _ = out
             if summ is not None and summ[ops.STATUS_NOT_UNIT_COST] and self.unit_cost == "auto":
                 # a non-binary map in a batch that went to the unit-cost kernel optimistically: the batch again on the general kernel
                 self.reruns += 1
@@ -353,8 +369,10 @@ class InFlightPlanner:
                     summ = None if r is None else r.copy()
                 finally:
                     board.release(r2)
-            if (summ is not None and summ[ops.SUMMARY_COUPLED] and not summ[ops.SUMMARY_ERRORS].any() and status.numel() > 1
-                    and ops.in_lds(ins[1].shape[-2], ins[1].shape[-1])):
+            coupled = summ is not None and summ[ops.SUMMARY_COUPLED] and not summ[ops.SUMMARY_ERRORS].any() and status.numel() > 1
+            if coupled and not ops.in_lds(ins[1].shape[-2], ins[1].shape[-1]):
+                _warn_coupled(astar.g_ratio)  # (no lock-step mode for maps whose state lives in HBM: each map as if searched alone)
+            elif coupled:
                 # a finished map of this batch is not at a fixed point of the reference's batch loop (g_ratio < 0.5 with an expensive goal cell;
                 # DESIGN.md section 2.3): the batch again in lock-step mode, exactly as planner.forward() does
                 self.reruns += 1
@@ -364,8 +382,6 @@ class InFlightPlanner:
                 failed = (ticket, status)
             outs.append(AstarOutput(hist, paths, []))
             astar.last_status, astar.last_iters = status, iters
-        self._inflight = []
-        self._k = 0
         if failed is not None:
             try:
                 _raise_unsolvable(failed[1], failed[0])
