@@ -4,7 +4,8 @@
 tests/golden/ pins the oracle on fixed vectors; this sweep widens the net: random map sizes (small, and some with sides above 140 cells where
 get_heuristic's square root starts to matter), obstacle densities, cost kinds (map / U(0,1) / U(0,10) / zeros), g_ratio, eval and training
 budgets.  The literal restatement (dense) must reproduce the reference's histories and paths bit for bit, the dense backward its autograd gradient to
-1e-5 (north_star).  The state-machine restatement (sm: per-map early exit, what the kernels implement) must do so too EXCEPT in the
+1e-5 (north_star) -- and where the reference's fp32 autograd is further than that from the oracle (searches of thousands of steps with costs up
+to 10), the reference's own graph evaluated in FLOAT64 arbitrates: the oracle must be within 1e-5 of that.  The state-machine restatement (sm: per-map early exit, what the kernels implement) must do so too EXCEPT in the
 batch-coupled class (a finished map whose goal's expansion opens a cell that beats the goal keeps closing cells while
 the rest of the batch searches) -- possible only for g_ratio < 0.5, g_ratio = 1 with zero costs, or negative costs; there sm must equal the
 reference run on each map ALONE, which is checked as well.
@@ -25,6 +26,18 @@ sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
 from neural_astar.utils import synthetic as syn  # noqa: E402
 from oracle import gen_golden as GG  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+
+
+def ref_grad_f64(ref, cost, start, goal, passable, g_ratio, Tmax, training, up, hist32, paths32):
+    """the reference module run in float64 on the same inputs: (dL/dcost, did it select as the fp32 run did?)"""
+    m = ref.DifferentiableAstar(g_ratio=g_ratio, Tmax=Tmax).double()
+    m.train(training)
+    c = torch.from_numpy(cost).double().requires_grad_(True)
+    s, g, p = (torch.from_numpy(x).double() for x in (start, goal, passable))
+    out = m(c, s, g, p)
+    same = np.array_equal(out.histories[:, 0].detach().numpy().astype(np.float32), hist32) and np.array_equal(out.paths[:, 0].numpy(), paths32)
+    (out.histories * torch.from_numpy(up).double()).sum().backward()
+    return c.grad.numpy(), bool(same)
 
 
 def main():
@@ -73,8 +86,20 @@ def main():
             ok = ok and in_class and alone_ok
         if want_grad:
             g = O.backward(up, cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, T)
-            err = float(np.abs(g - grad[:, 0]).max()) / max(1.0, float(np.abs(grad).max()))
-            ok = ok and err <= 1e-5
+            scale = max(1.0, float(np.abs(grad).max()))
+            err = float(np.abs(g - grad[:, 0]).max()) / scale
+            if err > 1e-5:
+                # beyond the tolerance: whose rounding is it?  The reference's OWN graph evaluated in float64 arbitrates (same selections
+                # required): the oracle must be within 1e-5 of THAT -- the reference's fp32 autograd accumulates over thousands of dense
+                # steps and can sit further from its float64 self than the oracle does
+                g64, same_fwd = ref_grad_f64(ref, cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, Tmax, train, up, hist, paths)
+                err64 = float(np.abs(g - g64[:, 0]).max()) / scale
+                ref_err64 = float(np.abs(grad - g64).max()) / scale
+                noise = {"case": case, "H": H, "W": W, "cost": kind, "g_ratio": gr, "oracle_vs_ref_fp32": err, "oracle_vs_ref_fp64": err64,
+                         "ref_fp32_vs_ref_fp64": ref_err64, "same_forward_in_fp64": same_fwd}
+                stats.setdefault("beyond_1e-5_against_fp32_autograd", []).append(noise)
+                print(json.dumps(noise), flush=True)
+                ok = ok and same_fwd and err64 <= 1e-5
             stats["backward"] += 1
         if not ok:
             d = {"case": case, "H": H, "W": W, "B": B, "cost": kind, "g_ratio": gr, "train": train, "Tmax": Tmax}
