@@ -153,7 +153,34 @@ __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybri
     }
 }
 
-template <bool kFastDiv>
+// How the search reaches its slab (kMem, A/B by NASTAR_FLAG_HYBRID_L1 / NASTAR_FLAG_HYBRID_NOFENCE):
+//   bit 0  plain accesses through the CU's vector L1 instead of agent-scope (sc1) ones served by L2.  The slab of a map is touched by ONE
+//          wavefront between the fill and the store launch, and the lanes of a wavefront are coherent through their L1 without further action
+//          (it is write-through and processes a wavefront's accesses in order): the neighbourhood of s* is mostly the neighbourhood of the
+//          previous one, i.e. L1 hits.
+//   bit 1  no wait for the previous step's stores before this step's loads are ISSUED: a wavefront's accesses to one address are performed in
+//          issue order (what lets any thread read back its own store), instruction-wide, so also across lanes; the loads then travel while
+//          the stores are being acknowledged.
+template <int kMem, typename T>
+__device__ __forceinline__ T hld(const T* p)
+{
+    if constexpr (kMem & 1) return *p;
+    else return gld(p);
+}
+template <int kMem, typename T>
+__device__ __forceinline__ void hst(T* p, T v)
+{
+    if constexpr (kMem & 1) *p = v;
+    else gst(p, v);
+}
+template <int kMem>
+__device__ __forceinline__ void hybrid_step_fence()
+{
+    if constexpr (kMem & 2) __builtin_amdgcn_wave_barrier();
+    else global_step_fence();
+}
+
+template <bool kFastDiv, int kMem = 0>
 __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,8 +210,8 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
         const int sr = hybrid_row(sidx, d, sc);
         const uint32_t k0 = hybrid_key<kFastDiv>(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
         const unsigned long long e = ((unsigned long long)k0 << 32) | (uint32_t)sidx;
-        gst(&g[sidx], 0.0f);
-        gst(&pdir[sidx], (uint8_t)(PARENT_UNSET | P_PASS));
+        hst<kMem>(&g[sidx], 0.0f);
+        hst<kMem>(&pdir[sidx], (uint8_t)(PARENT_UNSET | P_PASS));
         cmin[sidx >> 6] = e;
         smin[sidx >> 12] = e;
     }
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
                     const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
                     const int n = inb ? s + dr * d.W + dc : s;
                     global_step_fence();
-                    const float gs = gld(&g[s]), gn = gld(&g[n]);
+                    const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
                     const float cs = cost[s], cn = cost[n];
                     const float g2 = gs + cs;
                     const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
                     const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
                     if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
                 }
-                if (lane == 0) gst(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
+                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
                 solved = true;
                 break;
             }
@@ -237,11 +264,11 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             const int n = inb ? s + dr * d.W + dc : s;
             const int ic = C * 64 + lane;
             const bool icv = ic < d.HW;
-            global_step_fence();  // the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+            hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
             // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
-            const float gs = gld(&g[s]);
-            const float gn = gld(&g[n]);
-            const float gc = gld(&g[ic]);
+            const float gs = hld<kMem>(&g[s]);
+            const float gn = hld<kMem>(&g[n]);
+            const float gc = hld<kMem>(&g[ic]);
             const float cs = cost[s];
             const float cn = cost[n];
             const float cc = icv ? cost[ic] : 0.f;
@@ -255,10 +282,10 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
             const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
             // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
-            if (lane == 0) gst(&g[s], NASTAR_NEG_INF);
+            if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
             if (upd) {
-                gst(&g[n], g2);
-                gst(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
+                hst<kMem>(&g[n], g2);
+                hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
             }
             // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
             const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
@@ -284,16 +311,16 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     // ---- backtrack (:96-125): walk to the start, cap = this map's own step count in the budget-truncated case ----------
     if (gidx >= 0 && lane == 0) {
         const int cap = solved ? d.HW : iters - 1;
-        uint32_t m = gld(&pdir[gidx]);
-        gst(&pdir[gidx], (uint8_t)(m | P_PATH));
+        uint32_t m = hld<kMem>(&pdir[gidx]);
+        hst<kMem>(&pdir[gidx], (uint8_t)(m | P_PATH));
         uint32_t code = m & P_DIRMASK;
         if (code != PARENT_UNSET) {
             int pdr, pdc;
             neighbour_delta((int)code, pdr, pdc);
             int loc = gidx - (pdr * d.W + pdc);
             for (int k2 = 0; k2 < cap; ++k2) {
-                const uint32_t ml = gld(&pdir[loc]);
-                gst(&pdir[loc], (uint8_t)(ml | P_PATH));
+                const uint32_t ml = hld<kMem>(&pdir[loc]);
+                hst<kMem>(&pdir[loc], (uint8_t)(ml | P_PATH));
                 if (loc == sidx) break;
                 const uint32_t cd = ml & P_DIRMASK;
                 if (cd == PARENT_UNSET) break;
