@@ -75,6 +75,8 @@ extern "C" {
                                    * records every step, goal selections included */
 #define NASTAR_FLAG_HYBRID_L1 2048 /* forward, maps larger than LDS (A/B): the search reaches its slab with plain accesses through the vector L1 instead of agent-scope ones */
 #define NASTAR_FLAG_HYBRID_NOFENCE 4096 /* forward, maps larger than LDS (A/B): a step's loads are issued without waiting for the previous step's stores */
+#define NASTAR_FLAG_HYBRID_SCALAR 8192 /* forward, maps larger than LDS (A/B): the selected cell in a scalar register, scalar loop exits, branch-free row / column arithmetic */
+#define NASTAR_FLAG_HYBRID_BALLOT 16384 /* ... and (implies _SCALAR) the selection's tie-break by ballot + first lane instead of a second wave minimum */
 #define NASTAR_FLAG_GLOBAL_V1 512 /* forward, maps larger than LDS: the round-4 kernel with all three open-list levels in HBM (A/B; needs its own, larger workspace) */
 #define NASTAR_FLAG_CHECK_ORDER 256 /* nastar_forward_ex / nastar_forward_ordered / nastar_backward_replay_ordered: verify on the device that `order` is a
                                      * permutation of 0..B-1 (one small launch before the search) and IGNORE it when it is not -- every map is then

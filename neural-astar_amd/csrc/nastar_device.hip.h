@@ -133,14 +133,13 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic) { retu
 // One FMA residual test against each neighbour (LLVM's own IEEE lowering of sqrt) fixes every integer below 2^24.
 __device__ __forceinline__ float sqrt_rn_int(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    if (x > 0.f) {
-        const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
-        const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
-        if (vp <= 0.f) s = sd;
-        if (vs > 0.f) s = su;
-    }
-    return s;
+    // (no guard for x = 0: s = 0, its lower neighbour is a NaN pattern and fails `<=`, its upper neighbour gives a residual of 0 -- s stays 0;
+    //  a guard would cost every caller a divergent region)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = __builtin_fmaf(-sd, s, x), vs = __builtin_fmaf(-su, s, x);
+    const float t = vp <= 0.f ? sd : s;
+    return vs > 0.f ? su : t;
 }
 
 // ---- get_heuristic (differentiable_astar.py:26-52), one cell ------------------------------------------

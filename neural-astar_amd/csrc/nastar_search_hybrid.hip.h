@@ -74,6 +74,16 @@ __device__ __forceinline__ int hybrid_row(int i, const HybridDims& d, int& c)
     return r;
 }
 
+// the same without branches (selects): the if / else-if form above compiles to two divergent regions, i.e. two VALU -> SALU -> VALU hops
+__device__ __forceinline__ int hybrid_row_nb(int i, const HybridDims& d, int& c)
+{
+    const int r0 = (int)(((float)i + 0.5f) * d.inv_W);
+    const int c0 = i - r0 * d.W;
+    const bool lo = c0 < 0, hi = c0 >= d.W;
+    c = lo ? c0 + d.W : (hi ? c0 - d.W : c0);
+    return lo ? r0 - 1 : (hi ? r0 + 1 : r0);
+}
+
 // first-index minimum of per-lane (key, cell) entries = the u64 minimum of (key << 32 | cell), in every lane and without leaving the vector
 // registers: the key minimum, then the cell minimum among the lanes that hold it.  (A scalar form -- v_readlane of the minimum, ballot, s_ff1,
 // v_readlane of the cell -- is three instructions shorter and was 28 % SLOWER per step: each VALU -> SALU -> VALU hop costs a lone wavefront
@@ -161,6 +171,11 @@ __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybri
 //   bit 1  no wait for the previous step's stores before this step's loads are ISSUED: a wavefront's accesses to one address are performed in
 //          issue order (what lets any thread read back its own store), instruction-wide, so also across lanes; the loads then travel while
 //          the stores are being acknowledged.
+//   bit 2  s* travels in a SCALAR register (v_readfirstlane of the reduction's result): the loop's exits (open list empty, goal selected,
+//          budget) become scalar branches and the step counter a scalar -- the compiler otherwise treats the wave-uniform s* as divergent and
+//          wraps every exit in exec-mask bookkeeping; rows / columns by selects instead of branches (hybrid_row_nb).
+//   bit 3  (with bit 2) the selection's tie-break by ballot + first set lane + v_readlane instead of a second wave minimum (entries ascend with
+//          the lane, first_min_entry).
 template <int kMem, typename T>
 __device__ __forceinline__ T hld(const T* p)
 {
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     const float* cost = a.cost + off;
 
     // ---- start / goal from the fill launch; empty open list -------------------------------------------------------------
-    const int sidx = hdr[0], gidx = hdr[1];
+    const int sidx = (kMem & 4) ? __builtin_amdgcn_readfirstlane(hdr[0]) : hdr[0], gidx = (kMem & 4) ? __builtin_amdgcn_readfirstlane(hdr[1]) : hdr[1];
     for (int c = lane; c < d.nsuper * 64; c += 64) cmin[c] = ~0ull;
     smin[lane] = ~0ull;
     const int gi = gidx < 0 ? 0 : gidx;
@@ -225,80 +240,165 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     if (sidx < 0 || gidx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start / goal map
     } else {
-        while (iters < a.max_iters) {  // :203
-            // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-            const unsigned long long e0 = smin[lane];
-            const unsigned long long M = first_min_entry((uint32_t)(e0 >> 32), (uint32_t)e0);
-            if (M == ~0ull) {  // open list empty (:68 would divide by zero)
-                status = NASTAR_ERR_UNSOLVABLE;
-                break;
-            }
-            const int s = (int)(uint32_t)M;
-            if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-            ++iters;
-            if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
-                if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
-                    int gc0;
-                    const int gr0 = hybrid_row(s, d, gc0);
-                    const int nr = gr0 + dr, nc = gc0 + dc;
-                    const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
-                    const int n = inb ? s + dr * d.W + dc : s;
-                    global_step_fence();
-                    const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
-                    const float cs = cost[s], cn = cost[n];
-                    const float g2 = gs + cs;
-                    const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-                    const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
-                    const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
-                    if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+        if constexpr ((kMem & 4) != 0) {
+            while (iters < a.max_iters) {  // :203
+                // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
+                const unsigned long long e0 = smin[lane];
+                const uint32_t k0 = (uint32_t)(e0 >> 32), c0 = (uint32_t)e0;
+                int s;  // wave-uniform, in a scalar register
+                if constexpr ((kMem & 8) != 0) {
+                    const uint32_t m = wave_min_all_u32(k0);
+                    s = __builtin_amdgcn_readlane((int)c0, __builtin_ctzll(__ballot(k0 == m)));  // (the lane that holds m exists)
+                } else {
+                    const uint32_t m = wave_min_all_u32(k0);
+                    s = __builtin_amdgcn_readfirstlane((int)wave_min_all_u32(k0 == m ? c0 : 0xFFFFFFFFu));
                 }
-                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
-                solved = true;
-                break;
+                if (s < 0) {  // every entry idle (~0ull: key KEY_INF, cell ~0): open list empty (:68 would divide by zero)
+                    status = NASTAR_ERR_UNSOLVABLE;
+                    break;
+                }
+                if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+                ++iters;
+                if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
+                    if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
+                        int gc0;
+                        const int gr0 = hybrid_row_nb(s, d, gc0);
+                        const int nr = gr0 + dr, nc = gc0 + dc;
+                        const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+                        const int n = inb ? s + dr * d.W + dc : s;
+                        global_step_fence();
+                        const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
+                        const float cs = cost[s], cn = cost[n];
+                        const float g2 = gs + cs;
+                        const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+                        const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
+                        const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
+                        if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+                    }
+                    if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
+                    solved = true;
+                    break;
+                }
+                const int C = s >> 6, S = s >> 12;
+                int c;
+                const int r = hybrid_row_nb(s, d, c);
+                const int nr = r + dr, nc = c + dc;
+                const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+                const int n = inb ? s + dr * d.W + dc : s;
+                const int ic = C * 64 + lane;
+                const bool icv = ic < d.HW;
+                hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+                // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
+                const float gs = hld<kMem>(&g[s]);
+                const float gn = hld<kMem>(&g[n]);
+                const float gc = hld<kMem>(&g[ic]);
+                const float cs = cost[s];
+                const float cn = cost[n];
+                const float cc = icv ? cost[ic] : 0.f;
+                int icc;
+                const int icr = hybrid_row_nb(icv ? ic : 0, d, icc);
+                const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
+                const bool upd = inb & (gn > g2);                                      // :229,:235
+                const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+                // chunk minimum without s*: open <=> finite g
+                const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
+                const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
+                const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
+                // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
+                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
+                if (upd) {
+                    hst<kMem>(&g[n], g2);
+                    hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
+                }
+                // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
+                const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
+                if (lane == 0) cmin[C] = newC;
+                wave_order();
+                if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
+                wave_order();
+                const unsigned long long ev = cmin[S * 64 + lane];
+                const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
+                if (lane == 0) smin[S] = newS;
+                wave_order();
+                if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
+                wave_order();
             }
-            const int C = s >> 6, S = s >> 12;
-            int c;
-            const int r = hybrid_row(s, d, c);
-            const int nr = r + dr, nc = c + dc;
-            const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
-            const int n = inb ? s + dr * d.W + dc : s;
-            const int ic = C * 64 + lane;
-            const bool icv = ic < d.HW;
-            hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
-            // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
-            const float gs = hld<kMem>(&g[s]);
-            const float gn = hld<kMem>(&g[n]);
-            const float gc = hld<kMem>(&g[ic]);
-            const float cs = cost[s];
-            const float cn = cost[n];
-            const float cc = icv ? cost[ic] : 0.f;
-            int icc;
-            const int icr = hybrid_row(icv ? ic : 0, d, icc);
-            const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
-            const bool upd = inb & (gn > g2);                                      // :229,:235
-            const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-            // chunk minimum without s*: open <=> finite g
-            const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
-            const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
-            const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
-            // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
-            if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
-            if (upd) {
-                hst<kMem>(&g[n], g2);
-                hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
+        } else {
+            while (iters < a.max_iters) {  // :203
+                // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
+                const unsigned long long e0 = smin[lane];
+                const unsigned long long M = first_min_entry((uint32_t)(e0 >> 32), (uint32_t)e0);
+                if (M == ~0ull) {  // open list empty (:68 would divide by zero)
+                    status = NASTAR_ERR_UNSOLVABLE;
+                    break;
+                }
+                const int s = (int)(uint32_t)M;
+                if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+                ++iters;
+                if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
+                    if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
+                        int gc0;
+                        const int gr0 = hybrid_row(s, d, gc0);
+                        const int nr = gr0 + dr, nc = gc0 + dc;
+                        const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+                        const int n = inb ? s + dr * d.W + dc : s;
+                        global_step_fence();
+                        const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
+                        const float cs = cost[s], cn = cost[n];
+                        const float g2 = gs + cs;
+                        const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+                        const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
+                        const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
+                        if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+                    }
+                    if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
+                    solved = true;
+                    break;
+                }
+                const int C = s >> 6, S = s >> 12;
+                int c;
+                const int r = hybrid_row(s, d, c);
+                const int nr = r + dr, nc = c + dc;
+                const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+                const int n = inb ? s + dr * d.W + dc : s;
+                const int ic = C * 64 + lane;
+                const bool icv = ic < d.HW;
+                hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+                // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
+                const float gs = hld<kMem>(&g[s]);
+                const float gn = hld<kMem>(&g[n]);
+                const float gc = hld<kMem>(&g[ic]);
+                const float cs = cost[s];
+                const float cn = cost[n];
+                const float cc = icv ? cost[ic] : 0.f;
+                int icc;
+                const int icr = hybrid_row(icv ? ic : 0, d, icc);
+                const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
+                const bool upd = inb & (gn > g2);                                      // :229,:235
+                const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+                // chunk minimum without s*: open <=> finite g
+                const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
+                const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
+                const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
+                // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
+                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
+                if (upd) {
+                    hst<kMem>(&g[n], g2);
+                    hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
+                }
+                // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
+                const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
+                if (lane == 0) cmin[C] = newC;
+                wave_order();
+                if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
+                wave_order();
+                const unsigned long long ev = cmin[S * 64 + lane];
+                const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
+                if (lane == 0) smin[S] = newS;
+                wave_order();
+                if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
+                wave_order();
             }
-            // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
-            const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
-            if (lane == 0) cmin[C] = newC;
-            wave_order();
-            if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
-            wave_order();
-            const unsigned long long ev = cmin[S * 64 + lane];
-            const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
-            if (lane == 0) smin[S] = newS;
-            wave_order();
-            if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
-            wave_order();
         }
     }
     global_step_fence();

@@ -35,6 +35,29 @@ def run(H, B, flags, cost_kind, reps=5):
             "ns_per_step_of_longest": ms * 1e6 / it.max(), "steps_per_s": it.sum() / (ms * 1e-3)}
 
 
+def variants():
+    """A/B of the hybrid kernel's variants (include/nastar.h NASTAR_FLAG_HYBRID_*): step time and equality of every output with the default"""
+    L1, NOFENCE, SCALAR, BALLOT = 2048, 4096, 8192, 16384
+    combos = [0, L1, NOFENCE, L1 | NOFENCE, SCALAR, SCALAR | L1 | NOFENCE, BALLOT, BALLOT | L1 | NOFENCE]
+    for H, B, ck in ((512, 256, "map"), (256, 256, "map"), (512, 1, "map"), (512, 256, "uniform"), (300, 64, "map")):
+        pr = syn.random_obstacle_maps(B, H, H, 0.2, seed=7)
+        m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+        c = m if ck == "map" else torch.from_numpy(syn.random_costs(B, H, H, seed=5)).to(dev)
+        ref = ops.search_nograd(c, s, g, m, 0.5, H * H, want_log=True)
+        for flags in combos:
+            r = run(H, B, flags, ck, reps=3)
+            out = ops.search_nograd(c, s, g, m, 0.5, H * H, want_log=True, flags=flags)
+            it = ref[2].long()
+            mask = torch.arange(H * H, device=dev)[None, :] < it[:, None]
+            r["equal_to_default"] = bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+                                         and torch.equal(out[3], ref[3]) and torch.equal(out[4][mask], ref[4][mask]))
+            print(json.dumps(r), flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "variants":
+    variants()
+    sys.exit(0)
+
 for H in (128, 256, 512):
     for B in (1, 256):
         for flags in ((0,) if H == 128 else (0, 512)):

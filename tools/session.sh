@@ -383,6 +383,20 @@ for seed in (9, 31, 77):
 P
   echo "module rc=$?"; tail -12 $O/module_signed.jsonl | cut -c1-220
   ;;
+r05_i)
+  # hybrid large-map kernel: A/B of the memory-path / scalar-control-flow variants, parity under the most aggressive ones
+  O=gpurun_out/r05/i; mkdir -p $O
+  timeout 200 python tools/probe_large.py variants > $O/probe_large_variants.jsonl 2> $O/probe.err; echo "probe rc=$?"; tail -2 $O/probe.err
+  python - <<'P'
+import json
+for l in open("gpurun_out/r05/i/probe_large_variants.jsonl"):
+    r = json.loads(l)
+    print(r["H"], r["B"], r["cost"], "flags", r["flags"], "ms", round(r["launch_ms"], 3), "ns/step", round(r["ns_per_step_of_longest"]), "equal", r["equal_to_default"])
+P
+  for F in 22528 14336; do
+    NASTAR_FORWARD_FLAGS=$F timeout 400 python -m pytest tests/test_large_maps_gpu.py tests/test_fuzz_parity_gpu.py -q -x -k "not gradients and not module" > $O/parity_flags_$F.log 2>&1; echo "parity flags=$F rc=$?"; tail -3 $O/parity_flags_$F.log | cut -c1-200
+  done
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
