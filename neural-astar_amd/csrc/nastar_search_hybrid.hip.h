@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybri
     }
 }
 
-// How the search reaches its slab (kMem, A/B by NASTAR_FLAG_HYBRID_L1 / NASTAR_FLAG_HYBRID_NOFENCE):
-//   bit 0  plain accesses through the CU's vector L1 instead of agent-scope (sc1) ones served by L2.  The slab of a map is touched by ONE
+// How the search reaches its slab (kMem; the default is 1, the other bits are A/B switches: NASTAR_FLAG_HYBRID_* of include/nastar.h):
+//   bit 0  plain accesses through the CU's vector L1 instead of agent-scope (sc1) ones served by L2 (measured: 986 instead of 1275 ns per step).  The slab of a map is touched by ONE
 //          wavefront between the fill and the store launch, and the lanes of a wavefront are coherent through their L1 without further action
 //          (it is write-through and processes a wavefront's accesses in order): the neighbourhood of s* is mostly the neighbourhood of the
 //          previous one, i.e. L1 hits.
@@ -195,7 +195,7 @@ __device__ __forceinline__ void hybrid_step_fence()
     else global_step_fence();
 }
 
-template <bool kFastDiv, int kMem = 0>
+template <bool kFastDiv, int kMem = 1>
 __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -42,7 +42,7 @@ SUMMARY_WORDS = 16  # NASTAR_SUMMARY_WORDS
 SUMMARY_BAD_ORDER = 15  # NASTAR_SUMMARY_BAD_ORDER
 SUMMARY_COUPLED = 14  # NASTAR_SUMMARY_COUPLED: a NOTE (a finished map is not at a fixed point of the reference's batch loop), cells 1..13 are errors
 SUMMARY_ERRORS = slice(1, 14)
-# development knob: NASTAR_FLAG_* of include/nastar.h OR-ed into every forward launch (A/B switches: NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128, HYBRID_L1 = 2048, HYBRID_NOFENCE = 4096, HYBRID_SCALAR = 8192, HYBRID_BALLOT = 16384)
+# development knob: NASTAR_FLAG_* of include/nastar.h OR-ed into every forward launch (A/B switches: NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128, HYBRID_SC1 = 2048, HYBRID_NOFENCE = 4096, HYBRID_SCALAR = 8192, HYBRID_BALLOT = 16384)
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
 if FORWARD_FLAGS & ~(8 | 16 | 32 | 64 | 128 | 2048 | 4096 | 8192 | 16384):
     raise ValueError(f"NASTAR_FORWARD_FLAGS={FORWARD_FLAGS}: unknown flag bits (include/nastar.h NASTAR_FLAG_*)")

@@ -397,6 +397,29 @@ P
     NASTAR_FORWARD_FLAGS=$F timeout 400 python -m pytest tests/test_large_maps_gpu.py tests/test_fuzz_parity_gpu.py -q -x -k "not gradients and not module" > $O/parity_flags_$F.log 2>&1; echo "parity flags=$F rc=$?"; tail -3 $O/parity_flags_$F.log | cut -c1-200
   done
   ;;
+r05_final2)
+  # the final tree after the hybrid kernel's L1 path became the default: GPU suite, smoke, the driver's bench command, then the hybrid A/B
+  O=gpurun_out/r05/final2; mkdir -p $O
+  timeout 240 python -m pytest tests -q -m gpu > $O/gpu_tests_final.log 2>&1; echo "suite rc=$?"; tail -3 $O/gpu_tests_final.log | cut -c1-200
+  timeout 60 python __graft_entry__.py smoke 2>&1 | tail -1
+  timeout 110 python bench.py --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench.err; echo "bench rc=$?"; tail -2 $O/bench.err
+  python - <<'P'
+import json
+try:
+    j = json.load(open("gpurun_out/r05/final2/bench_driver_command.json"))
+    print("value", round(j["value"] / 1e6, 2), "M maps/s  ms/step", round(j["ms_per_step"], 4), "natural", round(j["value_natural_order"] / 1e6, 2), "hinted", round(j["value_hinted"] / 1e6, 2))
+    print("roofline", {k: j["roofline"][k] for k in ("frac", "frac_28B_per_cell", "launch_ms_avg")}, "through_module", {k: round(v, 4) for k, v in j.get("through_module", {}).items() if isinstance(v, float)})
+except Exception as e:
+    print("bench line unreadable", e)
+P
+  timeout 90 python tools/probe_large.py variants > $O/probe_large_variants.jsonl 2> $O/probe.err; echo "probe rc=$?"
+  python - <<'P'
+import json
+for l in open("gpurun_out/r05/final2/probe_large_variants.jsonl"):
+    r = json.loads(l)
+    print(r["H"], r["B"], r["cost"], "flags", r["flags"], "ms", round(r["launch_ms"], 3), "ns/step", round(r["ns_per_step_of_longest"]), "equal", r["equal_to_default"])
+P
+  ;;
 *)
   echo "unknown session $S"; exit 2;;
 esac
