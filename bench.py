@@ -1051,8 +1051,9 @@ def through_module_ms(pr, dev, reps=60):
             out[("" if hinted else "no_placement_") + label] = (time.perf_counter() - t0) / reps * 1e3
             va.astar.raise_if_unsolvable()
     out["unit"] = "ms per VanillaAstar.forward() call, wall clock, same input batch each call"
-    out["note"] = ("default mode runs the unit-cost kernel (unit_cost='auto' needs the same-call verdict); deferred / false run the general kernel "
-                   "back to back without a host wait, i.e. at the kernel's own duration")
+    out["note"] = ("all three modes run the general kernel (forward() takes the unit-cost layout only with unit_cost=True); the default waits for "
+                   "the launch's completion flag in the same call, deferred / false issue the launches back to back without a host wait, i.e. "
+                   "run at the kernel's own duration")
     return out
 
 
