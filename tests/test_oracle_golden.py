@@ -57,6 +57,26 @@ def test_oracle_backward_matches_reference_autograd(name):
     assert float(np.abs(got - g.grad_cost[:, 0]).max()) <= tol * scale
 
 
+def test_gradient_tolerance_is_arbitrated_by_the_reference_graph_in_float64():
+    """The one random case (of 836 against the live reference) in which the oracle is further than 1e-5 from the reference's fp32 autograd
+    gradient: 45x47, U(0,10) costs, 1827 steps.  The golden also holds the gradient of the reference's OWN graph evaluated in float64 (same
+    selections): the oracle must be within 1e-5 of THAT; the fp32 reference is pinned at what it is -- further from its float64 self than
+    the tolerance (oracle/gen_golden_gradnoise.py)."""
+    name = "gradnoise_u10_45x47"
+    assert name not in G.names()  # not a 1e-5-against-fp32 case: kept out of the parametrised gradient tests
+    g = G.load(name)
+    g64 = np.load(G.os.path.join(G.GOLDEN_DIR, name + ".npz"))["grad_f64"]
+    o = O.forward(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode="dense")
+    assert np.array_equal(o.histories, g.histories[:, 0]) and np.array_equal(o.paths, g.paths[:, 0])
+    got = O.backward(g.grad_up, g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters)
+    scale = max(1.0, float(np.abs(g.grad_cost).max()))
+    to_f64 = float(np.abs(got - g64[:, 0]).max()) / scale
+    to_f32 = float(np.abs(got - g.grad_cost[:, 0]).max()) / scale
+    ref_noise = float(np.abs(g.grad_cost - g64).max()) / scale
+    assert to_f64 <= 1e-5 and to_f64 < 0.1 * ref_noise, (to_f64, ref_noise)
+    assert 1e-5 < to_f32 < 2e-5 and 1e-5 < ref_noise < 2e-5, (to_f32, ref_noise)  # the reference's accumulation noise, not the oracle's
+
+
 def test_heuristic_known_values():
     h = O.heuristic(64, 64, 63, 63)
     assert h[0, 0] == np.float32(63.08909606933594)
