@@ -86,6 +86,26 @@ def test_backward_matches_reference_autograd(name):
     assert np.array_equal(out.histories.detach().cpu().numpy(), g.histories)
 
 
+def test_backward_is_within_tolerance_of_the_reference_graph_in_float64_where_fp32_autograd_is_not():
+    """tests/golden/gradnoise_u10_45x47.npz: the one random case in which the reference's fp32 autograd gradient sits further than 1e-5 from
+    its own graph evaluated in float64 (1827 steps, costs up to 10).  The kernels (fp64 accumulators) must be within 1e-5 of the float64
+    gradient -- measured 5.5e-7 -- and their distance to the fp32 gradient is the reference's noise, not theirs."""
+    import os
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    name = "gradnoise_u10_45x47"
+    g = G.load(name)
+    g64 = np.load(os.path.join(G.GOLDEN_DIR, name + ".npz"))["grad_f64"]
+    m = DifferentiableAstar(g_ratio=g.g_ratio, Tmax=g.Tmax).to(_dev()).eval()
+    cost = _t(g.cost_maps).requires_grad_(True)
+    out = m(cost, _t(g.start_maps), _t(g.goal_maps), _t(g.passable))
+    (out.histories * _t(g.grad_up)).sum().backward()
+    got = cost.grad.cpu().numpy()
+    assert np.array_equal(out.histories.detach().cpu().numpy(), g.histories) and np.array_equal(out.paths.cpu().numpy(), g.paths)
+    scale = max(1.0, float(np.abs(g.grad_cost).max()))
+    ref_noise = float(np.abs(g.grad_cost - g64).max()) / scale
+    assert float(np.abs(got - g64).max()) / scale <= GRAD_TOL and ref_noise > GRAD_TOL
+
+
 def test_backward_replay_large_map_matches_oracle():
     """Backward of a map whose state does not fit LDS (150x200 = 30 k cells: HBM-workspace state) against the oracle's literal
     reverse-mode restatement, and the fused-L1 replay against autograd's L1Loss on the same maps."""
