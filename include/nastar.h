@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define NASTAR_VERSION 500 /* 0.5.0: nastar_forward_ex (status summary, checked placement), nastar_placement_from_levels; 0.4.1: nastar_forward_ordered (placement); 0.4.0: round-4 search instruction stream, unit-cost LDS layout */
+#define NASTAR_VERSION 600 /* 0.6.0: nastar_forward_batchloop_finish (the reference's batch loop to the letter, any size, no host round trip), NASTAR_FLAG_MARK_COUPLED; the A/B flags left the ABI; 0.5.0: nastar_forward_ex (status summary, checked placement), nastar_placement_from_levels; 0.4.1: nastar_forward_ordered (placement); 0.4.0: round-4 search instruction stream, unit-cost LDS layout */
 
 /* status codes (function return values) */
 #define NASTAR_OK 0
@@ -56,29 +56,24 @@ extern "C" {
 #define NASTAR_ERR_NOT_UNIT_COST 7 /* per-map status only: NASTAR_FLAG_UNIT_COST was passed but this map holds a value other than 0.0 / 1.0;
                                       its outputs are all-zero -- run it again without the flag */
 
-/* flags for nastar_workspace_bytes / nastar_forward / nastar_backward_replay */
+/* flags for nastar_workspace_bytes / nastar_forward* / nastar_backward_replay*.  (The A/B switches of earlier rounds -- older instruction
+ * streams, the compiler-generated step, variants of the large-map kernel -- are not part of this ABI any more: they exist in the development
+ * build only, `make -C neural-astar_amd/csrc dev`, csrc/nastar_dev_flags.h; an unknown flag bit is NASTAR_ERR_UNSUPPORTED.) */
 #define NASTAR_FLAG_NONE 0
-#define NASTAR_FLAG_NO_ASM 8     /* forward: compiler-generated step instead of the hand-scheduled instruction stream (A/B) */
-#define NASTAR_FLAG_ASM_V2 16   /* forward: the round-2 instruction stream even where the round-3 one applies (costs >= 0) (A/B) */
-#define NASTAR_FLAG_NO_DIVE 32   /* forward, 64x64 maps: the hand-scheduled stream without its "dive" fast path (A/B) */
 #define NASTAR_FLAG_UNIT_COST 64 /* forward: the caller promises that `cost` and `passable` are ONE binary tensor (VanillaAstar, reference
                                     astar.py:93-94; pass the same pointer twice): the LDS state drops the per-cell cost word (5.5 instead
                                     of 9.75 B/cell, 29 instead of 16 resident 32x32 maps per CU).  Same outputs as without the flag; the
                                     kernel checks every map while loading it and marks a map that breaks the promise with status
                                     NASTAR_ERR_NOT_UNIT_COST.  Ignored (general kernel) when cost != passable, a selection log is
                                     wanted or the map is not 32x32 / 64x64 */
-#define NASTAR_FLAG_ASM_V3 128   /* forward: the round-3 instruction stream where the round-4 one applies (A/B, stream-equality test) */
 #define NASTAR_FLAG_LOCKSTEP 1024 /* forward: the reference's batch loop TO THE LETTER for every map -- no exit at the goal: a selected goal is expanded like any cell, stays
                                    * on the open list (differentiable_astar.py:224) and the map is stepped on until exactly max_iters steps have been executed (or its
-                                   * open list is empty).  What the Python layer uses, with max_iters = the step at which every map of the batch selects its goal, when a
-                                   * launch reports NASTAR_SUMMARY_COUPLED.  Compiled step loops, LDS-resident sizes (NASTAR_ERR_UNSUPPORTED beyond); sel_log_out then
-                                   * records every step, goal selections included */
-#define NASTAR_FLAG_HYBRID_SC1 2048 /* forward, maps larger than LDS (A/B): the search reaches its slab with agent-scope accesses served by L2 (the round-5 default until the
-                                     * plain accesses through the CU's vector L1 measured 23 % faster per step) */
-#define NASTAR_FLAG_HYBRID_NOFENCE 4096 /* forward, maps larger than LDS (A/B): a step's loads are issued without waiting for the previous step's stores */
-#define NASTAR_FLAG_HYBRID_SCALAR 8192 /* forward, maps larger than LDS (A/B): the selected cell in a scalar register, scalar loop exits, branch-free row / column arithmetic */
-#define NASTAR_FLAG_HYBRID_BALLOT 16384 /* ... and (implies _SCALAR) the selection's tie-break by ballot + first lane instead of a second wave minimum */
-#define NASTAR_FLAG_GLOBAL_V1 512 /* forward, maps larger than LDS: the round-4 kernel with all three open-list levels in HBM (A/B; needs its own, larger workspace) */
+                                   * open list is empty); sel_log_out then records every step, goal selections included.  Any map size.  nastar_forward_batchloop_finish
+                                   * is built from it.  backward (nastar_backward_replay*): the selection log comes from such a run -- the goal may be selected before
+                                   * the log's last entry -- and is replayed by the general loop */
+#define NASTAR_FLAG_MARK_COUPLED 32768 /* nastar_forward_ex: the launch also writes, per map, whether the map is in the BATCH-COUPLED class (see
+                                   * NASTAR_SUMMARY_COUPLED) into the workspace (nastar_workspace_bytes(B,H,W,flags) bytes, or the larger
+                                   * nastar_batchloop_workspace_bytes): the input of nastar_forward_batchloop_finish */
 #define NASTAR_FLAG_CHECK_ORDER 256 /* nastar_forward_ex / nastar_forward_ordered / nastar_backward_replay_ordered: verify on the device that `order` is a
                                      * permutation of 0..B-1 (one small launch before the search) and IGNORE it when it is not -- every map is then
                                      * searched in the natural order and status_summary[NASTAR_SUMMARY_BAD_ORDER] is set.  Needs the workspace that
@@ -95,8 +90,9 @@ extern "C" {
  * finished map until EVERY map of its batch selects its goal in the same step (differentiable_astar.py:224, :251); the kernels stop each map
  * at its own goal.  The outputs agree iff the goal's own expansion would open nothing that beats the goal -- always true for g_ratio in
  * [0.5, 1) with costs >= 0 (every shipped configuration), not for g_ratio < 0.5 with an expensive goal cell, g_ratio = 1 with a zero-cost one,
- * or negative costs: there the reference's histories of that map depend on the rest of its batch, and the kernels return what the reference
- * returns for the map searched alone.  (The unit-cost layout never sets it: cost = 1 everywhere.) */
+ * or negative costs: there the reference's histories of that map depend on the rest of its batch; ONE launch returns what the reference
+ * returns for the map searched alone, nastar_forward_batchloop_finish completes it to the batch run.  (The unit-cost layout never sets it:
+ * cost = 1 everywhere.) */
 #define NASTAR_SUMMARY_COUPLED 14
 
 int nastar_version(void);
@@ -171,6 +167,29 @@ int nastar_forward_ex(const float* cost, const float* start, const float* goal, 
  * ignored for larger maps, whose status_summary[0] is never set.
  */
 int nastar_completion_supported(int H, int W);
+
+/*
+ * The reference's BATCH LOOP to the letter (differentiable_astar.py:203-252, :219-225, :251-252), for the class of inputs in which it matters.
+ * The reference steps EVERY map until all maps of the batch select their goal in the same step; a finished map keeps its goal on the open
+ * list.  The search kernels stop each map at its own goal, which is the same thing iff the goal's own expansion opens nothing that beats the
+ * goal (NASTAR_SUMMARY_COUPLED above: always so for g_ratio in [0.5, 1) with costs >= 0).  Otherwise the finished map goes on closing cells
+ * while the rest of the batch searches, and its histories / paths -- and the gradient -- depend on when the batch stops.  Two calls on one
+ * stream reproduce that exactly, with no host round trip in between:
+ *   1. nastar_forward_ex(..., flags | NASTAR_FLAG_MARK_COUPLED, workspace)   the ordinary launch; it marks the maps of the class
+ *   2. nastar_forward_batchloop_finish(same buffers, same workspace)         three launches that do nothing when no map is marked:
+ *        PROBE  the marked maps in lock-step mode over the whole budget: a bitmap of the steps at which each selects its goal
+ *        T_END  the first step at which every map of the batch selects its goal (one workgroup; unmarked maps do so from their goal step on)
+ *        FINAL  the marked maps again in lock-step mode for exactly t_end + 1 steps: their rows of histories / paths / sel_log are rewritten,
+ *               iters_out[b] = t_end + 1 (so that max(iters) - 1 is the reference's loop index, as always)
+ * Unmarked maps are untouched: at a fixed point their outputs do not depend on when the loop stops.  The marks are cheap enough to ask for
+ * always; a caller that reads the status summary may skip call 2 when NASTAR_SUMMARY_COUPLED is clear.  Gradients: pass
+ * NASTAR_FLAG_LOCKSTEP to nastar_backward_replay* for a log this produced.  Any map size the forward takes.
+ * workspace: nastar_batchloop_workspace_bytes(B,H,W,max_iters) bytes, the SAME buffer in both calls.
+ */
+size_t nastar_batchloop_workspace_bytes(int B, int H, int W, int max_iters);
+int nastar_forward_batchloop_finish(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W,
+                                    double g_ratio, int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out,
+                                    int32_t* iters_out, int32_t* status_out, void* workspace, size_t workspace_bytes, void* stream);
 /* Spin (pause loop, at most timeout_us) until *word_host != 0; returns 1 when it is, 0 on timeout.  HOST pointer (pinned memory). */
 int nastar_host_wait_nonzero(const volatile int32_t* word_host, int timeout_us);
 

@@ -19,7 +19,6 @@
 // Prototype with the same arithmetic, checked against the reference's autograd: tools/proto_backward_events.py.
 #pragma once
 #include "nastar_search_compact.hip.h"
-#include "nastar_search_global.hip.h"
 
 namespace nastar {
 
@@ -59,7 +58,7 @@ __device__ __forceinline__ float bwdr_upstream(const BwdRArgs& a, size_t i)
     return sg * (a.l1_scale * (a.l1_up != nullptr ? *a.l1_up : 1.f));
 }
 
-// state accessors: LDS (plain) or the HBM workspace (agent-scope relaxed atomics = sc1, served by L2; see nastar_search_global.hip.h)
+// state accessors: LDS (plain) or the HBM workspace (agent-scope relaxed atomics = sc1, served by L2)
 template <bool kGlobal, typename T>
 __device__ __forceinline__ T st_ld(const T* p)
 {
@@ -152,8 +151,24 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     // its upstream gradient.
     int extra = 0;
     if (a.t_batch != nullptr) extra = *a.t_batch - (n_steps - 1);
+    const int* log = a.sel_log + (size_t)b * (size_t)a.max_iters;
+    // A log written in LOCK-STEP mode (nastar_forward_batchloop_finish: a map of the batch-coupled class) may select the goal BEFORE its last
+    // entry: the goal is then expanded like any cell and stays open (:224), and every RE-selection finds it in histories already -- clamp's
+    // backward (:223) zeroes the goal's upstream gradient for that step and all earlier ones.  An ordinary log selects the goal once, last.
+    int n_goal = 0, t_last_goal = -1;
+    for (int t = lane; t < n_steps; t += 64)
+        if (log[t] == gidx) {
+            ++n_goal;
+            t_last_goal = t;
+        }
+    n_goal = (int)wave_sum_f32((float)n_goal);  // (exact: < 2^24 selections)
+    t_last_goal = wave_max_i32(t_last_goal);
+    const bool goal_zeroed = n_goal + (extra > 0 ? extra : 0) >= 2;
+    // ... and from the step after its last re-selection on (budget-truncated runs only) the goal's gradient counts again
+    const int t_restore = (goal_zeroed && extra <= 0 && t_last_goal < n_steps - 1) ? t_last_goal : -1;
+    const float goal_up = bwdr_upstream(a, off + (size_t)gidx);
     if (lane == 0) {
-        if (extra > 0) st_st<kGlobal>(&G[gidx], 0.f);
+        if (goal_zeroed) st_st<kGlobal>(&G[gidx], 0.f);
         // open list = {start} (:187), g[start] = 0 (:193): the start is open from history index 0
         const int r = sidx / d.W, c = sidx - r * d.W;
         const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + st_ld<kGlobal>(&cst[sidx]));
@@ -169,7 +184,6 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     neighbour_delta(lane & 7, dr, dc);
     const bool is_nb = lane < 8;
     const int noff = dr * d.W + dc;
-    const int* log = a.sel_log + (size_t)b * (size_t)a.max_iters;
     double A = 0.0, B = 0.0;
     // pending interval (closed in the previous step, its history entry still in flight)
     bool pend = false;
@@ -194,7 +208,8 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         A += (double)rS;
         B += (double)((float)D * rS * rS);
         const bool goal_step = s == gidx;
-        if (goal_step && extra <= 0) {
+        const bool last_step = t == n_steps - 1;
+        if (goal_step && last_step && extra <= 0) {  // the step that ends the batch loop: its softmax counted, nothing follows
             pend = false;
             break;
         }
@@ -212,12 +227,15 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         const float g2 = gs + cs;
         const bool upd = inb & (gl > g2);
         const bool was_open = fabsf(gl) < NASTAR_POS_INF;
-        const bool flushing = (upd & was_open) | ((lane == 8) & !goal_step);
+        // lane 8 at the goal's last re-selection of a budget-truncated lock-step log: the goal stays open with the same v, but its interval with
+        // G = 0 ends here and one with the upstream value begins (D gains v * G_up)
+        const bool restore = (lane == 8) & goal_step & (t == t_restore);
+        const bool flushing = (upd & was_open) | ((lane == 8) & !goal_step) | restore;
         const float v_old = bwdr_v<kFastDiv>(d, gl, hh, rcp_sqrtW);
         const float v_new = bwdr_v<kFastDiv>(d, g2, hh, rcp_sqrtW);
         if (upd | flushing) {
-            const double dS = (upd ? (double)v_new : 0.0) - (flushing ? (double)v_old : 0.0);
-            const double dD = (upd ? (double)(Gl * v_new) : 0.0) - (flushing ? (double)(Gl * v_old) : 0.0);
+            const double dS = (upd ? (double)v_new : 0.0) - ((flushing & !restore) ? (double)v_old : 0.0);
+            const double dD = (upd ? (double)(Gl * v_new) : 0.0) - (flushing ? (double)(Gl * v_old) : 0.0) + (restore ? (double)(goal_up * v_old) : 0.0);
             // ds_add_f64 issued directly: for a wave-uniform address hipcc's atomic optimizer would first reduce the lanes in a
             // scalar loop (one iteration per active lane); the LDS unit serialises the <= 9 same-address adds much faster
             const uint32_t sda = (uint32_t)(uintptr_t)sd;
@@ -228,6 +246,10 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
             st_st<kGlobal>(&t0[il], (unsigned short)(t + 1));
         }
         if ((lane == 8) & !goal_step) st_st<kGlobal>(&g[s], NASTAR_NEG_INF);
+        if (restore) {
+            st_st<kGlobal>(&G[s], goal_up);
+            st_st<kGlobal>(&t0[s], (unsigned short)(t + 1));
+        }
         if (lane == 0) {  // history entry t+1 = (A, B) after step t
             hist_st<kHistLds>(&hist[2 * (t + 1)], A);
             hist_st<kHistLds>(&hist[2 * (t + 1) + 1], B);
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
             pB0 = hist_ld<kHistLds>(&hist[2 * tl + 1]);
         }
         wave_order();
-        if (goal_step) {  // extra > 0: `extra` more identical steps on the open list left by the goal's own expansion
+        if (goal_step && last_step) {  // extra > 0: `extra` more identical steps on the open list left by the goal's own expansion
             goal_fixed_point = true;
             break;
         }

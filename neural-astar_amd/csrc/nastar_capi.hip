@@ -9,12 +9,13 @@
 
 #include "nastar_host.hip.h"
 #include "nastar_search.hip.h"
-#include "nastar_search_global.hip.h"
 #include "nastar_search_hybrid.hip.h"
 #include "nastar_search_compact.hip.h"
 #include "nastar_search_asm.hip.h"
-#include "nastar_search_asm3.hip.h"
-#include "nastar_search_asm4.hip.h"
+#ifdef NASTAR_DEV
+#include "nastar_dev_flags.h"  // A/B switches of the development build (make dev): round-3 / round-2 streams, no dive, compiled step
+#endif
+#include "nastar_search_asm4.hip.h"  // (reuses the instruction sections of nastar_search_asm3.hip.h; the round-3 LOOP itself is only instantiated by the development build)
 #include "nastar_search_unit.hip.h"
 #include "nastar_placement.hip.h"
 #include "nastar_backward_replay.hip.h"
@@ -40,6 +41,11 @@ struct FwdCArgs {
     int* summary;      // optional [NASTAR_SUMMARY_WORDS]: summary[c] = 1 when some map of this launch ends with per-map status c != 0 (device or host-mapped)
     const int* order_bad;  // optional: *order_bad != 0 (written by nastar_order_check_kernel earlier on the stream) = `order` is not a permutation, ignore it
     int* done_counter;     // optional device cell (0 on entry, 0 again at the end): the workgroup whose search finishes LAST sets summary[0] = 1
+    int* marks_out;        // early-exit launch, optional [B] (NASTAR_FLAG_MARK_COUPLED): 1 = this map reached its goal but is not at a fixed point of the reference's batch loop
+    const int* marks;      // lock-step launches, optional [B]: search only the maps marked 1 (the others return at once: their outputs stand)
+    const int* t_end;      // lock-step FINAL launch, optional device cell: the budget is *t_end + 1 steps
+    uint32_t* bitmap;      // lock-step PROBE launch: [B][bitmap_words], bit t = the goal was selected at step t; no outputs are written
+    int bitmap_words;
     int max_iters;
     int B;
     int flags;
@@ -110,6 +116,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = placed_map(a.order, a.order_bad, a.B);
     if ((unsigned)b >= (unsigned)a.B) return;  // not a permutation (and not checked: NASTAR_FLAG_CHECK_ORDER): never read or write outside the batch
+    const bool lockstep = !kAsm && (a.flags & NASTAR_FLAG_LOCKSTEP);  // (forward_impl picks a compiled instantiation for it)
+    if (lockstep && a.marks != nullptr && a.marks[b] == 0) return;    // not in the batch-coupled class: the early-exit launch's outputs stand
     const int lane = threadIdx.x;
     CompactDims d = a.d;
     if constexpr (LOGH > 0 && LOGW > 0) {
@@ -131,7 +139,11 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     // round-3 instruction stream (raw-bit keys): every cost >= +0 and 0 <= g_ratio <= 1 so that every priority is >= +0
     compact_load_map<kVec4, kLoadIter>(d, l, a.cost + off, a.start + off, a.goal + off, a.passable + off, lane, start_idx, goal_idx,
                                        kAsm ? &any_signed : nullptr);
-    const bool asm3 = kAsm && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
+#ifdef NASTAR_DEV
+    const bool raw = kAsm && !any_signed && !(a.flags & NASTAR_FLAG_ASM_V2) && d.gr >= 0.f && d.omg >= 0.f;
+#else
+    const bool raw = kAsm && !any_signed && d.gr >= 0.f && d.omg >= 0.f;
+#endif
     const int gi = goal_idx < 0 ? 0 : goal_idx;
     const int goal_r = (int)div_magic((uint32_t)gi, d.magicW);
     const int goal_c = gi - goal_r * d.W;
@@ -139,17 +151,27 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     const CompactLane lc = make_compact_lane(d, lane);
     int status = NASTAR_OK;
     int iters = 0;
-    bool solved = false;
-    const bool lockstep = !kAsm && (a.flags & NASTAR_FLAG_LOCKSTEP);  // (forward_impl picks a compiled instantiation for it)
+    bool solved = false, coupled = false;
     bool goal_hit = false;
+    const bool probe = lockstep && a.bitmap != nullptr;
+    const int budget = (lockstep && a.t_end != nullptr) ? __builtin_amdgcn_readfirstlane(*a.t_end + 1) : a.max_iters;
+    uint32_t bits = 0u;  // probe: goal selections of the current 32 steps
+    uint32_t* const bm = probe ? a.bitmap + (size_t)b * (size_t)a.bitmap_words : nullptr;
     if (start_idx < 0 || goal_idx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start/goal map
     } else {
-        // round-4 stream (nastar_search_asm4.hip.h) wherever the round-3 one applies; NASTAR_FLAG_ASM_V3 keeps the round-3 stream (A/B);
+        // round-4 stream (nastar_search_asm4.hip.h) wherever raw-bit keys apply (costs >= +0, 0 <= g_ratio <= 1: every priority is >= +0); a map with a
+        // negative / NaN cost takes the round-2 stream with its order-preserving key transform (nastar_search_asm.hip.h).  The development build
+        // (make dev) can also select the round-3 stream and switch the 64x64 dive off: csrc/nastar_dev_flags.h, stream-equality tests.
         // half: g_ratio == 0.5 -- the two products of f = g_ratio g + (1 - g_ratio) h are exact and drop out of the key
-        const bool asm4 = asm3 && !(a.flags & NASTAR_FLAG_ASM_V3);
+#ifdef NASTAR_DEV
+        const bool asm4 = raw && !(a.flags & NASTAR_FLAG_ASM_V3);
+        const bool no_dive = (a.flags & NASTAR_FLAG_NO_DIVE) != 0;
+#else
+        const bool asm4 = raw;
+#endif
         const bool half = asm4 && d.gr == 0.5f && d.omg == 0.5f;
-        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, asm3, half);
+        compact_open_start<kFastDiv>(d, l, lane, start_idx, goal_r, goal_c, rcp_sqrtW, raw, half);
         int s = 0;
         if constexpr (kAsm) {
             static_assert(LOGW > 0 && LOGW == LOGH && (CPL_T == 1 || CPL_T == 4) && kFastDiv, "asm loop: 16x16, 32x32, 64x64");
@@ -157,29 +179,38 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             // searching wavefronts issue ahead of the ones still loading their map or already storing their result (the launch waits for the
             // longest SEARCH): maze32 159.4 -> 157.7 us, rand32 75.6 -> 75.0 us per 4096 maps, same box, two runs each; 3-4 batches in flight unchanged at 57 M maps/s (profiles/r03/prio_*.json, prio_streams.txt)
             __builtin_amdgcn_s_setprio(3);
-            constexpr bool kD = CPL_T == 4;  // only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
-            if (asm4 && kD && (a.flags & NASTAR_FLAG_NO_DIVE)) {
+            constexpr bool kD = CPL_T == 4;  // only the 64x64 instantiation dives (nastar_search_asm4.hip.h)
+#ifdef NASTAR_DEV
+            if (asm4 && kD && no_dive) {
                 if (half) s = search_loop_asm4<LOGW, kLog, false, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
                 else s = search_loop_asm4<LOGW, kLog, false, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-            } else if (asm4) {
-                auto run = [&](int budget) {
-                    return half ? search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, budget, iters, rcp_sqrtW, log_row)
-                                : search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, budget, iters, rcp_sqrtW, log_row);
-                };
-                s = run(a.max_iters);
-            } else
-            if (asm3 && CPL_T == 4 && (a.flags & NASTAR_FLAG_NO_DIVE))  // A/B: only the 64x64 instantiation dives (nastar_search_asm3.hip.h)
+            } else if (raw && !asm4 && kD && no_dive) {
                 s = compact_search_loop_asm3<LOGW, kLog, false>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-            else if (asm3) s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
-            else s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            } else if (raw && !asm4) {
+                s = compact_search_loop_asm3<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            } else
+#endif
+            if (asm4) {
+                s = half ? search_loop_asm4<LOGW, kLog, kD, true, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row)
+                         : search_loop_asm4<LOGW, kLog, kD, false, false>(d.gr, d.omg, d.sqrtW, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            } else {
+                s = compact_search_loop_asm<LOGW, kLog>(d, lane, goal_idx, goal_r, goal_c, a.max_iters, iters, rcp_sqrtW, log_row);
+            }
             __builtin_amdgcn_s_setprio(0);
         } else
-        while (iters < a.max_iters) {  // :203 for t in range(Tmax)
+        while (iters < budget) {  // :203 for t in range(Tmax)
             uint2 mine;
             s = compact_select<CPL_T>(d, l, lane, mine);
             if (s < 0 || (s == goal_idx && !lockstep)) break;  // single exit test: open list empty (:68 would divide by zero) or goal
             if constexpr (kLog) {
                 if (lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            }
+            if (probe) {
+                if (s == goal_idx) bits |= 1u << (iters & 31);
+                if ((iters & 31) == 31) {
+                    if (lane == 0) bm[iters >> 5] = bits;
+                    bits = 0u;
+                }
             }
             ++iters;
             // lock-step mode: the reference's loop to the letter -- a selected goal is expanded like any cell, stays open, and the map is stepped
@@ -187,8 +218,15 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
             goal_hit |= s == goal_idx;
             compact_expand<LOGW, kFastDiv, CPL_T>(d, l, lc, lane, s, goal_r, goal_c, rcp_sqrtW, mine, s == goal_idx);
         }
+        if (probe) {  // the words this map's search did not reach say "no goal selection"; nothing else is written
+            if (lane == 0) {
+                if (iters & 31) bm[iters >> 5] = bits;
+                for (int w = (iters + 31) >> 5; w < a.bitmap_words; ++w) bm[w] = 0u;
+            }
+            return;
+        }
         if (lockstep && goal_hit && lane == 0) l.gc[goal_idx].x = NASTAR_NEG_INF;  // histories holds the goal (:222-223); nothing reads its g any more
-        if (kAsm ? (s != -2) : (iters < a.max_iters)) {
+        if (kAsm ? (s != -2) : (iters < budget)) {
             if (s < 0) {
                 status = NASTAR_ERR_UNSOLVABLE;
             } else {  // :219-220,:251 reached the goal: every later step of the reference is a fixed point
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
                 }
                 ++iters;
                 solved = true;
-                if (a.summary) {
+                if (a.summary != nullptr || a.marks_out != nullptr) {
                     // Is this map now at a FIXED POINT of the reference's batch loop?  The reference keeps stepping a finished map until every
                     // map of the batch selects its goal in the same step (:224 the goal stays open, :251); this kernel stops here.  The two
                     // agree iff the goal's own expansion opens nothing that beats the goal: true for every g_ratio in [0.5, 1) with costs >= 0
@@ -211,7 +249,8 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
                     const uint32_t kn = compact_key<kFastDiv>(d, g2, d.omg * (heuristic0_fast(nr, nc, goal_r, goal_c) + gn.y), rcp_sqrtW);
                     const uint32_t kg = compact_key<kFastDiv>(d, gg.x, d.omg * (heuristic0_fast(goal_r, goal_c, goal_r, goal_c) + gg.y), rcp_sqrtW);
                     const bool beats = inb & (gn.x > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
-                    if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+                    coupled = __ballot(beats) != 0ull;
+                    if (coupled && a.summary != nullptr && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
                     wave_order();
                 }
                 if (lane == 0) l.gc[s].x = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
@@ -221,12 +260,15 @@ __global__ __launch_bounds__(64) void nastar_forward_compact_kernel(const FwdCAr
     wave_sync();
     // histories depend on the closed list only: their stores are issued first and drain under the serial backtrack
     compact_store_hist<kVec4>(d, l, lane, a.hist + off);
+    if (probe) return;  // (a map without a one-hot start / goal: the early-exit launch reported it, it is never marked)
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
+        if (a.marks_out != nullptr) a.marks_out[b] = coupled ? 1 : 0;
         if (status != NASTAR_OK && a.summary) a.summary[status] = 1;  // plain idempotent store: the word may be host-mapped (no atomics over PCIe)
         if (a.order_out) note_completion(a.order_out, a.B, b);
-        if (a.done_counter) note_done(a.done_counter, a.summary, a.B, status != NASTAR_OK);
+        // (the COUPLED note above is a summary cell like any other: it must be visible before this search counts itself -- ADVICE r5)
+        if (a.done_counter) note_done(a.done_counter, a.summary, a.B, status != NASTAR_OK || coupled);
     }
     if (goal_idx >= 0) compact_backtrack<(LOGW == LOGH ? LOGW : 0)>(d, l, lane, start_idx, goal_idx, solved ? d.HW : iters - 1);
     compact_store_outputs<kVec4, false>(d, l, lane, a.hist + off, a.paths + off,
@@ -353,6 +395,73 @@ __global__ __launch_bounds__(256) void nastar_unpack_kernel(const uint8_t* __res
     }
 }
 
+
+// ---- the reference's stopping step for a batch with maps in the batch-coupled class (differentiable_astar.py:251-252) -------------------
+// t_end = the first step at which EVERY map selects its goal: a map that is not marked selects it at every step from its own goal step on
+// (fixed point), a marked one at the steps its PROBE bitmap names; without such a step the budget ends the loop (t_end = max_iters - 1).
+// tcell = {t_end (-1: no map is marked -- nothing to re-run), number of marked maps, t_max = max over the solved maps of their goal step}.
+// ONE workgroup: the bitmaps of the marked maps are AND-ed word by word in LDS (words from t_max on).
+constexpr int kTendThreads = 1024;
+__global__ __launch_bounds__(kTendThreads) void nastar_batchloop_tend_kernel(const int* __restrict__ iters, const int* __restrict__ status,
+                                                                            const int* __restrict__ marks, const uint32_t* __restrict__ bitmap,
+                                                                            int words, int B, int max_iters, int* __restrict__ tcell, int lds_words)
+{
+    extern __shared__ uint32_t s_and[];
+    __shared__ int s_tmax, s_nm;
+    __shared__ unsigned s_first;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_tmax = -1; s_nm = 0; s_first = 0xFFFFFFFFu; }
+    __syncthreads();
+    int tmax = -1, nm = 0;
+    for (int b = tid; b < B; b += kTendThreads) {
+        if (status[b] != NASTAR_OK) continue;  // (the reference crashes on an unsolvable map; here it is reported and takes no part)
+        tmax = max(tmax, iters[b] - 1);
+        nm += marks[b] != 0;
+    }
+    if (tmax >= 0) atomicMax(&s_tmax, tmax);
+    if (nm) atomicAdd(&s_nm, nm);
+    __syncthreads();
+    tmax = s_tmax;
+    nm = s_nm;
+    if (nm == 0 || tmax < 0) {
+        if (tid == 0) { tcell[0] = -1; tcell[1] = 0; tcell[2] = tmax; }
+        return;
+    }
+    const int w0 = tmax >> 5, nw = words - w0;
+    unsigned first = 0xFFFFFFFFu;
+    if (nw <= lds_words) {
+        for (int w = tid; w < nw; w += kTendThreads) s_and[w] = 0xFFFFFFFFu;
+        __syncthreads();
+        const long long total = (long long)B * nw;
+        for (long long i = tid; i < total; i += kTendThreads) {
+            const int b = (int)(i / nw), w = (int)(i - (long long)b * nw);
+            if (marks[b] != 0 && status[b] == NASTAR_OK) atomicAnd(&s_and[w], bitmap[(size_t)b * words + w0 + w]);
+        }
+        __syncthreads();
+        for (int w = tid; w < nw; w += kTendThreads) {
+            uint32_t v = s_and[w];
+            if (w == 0) v &= 0xFFFFFFFFu << (tmax & 31);
+            if (v) first = min(first, (unsigned)((w0 + w) * 32 + __builtin_ctz(v)));
+        }
+    } else {  // (a budget too long for LDS: each thread ANDs whole columns)
+        for (int w = tid; w < nw; w += kTendThreads) {
+            uint32_t v = 0xFFFFFFFFu;
+            for (int b = 0; b < B; ++b)
+                if (marks[b] != 0 && status[b] == NASTAR_OK) v &= bitmap[(size_t)b * words + w0 + w];
+            if (w == 0) v &= 0xFFFFFFFFu << (tmax & 31);
+            if (v) first = min(first, (unsigned)((w0 + w) * 32 + __builtin_ctz(v)));
+        }
+    }
+    if (first != 0xFFFFFFFFu) atomicMin(&s_first, first);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned f = s_first;
+        tcell[0] = (f < (unsigned)(max_iters - 1)) ? (int)f : max_iters - 1;
+        tcell[1] = nm;
+        tcell[2] = tmax;
+    }
+}
+
 thread_local char g_last_error[256] = "";
 
 constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
@@ -408,6 +517,41 @@ static bool needs_global_state(int H, int W)
 
 
 
+// Workspace of a forward launch: [hybrid slabs (maps larger than LDS)] [marks: B int32 + the t_end cell, NASTAR_FLAG_MARK_COUPLED]
+// [verdict word of NASTAR_FLAG_CHECK_ORDER].  The probe bitmaps of nastar_forward_batchloop_finish follow at a FIXED offset (as if both flags
+// had been given), so that the finish call finds the marks wherever the first launch put them.
+struct WsLayout {
+    size_t slabs, marks_off, tcell_off, chk_off, total;
+};
+static WsLayout ws_layout(int B, int H, int W, int flags)
+{
+    WsLayout l{};
+    l.slabs = needs_global_state(H, W) ? (size_t)B * hybrid_slab_bytes(H * W) : 0;
+    size_t off = l.slabs;
+    if (flags & NASTAR_FLAG_MARK_COUPLED) {
+        l.marks_off = off;
+        off += ((size_t)B * 4 + 15) & ~(size_t)15;
+        l.tcell_off = off;
+        off += 16;
+    }
+    if (flags & NASTAR_FLAG_CHECK_ORDER) {
+        l.chk_off = off;
+        off += kOrderCheckBytes;
+    }
+    l.total = off;
+    return l;
+}
+static int bitmap_words_for(int max_iters) { return (max_iters + 31) / 32; }
+
+// flag bits this build understands (the A/B switches exist in the development build only: csrc/nastar_dev_flags.h)
+#ifdef NASTAR_DEV
+constexpr int kKnownFlags = NASTAR_FLAG_UNIT_COST | NASTAR_FLAG_CHECK_ORDER | NASTAR_FLAG_LOCKSTEP | NASTAR_FLAG_MARK_COUPLED | NASTAR_FLAG_NO_ASM |
+                            NASTAR_FLAG_ASM_V2 | NASTAR_FLAG_ASM_V3 | NASTAR_FLAG_NO_DIVE;
+#else
+constexpr int kKnownFlags = NASTAR_FLAG_UNIT_COST | NASTAR_FLAG_CHECK_ORDER | NASTAR_FLAG_LOCKSTEP | NASTAR_FLAG_MARK_COUPLED;
+constexpr int NASTAR_FLAG_NO_ASM = 0, NASTAR_FLAG_ASM_V2 = 0, NASTAR_FLAG_ASM_V3 = 0, NASTAR_FLAG_NO_DIVE = 0;  // (host-side tests below fold away)
+#endif
+
 // map widths for which the FMA-based division by fl32(sqrt(W)) was verified bit-exact against IEEE division for
 // every fp32 f in [2^-100, FLT_MAX] (tools/fastdiv_check.c); widths whose sqrt is a power of two divide exactly.
 static bool fastdiv_verified(int W)
@@ -432,9 +576,13 @@ const char* nastar_last_error(void) { return g_last_error; }
 size_t nastar_workspace_bytes(int B, int H, int W, int flags)
 {
     if (B <= 0 || H <= 0 || W <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
-    const size_t chk = (flags & NASTAR_FLAG_CHECK_ORDER) ? kOrderCheckBytes : 0;  // the verdict word of nastar_order_check_kernel
-    if (!needs_global_state(H, W)) return chk;  // the whole search state lives in LDS
-    return (size_t)B * ((flags & NASTAR_FLAG_GLOBAL_V1) ? global_slab_bytes(H * W) : hybrid_slab_bytes(H * W)) + chk;
+    return ws_layout(B, H, W, flags).total;  // 0: the whole search state lives in LDS and neither marks nor an order check were asked for
+}
+
+size_t nastar_batchloop_workspace_bytes(int B, int H, int W, int max_iters)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
+    return ws_layout(B, H, W, NASTAR_FLAG_MARK_COUPLED | NASTAR_FLAG_CHECK_ORDER).total + (size_t)B * (size_t)bitmap_words_for(max_iters) * 4;
 }
 
 // NASTAR_FLAG_CHECK_ORDER: one small launch that decides whether `order` is a permutation of 0..B-1; its verdict word is the LAST
@@ -442,6 +590,7 @@ size_t nastar_workspace_bytes(int B, int H, int W, int flags)
 static int check_order(const int32_t* order, int B, void* workspace, size_t workspace_bytes, size_t need, int32_t* summary, hipStream_t s,
                        const int** order_bad)
 {
+    // `need` = end of the verdict word inside the workspace (the word is the 16 bytes before it)
     *order_bad = nullptr;
     if (!workspace) return NASTAR_ERR_NULL;
     if (need < kOrderCheckBytes || workspace_bytes < need) return NASTAR_ERR_WORKSPACE;
@@ -467,86 +616,71 @@ static int rank_order_after(const int32_t* iters, int B, int32_t* order_out, hip
     return NASTAR_OK;
 }
 
+// the lock-step launches of nastar_forward_batchloop_finish hand these through forward_impl
+struct LockArgs {
+    const int* marks = nullptr;
+    const int* t_end = nullptr;
+    uint32_t* bitmap = nullptr;
+    int bitmap_words = 0;
+};
+
 static int forward_impl(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
                         int W, double g_ratio, int max_iters, float* histories_out, int64_t* paths_out,
                         int32_t* sel_log_out, int32_t* iters_out, int32_t* status_out, void* workspace,
                         size_t workspace_bytes, int flags, void* stream, uint8_t* packed_out, bool* packed_done,
-                        const int32_t* order = nullptr, int32_t* order_out = nullptr, int32_t* summary = nullptr, int32_t* done_counter = nullptr)
+                        const int32_t* order = nullptr, int32_t* order_out = nullptr, int32_t* summary = nullptr, int32_t* done_counter = nullptr,
+                        const LockArgs* lock = nullptr)
 {
     *packed_done = false;
     if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out)
         return NASTAR_ERR_NULL;
-    if (B > 0 && H > 0 && W > 0 && max_iters > 0 && (long long)H * W <= kMaxGlobalCells && needs_global_state(H, W)) {
-        if (flags & NASTAR_FLAG_LOCKSTEP) return NASTAR_ERR_UNSUPPORTED;  // LDS-resident sizes only
+    if (flags & ~kKnownFlags) return NASTAR_ERR_UNSUPPORTED;  // (A/B switches of the development build: make dev, csrc/nastar_dev_flags.h)
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((long long)H * W > kMaxGlobalCells) return NASTAR_ERR_UNSUPPORTED;
+    const bool lockstep = (flags & NASTAR_FLAG_LOCKSTEP) != 0;
+    const WsLayout wl = ws_layout(B, H, W, flags);
+    if (wl.total > 0 && !lock) {  // (the lock-step launches of the finish call were checked there)
+        if (!workspace) return NASTAR_ERR_NULL;
+        if (workspace_bytes < wl.total) return NASTAR_ERR_WORKSPACE;
+    }
+    int* marks_out = (!lockstep && (flags & NASTAR_FLAG_MARK_COUPLED)) ? reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + wl.marks_off) : nullptr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (needs_global_state(H, W)) {
         // large map: cells in the caller's HBM workspace, open list in LDS (nastar_search_hybrid.hip.h)
         if (!workspace) return NASTAR_ERR_NULL;
-        if (!(flags & NASTAR_FLAG_GLOBAL_V1)) {
-            const size_t slab = hybrid_slab_bytes(H * W);
-            if (workspace_bytes < (size_t)B * slab) return NASTAR_ERR_WORKSPACE;
-            FwdHybridArgs ha;
-            ha.cost = cost; ha.start = start; ha.goal = goal; ha.passable = passable;
-            ha.hist = histories_out; ha.paths = reinterpret_cast<long long*>(paths_out);
-            ha.sel_log = sel_log_out; ha.iters = iters_out; ha.status = status_out; ha.summary = summary;
-            ha.workspace = static_cast<unsigned char*>(workspace); ha.slab_bytes = slab; ha.max_iters = max_iters;
-            HybridDims& hd = ha.d;
-            hd.H = H; hd.W = W; hd.HW = H * W;
-            hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
-            hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
-            hd.rcp_sqrtW = 1.0f / hd.sqrtW;
-            hd.inv_W = 1.0f / (float)W;
-            hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-            // headers (start / goal cell per map) to -1: the fill launch raises them with atomicMax
-            for (int bb = 0; bb < B; ++bb) {
-                hipError_t me = hipMemsetAsync(ha.workspace + (size_t)bb * slab + hybrid_header_offset(hd.HW), 0xFF, 8, hs);
-                if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync");
-                if (B > 64) break;  // (many maps: one strided fill kernel below instead of B memsets)
-            }
-            if (B > 64) {
-                hipLaunchKernelGGL(nastar_hybrid_header_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs, ha.workspace, slab,
-                                   hybrid_header_offset(hd.HW), B);
-            }
-            const unsigned per_map = (unsigned)((hd.nchunks * 64 + 255) / 256);
-            const dim3 grid2(per_map < 64u ? per_map : 64u, (unsigned)B);
-            hipLaunchKernelGGL(nastar_hybrid_fill_kernel, grid2, dim3(256), 0, hs, ha);
-            // the slab is reached through the CU's vector L1 (measured 23 % faster per step than agent-scope accesses served by L2); the rest is A/B
-            const int mem = ((flags & NASTAR_FLAG_HYBRID_SC1) ? 0 : 1) | ((flags & NASTAR_FLAG_HYBRID_NOFENCE) ? 2 : 0) | ((flags & NASTAR_FLAG_HYBRID_SCALAR) ? 4 : 0) |
-                            ((flags & NASTAR_FLAG_HYBRID_BALLOT) ? 12 : 0);
-            const bool fd = fastdiv_verified(W);
-            const size_t hl = hybrid_lds_bytes(hd.HW);
-            int rc2;
-#define NASTAR_HYB(M) case M: rc2 = fd ? launch(nastar_forward_hybrid_kernel<true, M>, B, hl, hs, ha) : launch(nastar_forward_hybrid_kernel<false, M>, B, hl, hs, ha); break;
-            switch (mem) {
-            NASTAR_HYB(1) NASTAR_HYB(2) NASTAR_HYB(3) NASTAR_HYB(4) NASTAR_HYB(5) NASTAR_HYB(6) NASTAR_HYB(7)
-            NASTAR_HYB(12) NASTAR_HYB(13) NASTAR_HYB(14) NASTAR_HYB(15)
-            NASTAR_HYB(0)
-            default: rc2 = NASTAR_ERR_UNSUPPORTED; break;
-            }
-#undef NASTAR_HYB
-            if (rc2) return rc2;
-            hipLaunchKernelGGL(nastar_hybrid_store_kernel, grid2, dim3(256), 0, hs, ha);
-            hipError_t he = hipGetLastError();
-            if (he != hipSuccess) return hip_fail(he, "kernel launch");
-            return NASTAR_OK;
-        }
-        // round-4 kernel (all three open-list levels in HBM), kept for the A/B of profiles/r05 only
-        const size_t slab = global_slab_bytes(H * W);
+        const size_t slab = hybrid_slab_bytes(H * W);
         if (workspace_bytes < (size_t)B * slab) return NASTAR_ERR_WORKSPACE;
-        FwdGlobalArgs ga;
-        ga.cost = cost; ga.start = start; ga.goal = goal; ga.passable = passable;
-        ga.hist = histories_out; ga.paths = reinterpret_cast<long long*>(paths_out);
-        ga.sel_log = sel_log_out; ga.iters = iters_out; ga.status = status_out; ga.summary = summary;
-        ga.workspace = static_cast<unsigned char*>(workspace); ga.slab_bytes = slab; ga.max_iters = max_iters;
-        GlobalDims& gd = ga.d;
-        gd.H = H; gd.W = W; gd.HW = H * W;
-        gd.nchunks = (gd.HW + 63) / 64; gd.HWp = gd.nchunks * 64; gd.NC64 = ((gd.nchunks + 63) / 64) * 64;
-        gd.nsuper = gd.NC64 / 64;
-        gd.gr = (float)g_ratio; gd.omg = (float)(1.0 - g_ratio); gd.sqrtW = (float)sqrt((double)W);
-        hipLaunchKernelGGL(nastar_forward_global_kernel, dim3((unsigned)B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ga);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        FwdHybridArgs ha;
+        ha.cost = cost; ha.start = start; ha.goal = goal; ha.passable = passable;
+        ha.hist = histories_out; ha.paths = reinterpret_cast<long long*>(paths_out);
+        ha.sel_log = sel_log_out; ha.iters = iters_out; ha.status = status_out; ha.summary = summary;
+        ha.workspace = static_cast<unsigned char*>(workspace); ha.slab_bytes = slab; ha.max_iters = max_iters;
+        ha.marks_out = marks_out;
+        ha.marks = lock ? lock->marks : nullptr; ha.t_end = lock ? lock->t_end : nullptr;
+        ha.bitmap = lock ? lock->bitmap : nullptr; ha.bitmap_words = lock ? lock->bitmap_words : 0;
+        HybridDims& hd = ha.d;
+        hd.H = H; hd.W = W; hd.HW = H * W;
+        hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
+        hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
+        hd.rcp_sqrtW = 1.0f / hd.sqrtW;
+        hd.inv_W = 1.0f / (float)W;
+        // headers (start / goal cell per map) to -1: the fill launch raises them with atomicMax
+        hipLaunchKernelGGL(nastar_hybrid_header_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, ha.workspace, slab,
+                           hybrid_header_offset(hd.HW), B);
+        const unsigned per_map = (unsigned)((hd.nchunks * 64 + 255) / 256);
+        const dim3 grid2(per_map < 64u ? per_map : 64u, (unsigned)B);
+        hipLaunchKernelGGL(nastar_hybrid_fill_kernel, grid2, dim3(256), 0, s, ha);
+        const bool fd = fastdiv_verified(W);
+        const size_t hl = hybrid_lds_bytes(hd.HW);
+        int rc2;
+        if (lockstep) rc2 = fd ? launch(nastar_forward_hybrid_kernel<true, true>, B, hl, s, ha) : launch(nastar_forward_hybrid_kernel<false, true>, B, hl, s, ha);
+        else rc2 = fd ? launch(nastar_forward_hybrid_kernel<true, false>, B, hl, s, ha) : launch(nastar_forward_hybrid_kernel<false, false>, B, hl, s, ha);
+        if (rc2) return rc2;
+        if (!ha.bitmap) hipLaunchKernelGGL(nastar_hybrid_store_kernel, grid2, dim3(256), 0, s, ha);  // (a probe launch has no outputs)
+        hipError_t he = hipGetLastError();
+        if (he != hipSuccess) return hip_fail(he, "kernel launch");
         return NASTAR_OK;
     }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     {
         FwdCArgs c;
         int rc = make_cdims(B, H, W, max_iters, g_ratio, c.d);
@@ -562,8 +696,11 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         c.summary = summary;
         c.done_counter = summary ? done_counter : nullptr;
         c.order_bad = nullptr;
+        c.marks_out = marks_out;
+        c.marks = lock ? lock->marks : nullptr; c.t_end = lock ? lock->t_end : nullptr;
+        c.bitmap = lock ? lock->bitmap : nullptr; c.bitmap_words = lock ? lock->bitmap_words : 0;
         if (order && (flags & NASTAR_FLAG_CHECK_ORDER)) {
-            rc = check_order(order, B, workspace, workspace_bytes, nastar_workspace_bytes(B, H, W, flags), summary, s, &c.order_bad);
+            rc = check_order(order, B, workspace, workspace_bytes, wl.chk_off + kOrderCheckBytes, summary, s, &c.order_bad);
             if (rc) return rc;
         }
         c.flags = flags;
@@ -588,6 +725,10 @@ static int forward_impl(const float* cost, const float* start, const float* goal
             const size_t ulds = W == 32 ? (size_t)AsmLayoutUnit<5>::BYTES : (size_t)AsmLayoutUnit<6>::BYTES;
             const bool rank_after = order_out && (long long)B > resident_capacity(ulds);
             if (rank_after) c.order_out = nullptr;
+            if (marks_out) {  // unit costs are never in the batch-coupled class (f(n) - f(goal) >= 1.001 - 0.001 g_ratio > 0 with every cost 1)
+                hipError_t me = hipMemsetAsync(marks_out, 0, (size_t)B * 4, s);
+                if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync");
+            }
             int urc;
             if (W == 32) urc = launch(&nastar_forward_unit_kernel<5, false>, B, ulds, s, c, rcp);
             else if (flags & NASTAR_FLAG_NO_DIVE) urc = launch(&nastar_forward_unit_kernel<6, false>, B, ulds, s, c, rcp);
@@ -616,7 +757,6 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         const int krc = launch(kern, B, lds, s, c, rcp);
         return (krc == NASTAR_OK && rank_after) ? rank_order_after(iters_out, B, order_out, s) : krc;
     }
-    return NASTAR_ERR_UNSUPPORTED;
 }
 
 int nastar_forward(const float* cost, const float* start, const float* goal, const float* passable, int B, int H,
@@ -652,6 +792,42 @@ int nastar_forward_ex(const float* cost, const float* start, const float* goal, 
     return nastar_pack_outputs(histories_out, paths_out, B, H, W, packed_out, stream);
 }
 
+int nastar_forward_batchloop_finish(const float* cost, const float* start, const float* goal, const float* passable, int B, int H, int W,
+                                    double g_ratio, int max_iters, float* histories_out, int64_t* paths_out, int32_t* sel_log_out,
+                                    int32_t* iters_out, int32_t* status_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cost || !start || !goal || !passable || !histories_out || !paths_out || !iters_out || !status_out || !workspace) return NASTAR_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((long long)H * W > kMaxGlobalCells) return NASTAR_ERR_UNSUPPORTED;
+    if (workspace_bytes < nastar_batchloop_workspace_bytes(B, H, W, max_iters)) return NASTAR_ERR_WORKSPACE;
+    const WsLayout wl = ws_layout(B, H, W, NASTAR_FLAG_MARK_COUPLED | NASTAR_FLAG_CHECK_ORDER);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    LockArgs la;
+    la.marks = reinterpret_cast<const int*>(ws + wl.marks_off);
+    int* tcell = reinterpret_cast<int*>(ws + wl.tcell_off);
+    la.bitmap_words = bitmap_words_for(max_iters);
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(ws + wl.total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    bool done;
+    // 1. PROBE: the marked maps in lock-step mode over the whole budget; which steps select the goal?  (no outputs)
+    la.bitmap = bitmap;
+    int rc = forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, nullptr, iters_out, status_out, workspace,
+                          workspace_bytes, NASTAR_FLAG_LOCKSTEP, stream, nullptr, &done, nullptr, nullptr, nullptr, nullptr, &la);
+    if (rc) return rc;
+    // 2. the first step at which EVERY map of the batch selects its goal
+    const int words = la.bitmap_words;
+    const int lds_words = words < 16384 ? words : 16384;
+    hipLaunchKernelGGL(nastar_batchloop_tend_kernel, dim3(1), dim3(kTendThreads), (size_t)lds_words * 4, s, iters_out, status_out, la.marks, bitmap, words,
+                       B, max_iters, tcell, lds_words);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    // 3. FINAL: the marked maps again, for exactly t_end + 1 steps, with outputs (and their rows of the selection log)
+    la.bitmap = nullptr;
+    la.t_end = tcell;
+    return forward_impl(cost, start, goal, passable, B, H, W, g_ratio, max_iters, histories_out, paths_out, sel_log_out, iters_out, status_out, workspace,
+                        workspace_bytes, NASTAR_FLAG_LOCKSTEP, stream, nullptr, &done, nullptr, nullptr, nullptr, nullptr, &la);
+}
+
 int nastar_completion_supported(int H, int W)
 {
     return (H > 0 && W > 0 && (long long)H * W <= kMaxGlobalCells && !needs_global_state(H, W)) ? 1 : 0;
@@ -664,7 +840,11 @@ int nastar_host_wait_nonzero(const volatile int32_t* word_host, int timeout_us)
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spin = 0;; ++spin) {
         if (*word_host != 0) return 1;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
         if ((spin & 255u) == 255u) {
             timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -716,7 +896,10 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
 
 
 // ---- backward by replay of the forward's selection log (nastar_backward_replay.hip.h) ------------------------------------
-static int bwdr_hist_len(int HW, int max_iters) { return (max_iters < HW + 1 ? max_iters : HW + 1) + 2; }
+// history entries per map: one per executed step.  An early-exit search executes at most HW + 1 selections whatever the budget; in LOCK-STEP mode
+// a goal selection does not close a cell, but between two of them a map of the batch-coupled class closes at least one, and once it closes none it
+// selects its goal at every step (the loop then ends as soon as every map does): at most 2 HW steps.  (Square maps: max_iters = W W = HW either way.)
+static int bwdr_hist_len(int HW, int max_iters) { return (max_iters < 2 * HW + 2 ? max_iters : 2 * HW + 2) + 2; }
 static bool bwdr_fits_lds(int HW) { return bwdr_state_bytes(((HW + 63) / 64) * 64) <= kMaxLdsBytes; }
 
 size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters)
@@ -753,7 +936,11 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
     const float rcp = 1.0f / a.d.sqrtW;
     const bool fast = fastdiv_verified(W);
     const int max_steps = hlen - 2;
-    if ((flags & NASTAR_FLAG_NO_ASM) == 0 && fast && H == W && (W == 32 || W == 16) && aligned16(cost) && aligned16(start) &&
+    if ((flags & ~(kKnownFlags)) != 0) return NASTAR_ERR_UNSUPPORTED;
+    // history stamps are 16-bit: a lock-step log of a map with more than ~32 k cells could outrun them
+    if ((flags & NASTAR_FLAG_LOCKSTEP) && hlen > 65535) return NASTAR_ERR_UNSUPPORTED;
+    // (the hand-scheduled loop closes every selected cell: a lock-step log, whose goal selections leave the goal open, takes the general loop)
+    if ((flags & (NASTAR_FLAG_NO_ASM | NASTAR_FLAG_LOCKSTEP)) == 0 && fast && H == W && (W == 32 || W == 16) && aligned16(cost) && aligned16(start) &&
         aligned16(goal) && aligned16(passable) && aligned16(grad_cost_out) && bwdr_asm_lds_bytes(a.d.HW, max_steps) <= kMaxLdsBytes) {
         // hand-scheduled replay loop (nastar_backward_replay_asm.hip.h): the reference's training sizes
         const size_t lds = bwdr_asm_lds_bytes(a.d.HW, max_steps);

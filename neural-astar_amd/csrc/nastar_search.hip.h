@@ -26,4 +26,13 @@ __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 // s_waitcnt -- only a compiler-level ordering point.
 __device__ __forceinline__ void wave_order() { __builtin_amdgcn_wave_barrier(); }
 
+// state in the HBM workspace (maps larger than LDS): all of this wave's stores / atomics have left the CU before any later load is issued.
+// The stores are write-through: once vmcnt drains they are in L2.  (An agent-scope release fence would add a buffer_wbl2 of ~1.7 us per
+// call for nothing: nothing here is cached dirty.)
+__device__ __forceinline__ void global_step_fence()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace nastar

@@ -12,7 +12,7 @@
 //     cmin[c] per 64-cell chunk: (key << 32 | cell) of its first minimal open cell, ~0 when it holds none   (u64 order = first-index tie-break)
 //     smin[s] per 64 chunks: the minimum of their cmin entries
 //
-// Three launches per call (fill / search / store, see below).  A step of the search (round 4's kernel, nastar_search_global.hip.h, kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
+// Three launches per call (fill / search / store, see below).  A step of the search (round 4's kernel kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
 //   select   ONE ds_read_b64 per lane of smin + a wave minimum: the entry itself names s*                               (LDS only)
 //   load     g / cost of s*, of its 8 neighbours and of the 64 cells of its chunk: issued together, ONE round trip       (HBM)
 //   update   g / pdir stores of the relaxed neighbours (drain overlapped with the LDS work below); chunk minimum without s*
@@ -20,7 +20,6 @@
 // Keys are never stored: q = fl(f / fl32(sqrt(W))) is re-derived from (g, cost, coordinates), with the IEEE division (no reciprocal).
 #pragma once
 #include "nastar_search.hip.h"
-#include "nastar_search_global.hip.h"  // gld / gst / global_step_fence: agent-scope accesses served by L2
 
 namespace nastar {
 
@@ -60,6 +59,11 @@ struct FwdHybridArgs {
     unsigned char* workspace;
     size_t slab_bytes;
     int max_iters;
+    int* marks_out;        // early-exit launch, optional [B]: 1 = this map reached its goal but is not at a fixed point of the reference's batch loop
+    const int* marks;      // lock-step launches, optional [B]: search only the maps marked 1
+    const int* t_end;      // lock-step FINAL launch, optional device cell: the budget is *t_end + 1 steps
+    uint32_t* bitmap;      // lock-step PROBE launch: [B][bitmap_words], bit t = the goal was selected at step t
+    int bitmap_words;
     HybridDims d;
 };
 
@@ -117,6 +121,7 @@ __device__ __forceinline__ uint32_t hybrid_key(const HybridDims& d, float g, flo
 __global__ __launch_bounds__(256) void nastar_hybrid_fill_kernel(const FwdHybridArgs a)
 {
     const int b = blockIdx.y;
+    if (a.marks != nullptr && a.marks[b] == 0) return;  // lock-step launches touch only the marked maps
     const HybridDims d = a.d;
     const int HWp = d.nchunks * 64;
     unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void nastar_hybrid_fill_kernel(const FwdHybrid
 __global__ __launch_bounds__(256) void nastar_hybrid_header_kernel(unsigned char* workspace, size_t slab_bytes, size_t header_off, int B)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b < B) {
+    if (b < B) {  // (also for maps a lock-step launch skips: their headers are not read again)
         int* hdr = reinterpret_cast<int*>(workspace + (size_t)b * slab_bytes + header_off);
         hdr[0] = -1;
         hdr[1] = -1;
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(256) void nastar_hybrid_header_kernel(unsigned char
 __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybridArgs a)
 {
     const int b = blockIdx.y;
+    if (a.marks != nullptr && a.marks[b] == 0) return;
     const HybridDims d = a.d;
     const int HWp = d.nchunks * 64;
     const unsigned char* const slab = a.workspace + (size_t)b * a.slab_bytes;
@@ -163,43 +169,53 @@ __global__ __launch_bounds__(256) void nastar_hybrid_store_kernel(const FwdHybri
     }
 }
 
-// How the search reaches its slab (kMem; the default is 1, the other bits are A/B switches: NASTAR_FLAG_HYBRID_* of include/nastar.h):
-//   bit 0  plain accesses through the CU's vector L1 instead of agent-scope (sc1) ones served by L2 (measured: 986 instead of 1275 ns per step).  The slab of a map is touched by ONE
-//          wavefront between the fill and the store launch, and the lanes of a wavefront are coherent through their L1 without further action
-//          (it is write-through and processes a wavefront's accesses in order): the neighbourhood of s* is mostly the neighbourhood of the
-//          previous one, i.e. L1 hits.
-//   bit 1  no wait for the previous step's stores before this step's loads are ISSUED: a wavefront's accesses to one address are performed in
-//          issue order (what lets any thread read back its own store), instruction-wide, so also across lanes; the loads then travel while
-//          the stores are being acknowledged.
-//   bit 2  s* travels in a SCALAR register (v_readfirstlane of the reduction's result): the loop's exits (open list empty, goal selected,
-//          budget) become scalar branches and the step counter a scalar -- the compiler otherwise treats the wave-uniform s* as divergent and
-//          wraps every exit in exec-mask bookkeeping; rows / columns by selects instead of branches (hybrid_row_nb).
-//   bit 3  (with bit 2) the selection's tie-break by ballot + first set lane + v_readlane instead of a second wave minimum (entries ascend with
-//          the lane, first_min_entry).
-template <int kMem, typename T>
-__device__ __forceinline__ T hld(const T* p)
+// How the search reaches its slab -- decided by measurement in round 5 (profiles/r05/probe_large_variants_*.jsonl; the A/B switches lived in
+// the library until round 6):
+//   * plain accesses through the CU's vector L1 instead of agent-scope (sc1) ones served by L2 (986 instead of 1275 ns per step).  The slab of a
+//     map is touched by ONE wavefront between the fill and the store launch, and the lanes of a wavefront are coherent through their L1 without
+//     further action (it is write-through and processes a wavefront's accesses in order): the neighbourhood of s* is mostly the neighbourhood
+//     of the previous one, i.e. L1 hits.
+//   * s* travels in a SCALAR register (v_readlane of the reduction's result): the loop's exits (open list empty, goal selected, budget) are
+//     scalar branches and the step counter a scalar -- the compiler otherwise treats the wave-uniform s* as divergent and wraps every exit in
+//     exec-mask bookkeeping; rows / columns by selects instead of branches (hybrid_row_nb): -7 %.
+//   * the selection's tie-break by ballot + first set lane + v_readlane instead of a second wave minimum (entries ascend with the lane): -1 %.
+//   * the wait for the previous step's stores before this step's loads stays (dropping it changed nothing: 938-940 ns).
+//
+// kLock: the LOCK-STEP modes (the reference's batch loop to the letter, differentiable_astar.py:219-225, :251): a selected goal is expanded
+// like any cell and stays on the open list, and the map is stepped on -- PROBE (a.bitmap != nullptr: no outputs; bit t of the map's bitmap
+// row = "the goal was selected at step t", over the whole budget) and FINAL (outputs after exactly *a.t_end + 1 steps).  With a.marks only
+// the maps the early-exit launch marked as batch-coupled are searched; the others return at once (their outputs stand).
+__device__ __forceinline__ float hld(const float* p) { return *p; }
+__device__ __forceinline__ uint32_t hld(const uint8_t* p) { return *p; }
+
+// does the expansion of the goal cell s (selected just now) open or lower a neighbour that BEATS the goal?  (wave-uniform; lanes 0..7)
+template <bool kFastDiv>
+__device__ __forceinline__ bool hybrid_goal_beaten(const HybridDims& d, const float* g, const float* cost, int s, int lane, int dr, int dc,
+                                                   int goal_r, int goal_c)
 {
-    if constexpr (kMem & 1) return *p;
-    else return gld(p);
-}
-template <int kMem, typename T>
-__device__ __forceinline__ void hst(T* p, T v)
-{
-    if constexpr (kMem & 1) *p = v;
-    else gst(p, v);
-}
-template <int kMem>
-__device__ __forceinline__ void hybrid_step_fence()
-{
-    if constexpr (kMem & 2) __builtin_amdgcn_wave_barrier();
-    else global_step_fence();
+    int gc0;
+    const int gr0 = hybrid_row_nb(s, d, gc0);
+    const int nr = gr0 + dr, nc = gc0 + dc;
+    const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
+    const int n = inb ? s + dr * d.W + dc : s;
+    global_step_fence();
+    const float gs = g[s], gn = g[n];
+    const float cs = cost[s], cn = cost[n];
+    const float g2 = gs + cs;
+    const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+    const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
+    const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
+    return __ballot(beats) != 0ull;
 }
 
-template <bool kFastDiv, int kMem = 1>
+template <bool kFastDiv, bool kLock = false>
 __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybridArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
+    if constexpr (kLock) {
+        if (a.marks != nullptr && a.marks[b] == 0) return;  // not in the batch-coupled class: the early-exit launch's outputs stand
+    }
     const int lane = threadIdx.x;
     const HybridDims d = a.d;
     const int HWp = d.nchunks * 64;
@@ -211,9 +227,11 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     const int* const hdr = reinterpret_cast<const int*>(slab + hybrid_header_offset(d.HW));
     const size_t off = (size_t)b * (size_t)d.HW;
     const float* cost = a.cost + off;
+    const bool probe = kLock && a.bitmap != nullptr;
+    const int budget = (kLock && a.t_end != nullptr) ? __builtin_amdgcn_readfirstlane(*a.t_end + 1) : a.max_iters;
 
     // ---- start / goal from the fill launch; empty open list -------------------------------------------------------------
-    const int sidx = (kMem & 4) ? __builtin_amdgcn_readfirstlane(hdr[0]) : hdr[0], gidx = (kMem & 4) ? __builtin_amdgcn_readfirstlane(hdr[1]) : hdr[1];
+    const int sidx = __builtin_amdgcn_readfirstlane(hdr[0]), gidx = __builtin_amdgcn_readfirstlane(hdr[1]);
     for (int c = lane; c < d.nsuper * 64; c += 64) cmin[c] = ~0ull;
     smin[lane] = ~0ull;
     const int gi = gidx < 0 ? 0 : gidx;
@@ -225,8 +243,8 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
         const int sr = hybrid_row(sidx, d, sc);
         const uint32_t k0 = hybrid_key<kFastDiv>(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
         const unsigned long long e = ((unsigned long long)k0 << 32) | (uint32_t)sidx;
-        hst<kMem>(&g[sidx], 0.0f);
-        hst<kMem>(&pdir[sidx], (uint8_t)(PARENT_UNSET | P_PASS));
+        g[sidx] = 0.0f;
+        pdir[sidx] = (uint8_t)(PARENT_UNSET | P_PASS);
         cmin[sidx >> 6] = e;
         smin[sidx >> 12] = e;
     }
@@ -236,191 +254,122 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     neighbour_delta(lane & 7, dr, dc);
     int status = NASTAR_OK;
     int iters = 0;
-    bool solved = false;
+    bool solved = false, goal_hit = false, coupled = false;
+    uint32_t bits = 0u;  // probe: goal selections of the current 32 steps
+    uint32_t* const bm = probe ? a.bitmap + (size_t)b * (size_t)a.bitmap_words : nullptr;
     if (sidx < 0 || gidx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start / goal map
     } else {
-        if constexpr ((kMem & 4) != 0) {
-            while (iters < a.max_iters) {  // :203
-                // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-                const unsigned long long e0 = smin[lane];
-                const uint32_t k0 = (uint32_t)(e0 >> 32), c0 = (uint32_t)e0;
-                int s;  // wave-uniform, in a scalar register
-                if constexpr ((kMem & 8) != 0) {
-                    const uint32_t m = wave_min_all_u32(k0);
-                    s = __builtin_amdgcn_readlane((int)c0, __builtin_ctzll(__ballot(k0 == m)));  // (the lane that holds m exists)
-                } else {
-                    const uint32_t m = wave_min_all_u32(k0);
-                    s = __builtin_amdgcn_readfirstlane((int)wave_min_all_u32(k0 == m ? c0 : 0xFFFFFFFFu));
-                }
-                if (s < 0) {  // every entry idle (~0ull: key KEY_INF, cell ~0): open list empty (:68 would divide by zero)
-                    status = NASTAR_ERR_UNSOLVABLE;
-                    break;
-                }
-                if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-                ++iters;
-                if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
-                    if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
-                        int gc0;
-                        const int gr0 = hybrid_row_nb(s, d, gc0);
-                        const int nr = gr0 + dr, nc = gc0 + dc;
-                        const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
-                        const int n = inb ? s + dr * d.W + dc : s;
-                        global_step_fence();
-                        const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
-                        const float cs = cost[s], cn = cost[n];
-                        const float g2 = gs + cs;
-                        const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-                        const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
-                        const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
-                        if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
-                    }
-                    if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
-                    solved = true;
-                    break;
-                }
-                const int C = s >> 6, S = s >> 12;
-                int c;
-                const int r = hybrid_row_nb(s, d, c);
-                const int nr = r + dr, nc = c + dc;
-                const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
-                const int n = inb ? s + dr * d.W + dc : s;
-                const int ic = C * 64 + lane;
-                const bool icv = ic < d.HW;
-                hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
-                // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
-                const float gs = hld<kMem>(&g[s]);
-                const float gn = hld<kMem>(&g[n]);
-                const float gc = hld<kMem>(&g[ic]);
-                const float cs = cost[s];
-                const float cn = cost[n];
-                const float cc = icv ? cost[ic] : 0.f;
-                int icc;
-                const int icr = hybrid_row_nb(icv ? ic : 0, d, icc);
-                const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
-                const bool upd = inb & (gn > g2);                                      // :229,:235
-                const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-                // chunk minimum without s*: open <=> finite g
-                const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
-                const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
-                const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
-                // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
-                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
-                if (upd) {
-                    hst<kMem>(&g[n], g2);
-                    hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
-                }
-                // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
-                const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
-                if (lane == 0) cmin[C] = newC;
-                wave_order();
-                if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
-                wave_order();
-                const unsigned long long ev = cmin[S * 64 + lane];
-                const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
-                if (lane == 0) smin[S] = newS;
-                wave_order();
-                if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
-                wave_order();
+        while (iters < budget) {  // :203
+            // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
+            const unsigned long long e0 = smin[lane];
+            const uint32_t k0 = (uint32_t)(e0 >> 32), c0 = (uint32_t)e0;
+            const uint32_t m = wave_min_all_u32(k0);
+            const int s = __builtin_amdgcn_readlane((int)c0, __builtin_ctzll(__ballot(k0 == m)));  // wave-uniform, in a scalar register (the lane that holds m exists)
+            if (s < 0) {  // every entry idle (~0ull: key KEY_INF, cell ~0): open list empty (:68 would divide by zero)
+                status = NASTAR_ERR_UNSOLVABLE;
+                break;
             }
-        } else {
-            while (iters < a.max_iters) {  // :203
-                // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-                const unsigned long long e0 = smin[lane];
-                const unsigned long long M = first_min_entry((uint32_t)(e0 >> 32), (uint32_t)e0);
-                if (M == ~0ull) {  // open list empty (:68 would divide by zero)
-                    status = NASTAR_ERR_UNSOLVABLE;
-                    break;
-                }
-                const int s = (int)(uint32_t)M;
-                if (a.sel_log != nullptr && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
-                ++iters;
-                if (s == gidx) {  // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a
-                    if (a.summary) {  // cell that beats it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED]
-                        int gc0;
-                        const int gr0 = hybrid_row(s, d, gc0);
-                        const int nr = gr0 + dr, nc = gc0 + dc;
-                        const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);
-                        const int n = inb ? s + dr * d.W + dc : s;
-                        global_step_fence();
-                        const float gs = hld<kMem>(&g[s]), gn = hld<kMem>(&g[n]);
-                        const float cs = cost[s], cn = cost[n];
-                        const float g2 = gs + cs;
-                        const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-                        const uint32_t kg = hybrid_key<kFastDiv>(d, gs, heuristic0(gr0, gc0, goal_r, goal_c) + cs);
-                        const bool beats = inb & (gn > g2) & ((kn < kg) | ((kn == kg) & (n < s)));
-                        if (__ballot(beats) != 0ull && lane == 0) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+            if (a.sel_log != nullptr && !probe && lane == 0) a.sel_log[(size_t)b * (size_t)a.max_iters + iters] = s;
+            const bool at_goal = s == gidx;
+            if constexpr (kLock) {
+                if (probe) {
+                    if (at_goal) bits |= 1u << (iters & 31);
+                    if ((iters & 31) == 31) {
+                        if (lane == 0) bm[iters >> 5] = bits;
+                        bits = 0u;
                     }
-                    if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);  // :222-223 the goal joins the closed list
-                    solved = true;
-                    break;
                 }
-                const int C = s >> 6, S = s >> 12;
-                int c;
-                const int r = hybrid_row(s, d, c);
-                const int nr = r + dr, nc = c + dc;
-                const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
-                const int n = inb ? s + dr * d.W + dc : s;
-                const int ic = C * 64 + lane;
-                const bool icv = ic < d.HW;
-                hybrid_step_fence<kMem>();  // kMem bit 1 clear: the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
-                // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
-                const float gs = hld<kMem>(&g[s]);
-                const float gn = hld<kMem>(&g[n]);
-                const float gc = hld<kMem>(&g[ic]);
-                const float cs = cost[s];
-                const float cn = cost[n];
-                const float cc = icv ? cost[ic] : 0.f;
-                int icc;
-                const int icr = hybrid_row(icv ? ic : 0, d, icc);
-                const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
-                const bool upd = inb & (gn > g2);                                      // :229,:235
-                const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
-                // chunk minimum without s*: open <=> finite g
-                const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & (ic != s);
-                const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
-                const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
-                // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
-                if (lane == 0) hst<kMem>(&g[s], NASTAR_NEG_INF);
-                if (upd) {
-                    hst<kMem>(&g[n], g2);
-                    hst<kMem>(&pdir[n], (uint8_t)(P_PASS | (uint32_t)lane));
-                }
-                // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
-                const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
-                if (lane == 0) cmin[C] = newC;
-                wave_order();
-                if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
-                wave_order();
-                const unsigned long long ev = cmin[S * 64 + lane];
-                const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
-                if (lane == 0) smin[S] = newS;
-                wave_order();
-                if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
-                wave_order();
             }
+            ++iters;
+            if (!kLock && at_goal) {
+                // :219-220,:251 every later step of the reference is a fixed point -- unless the goal's own expansion would open a cell that beats
+                // it (nastar_capi.hip, same test): reported as summary[NASTAR_SUMMARY_COUPLED] and, per map, in marks[]
+                if (a.summary != nullptr || a.marks_out != nullptr) coupled = hybrid_goal_beaten<kFastDiv>(d, g, cost, s, lane, dr, dc, goal_r, goal_c);
+                if (lane == 0) g[s] = NASTAR_NEG_INF;  // :222-223 the goal joins the closed list
+                solved = true;
+                break;
+            }
+            goal_hit |= at_goal;
+            const int C = s >> 6, S = s >> 12;
+            int c;
+            const int r = hybrid_row_nb(s, d, c);
+            const int nr = r + dr, nc = c + dc;
+            const bool inb = (lane < 8) & ((unsigned)nr < (unsigned)d.H) & ((unsigned)nc < (unsigned)d.W);  // conv2d zero padding
+            const int n = inb ? s + dr * d.W + dc : s;
+            const int ic = C * 64 + lane;
+            const bool icv = ic < d.HW;
+            global_step_fence();  // the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+            // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
+            const float gs = g[s];
+            const float gn = g[n];
+            const float gc = g[ic];
+            const float cs = cost[s];
+            const float cn = cost[n];
+            const float cc = icv ? cost[ic] : 0.f;
+            int icc;
+            const int icr = hybrid_row_nb(icv ? ic : 0, d, icc);
+            const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
+            const bool upd = inb & (gn > g2);                                      // :229,:235
+            const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
+            // chunk minimum without s* (lock-step: a selected goal stays on the open list, :224): open <=> finite g
+            const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & ((ic != s) | (kLock && at_goal));
+            const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
+            const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
+            // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
+            if (lane == 0 && !(kLock && at_goal)) g[s] = NASTAR_NEG_INF;
+            if (upd) {
+                g[n] = g2;
+                pdir[n] = (uint8_t)(P_PASS | (uint32_t)lane);
+            }
+            // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
+            const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
+            if (lane == 0) cmin[C] = newC;
+            wave_order();
+            if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
+            wave_order();
+            const unsigned long long ev = cmin[S * 64 + lane];
+            const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
+            if (lane == 0) smin[S] = newS;
+            wave_order();
+            if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
+            wave_order();
         }
     }
     global_step_fence();
+    if constexpr (kLock) {
+        if (probe) {  // the words this map's search did not reach say "no goal selection"
+            if (lane == 0) {
+                if (iters & 31) bm[iters >> 5] = bits;
+                for (int w = (iters + 31) >> 5; w < a.bitmap_words; ++w) bm[w] = 0u;
+            }
+            return;
+        }
+        if (goal_hit && lane == 0) g[gidx] = NASTAR_NEG_INF;  // histories holds the goal (:222-223); nothing reads its g any more
+    }
     if (lane == 0) {
         a.iters[b] = iters;
         a.status[b] = status;
-        if (status != NASTAR_OK && a.summary) a.summary[status] = 1;
+        if (a.marks_out != nullptr) a.marks_out[b] = coupled ? 1 : 0;
+        if (a.summary) {
+            if (status != NASTAR_OK) a.summary[status] = 1;
+            if (coupled) a.summary[NASTAR_SUMMARY_COUPLED] = 1;
+        }
     }
 
     // ---- backtrack (:96-125): walk to the start, cap = this map's own step count in the budget-truncated case ----------
     if (gidx >= 0 && lane == 0) {
         const int cap = solved ? d.HW : iters - 1;
-        uint32_t m = hld<kMem>(&pdir[gidx]);
-        hst<kMem>(&pdir[gidx], (uint8_t)(m | P_PATH));
+        uint32_t m = pdir[gidx];
+        pdir[gidx] = (uint8_t)(m | P_PATH);
         uint32_t code = m & P_DIRMASK;
         if (code != PARENT_UNSET) {
             int pdr, pdc;
             neighbour_delta((int)code, pdr, pdc);
             int loc = gidx - (pdr * d.W + pdc);
             for (int k2 = 0; k2 < cap; ++k2) {
-                const uint32_t ml = hld<kMem>(&pdir[loc]);
-                hst<kMem>(&pdir[loc], (uint8_t)(ml | P_PATH));
+                const uint32_t ml = pdir[loc];
+                pdir[loc] = (uint8_t)(ml | P_PATH);
                 if (loc == sidx) break;
                 const uint32_t cd = ml & P_DIRMASK;
                 if (cd == PARENT_UNSET) break;

@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = (
     "nastar_forward_packed",
     "nastar_forward_ordered",
     "nastar_forward_ex",
+    "nastar_batchloop_workspace_bytes",
+    "nastar_forward_batchloop_finish",
     "nastar_completion_supported",
     "nastar_host_wait_nonzero",
     "nastar_placement_from_levels",
@@ -118,6 +120,40 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+DEV_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libnastar_hip_dev.so")
+_dev_lib: Optional[ctypes.CDLL] = None
+
+
+def _bind_search(lib: ctypes.CDLL) -> None:
+    """argument types of the search entry points (shared by the product library and the development build)"""
+    vp, ci, cd, cz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    lib.nastar_workspace_bytes.restype = cz
+    lib.nastar_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_forward_ex.restype = ci
+    lib.nastar_forward_ex.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, vp, cz, ci, vp, vp, vp, vp, vp]
+    lib.nastar_batchloop_workspace_bytes.restype = cz
+    lib.nastar_batchloop_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_forward_batchloop_finish.restype = ci
+    lib.nastar_forward_batchloop_finish.argtypes = [vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, vp, vp, cz, vp]
+    lib.nastar_backward_workspace_bytes.restype = cz
+    lib.nastar_backward_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.nastar_backward_replay.restype = ci
+    lib.nastar_backward_replay.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, cd, ci, vp, vp, vp, vp, cz, ci, vp]
+
+
+def load_dev() -> ctypes.CDLL:
+    """The DEVELOPMENT build of the search translation unit (``make -C csrc dev``: the A/B switches of csrc/nastar_dev_flags.h -- older
+    instruction streams, the compiled step).  Test / probe infrastructure: nothing in the package calls it; ``ops.search_nograd(lib=...)``
+    runs a search through it."""
+    global _dev_lib
+    if _dev_lib is None:
+        if not os.path.exists(DEV_LIB_PATH):
+            raise NativeLibraryMissing(f"{DEV_LIB_PATH} not found: build it with `make -C {CSRC_DIR} dev`")
+        _dev_lib = ctypes.CDLL(DEV_LIB_PATH)
+        _bind_search(_dev_lib)
+    return _dev_lib
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
@@ -128,6 +164,7 @@ def load() -> ctypes.CDLL:
             f"(no CPU fallback). Build it with `make -C {CSRC_DIR}` or `python __graft_entry__.py build`.")
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cd, cz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+    _bind_search(lib)
     lib.nastar_version.restype = ci
     lib.nastar_version.argtypes = []
     lib.nastar_last_error.restype = ctypes.c_char_p

@@ -36,16 +36,25 @@ def _require_device(*tensors: torch.Tensor) -> None:
 FLAG_UNIT_COST = 64  # include/nastar.h NASTAR_FLAG_UNIT_COST
 FLAG_LOCKSTEP = 1024  # NASTAR_FLAG_LOCKSTEP: the reference's batch loop to the letter (no exit at the goal; exactly max_iters steps)
 FLAG_CHECK_ORDER = 256  # NASTAR_FLAG_CHECK_ORDER: the launch verifies `order` on the device and ignores it when it is not a permutation
+FLAG_MARK_COUPLED = 32768  # NASTAR_FLAG_MARK_COUPLED: the launch marks the maps of the batch-coupled class for nastar_forward_batchloop_finish
 STATUS_UNSOLVABLE = 3  # NASTAR_ERR_UNSOLVABLE (per-map status)
 STATUS_NOT_UNIT_COST = 7  # NASTAR_ERR_NOT_UNIT_COST (per-map status)
 SUMMARY_WORDS = 16  # NASTAR_SUMMARY_WORDS
 SUMMARY_BAD_ORDER = 15  # NASTAR_SUMMARY_BAD_ORDER
 SUMMARY_COUPLED = 14  # NASTAR_SUMMARY_COUPLED: a NOTE (a finished map is not at a fixed point of the reference's batch loop), cells 1..13 are errors
 SUMMARY_ERRORS = slice(1, 14)
-# development knob: NASTAR_FLAG_* of include/nastar.h OR-ed into every forward launch (A/B switches: NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128, HYBRID_SC1 = 2048, HYBRID_NOFENCE = 4096, HYBRID_SCALAR = 8192, HYBRID_BALLOT = 16384)
+# development knob: flag bits OR-ed into every forward launch.  NASTAR_FLAG_UNIT_COST = 64 works with the product library; the A/B switches
+# of csrc/nastar_dev_flags.h (NO_ASM = 8, ASM_V2 = 16, NO_DIVE = 32, ASM_V3 = 128) need the development build: NASTAR_LIB=.../libnastar_hip_dev.so
 FORWARD_FLAGS = int(os.environ.get("NASTAR_FORWARD_FLAGS", "0"))
-if FORWARD_FLAGS & ~(8 | 16 | 32 | 64 | 128 | 2048 | 4096 | 8192 | 16384):
-    raise ValueError(f"NASTAR_FORWARD_FLAGS={FORWARD_FLAGS}: unknown flag bits (include/nastar.h NASTAR_FLAG_*)")
+if FORWARD_FLAGS & ~(8 | 16 | 32 | 64 | 128):
+    raise ValueError(f"NASTAR_FORWARD_FLAGS={FORWARD_FLAGS}: unknown flag bits (include/nastar.h NASTAR_FLAG_*, csrc/nastar_dev_flags.h)")
+
+
+def coupling_possible(g_ratio: float) -> bool:
+    """Can a map that reached its goal fail to be at a fixed point of the reference's batch loop with costs >= 0?
+    f(n) - f(goal) = (2 g_ratio - 1) c_goal + (1 - g_ratio)(h0(n) + c_n) is positive for every g_ratio in [0.5, 1): never there.  (With
+    NEGATIVE costs any g_ratio can: the launch's status summary reports it, NASTAR_SUMMARY_COUPLED.)"""
+    return not (0.5 <= float(g_ratio) < 1.0)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -150,8 +159,11 @@ class StatusBoard:
             stream.synchronize()
         else:
             torch.cuda.synchronize(self.device)
-        if not self.np[row, 0]:
-            self.counters[row] = 0  # no flag although the launch is over: no counter was passed, or an aborted launch left the cell out of phase
+        if spin_us > 0 and not self.np[row, 0]:
+            # the launch was given the row's completion counter (callers spin only then) and is over without having raised the flag: an aborted
+            # launch left the cell out of phase.  (Launches WITHOUT a counter -- custom-op path, maps larger than LDS -- end up here on every
+            # call and must not pay a device write for it: ADVICE r5.)
+            self.counters[row] = 0
 
     def read(self, row: int):
         """the row as a numpy view if any STATUS cell (1..15) is set, else None (the launch that was handed the row must be over: wait())"""
@@ -175,11 +187,15 @@ def in_lds(H: int, W: int) -> bool:
 
 
 def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order, summary_ptr, dev,
-                   one_meta=False, stream_ptr=None, out_4d=False, counter_ptr=0, keep=None):
+                   one_meta=False, stream_ptr=None, out_4d=False, counter_ptr=0, keep=None, exact=False):
     """allocate the five outputs and issue ONE nastar_forward_ex launch on torch's current stream (shared by the custom ops and the
     no-autograd fast path).  cost / start / goal / passable: contiguous fp32 tensors of B*H*W elements (any leading shape).
     ``keep``: a list that receives the launch's temporaries (its workspace) when the launch goes to ANOTHER stream than the one the
-    caching allocator hands the memory out for -- the caller holds them until that stream is done."""
+    caching allocator hands the memory out for -- the caller holds them until that stream is done.
+    ``exact``: the reference's BATCH LOOP to the letter (include/nastar.h: nastar_forward_batchloop_finish) -- the launch marks the maps that
+    are not at a fixed point of that loop when they reach their goal, and three more launches on the same stream re-run exactly those in
+    lock-step mode up to the step at which every map of the batch selects its goal.  No host round trip; nothing happens when no map is
+    marked (always so for g_ratio in [0.5, 1) with costs >= 0)."""
     shape = (B, 1, H, W) if out_4d else (B, H, W)
     hist = torch.empty(shape, dtype=torch.float32, device=dev)
     paths = torch.empty(shape, dtype=torch.int64, device=dev)
@@ -201,8 +217,13 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
         if order_out.dtype != torch.int32 or order_out.numel() != B + 1 or order_out.device != dev or not order_out.is_contiguous():
             raise ValueError(f"order_out must be a contiguous int32 tensor of exactly {B + 1} elements on {dev} (ops.new_placement_buffer)")
         oo = order_out.data_ptr()
-    # workspace: > 0 for maps too large for LDS and for a checked order
-    ws_bytes = (16 if flags & FLAG_CHECK_ORDER else 0) if in_lds(H, W) else int(lib.nastar_workspace_bytes(B, H, W, flags))
+    # workspace: > 0 for maps too large for LDS, for a checked order and for the marks / probe bitmaps of an exact launch
+    if exact and B > 1 and not (flags & FLAG_LOCKSTEP):
+        flags |= FLAG_MARK_COUPLED
+        ws_bytes = int(lib.nastar_batchloop_workspace_bytes(B, H, W, int(max_iters)))
+    else:
+        exact = False  # (a map on its own is its own batch: the loop ends at its goal step)
+        ws_bytes = (16 if flags & FLAG_CHECK_ORDER else 0) if in_lds(H, W) else int(lib.nastar_workspace_bytes(B, H, W, flags))
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     if stream_ptr is not None and workspace is not None:
         if keep is None:
@@ -214,11 +235,19 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
             paths.data_ptr(), sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(), None,
             workspace.data_ptr() if workspace is not None else None, ws_bytes, flags, op or None, oo or None, summary_ptr or None,
             (counter_ptr or None) if summary_ptr else None, sp)
+    fin = None
+    if exact:
+        fin = args[:9] + (hist.data_ptr(), paths.data_ptr(), sel_log.data_ptr() if want_log else None, iters.data_ptr(), status.data_ptr(),
+                          workspace.data_ptr(), ws_bytes, sp)
     if dev.index is None or torch.cuda.current_device() == dev.index:
         rc = lib.nastar_forward_ex(*args)
+        if not rc and fin is not None:
+            rc = lib.nastar_forward_batchloop_finish(*fin)
     else:
         with torch.cuda.device(dev):
             rc = lib.nastar_forward_ex(*args)
+            if not rc and fin is not None:
+                rc = lib.nastar_forward_batchloop_finish(*fin)
     if rc:
         _native.check(rc, "nastar_forward_ex")
     return hist, paths, iters, status, sel_log
@@ -226,19 +255,20 @@ def _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters
 
 @torch.library.custom_op("nastar::astar_forward", mutates_args=())
 def astar_forward(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
-                  g_ratio: float, max_iters: int, want_log: bool, flags: int = 0, summary_ptr: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                  g_ratio: float, max_iters: int, want_log: bool, flags: int = 0, summary_ptr: int = 0, exact: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Returns (histories [B,H,W] f32, paths [B,H,W] i64, iters [B] i32, status [B] i32, sel_log [B,T] i32 or [0]).
     ``flags``: NASTAR_FLAG_* of include/nastar.h (e.g. ``FLAG_UNIT_COST`` when cost and passable are ONE binary tensor);
-    ``summary_ptr``: address of a ``StatusBoard`` row (0 = none) that receives the launch's status summary."""
+    ``summary_ptr``: address of a ``StatusBoard`` row (0 = none) that receives the launch's status summary; ``exact``: see ``_launch_search``."""
     _require_device(cost, start, goal, passable)
     lib = _native.load()
     cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
     B, H, W = cost.shape
-    return _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, None, None, False, summary_ptr, cost.device)
+    return _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, None, None, False, summary_ptr, cost.device,
+                          exact=exact)
 
 
 @astar_forward.register_fake
-def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0, summary_ptr=0):
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0, summary_ptr=0, exact=False):
     B, H, W = cost.shape
     return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
             cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
@@ -248,7 +278,7 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags=0, summar
 @torch.library.custom_op("nastar::astar_forward_ordered", mutates_args=("order_out",))
 def astar_forward_ordered(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor, g_ratio: float,
                           max_iters: int, want_log: bool, flags: int, order: Optional[torch.Tensor],
-                          order_out: Optional[torch.Tensor], check_order: bool = True, summary_ptr: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                          order_out: Optional[torch.Tensor], check_order: bool = True, summary_ptr: int = 0, exact: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """``astar_forward`` with a placement (include/nastar.h: nastar_forward_ex): workgroup i searches map ``order[i]`` (int32 [B], a
     permutation of 0..B-1, or None = identity).  Same five outputs as ``astar_forward``.  ``order_out`` (int32 [B + 1] from
     ``new_placement_buffer``, or None) receives in [:B] the maps in reverse order of search completion in this launch -- the ``order``
@@ -261,11 +291,11 @@ def astar_forward_ordered(cost: torch.Tensor, start: torch.Tensor, goal: torch.T
     cost, start, goal, passable = (x.contiguous() for x in (cost, start, goal, passable))
     B, H, W = cost.shape
     return _launch_search(lib, cost, start, goal, passable, B, H, W, g_ratio, max_iters, want_log, flags, order, order_out, check_order,
-                          summary_ptr, cost.device)
+                          summary_ptr, cost.device, exact=exact)
 
 
 @astar_forward_ordered.register_fake
-def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out, check_order=True, summary_ptr=0):
+def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, order_out, check_order=True, summary_ptr=0, exact=False):
     B, H, W = cost.shape
     return (cost.new_empty((B, H, W)), cost.new_empty((B, H, W), dtype=torch.int64),
             cost.new_empty((B,), dtype=torch.int32), cost.new_empty((B,), dtype=torch.int32),
@@ -275,7 +305,7 @@ def _(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, order, o
 def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, obstacles_maps: torch.Tensor, g_ratio: float,
                   max_iters: int, want_log: bool = False, flags: int = 0, order: Optional[torch.Tensor] = None,
                   order_out: Optional[torch.Tensor] = None, check_order: bool = True, summary_ptr: int = 0, stream_ptr: Optional[int] = None,
-                  out_4d: bool = False, counter_ptr: int = 0, keep: Optional[list] = None):
+                  out_4d: bool = False, counter_ptr: int = 0, keep: Optional[list] = None, exact: bool = False, lib=None):
     """The search launch WITHOUT the torch.library dispatch: what ``DifferentiableAstar.forward`` calls when no gradient can flow
     (``torch.no_grad()`` / inputs that do not require one) and nothing is being traced -- the custom-op machinery costs more host time
     than the launch itself at 4096 maps.  Takes the reference's [B,1,H,W] tensors (or [B,H,W]) as they are; same five outputs
@@ -284,7 +314,8 @@ def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: 
     ``stream_ptr``: a hipStream_t to launch on instead of torch's current stream (``parallel.InFlightPlanner``; the outputs are
     allocated on the CURRENT stream: the caller orders the two streams before anyone reads or frees them, passes contiguous inputs --
     a copy made here would be made on the current stream, after the caller ordered the streams -- and holds ``keep``, the list that
-    receives the launch's workspace, until that stream is done)."""
+    receives the launch's workspace, until that stream is done).  ``exact``: the reference's batch loop to the letter (``_launch_search``).
+    ``lib``: another build of the C ABI (``_native.load_dev()``: stream-equality tests)."""
     if stream_ptr is not None and not (cost_maps.is_contiguous() and start_maps.is_contiguous() and goal_maps.is_contiguous()
                                        and obstacles_maps.is_contiguous()):
         raise ValueError("search_nograd(stream_ptr=...): the maps must be contiguous (make the copies before ordering the streams)")
@@ -309,8 +340,8 @@ def search_nograd(cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: 
         start_maps = start_maps.contiguous()
     if not goal_maps.is_contiguous():
         goal_maps = goal_maps.contiguous()
-    return _launch_search(_native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters, want_log, flags,
-                          order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d, counter_ptr, keep)
+    return _launch_search(lib if lib is not None else _native.load(), cost_maps, start_maps, goal_maps, obstacles_maps, B, H, W, g_ratio, max_iters,
+                          want_log, flags, order, order_out, check_order, summary_ptr, cost_maps.device, True, stream_ptr, out_4d, counter_ptr, keep, exact)
 
 
 def order_from_levels(levels: torch.Tensor) -> torch.Tensor:
@@ -390,10 +421,11 @@ def placement_from_iters(iters: torch.Tensor) -> torch.Tensor:
 @torch.library.custom_op("nastar::astar_backward_replay", mutates_args=())
 def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor,
                           passable: torch.Tensor, sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
-                          t_batch: Optional[torch.Tensor], order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          t_batch: Optional[torch.Tensor], order: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
     """dL/dcost by replaying the forward's selection log (csrc/nastar_backward_replay.hip.h): any map size the forward takes
     up to 65519 cells, O(9) accounting work per step.  ``order`` (int32 permutation of 0..B-1): workgroup i replays map order[i] --
-    the forward's own completion order (``astar_forward_ordered``'s ``order_out``) puts the longest replays first."""
+    the forward's own completion order (``astar_forward_ordered``'s ``order_out``) puts the longest replays first.  ``flags``:
+    ``FLAG_LOCKSTEP`` for the log of an ``exact`` forward (goal selections before the last entry: the general replay loop)."""
     _require_device(grad_hist, cost, start, goal, passable)
     lib = _native.load()
     grad_hist, cost, start, goal, passable, sel_log = (x.contiguous() for x in (grad_hist, cost, start, goal, passable, sel_log))
@@ -409,18 +441,18 @@ def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: to
             rc = lib.nastar_backward_replay(grad_hist.data_ptr(), cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
                                             passable.data_ptr(), sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters),
                                             iters.data_ptr(), t_batch.data_ptr() if t_batch is not None else None,
-                                            grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, 0, _stream_ptr(dev))
+                                            grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, int(flags), _stream_ptr(dev))
         else:
             rc = lib.nastar_backward_replay_ordered(grad_hist.data_ptr(), None, None, None, cost.data_ptr(), start.data_ptr(), goal.data_ptr(),
                                                     passable.data_ptr(), sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters),
                                                     iters.data_ptr(), t_batch.data_ptr() if t_batch is not None else None,
-                                                    grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev, True), _stream_ptr(dev))
+                                                    grad_cost.data_ptr(), ws.data_ptr(), ws_bytes, int(flags), _order_ptr(order, B, dev, True), _stream_ptr(dev))
     _native.check(rc, "nastar_backward_replay")
     return grad_cost
 
 
 @astar_backward_replay.register_fake
-def _(grad_hist, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch, order=None):
+def _(grad_hist, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch, order=None, flags=0):
     return torch.empty_like(cost)
 
 
@@ -430,13 +462,14 @@ def _setup_context(ctx, inputs, output):
     ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
     ctx.g_ratio = g_ratio
     ctx.max_iters = max_iters
+    ctx.lockstep = bool(inputs[9]) if len(inputs) > 9 else False  # `exact`: the log may hold goal selections before its last entry
     ctx.set_materialize_grads(False)  # no zero-filled gradient tensors for paths / iters / status / sel_log (4 fill launches per step)
 
 
 def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
     cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
     if g_hist is None:
-        return (None,) * 9
+        return (None,) * 10
     # t_batch: the reference's batch-wide loop index (differentiable_astar.py:251-255).  BatchCoupling lets the
     # sharded planner substitute the maximum over ALL ranks so gradients match a single-device run.
     t_batch = BatchCoupling.t_batch(iters)
@@ -444,8 +477,8 @@ def _backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
         raise RuntimeError("backward needs the forward's selection log: call astar_forward(..., want_log=True) "
                            "(DifferentiableAstar.forward does whenever cost_maps.requires_grad)")
     grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log,
-                                                       ctx.g_ratio, ctx.max_iters, iters, t_batch)
-    return (grad_cost,) + (None,) * 8
+                                                       ctx.g_ratio, ctx.max_iters, iters, t_batch, None, FLAG_LOCKSTEP if ctx.lockstep else 0)
+    return (grad_cost,) + (None,) * 9
 
 
 astar_forward.register_autograd(_backward, setup_context=_setup_context)
@@ -498,9 +531,9 @@ def _(histories, opt_trajs):
 def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, grad_loss: Optional[torch.Tensor],
                              cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
                              sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
-                             t_batch: Optional[torch.Tensor], order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             t_batch: Optional[torch.Tensor], order: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
     """dL/dcost for L = grad_loss * mean|histories - opt_trajs| by replay of the selection log: the sign gradient is formed while the
-    upstream values are loaded (no gradient tensor is materialised)."""
+    upstream values are loaded (no gradient tensor is materialised).  ``flags``: ``FLAG_LOCKSTEP`` for the log of an ``exact`` forward."""
     _require_device(histories, opt_trajs, cost, start, goal, passable)
     lib = _native.load()
     histories, opt_trajs, cost, start, goal, passable, sel_log = (
@@ -512,7 +545,7 @@ def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, g
     ws_bytes = int(lib.nastar_backward_workspace_bytes(B, H, W, int(max_iters)))
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        if order is None:
+        if order is None and not flags:
             rc = lib.nastar_backward_l1_replay(histories.data_ptr(), opt_trajs.data_ptr(), gl.data_ptr() if gl is not None else None,
                                                cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(),
                                                sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
@@ -523,13 +556,14 @@ def astar_backward_l1_replay(histories: torch.Tensor, opt_trajs: torch.Tensor, g
                                                     cost.data_ptr(), start.data_ptr(), goal.data_ptr(), passable.data_ptr(),
                                                     sel_log.data_ptr(), B, H, W, float(g_ratio), int(max_iters), iters.data_ptr(),
                                                     t_batch.data_ptr() if t_batch is not None else None, grad_cost.data_ptr(),
-                                                    ws.data_ptr(), ws_bytes, 0, _order_ptr(order, B, dev, True), _stream_ptr(dev))
+                                                    ws.data_ptr(), ws_bytes, int(flags), _order_ptr(order, B, dev, True) if order is not None else None,
+                                                    _stream_ptr(dev))
     _native.check(rc, "nastar_backward_l1_replay")
     return grad_cost
 
 
 @astar_backward_l1_replay.register_fake
-def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch, order=None):
+def _(histories, opt_trajs, grad_loss, cost, start, goal, passable, sel_log, g_ratio, max_iters, iters, t_batch, order=None, flags=0):
     return torch.empty_like(cost)
 
 
@@ -537,18 +571,21 @@ class _AstarL1Loss(torch.autograd.Function):
     """search + L1 loss as ONE autograd node: forward = nastar_forward_ex + nastar_l1_loss, backward = nastar_backward_l1_replay."""
 
     @staticmethod
-    def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters, order_in, check_order, summary_ptr):
+    def forward(ctx, cost, start, goal, passable, opt_trajs, g_ratio, max_iters, order_in, check_order, summary_ptr, exact):
         B = cost.shape[0]
         with torch.no_grad():
             order = None
             if (order_in is not None or B >= PLACEMENT_MIN_BATCH) and workspace_bytes(cost.shape) == 0:
                 order = new_placement_buffer(B, cost.device)  # the forward writes the order its searches finish in
                 hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters,
-                                                                                             True, 0, order_in, order, check_order, summary_ptr)
+                                                                                             True, 0, order_in, order, check_order, summary_ptr, exact)
             else:
-                hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, True, 0, summary_ptr)
+                hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, g_ratio, max_iters, True, 0, summary_ptr,
+                                                                                     exact)
             loss = torch.ops.nastar.l1_loss(hist, opt_trajs)
-        ctx.order = order[:B] if order is not None else None
+        # (an exact forward may have re-run maps after the launch ranked their completion: the replay then takes the natural order)
+        ctx.order = order[:B] if (order is not None and not exact) else None
+        ctx.lockstep = bool(exact)
         ctx.save_for_backward(cost, start, goal, passable, opt_trajs, hist, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(hist, paths, iters, status)
@@ -559,10 +596,11 @@ class _AstarL1Loss(torch.autograd.Function):
     def backward(ctx, g_loss, g_hist, g_paths, g_iters, g_status):
         cost, start, goal, passable, opt_trajs, hist, iters, sel_log = ctx.saved_tensors
         if g_loss is None:
-            return (None,) * 10
+            return (None,) * 11
         grad_cost = torch.ops.nastar.astar_backward_l1_replay(hist, opt_trajs, g_loss, cost, start, goal, passable, sel_log,
-                                                              ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters), ctx.order)
-        return (grad_cost,) + (None,) * 9
+                                                              ctx.g_ratio, ctx.max_iters, iters, BatchCoupling.t_batch(iters), ctx.order,
+                                                              FLAG_LOCKSTEP if ctx.lockstep else 0)
+        return (grad_cost,) + (None,) * 10
 
 
 class _AstarForwardPlaced(torch.autograd.Function):
@@ -571,14 +609,15 @@ class _AstarForwardPlaced(torch.autograd.Function):
     ``histories`` carry no gradient).  ``order_in`` / ``order_out``: the forward's own placement (planner.Placement / OrderHint) or None."""
 
     @staticmethod
-    def forward(ctx, cost, start, goal, passable, g_ratio, max_iters, flags, order_in, order_out, check_order, summary_ptr):
+    def forward(ctx, cost, start, goal, passable, g_ratio, max_iters, flags, order_in, order_out, check_order, summary_ptr, exact):
         B = cost.shape[0]
         with torch.no_grad():
             if order_out is None:
                 order_out = new_placement_buffer(B, cost.device)
             hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, g_ratio, max_iters, True,
-                                                                                         flags, order_in, order_out, check_order, summary_ptr)
-        ctx.order = order_out[:B]
+                                                                                         flags, order_in, order_out, check_order, summary_ptr, exact)
+        ctx.order = order_out[:B] if not exact else None
+        ctx.lockstep = bool(exact)
         ctx.save_for_backward(cost, start, goal, passable, iters, sel_log)
         ctx.g_ratio, ctx.max_iters = g_ratio, max_iters
         ctx.mark_non_differentiable(paths, iters, status, sel_log)
@@ -588,26 +627,28 @@ class _AstarForwardPlaced(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_hist, g_paths, g_iters, g_status, g_log):
         if g_hist is None:
-            return (None,) * 11
+            return (None,) * 12
         cost, start, goal, passable, iters, sel_log = ctx.saved_tensors
         grad_cost = torch.ops.nastar.astar_backward_replay(g_hist.contiguous(), cost, start, goal, passable, sel_log, ctx.g_ratio, ctx.max_iters,
-                                                           iters, BatchCoupling.t_batch(iters), ctx.order)
-        return (grad_cost,) + (None,) * 10
+                                                           iters, BatchCoupling.t_batch(iters), ctx.order, FLAG_LOCKSTEP if ctx.lockstep else 0)
+        return (grad_cost,) + (None,) * 11
 
 
 def astar_forward_placed(cost, start, goal, passable, g_ratio: float, max_iters: int, flags: int = 0, order_in=None, order_out=None,
-                         check_order: bool = True, summary_ptr: int = 0):
+                         check_order: bool = True, summary_ptr: int = 0, exact: bool = False):
     """differentiable ``astar_forward`` (selection log kept) whose backward replays longest-first; see ``_AstarForwardPlaced``"""
     return _AstarForwardPlaced.apply(cost, start, goal, passable, float(g_ratio), int(max_iters), int(flags), order_in, order_out,
-                                     bool(check_order), int(summary_ptr))
+                                     bool(check_order), int(summary_ptr), bool(exact))
 
 
 def astar_l1_loss(cost: torch.Tensor, start: torch.Tensor, goal: torch.Tensor, passable: torch.Tensor,
                   opt_trajs: torch.Tensor, g_ratio: float, max_iters: int, order_in: Optional[torch.Tensor] = None,
-                  check_order: bool = True, summary_ptr: int = 0):
+                  check_order: bool = True, summary_ptr: int = 0, exact: bool = False):
     """[B,H,W] maps -> (loss scalar, histories, paths, iters, status); only ``loss`` carries gradient (to ``cost``).
-    ``order_in``: a placement for the forward launch (``OrderHint.order``); the backward replays by the forward's completion order."""
-    return _AstarL1Loss.apply(cost, start, goal, passable, opt_trajs, float(g_ratio), int(max_iters), order_in, bool(check_order), int(summary_ptr))
+    ``order_in``: a placement for the forward launch (``OrderHint.order``); the backward replays by the forward's completion order.
+    ``exact``: the reference's batch loop to the letter (``_launch_search``)."""
+    return _AstarL1Loss.apply(cost, start, goal, passable, opt_trajs, float(g_ratio), int(max_iters), order_in, bool(check_order), int(summary_ptr),
+                              bool(exact))
 
 
 def heuristic(goal_maps: torch.Tensor) -> torch.Tensor:

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .planner.differentiable_astar import AstarOutput, UnsolvableMapError, _raise_unsolvable, _warn_coupled
+from .planner.differentiable_astar import AstarOutput, UnsolvableMapError, _raise_unsolvable
 
 _BIT_WEIGHTS = None
 _SEARCH_STREAMS: dict = {}
@@ -240,11 +240,15 @@ class InFlightPlanner:
         self._device = None
         self._inflight: List[tuple] = []  # (ticket, stream index, row, inputs, outputs, flags, order, check, workspace)
         self._k = 0
-        self.reruns = 0  # batches that were re-run on the general kernel (a non-binary map under unit_cost="auto")
+        self.reruns = 0  # batches that were re-run at collection (a non-binary map under unit_cost="auto"; the batch-coupled note with g_ratio in [0.5, 1))
 
     def __del__(self):  # dropped with batches in flight: their status rows go back once the device has caught up (StatusBoard.retire)
         try:
             if self._inflight and self._device is not None:
+                # the outputs of those batches were allocated for the current stream and are being written on the side streams: nothing may
+                # hand their memory out again before those launches are over
+                for st in self._streams:
+                    st.synchronize()
                 board = ops.StatusBoard.of(self._device)
                 for item in self._inflight:
                     if item[2] >= 0:
@@ -298,19 +302,22 @@ class InFlightPlanner:
             if start_maps_c is not start_maps and hasattr(start_maps, "placement_order"):
                 start_maps_c.placement_order = start_maps.placement_order
             start_maps = start_maps_c
-            if not inputs_ready:
-                cur = torch.cuda.current_stream(dev)
-                # the batch's inputs (and the memory the allocator hands out for its outputs) belong to the CURRENT stream: the launch stream
-                # must come after whatever is still pending there.  An idle current stream -- resident inputs, the usual case of an
-                # evaluation sweep -- needs no dependency, and it matters: a cross-stream event costs ~20 us of GPU time per batch
-                # (probe_boundary: 45 M instead of 66 M maps/s on 4096-map maze batches)
-                if not cur.query():
-                    ev = self._events[k]
-                    ev.record(cur)
-                    st.wait_event(ev)
+            cur = torch.cuda.current_stream(dev)
+            # the batch's inputs AND the memory the allocator hands out for its outputs belong to the CURRENT stream (a recycled block may
+            # still be read by kernels pending there): the launch stream must come after whatever is still pending -- `inputs_ready` only
+            # says the inputs are complete, the outputs' blocks are not the caller's to vouch for.  An idle current stream --
+            # resident inputs, the usual case of an evaluation sweep -- needs no dependency, and it matters: a cross-stream event costs
+            # ~20 us of GPU time per batch (probe_boundary: 45 M instead of 66 M maps/s on 4096-map maze batches)
+            if not cur.query():
+                ev = self._events[k]
+                ev.record(cur)
+                st.wait_event(ev)
             max_iters = ops.max_iters_for(start_maps.shape[-1], 1.0, False)
             unit = same and self.unit_cost in (True, "auto")
             flags = ops.FLAG_UNIT_COST if unit else 0
+            # batch semantics: outside g_ratio in [0.5, 1) a finished map may not be at a fixed point of the reference's
+            # batch loop -- the exact pipeline (marks + lock-step re-run of the marked maps) goes to the stream with the search; unit costs never are
+            exact = (not unit) and start_maps.shape[0] > 1 and ops.coupling_possible(astar.g_ratio)
             order = check = None
             hint = getattr(start_maps, "placement_order", None) if self.use_placement else None
             if hint is not None and ops.in_lds(start_maps.shape[-2], start_maps.shape[-1]):
@@ -322,13 +329,13 @@ class InFlightPlanner:
             keep: list = []  # the launch's workspace (maps larger than LDS, a checked order): allocated for the current stream, used on stream k
             try:
                 out = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio, max_iters, False, flags, order, None, bool(check),
-                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k], True, 0, keep)
+                                        board.ptr(row) if row >= 0 else 0, self._ptrs[k], True, 0, keep, exact)
             except BaseException:
                 if row >= 0:
                     board.release(row)
                 raise
         ticket = len(self._inflight)
-        self._inflight.append((ticket, k, row, (cost, start_maps, goal_maps, passable), out, flags, order, check, keep))
+        self._inflight.append((ticket, k, row, (cost, start_maps, goal_maps, passable), out, flags, order, check, keep, exact))
         self._k += 1
         return ticket
 
@@ -353,7 +360,7 @@ class InFlightPlanner:
             summaries.append(None if r is None else r.copy())
             if row >= 0:
                 board.release(row)
-        for (ticket, k, row, ins, out, flags, order, check, _keep), summ in zip(inflight, summaries):
+        for (ticket, k, row, ins, out, flags, order, check, _keep, exact), summ in zip(inflight, summaries):
             hist, paths, iters, status, _ = out
             if summ is not None and summ[ops.STATUS_NOT_UNIT_COST] and self.unit_cost == "auto":
                 # a non-binary map in a batch that went to the unit-cost kernel optimistically: the batch again on the general kernel
@@ -361,23 +368,22 @@ class InFlightPlanner:
                 cost, start_maps, goal_maps, passable = ins
                 r2 = board.acquire()
                 try:
+                    exact = start_maps.shape[0] > 1 and ops.coupling_possible(astar.g_ratio)
                     hist, paths, iters, status, _ = ops.search_nograd(cost, start_maps, goal_maps, passable, astar.g_ratio,
                                                                       ops.max_iters_for(start_maps.shape[-1], 1.0, False), False, 0, order, None,
-                                                                      bool(check), board.ptr(r2), None, True)
+                                                                      bool(check), board.ptr(r2), None, True, 0, None, exact)
                     torch.cuda.current_stream(dev).synchronize()
                     r = board.read(r2)
                     summ = None if r is None else r.copy()
                 finally:
                     board.release(r2)
             coupled = summ is not None and summ[ops.SUMMARY_COUPLED] and not summ[ops.SUMMARY_ERRORS].any() and status.numel() > 1
-            if coupled and not ops.in_lds(ins[1].shape[-2], ins[1].shape[-1]):
-                _warn_coupled(astar.g_ratio)  # (no lock-step mode for maps whose state lives in HBM: each map as if searched alone)
-            elif coupled:
-                # a finished map of this batch is not at a fixed point of the reference's batch loop (g_ratio < 0.5 with an expensive goal cell;
-                # DESIGN.md section 2.3): the batch again in lock-step mode, exactly as planner.forward() does
+            if coupled and not exact:
+                # a finished map of this batch is not at a fixed point of the reference's batch loop although g_ratio is in [0.5, 1) (negative
+                # costs): the batch again through the exact pipeline, exactly as planner.forward() does
                 self.reruns += 1
                 cost, start_maps, goal_maps, passable = ins
-                hist, paths, iters, status, _ = astar._lockstep(cost, start_maps, goal_maps, passable, ops.max_iters_for(start_maps.shape[-1], 1.0, False))
+                hist, paths, iters, status, _ = astar.exact_search(cost, start_maps, goal_maps, passable, ops.max_iters_for(start_maps.shape[-1], 1.0, False))
             if summ is not None and summ[ops.SUMMARY_ERRORS].any() and self.check_solvable and failed is None:
                 failed = (ticket, status)
             outs.append(AstarOutput(hist, paths, []))
@@ -391,9 +397,24 @@ class InFlightPlanner:
 
     def plan_many(self, batches: Iterable) -> List[AstarOutput]:
         """``[planner(*b[:3]) for b in batches]`` with the batches in flight; each item is ``(map_designs, start_maps, goal_maps, ...)``."""
-        for b in batches:
-            self.submit(b[0], b[1], b[2])
+        try:
+            for b in batches:
+                self.submit(b[0], b[1], b[2])
+        except BaseException:
+            self.collect_quietly()  # (launches already issued keep writing their outputs: wait for them before the tensors can go away)
+            raise
         return self.collect()
+
+    def collect_quietly(self) -> None:
+        """wait for every launch in flight and hand the status rows back, reporting nothing (the clean-up of an exception path)"""
+        if self._inflight and self._device is not None:
+            for st in self._streams:
+                st.synchronize()
+            board = ops.StatusBoard.of(self._device)
+            for item in self._inflight:
+                if item[2] >= 0:
+                    board.release(item[2])
+            self._inflight, self._k = [], 0
 
     def plan_iter(self, batches: Iterable, window: Optional[int] = None) -> Iterator[AstarOutput]:
         """Lazy form: yields the outputs in order while keeping at most ``window`` (default 2 x streams) batches in flight; a window is

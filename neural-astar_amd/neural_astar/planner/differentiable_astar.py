@@ -36,10 +36,11 @@ class _PendingStatus:
     completion flag -- into a pinned ``ops.StatusBoard`` row.  Nothing is recorded, copied or launched for it: ``done()`` is one host
     read; ``stream`` is only the fall-back for launches that carry no completion counter (maps larger than LDS)."""
 
-    def __init__(self, status: torch.Tensor, row: int, seq: int = 0, flagged: bool = True):
+    def __init__(self, status: torch.Tensor, row: int, seq: int = 0, flagged: bool = True, repair=None):
         self.status = status
         self.seq = seq
         self.row = row
+        self.repair = repair  # callable or None: completes a launch that reported NASTAR_SUMMARY_COUPLED to the reference's batch loop, in place
         self.board = ops.StatusBoard.of(status.device)
         self.stream = torch.cuda.current_stream(status.device)
         self.event = None
@@ -53,19 +54,21 @@ class _PendingStatus:
 
     def raise_if_unsolvable(self) -> None:
         if self.event is None:
-            self.board.wait(self.row, self.stream)
+            self.board.wait(self.row, self.stream)  # (flagged launch: spins on the completion flag first)
         else:
             self.event.synchronize()
         r = self.board.read(self.row)
         bad = r is not None and bool(r[ops.SUMMARY_ERRORS].any())
-        if r is not None and r[ops.SUMMARY_COUPLED] and self.status.numel() > 1:
-            _warn_coupled(None)
+        coupled = r is not None and bool(r[ops.SUMMARY_COUPLED]) and self.status.numel() > 1
         if r is not None and r[ops.SUMMARY_BAD_ORDER]:
             _warn_bad_order()
         self.board.release(self.row)
         self.released = True
+        repair, self.repair = self.repair, None
         if bad:
             _raise_unsolvable(self.status, self.seq, deferred=True)
+        if coupled and repair is not None:
+            repair()
 
     def __del__(self):  # a planner dropped with verdicts pending: the row goes back once its launch is over (never while it may still be written)
         try:
@@ -142,6 +145,11 @@ class DifferentiableAstar(nn.Module):
                 names the call it belongs to;
                 ``False`` -- never raise.  Inside a hipGraph capture nothing is checked (nothing may synchronise there).
                 The per-map status of the latest call is always available as ``self.last_status``.
+                BATCH SEMANTICS are exact in every mode for costs >= 0: a ``g_ratio`` outside [0.5, 1) -- where a map that reached its goal
+                may not be at a fixed point of the reference's batch loop -- runs the exact pipeline (``ops._launch_search``: marks + lock-step
+                re-run of the marked maps, no host round trip); inside [0.5, 1) only NEGATIVE costs can do that: the same-call verdict
+                re-runs such a batch, a deferred verdict completes the outputs in place when it is delivered (or raises, under autograd), and
+                ``False`` -- which reads nothing back -- is then each map as if searched alone (the one documented gap).
             unit_cost: the UNIT-COST search kernel (``NASTAR_FLAG_UNIT_COST``, csrc/nastar_search_unit.hip.h) for calls in which
                 the cost map and the obstacle map are ONE tensor -- ``VanillaAstar.forward`` (reference astar.py:93-94) -- and no
                 gradient or selection log is wanted.  On binary maps every cell the search can touch then costs 1.0, the LDS state
@@ -222,15 +230,16 @@ class DifferentiableAstar(nn.Module):
         return r
 
     def note_status(self, status: torch.Tensor, iters: torch.Tensor, clean: Optional[bool] = None, row: int = -1, flagged: bool = False,
-                    warn_coupled: bool = True) -> bool:
+                    repair=None) -> bool:
         """record a launch's per-map status / step counts and apply the ``check_solvable`` policy (also used by the fused training
         step and the validation pair, which launch the search themselves).  ``row``: the ``begin_launch()`` row whose address the
         launch was given as ``summary_ptr`` (``flagged``: and its ``counter_ptr``) -- the verdict is then a poll of the row's completion flag
         (unflagged: a stream wait / an event) and one 64-byte host read; without a row the status tensor is reduced on the device (one
         more launch + a blocking copy).  ``clean``: the
         caller has already read the verdict on the host (True = all zero) -- the "sync" policy then does not wait a second time.
-        Returns True when the launch reported NASTAR_SUMMARY_COUPLED and the verdict was read in this call (``warn_coupled`` False: the
-        caller deals with it -- ``forward`` re-runs the batch in lock-step mode -- instead of the warning)."""
+        Returns True when the launch reported NASTAR_SUMMARY_COUPLED and the verdict was read in THIS call: the caller then runs the batch
+        again with ``exact=True`` (the reference's batch loop to the letter, ``ops._launch_search``).  ``repair``: what a DEFERRED verdict
+        that reports the note calls to do the same in place (``_repair_in_place``)."""
         self.last_status, self.last_iters = status, iters
         self._calls += 1
         mode = self.check_solvable
@@ -248,8 +257,6 @@ class DifferentiableAstar(nn.Module):
                 if summ is not None and summ[ops.SUMMARY_BAD_ORDER]:
                     _warn_bad_order()
                 coupled = summ is not None and bool(summ[ops.SUMMARY_COUPLED]) and status.numel() > 1
-                if coupled and warn_coupled:
-                    _warn_coupled(self.g_ratio)
             else:
                 coupled = False
             if row >= 0:
@@ -261,24 +268,28 @@ class DifferentiableAstar(nn.Module):
             row = ops.StatusBoard.of(status.device).acquire()
             ops.StatusBoard.of(status.device).t[row, ops.STATUS_UNSOLVABLE:ops.STATUS_UNSOLVABLE + 1].copy_((status != 0).any().reshape(1), non_blocking=True)
             flagged = False
-        self._pending.append(_PendingStatus(status, row, self._calls, flagged))
+        self._pending.append(_PendingStatus(status, row, self._calls, flagged, repair))
         if len(self._pending) > 64:  # a caller that never lets the device catch up: bound the queue (one wait)
             self._pending.pop(0).raise_if_unsolvable()
         return False
 
-    def _lockstep(self, cost_maps, start_maps, goal_maps, passable, max_iters):
+    def exact_search(self, cost_maps, start_maps, goal_maps, passable, max_iters, want_log=False, out_4d=True):
         """The reference's batch loop to the letter for a batch in which a finished map is NOT at a fixed point (NASTAR_SUMMARY_COUPLED;
-        DESIGN.md section 2.3): every map is stepped, goal selections included, until the first step at which ALL maps select their goal
-        (reference :219-225, :251) or the budget ends.  Two launches of the lock-step mode (NASTAR_FLAG_LOCKSTEP, compiled step loops):
-        one with the selection log over the whole budget to find that step, one that stops exactly there."""
-        B = cost_maps.shape[0]
-        log = ops.search_nograd(cost_maps, start_maps, goal_maps, passable, self.g_ratio, max_iters, True, ops.FLAG_LOCKSTEP)[4]
-        goal_idx = goal_maps.reshape(B, -1).argmax(1).to(torch.int32)
-        hit = (log == goal_idx[:, None]).all(0)  # [max_iters]: every map selects its goal at step t
-        first = torch.nonzero(hit)
-        t_end = int(first[0]) if first.numel() else max_iters - 1  # (one host read; the budget ends the loop otherwise, :203)
-        return ops.search_nograd(cost_maps, start_maps, goal_maps, passable, self.g_ratio, t_end + 1, False, ops.FLAG_LOCKSTEP, None, None, False, 0,
-                                 None, True)
+        DESIGN.md section 2.3): every map of the class is stepped, goal selections included, until the first step at which ALL maps of the
+        batch select their goal (reference :219-225, :251) or the budget ends -- the search launch with marks + nastar_forward_batchloop_finish
+        (include/nastar.h), any map size, no host round trip.  -> (histories, paths, iters, status, sel_log)"""
+        return ops.search_nograd(cost_maps, start_maps, goal_maps, passable, self.g_ratio, max_iters, want_log, 0, None, None, False, 0, None, out_4d,
+                                 0, None, True)
+
+    def _repair_in_place(self, inputs, outputs, max_iters, want_log):
+        """for a DEFERRED verdict: the launch it belongs to reported the note after its outputs had been handed out -- run the exact search now
+        and overwrite those tensors (histories, paths, iters, status, sel_log) before the caller, who asked for the verdict first, reads them"""
+        def repair():
+            new = self.exact_search(*inputs, max_iters, want_log, out_4d=False)
+            for old, fresh in zip(outputs, new):
+                if old is not None and fresh is not None and old.numel() == fresh.numel():
+                    old.data.copy_(fresh.reshape(old.shape))
+        return repair
 
     def resolve_placement(self, B: int, start_maps: torch.Tensor, in_lds: bool):
         """(order, order_out, check_order, placement) for the next launch.  The ``OrderHint`` the batch's loader attached to ``start_maps``
@@ -343,36 +354,48 @@ class DifferentiableAstar(nn.Module):
         cptr = board.counter_ptr(row) if (board is not None and in_lds) else 0
         flags = ops.FLAG_UNIT_COST if unit else 0
         traced = needs_grad or type(cost_maps) is not torch.Tensor or compiling
-        try:
+        passable_maps = cost_maps if same else obstacles_maps
+        # Batch semantics.  For g_ratio in [0.5, 1) with costs >= 0 a finished map is at a fixed point of the reference's
+        # batch loop and ONE launch is the whole story; the launch reports the rare exception (negative costs) in its status summary.  Outside
+        # that range the class is reachable with ordinary costs: the exact pipeline runs straight away (marks + three launches that do nothing
+        # when no map is marked) -- under autograd, with deferred or no checking, inside a hipGraph capture or a trace alike.
+        exact = B > 1 and ops.coupling_possible(self.g_ratio) and not unit
+
+        def launch(exact_now: bool, sptr_now: int, cptr_now: int):
             if not traced:
                 # no gradient can flow and nothing is tracing: straight to the C ABI (no torch.library dispatch)
-                hist, paths, iters, status, sel_log = ops.search_nograd(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
-                                                                        self.g_ratio, max_iters, want_log, flags, order, order_out, check_order, sptr,
-                                                                        None, True, cptr)
+                return ops.search_nograd(cost_maps, start_maps, goal_maps, passable_maps, self.g_ratio, max_iters, want_log, flags, order, order_out,
+                                         check_order, sptr_now, None, True, cptr_now, None, exact_now)
+            cost, start, goal, passable = cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles_maps[:, 0]
+            if needs_grad and in_lds and (order is not None or order_out is not None or B >= ops.PLACEMENT_MIN_BATCH):
+                # large batches under autograd: the replay backward starts longest-first, by the order THIS forward's searches finish in
+                o = ops.astar_forward_placed(cost, start, goal, passable, self.g_ratio, max_iters, 0, order, order_out, check_order, sptr_now, exact_now)
+            elif order is None and order_out is None:
+                o = torch.ops.nastar.astar_forward(cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, flags, sptr_now, exact_now)
             else:
-                cost, start, goal, passable = cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles_maps[:, 0]
-                if needs_grad and in_lds and (order is not None or order_out is not None or B >= ops.PLACEMENT_MIN_BATCH):
-                    # large batches under autograd: the replay backward starts longest-first, by the order THIS forward's searches finish in
-                    hist, paths, iters, status, sel_log = ops.astar_forward_placed(cost, start, goal, passable, self.g_ratio, max_iters, 0, order, order_out,
-                                                                                   check_order, sptr)
-                elif order is None and order_out is None:
-                    hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward(cost, start, goal, passable, float(self.g_ratio), max_iters,
-                                                                                         want_log, flags, sptr)
-                else:
-                    hist, paths, iters, status, sel_log = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, float(self.g_ratio), max_iters,
-                                                                                                 want_log, flags, order, order_out, check_order, sptr)
-                hist, paths = hist.unsqueeze(1), paths.unsqueeze(1)
+                o = torch.ops.nastar.astar_forward_ordered(cost, start, goal, passable, float(self.g_ratio), max_iters, want_log, flags, order, order_out,
+                                                           check_order, sptr_now, exact_now)
+            return o[0].unsqueeze(1), o[1].unsqueeze(1), o[2], o[3], o[4]
+
+        try:
+            hist, paths, iters, status, sel_log = launch(exact, sptr, cptr)
         except BaseException:
             if row >= 0:
                 board.release(row)
             raise
-        clean = None
         if pl is not None and order_out is not None:
             pl.commit()
-        exact = (not traced) and in_lds and not want_log  # (this call can re-run the batch in lock-step mode when a finished map is not at a fixed point)
-        coupled = self.note_status(status, iters, clean, row, flagged=bool(cptr) and not traced, warn_coupled=not exact)
-        if coupled and exact:
-            hist, paths, iters, status, sel_log = self._lockstep(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps, max_iters)
+        repair = None
+        if mode == "deferred" and not exact and B > 1 and row >= 0:
+            if needs_grad:
+                repair = _refuse_late_repair
+            else:  # (no graph holds these tensors: a late verdict that reports the note completes them in place)
+                repair = self._repair_in_place((cost_maps, start_maps, goal_maps, passable_maps), (hist, paths, iters, status, sel_log), max_iters, want_log)
+        coupled = self.note_status(status, iters, None, row, flagged=bool(cptr) and not traced, repair=repair)
+        if coupled and not exact:
+            # the same-call verdict says a finished map of this batch is not at a fixed point (negative costs): the batch again, exactly
+            order = order_out = None
+            hist, paths, iters, status, sel_log = launch(True, 0, 0)
             self.last_status, self.last_iters = status, iters
 
         intermediate_results: List[dict] = []
@@ -382,21 +405,15 @@ class DifferentiableAstar(nn.Module):
 
 
 _BAD_ORDER_WARNED = False
-_COUPLED_WARNED = False
 
 
-def _warn_coupled(g_ratio) -> None:
-    """summary[NASTAR_SUMMARY_COUPLED]: see include/nastar.h"""
-    global _COUPLED_WARNED
-    if not _COUPLED_WARNED:
-        _COUPLED_WARNED = True
-        import warnings
-        warnings.warn("a map of this batch reached its goal but is not at a fixed point of the reference's batch loop (possible only for g_ratio < 0.5 "
-                      "with an expensive goal cell, g_ratio = 1 with a zero-cost one, or negative costs"
-                      + (f"; g_ratio = {g_ratio}" if g_ratio is not None else "") + "): the reference would keep expanding cells of that map until "
-                      "every map of the batch selects its goal in the same step, so its histories there depend on the rest of the batch; this "
-                      "implementation returns what the reference returns for each map searched alone (DESIGN.md section 2.3)", RuntimeWarning, stacklevel=3)
-
+def _refuse_late_repair() -> None:
+    """``check_solvable="deferred"`` under autograd, and the late verdict reports NASTAR_SUMMARY_COUPLED (possible only with NEGATIVE costs when
+    g_ratio is in [0.5, 1); every other g_ratio runs the exact pipeline up front): the graph of that call already holds the early-exit
+    launch's selection log.  Loud, not silent."""
+    raise RuntimeError("a batch searched with check_solvable='deferred' under autograd holds a map that is not at a fixed point of the reference's "
+                       "batch loop (negative costs with g_ratio in [0.5, 1)): its histories and gradients depend on the rest of the batch and the call "
+                       "that could have completed them has returned.  Use check_solvable=True (the default) for such inputs (DESIGN.md section 2.3)")
 
 
 def _warn_bad_order() -> None:

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..planner.astar import VanillaAstar
-from ..planner.differentiable_astar import AstarOutput, Placement
+from ..planner.differentiable_astar import AstarOutput, Placement, _refuse_late_repair
 from .metrics import plan_with_vanilla, validation_metrics
 
 try:  # the reference's trainer; optional here (not in the MI355X image)
@@ -116,10 +116,12 @@ class PlannerModule(_ModuleBase):
         return loss
 
 
-def validate_in_flight(module: "PlannerModule", loader, streams: int = 4) -> dict:
-    """One validation pass over ``loader`` with the searches IN FLIGHT (``parallel.InFlightPlanner``): the mean, over the batches, of what
+def validate_in_flight(module: "PlannerModule", loader, streams: int = 4, window: int = 32) -> dict:
+    """One validation pass over ``loader`` with the searches IN FLIGHT (``parallel.InFlightPlanner``): the mean of what
     ``PlannerModule.validation_step`` logs per batch (``metrics/val_loss`` and, for shortest-path problems, ``p_opt`` / ``p_exp`` /
-    ``h_mean``; reference utils/training.py:63-87 -- Lightning averages the per-batch values the same way).  Per batch the planner's
+    ``h_mean``; reference utils/training.py:63-87), each batch weighted by its SIZE -- Lightning's epoch-end reduction of ``self.log`` in a
+    validation step weights by batch size, which matters when the last batch is smaller.  Batches are collected in windows of ``window``
+    (inputs, outputs and status rows of at most that many launches are alive at a time).  Per batch the planner's
     and the VanillaAstar search are ONE launch, as in ``validation_step``; the launches of consecutive batches overlap (a 4096-map
     launch is as long as its longest search: 3-4 in flight sustain 2-3x the maps/s), the encoder runs batch after batch on the current
     stream, the metrics are reduced on the device when everything has been collected.  Falls back to ``validation_step`` per batch for
@@ -133,12 +135,28 @@ def validate_in_flight(module: "PlannerModule", loader, streams: int = 4) -> dic
         for i, batch in enumerate(loader):
             module.logged = {}
             module.validation_step(batch, i)
+            w = batch[0].shape[0]
             for k, v in module.logged.items():
-                sums[k] = sums.get(k, 0.0) + v.detach().double()
-            n += 1
+                sums[k] = sums.get(k, 0.0) + v.detach().double() * w
+            n += w
         return {k: v / max(n, 1) for k, v in sums.items()}
     fly = InFlightPlanner(planner, streams=streams, unit_cost=False)
     kept = []
+
+    def drain():
+        nonlocal n
+        outs = fly.collect()
+        for out, (opt_trajs, shortest, B) in zip(outs, kept):
+            o = AstarOutput(out.histories[:B], out.paths[:B], [])
+            vals = {"metrics/val_loss": nn.L1Loss()(o.histories, opt_trajs)}
+            if shortest:
+                m = validation_metrics(o, AstarOutput(out.histories[B:], out.paths[B:], []))
+                vals.update({"metrics/p_opt": m.p_opt, "metrics/p_exp": m.p_exp, "metrics/h_mean": m.h_mean})
+            for k, v in vals.items():
+                sums[k] = sums.get(k, 0.0) + v.double() * B
+            n += B
+        kept.clear()
+
     with torch.no_grad():
         for map_designs, start_maps, goal_maps, opt_trajs in loader:
             shortest = map_designs.shape[1] == 1
@@ -150,16 +168,9 @@ def validate_in_flight(module: "PlannerModule", loader, streams: int = 4) -> dic
             else:
                 fly.submit_search(cost, start_maps, goal_maps, passable)
             kept.append((opt_trajs, shortest, map_designs.shape[0]))
-        outs = fly.collect()
-        for out, (opt_trajs, shortest, B) in zip(outs, kept):
-            o = AstarOutput(out.histories[:B], out.paths[:B], [])
-            vals = {"metrics/val_loss": nn.L1Loss()(o.histories, opt_trajs)}
-            if shortest:
-                m = validation_metrics(o, AstarOutput(out.histories[B:], out.paths[B:], []))
-                vals.update({"metrics/p_opt": m.p_opt, "metrics/p_exp": m.p_exp, "metrics/h_mean": m.h_mean})
-            for k, v in vals.items():
-                sums[k] = sums.get(k, 0.0) + v.double()
-            n += 1
+            if len(kept) >= window:
+                drain()
+        drain()
     res = {k: v / max(n, 1) for k, v in sums.items()}
     for k, v in res.items():
         module.log(k, v)
@@ -189,14 +200,24 @@ def fused_l1_step(planner: VanillaAstar, map_designs: torch.Tensor, start_maps: 
     W = cost_maps.shape[-1]
     max_iters = ops.max_iters_for(W, astar.Tmax, astar.training)
     # a batch assembled by DeviceMazeBatches carries a placement (start_maps.placement_order: by the optimal distance of its start cells)
+    # (read-only use: this step records no completion order, so a Placement the caller attached stays attached for the call it was meant for -- ADVICE r5)
+    pl_keep = astar.placement
     order, _, check, _ = astar.resolve_placement(cost_maps.shape[0], start_maps, ops.workspace_bytes(cost_maps.shape) == 0)
+    astar.placement = pl_keep
     row = astar.begin_launch(cost_maps)
+    # batch semantics as in DifferentiableAstar.forward: outside g_ratio in [0.5, 1) the exact pipeline runs with the launch; inside, the same-call
+    # verdict re-runs a batch that reports the batch-coupled note (negative costs), a deferred one refuses (the graph is built by then)
+    exact = cost_maps.shape[0] > 1 and ops.coupling_possible(astar.g_ratio)
+    args = (cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0], opt_trajs[:, 0], astar.g_ratio, max_iters)
     try:
-        loss, hist, paths, iters, status = ops.astar_l1_loss(cost_maps[:, 0], start_maps[:, 0], goal_maps[:, 0], obstacles[:, 0],
-                                                             opt_trajs[:, 0], astar.g_ratio, max_iters, order, check, astar.summary_ptr(row, cost_maps))
+        loss, hist, paths, iters, status = ops.astar_l1_loss(*args, order, check, astar.summary_ptr(row, cost_maps), exact)
     except BaseException:
         if row >= 0:
             ops.StatusBoard.of(cost_maps.device).release(row)
         raise
-    astar.note_status(status, iters, row=row)  # same contract as DifferentiableAstar.forward (default: raises in THIS call, before any backward)
+    repair = _refuse_late_repair if (astar.check_solvable == "deferred" and not exact and cost_maps.shape[0] > 1) else None
+    # same contract as DifferentiableAstar.forward (default: raises in THIS call, before any backward)
+    if astar.note_status(status, iters, row=row, repair=repair) and not exact:
+        loss, hist, paths, iters, status = ops.astar_l1_loss(*args, None, False, 0, True)
+        astar.last_status, astar.last_iters = status, iters
     return loss, AstarOutput(hist.unsqueeze(1), paths.unsqueeze(1), [])

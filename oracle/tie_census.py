@@ -14,6 +14,10 @@ q < ~2 (f < 2 sqrt(W)) -- AND the cell with the larger quotient has the lower fl
       divergent        ... where the reference's pick is not the first-index arg-min of q (the outputs may differ from here on)
 
 Usage: python oracle/tie_census.py [--out profiles/r05/tie_census.json]
+       python oracle/tie_census.py --encoder-costs [--out profiles/r06/tie_census_encoder_costs.json]
+           round 6: the regime DESIGN.md 2.5 names as the class's exposure -- cost maps of the reference's SHIPPED checkpoint through the
+           reference's own CNN encoder (oracle/gen_golden.py: cnn_cost_maps), scaled by `const` in {1, 2, 5, 10} as NeuralAstar(const=...) scales
+           them (astar.py:150-152, encoder.py:32-34), at g_ratio 0.5 / 0.2 / 0.8, plus U(0, 10) costs
 """
 from __future__ import annotations
 
@@ -94,11 +98,44 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05", "tie_census.json"))
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--encoder-costs", action="store_true")
     args = ap.parse_args()
     ref = load_reference()
     torch.set_num_threads(os.cpu_count() or 1)
     res = {}
     B = args.batch
+    if args.encoder_costs:
+        sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != os.path.join(ROOT, "oracle")]  # (the script's own directory shadows the package)
+        sys.path.insert(0, ROOT)
+        from oracle import gen_golden as GG
+        if args.out.endswith(os.path.join("r05", "tie_census.json")):
+            args.out = os.path.join(ROOT, "profiles", "r06", "tie_census_encoder_costs.json")
+        total = dict(steps=0, low_f=0, merged=0, divergent=0)
+        for wname, pr in (("maze32", syn.maze_maps(B, 32, seed=1234)), ("rand32", syn.random_obstacle_maps(B, 32, 32, 0.25, seed=1234))):
+            enc = GG.cnn_cost_maps((pr.map_designs, pr.start_maps, pr.goal_maps))  # sigmoid outputs in (0, 1): the shipped mazes_032_moore_c8 model
+            for const in (1.0, 2.0, 5.0, 10.0):
+                for gr in (0.5, 0.2, 0.8):
+                    c = census(ref, (enc * np.float32(const)).astype(np.float32), pr.start_maps, pr.goal_maps, pr.map_designs, g_ratio=gr)
+                    name = f"{wname}, shipped-checkpoint CNN cost x const {const:g}, g_ratio {gr}"
+                    res[name] = c
+                    for k in total:
+                        total[k] += c[k]
+                    print(name, c, flush=True)
+            for gr in (0.5, 0.2, 0.8):
+                c = census(ref, syn.random_costs(B, 32, 32, seed=4321, hi=10.0), pr.start_maps, pr.goal_maps, pr.map_designs, g_ratio=gr)
+                name = f"{wname}, cost ~ U(0,10), g_ratio {gr}"
+                res[name] = c
+                for k in total:
+                    total[k] += c[k]
+                print(name, c, flush=True)
+        res["_total"] = total
+        res["_meta"] = {"torch": torch.__version__, "threads": torch.get_num_threads(), "batch": B,
+                        "cpu_flags": [f for f in ("avx2", "avx512f") if f in open("/proc/cpuinfo").read()]}
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+        print("TOTAL", total)
+        return
     cases = []
     for name, pr in (("maze32 (bench headline batch, seed 1234)", syn.maze_maps(B, 32, seed=1234)),
                      ("rand32 (seed 1234)", syn.random_obstacle_maps(B, 32, 32, 0.25, seed=1234)),

@@ -31,7 +31,10 @@ def test_library_builds_loads_and_exports_everything():
     assert lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
     assert lib.nastar_workspace_bytes(2, 128, 128, 0) == 0  # 9 B/cell compact state: 128x128 still fits one CU's LDS
     assert 2 * 200 * 150 * 5 <= lib.nastar_workspace_bytes(2, 200, 150, 0) < 2 * 200 * 150 * 6  # larger maps: 5 B/cell in the workspace (open list in LDS)
-    assert lib.nastar_workspace_bytes(2, 200, 150, 512) >= 2 * 200 * 150 * 17  # ... 17 B/cell for the round-4 kernel (NASTAR_FLAG_GLOBAL_V1, A/B)
+    # round 6: the marks of NASTAR_FLAG_MARK_COUPLED (B int32, 16-byte aligned, + the t_end cell) behind the slabs; the probe bitmaps of the finish call behind those
+    assert lib.nastar_workspace_bytes(6, 32, 32, 32768) == 32 + 16 and lib.nastar_workspace_bytes(6, 32, 32, 32768 | 256) == 32 + 16 + 16
+    assert lib.nastar_batchloop_workspace_bytes(6, 32, 32, 1024) == 32 + 16 + 16 + 6 * 32 * 4
+    assert lib.nastar_batchloop_workspace_bytes(2, 200, 150, 22500) == lib.nastar_workspace_bytes(2, 200, 150, 32768 | 256) + 2 * 704 * 4
     assert lib.nastar_completion_supported(32, 32) == 1 and lib.nastar_completion_supported(200, 150) == 0
     assert lib.nastar_host_wait_nonzero(None, 10) == 0
     assert lib.nastar_backward_workspace_bytes(4, 32, 32, 256) >= 4 * 258 * 16  # replay backward: 16 B of history per step
@@ -63,6 +66,12 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_placement_from_levels(None, 4, one, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_placement_from_levels(one, 0, one, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_backward_replay(None, one, one, one, one, one, 1, 8, 8, 0.5, 64, one, None, one, one, 64, 0, None) == _native.NASTAR_ERR_NULL
+    # round 6: the A/B switches of earlier rounds (8 = NO_ASM, 16 / 128 = older streams, 32 = NO_DIVE, 512 = the round-4 large-map kernel, 2048.. = hybrid variants)
+    # left the product ABI: unknown flag bits are refused (csrc/nastar_dev_flags.h, `make dev`)
+    for bit in (8, 16, 32, 128, 512, 2048, 4096, 8192, 16384):
+        assert lib.nastar_forward(one, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, bit, None) == _native.NASTAR_ERR_UNSUPPORTED, bit
+    assert lib.nastar_forward_batchloop_finish(one, one, one, one, 2, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, None) == _native.NASTAR_ERR_NULL
+    assert lib.nastar_forward_batchloop_finish(one, one, one, one, 2, 8, 8, 0.5, 64, one, one, None, one, one, one, 16, None) == _native.NASTAR_ERR_WORKSPACE
     for sym in ("nastar_backward", "nastar_backward_l1", "nastar_has_dev_kernels"):  # rounds 1-3 legacy entry points: gone in 0.4.0
         assert not hasattr(lib, sym), sym
     assert lib.nastar_heuristic(None, 1, 8, 8, one, None) == _native.NASTAR_ERR_NULL

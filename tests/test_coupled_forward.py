@@ -1,12 +1,18 @@
-"""The class of inputs in which the reference's FORWARD outputs of a map depend on the rest of its batch, documented
-by a reference golden -- not by a loosened bar.
+"""The class of inputs in which the reference's outputs of a map depend on the REST OF ITS BATCH, pinned by reference
+goldens -- forward, per-step selections and gradients.
 
 The reference steps every map until ALL maps of the batch select their goal in the same step (differentiable_astar.py:219-225, :251); a map
 that is done keeps its goal on the open list.  If the goal's own expansion opens a neighbour that BEATS the goal (g_ratio < 0.5 with an
-expensive goal cell; g_ratio = 1 with a zero-cost one; negative costs -- never for g_ratio in [0.5, 1) with costs >= 0, i.e. never in a
-shipped configuration), the finished map goes on closing cells while the slower maps search.  The kernels stop each map at its own goal:
-what the reference returns for the map searched ALONE.  tests/golden/coupled_forward_g020.npz (oracle/gen_golden_coupled.py) holds both
-reference outputs for one small batch; the kernels DETECT the situation (status summary cell NASTAR_SUMMARY_COUPLED) and the planner warns."""
+expensive goal cell; g_ratio = 1 with a zero-cost one; costs below -1 -- never for g_ratio in [0.5, 1) with costs >= 0, i.e. never in a
+shipped configuration), the finished map goes on closing cells while the slower maps search.  ONE early-exit launch stops each map at its own
+goal (what the reference returns for the map searched ALONE) and MARKS the maps of the class; `nastar_forward_batchloop_finish` re-runs exactly
+those in lock-step mode up to the step at which every map selects its goal.  Round 6: every path of the package does that -- no-grad and
+autograd, same-call / deferred / no checking, store_intermediate_results, batches in flight, the fused training step, LDS-resident sizes and
+the hybrid large-map kernel -- the round-5 warning is gone.
+
+Goldens (oracle/gen_golden_coupled.py, oracle/gen_golden_coupled2.py: outputs of the reference itself): coupled_forward_g020 (batch run AND
+each map alone), coupled_grad_g020 (+ selection log + gradient), coupled_grad_train_g010 (training budget ends the loop while a finished map
+wanders), coupled_signed_g050 (costs below -1 at the DEFAULT g_ratio: found through the status summary), coupled_large140x150_g020 (hybrid)."""
 import warnings
 
 import numpy as np
@@ -15,11 +21,22 @@ import pytest
 import golden_util as G
 
 NAME = "coupled_forward_g020"
+GRAD_NAMES = ("coupled_grad_g020", "coupled_grad_train_g010", "coupled_signed_g050")
 
 
 def _alone(g):
     z = np.load(G.GOLDEN_DIR + "/" + NAME + ".npz")
     return (G._unpack(z["hist_alone_bits"], g.B, g.H, g.W).astype(np.float32)[:, 0], G._unpack(z["path_alone_bits"], g.B, g.H, g.W).astype(np.int64)[:, 0])
+
+
+def _large():
+    """coupled_large140x150_g020: costs / upstream gradient regenerated from the stored seeds"""
+    from neural_astar.utils import synthetic as syn
+    g = G.load("coupled_large140x150_g020")
+    z = np.load(G.GOLDEN_DIR + "/coupled_large140x150_g020.npz")
+    cost = syn.random_costs(g.B, g.H, g.W, seed=int(z["cost_seed"]), hi=float(z["cost_hi"]))
+    up = np.random.Generator(np.random.PCG64(int(z["up_seed"]))).standard_normal((g.B, 1, g.H, g.W)).astype(np.float32)
+    return g, cost, up, z["grad_cost_ref"]
 
 
 def test_literal_oracle_follows_the_batch_and_the_state_machine_each_map_alone():
@@ -40,17 +57,100 @@ def test_literal_oracle_follows_the_batch_and_the_state_machine_each_map_alone()
     assert np.array_equal(d5.histories, s5.histories) and np.array_equal(d5.paths, s5.paths)
 
 
-def _gpu_inputs(g):
+@pytest.mark.parametrize("name", GRAD_NAMES)
+def test_oracle_reproduces_the_reference_selections_and_gradients_in_the_coupled_class(name):
+    """the checker itself, pinned: forward outputs and EVERY selection of the reference's batch loop (goal re-selections included) exact,
+    dL/dcost within 1e-5 of the reference's autograd"""
+    from oracle import oracle as O
+    g = G.load(name)
+    d = O.forward(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode="dense", want_log=True)
+    sm = O.forward(g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode="sm")
+    T = d.t_batch + 1
+    assert np.array_equal(d.histories, g.histories[:, 0]) and np.array_equal(d.paths, g.paths[:, 0])
+    assert g.sel_log.shape[1] == T and np.array_equal(d.sel_log[:, :T], g.sel_log)
+    assert not np.array_equal(sm.histories, d.histories)  # a member of the class: each map alone is NOT the batch run
+    gi = g.goal_maps.reshape(g.B, -1).argmax(1)
+    assert any((g.sel_log[b] == gi[b]).sum() >= 1 and (g.sel_log[b][np.argmax(g.sel_log[b] == gi[b]):] != gi[b]).any() for b in range(g.B))  # a map wanders on after its goal
+    gr = O.backward(g.grad_up, g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters)
+    assert np.abs(gr - g.grad_cost[:, 0]).max() <= 1e-5 * max(1.0, float(np.abs(g.grad_cost).max()))
+
+
+def test_oracle_reproduces_the_large_coupled_golden():
+    from oracle import oracle as O
+    g, cost, up, grad_ref = _large()
+    d = O.forward(cost, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode="dense")
+    assert np.array_equal(d.histories, g.histories[:, 0]) and np.array_equal(d.paths, g.paths[:, 0])
+
+
+# ---- a dense emulator of "replay THIS selection log" (float64): what the replay backward computes for ANY log, lock-step logs included ------
+def replay_reference(cost, start, goal, passable, log, g_ratio, up, t_batch):
+    """dL/dcost for one map [H,W] whose search executed the selections `log` (a 1-D int array) inside a batch whose loop ran to step t_batch
+    (>= len(log) - 1: the steps past the log re-select the goal at a fixed point).  Literal reverse mode of the reference's graph
+    (differentiable_astar.py:203-252 under autograd: y_t = softmax over the open list, histories = clamp(histories + onehot, 0, 1))."""
+    H, W = cost.shape
+    HW = H * W
+    c = cost.reshape(-1).astype(np.float64)
+    gi = int(goal.reshape(-1).argmax())
+    gr_, gc_ = divmod(gi, W)
+    rr, cc = np.divmod(np.arange(HW), W)
+    dr, dc = np.abs(rr - gr_).astype(np.float32), np.abs(cc - gc_).astype(np.float32)
+    h0 = ((dr + dc) - np.minimum(dr, dc) + np.float32(0.001) * np.sqrt(((rr - gr_) ** 2 + (cc - gc_) ** 2).astype(np.float32))).astype(np.float32)
+    h = (h0 + cost.reshape(-1).astype(np.float32)).astype(np.float32)
+    open_ = start.reshape(-1).astype(bool).copy()
+    closed = np.zeros(HW, bool)
+    hist = np.zeros(HW)
+    gval = np.zeros(HW, np.float32)
+    pas = passable.reshape(-1) != 0
+    ys, masks = [], []
+    sels = list(log) + [gi] * (t_batch + 1 - len(log))
+    sq = np.float32(np.sqrt(np.float64(W)))
+    for s in sels:
+        f = (np.float32(g_ratio) * gval + np.float32(1.0 - g_ratio) * h).astype(np.float32)
+        v = np.exp(-(f / sq).astype(np.float64)) * open_
+        ys.append(v / v.sum())
+        m = np.ones(HW)
+        if hist[s] >= 1:
+            m[s] = 0.0  # clamp backward: histories + onehot = 2 at s
+        masks.append(m)
+        hist[s] = 1
+        if s != gi:
+            open_[s] = False
+        closed[s] = True
+        r0, c0 = divmod(s, W)
+        g2 = np.float32(gval[s] + np.float32(cost.reshape(-1)[s]))
+        for ddr in (-1, 0, 1):
+            for ddc in (-1, 0, 1):
+                if ddr == 0 and ddc == 0:
+                    continue
+                r1, c1 = r0 + ddr, c0 + ddc
+                if not (0 <= r1 < H and 0 <= c1 < W):
+                    continue
+                n = r1 * W + c1
+                if not pas[n]:
+                    continue
+                if ((not open_[n]) and (not closed[n])) or (open_[n] and gval[n] > g2):
+                    gval[n] = g2
+                    open_[n] = True
+    kfac = (1.0 - g_ratio) * (-1.0 / float(sq))
+    G_ = up.reshape(-1).astype(np.float64).copy()
+    grad = np.zeros(HW)
+    for y, m in zip(reversed(ys), reversed(masks)):
+        G_ = G_ * m
+        grad += kfac * y * (G_ - (G_ * y).sum())
+    return grad.reshape(H, W)
+
+
+def _gpu_inputs(g, cost=None):
     import torch
     dev = torch.device("cuda:0")
-    return tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (g.cost_maps, g.start_maps, g.goal_maps, g.passable))
+    return tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (g.cost_maps if cost is None else cost, g.start_maps, g.goal_maps, g.passable))
 
 
 @pytest.mark.gpu
-def test_kernels_return_each_map_alone_and_report_the_coupling():
+def test_kernels_mark_the_class_and_the_finish_call_completes_the_batch_run():
+    """the C ABI itself: nastar_forward_ex marks, nastar_forward_batchloop_finish re-runs the marked maps -- two calls, no host round trip"""
     import torch
     from neural_astar import ops
-    import neural_astar.planner.differentiable_astar as DA
     g = G.load(NAME)
     h_alone, p_alone = _alone(g)
     c, s, go, p = _gpu_inputs(g)
@@ -64,58 +164,192 @@ def test_kernels_return_each_map_alone_and_report_the_coupling():
         assert int(r[ops.SUMMARY_COUPLED]) == want and not r[ops.SUMMARY_ERRORS].any() and (status == 0).all()
         if want:
             assert np.array_equal(hist.cpu().numpy(), h_alone) and np.array_equal(paths.cpu().numpy(), p_alone)
-    # THE MODULE (default check_solvable: the call reads the launch's summary) reproduces the reference's batch run exactly: it re-runs the batch in
-    # lock-step mode (NASTAR_FLAG_LOCKSTEP) up to the first step at which every map selects its goal -- no warning needed
-    DA._COUPLED_WARNED = False
-    da = DA.DifferentiableAstar(g.g_ratio, 1.0).to(c.device).eval()
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        with torch.no_grad():
-            out = da(c, s, go, p)
-    assert not any("fixed point" in str(w.message) for w in rec)
-    assert np.array_equal(out.histories[:, 0].cpu().numpy(), g.histories[:, 0]) and np.array_equal(out.paths[:, 0].cpu().numpy(), g.paths[:, 0])
-    assert out.histories.shape == (g.B, 1, g.H, g.W) and out.paths.dtype == torch.int64
-    # a map searched alone is never affected (and never re-run)
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        with torch.no_grad():
-            for b in range(g.B):
-                o1 = da(c[b:b + 1], s[b:b + 1], go[b:b + 1], p[b:b + 1])
-                assert np.array_equal(o1.histories[0, 0].cpu().numpy(), h_alone[b])
-    assert not any("fixed point" in str(w.message) for w in rec)
-    # deferred checking cannot re-run in the same call: each map alone, and the warning when the verdict is delivered
-    DA._COUPLED_WARNED = False
-    da.check_solvable = "deferred"
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        with torch.no_grad():
-            out = da(c, s, go, p)
-        da.raise_if_unsolvable()
-    assert np.array_equal(out.histories[:, 0].cpu().numpy(), h_alone) and any("fixed point" in str(w.message) for w in rec)
-    # batches in flight: the flagged batch is re-run in lock-step mode when the results are collected
-    from neural_astar.parallel import InFlightPlanner
-
-    class _P:  # the planner surface InFlightPlanner needs
-        astar = DA.DifferentiableAstar(g.g_ratio, 1.0).to(c.device).eval()
-    fly = InFlightPlanner(_P(), streams=2, unit_cost=False)
-    fly.submit_search(c, s, go, p)
-    fly.submit_search(c, s, go, p)
-    outs = fly.collect()
-    assert fly.reruns == 2 and all(np.array_equal(o.histories[:, 0].cpu().numpy(), g.histories[:, 0]) for o in outs)
-    # lock-step mode itself: on a batch of fixed points (g_ratio 0.5) it returns exactly what the early-exit kernels return
+    hist, paths, iters, status, log = ops.search_nograd(c, s, go, p, g.g_ratio, g.max_iters, want_log=True, exact=True)
+    assert np.array_equal(hist.cpu().numpy(), g.histories[:, 0]) and np.array_equal(paths.cpu().numpy(), g.paths[:, 0]) and (status == 0).all()
+    # on a batch of fixed points (g_ratio 0.5) the exact pipeline changes nothing, and lock-step mode itself returns what the early-exit kernels return
     ref5 = ops.search_nograd(c, s, go, p, 0.5, g.max_iters)
+    ex5 = ops.search_nograd(c, s, go, p, 0.5, g.max_iters, exact=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref5[:4], ex5[:4]))
     t_end = int(ref5[2].max())
     ls5 = ops.search_nograd(c, s, go, p, 0.5, t_end, flags=ops.FLAG_LOCKSTEP)
     assert torch.equal(ref5[0], ls5[0]) and torch.equal(ref5[1], ls5[1]) and (ls5[2] == t_end).all()
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=True, reason="DESIGN.md 2.3: ONE early-exit launch through the C ABI returns each map searched alone and flags the launch "
-                                       "(NASTAR_SUMMARY_COUPLED); the reference's batch-dependent result needs the lock-step re-run the planner module does "
-                                       "(test above).  Impossible for g_ratio in [0.5, 1) with costs >= 0: every shipped configuration")
-def test_one_early_exit_launch_equals_the_reference_batch_run_in_the_coupled_class():
-    from neural_astar import ops
-    g = G.load(NAME)
+@pytest.mark.parametrize("name", GRAD_NAMES + (NAME,))
+def test_module_equals_the_reference_batch_run_in_every_mode(name):
+    """DifferentiableAstar.forward(): same-call checking, deferred, unchecked, under autograd, with the intermediate results -- histories, paths
+    and (where the golden holds it) every selection equal the reference's batch run; nothing warns"""
+    import torch
+    import neural_astar.planner.differentiable_astar as DA
+    g = G.load(name)
     c, s, go, p = _gpu_inputs(g)
-    hist, *_ = ops.search_nograd(c, s, go, p, g.g_ratio, g.max_iters)
-    assert np.array_equal(hist.cpu().numpy(), g.histories[:, 0])
+    want_h, want_p = g.histories[:, 0], g.paths[:, 0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for mode in (True, "deferred", False):
+            if mode is False and not DA.ops.coupling_possible(g.g_ratio):
+                continue  # (the documented gap: nothing is read back, and only negative costs reach the class at this g_ratio)
+            da = DA.DifferentiableAstar(g.g_ratio, g.Tmax, check_solvable=mode).to(c.device).train(g.training)
+            with torch.no_grad():
+                out = da(c, s, go, p)
+                da.raise_if_unsolvable()  # deferred: the verdict (and with it the in-place completion of a late-flagged batch) before the outputs are read
+            assert np.array_equal(out.histories[:, 0].cpu().numpy(), want_h), mode
+            assert np.array_equal(out.paths[:, 0].cpu().numpy(), want_p), mode
+            assert out.histories.shape == (g.B, 1, g.H, g.W) and out.paths.dtype == torch.int64
+        da = DA.DifferentiableAstar(g.g_ratio, g.Tmax).to(c.device).train(g.training)
+        with torch.no_grad():
+            out = da(c, s, go, p, store_intermediate_results=True)
+        assert np.array_equal(out.histories[:, 0].cpu().numpy(), want_h)
+        if g.sel_log is not None:  # the reference's per-step side channel (:210-216): entry t = histories before step t + the node selected at step t
+            T = g.sel_log.shape[1]
+            assert len(out.intermediate_results) == T + 1
+            sel = np.stack([st["paths"].reshape(g.B, -1).argmax(1).cpu().numpy() for st in out.intermediate_results[:-1]], 1)
+            assert np.array_equal(sel, g.sel_log)
+        # a map searched alone is its own batch
+        if name == NAME:
+            h_alone, _ = _alone(g)
+            with torch.no_grad():
+                for b in range(g.B):
+                    o1 = da(c[b:b + 1], s[b:b + 1], go[b:b + 1], p[b:b + 1])
+                    assert np.array_equal(o1.histories[0, 0].cpu().numpy(), h_alone[b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GRAD_NAMES)
+def test_gradients_equal_the_reference_autograd_in_the_coupled_class(name):
+    """loss.backward() through forward() under autograd: the lock-step selection log is the tape (1e-5 of the gradient's scale, north_star);
+    also through the fused L1 training node against the oracle"""
+    import torch
+    import torch.nn as nn
+    import neural_astar.planner.differentiable_astar as DA
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils.training import fused_l1_step
+    from oracle import oracle as O
+    g = G.load(name)
+    c, s, go, p = _gpu_inputs(g)
+    tol = 1e-5 * max(1.0, float(np.abs(g.grad_cost).max()))
+    for mode in (True, "deferred"):
+        if mode == "deferred" and not DA.ops.coupling_possible(g.g_ratio):
+            continue  # (deferred + autograd + negative costs: refused loudly, below)
+        da = DA.DifferentiableAstar(g.g_ratio, g.Tmax, check_solvable=mode).to(c.device).train(g.training)
+        cost = c.clone().requires_grad_(True)
+        out = da(cost, s, go, p)
+        (out.histories * torch.from_numpy(g.grad_up).to(c.device)).sum().backward()
+        da.raise_if_unsolvable()
+        assert np.array_equal(out.histories[:, 0].detach().cpu().numpy(), g.histories[:, 0])
+        err = float(np.abs(cost.grad[:, 0].cpu().numpy() - g.grad_cost[:, 0]).max())
+        assert err <= tol, (mode, err)
+    if not DA.ops.coupling_possible(g.g_ratio):
+        da = DA.DifferentiableAstar(g.g_ratio, g.Tmax, check_solvable="deferred").to(c.device).train(g.training)
+        out = da(c.clone().requires_grad_(True), s, go, p)
+        with pytest.raises(RuntimeError, match="fixed point"):
+            da.raise_if_unsolvable()
+    # the fused training node (L1 loss + sign gradient inside the replay): against the oracle's literal reverse mode
+    va = VanillaAstar(g_ratio=g.g_ratio).to(c.device).train(g.training)
+    va.astar.Tmax = g.Tmax
+    opt = (torch.from_numpy(g.paths.astype(np.float32))).to(c.device)
+
+    class _P(nn.Module):  # a planner whose cost map is a leaf (fused_l1_step's NeuralAstar surface)
+        learn_obstacles = False
+        use_differentiable_astar = True
+
+        def __init__(self):
+            super().__init__()
+            self.astar = va.astar
+            self.cost = nn.Parameter(c.clone())
+
+        def encode(self, m, st, gl):
+            return self.cost
+    pl = _P()
+    loss, out = fused_l1_step(pl, p, s, go, opt)
+    loss.backward()
+    assert np.array_equal(out.histories[:, 0].cpu().numpy(), g.histories[:, 0])
+    upl1 = np.sign(g.histories - g.paths.astype(np.float32)) / g.histories.size
+    ref = O.backward(upl1.astype(np.float32), g.cost_maps, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters)
+    assert abs(float(loss) - float(np.abs(g.histories - g.paths).mean())) < 1e-6
+    assert float(np.abs(pl.cost.grad[:, 0].cpu().numpy() - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_large_maps_in_the_coupled_class_forward_and_gradient():
+    """140x150: the hybrid kernel's lock-step modes and the replay with its state in HBM, against the reference golden"""
+    import torch
+    import neural_astar.planner.differentiable_astar as DA
+    g, cost, up, grad_ref = _large()
+    c, s, go, p = _gpu_inputs(g, cost)
+    assert DA.ops.workspace_bytes((g.B, g.H, g.W)) > 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for mode in (True, "deferred"):
+            da = DA.DifferentiableAstar(g.g_ratio, 1.0, check_solvable=mode).to(c.device).eval()
+            with torch.no_grad():
+                out = da(c, s, go, p)
+                da.raise_if_unsolvable()
+            assert np.array_equal(out.histories[:, 0].cpu().numpy(), g.histories[:, 0]) and np.array_equal(out.paths[:, 0].cpu().numpy(), g.paths[:, 0])
+        da = DA.DifferentiableAstar(g.g_ratio, 1.0).to(c.device).eval()
+        cg = c.clone().requires_grad_(True)
+        out = da(cg, s, go, p)
+        (out.histories * torch.from_numpy(up).to(c.device)).sum().backward()
+    assert np.array_equal(out.histories[:, 0].detach().cpu().numpy(), g.histories[:, 0])
+    err = float(np.abs(cg.grad.cpu().numpy() - grad_ref).max())
+    assert err <= 1e-5 * max(1.0, float(np.abs(grad_ref).max())), err
+
+
+@pytest.mark.gpu
+def test_batches_in_flight_and_the_late_verdict_complete_the_batch_run():
+    import torch
+    import neural_astar.planner.differentiable_astar as DA
+    from neural_astar.parallel import InFlightPlanner
+    for name in (NAME, "coupled_signed_g050"):
+        g = G.load(name)
+        c, s, go, p = _gpu_inputs(g)
+
+        class _P:  # the planner surface InFlightPlanner needs
+            astar = DA.DifferentiableAstar(g.g_ratio, 1.0).to(c.device).eval()
+        fly = InFlightPlanner(_P(), streams=2, unit_cost=False)
+        fly.submit_search(c, s, go, p)
+        fly.submit_search(c, s, go, p)
+        outs = fly.collect()
+        # g_ratio 0.2: the exact pipeline goes to the stream with the search (no re-run); negative costs at 0.5: found in the summary, re-run at collection
+        assert fly.reruns == (0 if DA.ops.coupling_possible(g.g_ratio) else 2)
+        assert all(np.array_equal(o.histories[:, 0].cpu().numpy(), g.histories[:, 0]) and np.array_equal(o.paths[:, 0].cpu().numpy(), g.paths[:, 0]) for o in outs)
+
+
+@pytest.mark.gpu
+def test_replay_of_an_arbitrary_lockstep_log_equals_the_dense_reverse_mode():
+    """The replay backward computes, for ANY selection log, the gradient of the graph that log implies -- including the shapes natural searches
+    (almost) never produce: a goal selected, left, re-selected and left AGAIN with the budget ending mid-wander (the goal's upstream gradient is
+    zero up to its last re-selection and counts again after it: torch.clamp's backward, :223).  Fabricated logs on a small open map against
+    a float64 dense emulation of the reference's graph (replay_reference above)."""
+    import torch
+    from neural_astar import ops
+    rng = np.random.Generator(np.random.PCG64(9))
+    H, W = 6, 7
+    dev = torch.device("cuda:0")
+    for case in range(6):
+        cost = rng.uniform(0.1, 3.0, (1, H, W)).astype(np.float32)
+        m = np.ones((1, H, W), np.float32)
+        s = np.zeros((1, H, W), np.float32)
+        go = np.zeros((1, H, W), np.float32)
+        s[0, 2, 1] = 1
+        go[0, 3, 3] = 1
+        gi = 3 * W + 3
+        # a legal selection sequence: every selected cell must be OPEN at its step; walk outwards from the start, visiting the goal several times
+        base = [2 * W + 1, 2 * W + 2, 3 * W + 2, gi, 2 * W + 3, 4 * W + 3, gi, 3 * W + 4, 4 * W + 4, 2 * W + 4][:6 + case % 5]
+        if case == 5:
+            base = [2 * W + 1, 2 * W + 2, 3 * W + 2, gi, 2 * W + 3, gi, gi]  # re-selected twice in a row, loop ends on the goal
+        log = np.array(base, np.int32)
+        n = len(log)
+        up = rng.standard_normal((1, H, W)).astype(np.float32)
+        extra = 2 if case == 5 else 0
+        t_batch = n - 1 + extra
+        want = replay_reference(cost[0], s[0], go[0], m[0], log, 0.3, up[0], t_batch)
+        T = W * W
+        lg = np.zeros((1, T), np.int32)
+        lg[0, :n] = log
+        grad = torch.ops.nastar.astar_backward_replay(*(torch.from_numpy(x).to(dev) for x in (up, cost, s, go, m, lg)), 0.3, T,
+                                                      torch.tensor([n], dtype=torch.int32, device=dev), torch.tensor([t_batch], dtype=torch.int32, device=dev),
+                                                      None, ops.FLAG_LOCKSTEP)
+        err = float(np.abs(grad[0].cpu().numpy() - want).max())
+        assert err <= 1e-5 * max(1.0, float(np.abs(want).max())), (case, err)

@@ -771,21 +771,32 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
     (NASTAR_FLAG_ASM_V3), round-2 stream (NASTAR_FLAG_ASM_V2; also what signed costs take) and hipcc's own code for the same step
     (NASTAR_FLAG_NO_ASM) must give identical histories, paths, step counts AND selection logs on the full bench batches: cost = map,
     U(0,1) costs, costs shifted below zero (raw-bit keys would misorder those), a truncated budget, g_ratio 0.3; the log-free
-    instantiations (a different instruction stream: no log store) are compared on histories / paths / step counts."""
-    from neural_astar import ops
+    instantiations (a different instruction stream: no log store) are compared on histories / paths / step counts.
+    Round 6: the older streams and the A/B flags live in the DEVELOPMENT build only (csrc/nastar_dev_flags.h, lib/libnastar_hip_dev.so,
+    built by __graft_entry__.build()); flags 0 runs through the PRODUCT library, which rejects those bits."""
+    from neural_astar import _native, ops
     from neural_astar.utils import synthetic as syn
+    dev_lib = _native.load_dev()
     pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=1234)
     u = syn.random_costs(B, H, H, seed=5)
     prev = ops.FORWARD_FLAGS
+
+    def _run_flags(cost, start, goal, passable, g_ratio, max_iters, want_log, flags):
+        c, s, g, p = (_t(x[:, 0]) for x in (cost, start, goal, passable))
+        hist, paths, iters, status, log = ops.search_nograd(c, s, g, p, float(g_ratio), int(max_iters), want_log, flags, lib=dev_lib if flags else None)
+        torch.cuda.synchronize()
+        return hist.cpu().numpy(), paths.cpu().numpy(), iters.cpu().numpy(), status.cpu().numpy(), log.cpu().numpy()
+
+    with pytest.raises(RuntimeError):  # the product ABI has no A/B switches any more
+        _run_flags(u[:2], pr.start_maps[:2], pr.goal_maps[:2], pr.map_designs[:2], 0.5, H * H, False, 128)
     try:
         for label, cost, mi, gr, log in (("vanilla", pr.map_designs, H * H, 0.5, True), ("ucost", u, H * H, 0.5, True),
                                          ("signed", u - np.float32(0.3), H * H, 0.5, True), ("budget", u, H * H // 4, 0.5, True),
                                          ("g03", u, H * H, 0.3, True), ("vanilla_nolog", pr.map_designs, H * H, 0.5, False),
                                          ("g08_nolog", u, H * H, 0.8, False)):
             outs = {}
-            for flags in (0, 32, 128, 16, 8):  # 32 = without the dive (64x64) / without the per-map dive switch (32x32, 16x16)
-                ops.FORWARD_FLAGS = flags
-                outs[flags] = _run_capi(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, mi, want_log=log)
+            for flags in (0, 32, 128, 16, 8):  # 32 = without the dive (64x64)
+                outs[flags] = _run_flags(cost, pr.start_maps, pr.goal_maps, pr.map_designs, gr, mi, log, flags)
             for flags in (32, 128, 16, 8):
                 for k, name in enumerate(("histories", "paths", "iters", "status", "sel_log")):
                     a, b = outs[0][k], outs[flags][k]
