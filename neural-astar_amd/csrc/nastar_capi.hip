@@ -464,7 +464,9 @@ __global__ __launch_bounds__(kTendThreads) void nastar_batchloop_tend_kernel(con
 
 thread_local char g_last_error[256] = "";
 
-constexpr long long kMaxGlobalCells = 64ll * 64 * 64;  // three 64-way levels: key -> chunkmin -> supermin
+// maps whose state lives in HBM: three levels (cell -> chunk minimum per 64 cells -> super-chunk minimum per 64 chunks), the two minima arrays in
+// LDS: 8 B per 64 cells must fit one CU -- 1,179,648 cells (1024 x 1152; 1024 x 1024 takes 130 KiB)
+constexpr long long kMaxGlobalCells = 1179648;
 constexpr size_t kOrderCheckBytes = 16;                // NASTAR_FLAG_CHECK_ORDER: verdict word at the end of the workspace
 
 // maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
@@ -660,7 +662,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         ha.bitmap = lock ? lock->bitmap : nullptr; ha.bitmap_words = lock ? lock->bitmap_words : 0;
         HybridDims& hd = ha.d;
         hd.H = H; hd.W = W; hd.HW = H * W;
-        hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64;
+        hd.nchunks = (hd.HW + 63) / 64; hd.nsuper = (hd.nchunks + 63) / 64; hd.spl = (hd.nsuper + 63) / 64;
         hd.gr = (float)g_ratio; hd.omg = (float)(1.0 - g_ratio); hd.sqrtW = (float)sqrt((double)W);
         hd.rcp_sqrtW = 1.0f / hd.sqrtW;
         hd.inv_W = 1.0f / (float)W;
@@ -672,6 +674,7 @@ static int forward_impl(const float* cost, const float* start, const float* goal
         hipLaunchKernelGGL(nastar_hybrid_fill_kernel, grid2, dim3(256), 0, s, ha);
         const bool fd = fastdiv_verified(W);
         const size_t hl = hybrid_lds_bytes(hd.HW);
+        if (hl > kMaxLdsBytes) return NASTAR_ERR_UNSUPPORTED;
         int rc2;
         if (lockstep) rc2 = fd ? launch(nastar_forward_hybrid_kernel<true, true>, B, hl, s, ha) : launch(nastar_forward_hybrid_kernel<false, true>, B, hl, s, ha);
         else rc2 = fd ? launch(nastar_forward_hybrid_kernel<true, false>, B, hl, s, ha) : launch(nastar_forward_hybrid_kernel<false, false>, B, hl, s, ha);

@@ -1,4 +1,5 @@
-// nastar_search_hybrid.hip.h -- forward search for maps too large for LDS (129x129 ... 512x512): the OPEN LIST lives in LDS, the cells in HBM.
+// nastar_search_hybrid.hip.h -- forward search for maps too large for LDS (129x129 ... 1024x1024: as long as the open list's chunk minima fit
+// the 160 KiB of one CU, 8 B per 64 cells): the OPEN LIST lives in LDS, the cells in HBM.
 //
 // The reference's answer to large maps is "use the CPU pq_astar" (astar.py:36-37) because its loop touches every cell of every map
 // per step (differentiable_astar.py:203-252).  Here a step touches 64 + 8 + 1 cells.  State of one map (one 64-lane wavefront):
@@ -8,7 +9,7 @@
 //             opened, -inf closed or obstacle, finite = open.  "relax neighbour n" (:229,:235) is the one comparison g[n] > g2.
 //     pdir[]  parent direction | passable | on-path bits (1 B)
 //     cost is NOT copied: it is read from the caller's tensor when a cell is touched; h0 is recomputed from the coordinates.
-//   LDS (8 B per 64 cells + 512 B: 33 KB at 512x512)
+//   LDS (8 B per 64 cells + 512 B: 33 KB at 512x512, 130 KB at 1024x1024)
 //     cmin[c] per 64-cell chunk: (key << 32 | cell) of its first minimal open cell, ~0 when it holds none   (u64 order = first-index tie-break)
 //     smin[s] per 64 chunks: the minimum of their cmin entries
 //
@@ -26,9 +27,10 @@ namespace nastar {
 struct HybridDims {
     int H, W, HW;
     int nchunks;   // ceil(HW / 64)
-    int nsuper;    // ceil(nchunks / 64) <= 64
+    int nsuper;    // ceil(nchunks / 64)
+    int spl;       // super-chunk entries per lane = ceil(nsuper / 64): 1 up to 512x512, 4 at 1024x1024 (lane l owns entries [l spl, (l + 1) spl))
     float gr, omg, sqrtW, rcp_sqrtW;
-    float inv_W;   // 1 / W: row of a flat index by one multiply (exact for HW <= 2^18, W <= 512: see hybrid_row)
+    float inv_W;   // 1 / W: row of a flat index by one multiply + one correction step (see hybrid_row)
 };
 
 // per map: g[HWp] fp32 | pdir[HWp] u8 | (256-byte aligned) header {start cell, goal cell} written by the fill kernel
@@ -38,11 +40,13 @@ __host__ __device__ inline size_t hybrid_header_offset(int HW)
     return (HWp * 5 + 255) & ~(size_t)255;
 }
 __host__ __device__ inline size_t hybrid_slab_bytes(int HW) { return hybrid_header_offset(HW) + 256; }
+// cmin: one entry per chunk, padded to whole super-chunks; smin: one entry per super-chunk, padded to `spl` entries for each of the 64 lanes
 __host__ __device__ inline size_t hybrid_lds_bytes(int HW)
 {
     const size_t nchunks = ((size_t)HW + 63) / 64;
     const size_t nsuper = (nchunks + 63) / 64;
-    return nsuper * 64 * 8 + 64 * 8;
+    const size_t spl = (nsuper + 63) / 64;
+    return nsuper * 64 * 8 + spl * 64 * 8;
 }
 
 struct FwdHybridArgs {
@@ -67,8 +71,8 @@ struct FwdHybridArgs {
     HybridDims d;
 };
 
-// row of flat index i (< 2^18) for W <= 512: (i + 0.5) / W is at least 0.5 / W away from an integer and the fp32 product is within
-// 2^-23 * 512 of it; one correction step keeps it exact even so
+// row of flat index i (< 2^21): (i + 0.5) / W in fp32 lands within one row of the true quotient (the product's error is ~2^-23 of a row
+// index below 2^11); one correction step either way makes it exact
 __device__ __forceinline__ int hybrid_row(int i, const HybridDims& d, int& c)
 {
     int r = (int)(((float)i + 0.5f) * d.inv_W);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     // ---- start / goal from the fill launch; empty open list -------------------------------------------------------------
     const int sidx = __builtin_amdgcn_readfirstlane(hdr[0]), gidx = __builtin_amdgcn_readfirstlane(hdr[1]);
     for (int c = lane; c < d.nsuper * 64; c += 64) cmin[c] = ~0ull;
-    smin[lane] = ~0ull;
+    for (int c = lane; c < d.spl * 64; c += 64) smin[c] = ~0ull;
     const int gi = gidx < 0 ? 0 : gidx;
     int goal_c;
     const int goal_r = hybrid_row(gi, d, goal_c);
@@ -262,7 +266,11 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     } else {
         while (iters < budget) {  // :203
             // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-            const unsigned long long e0 = smin[lane];
+            unsigned long long e0 = smin[lane * d.spl];
+            for (int j = 1; j < d.spl; ++j) {  // (maps above 512x512: several super-chunk entries per lane, contiguous -- the first minimal one wins)
+                const unsigned long long ej = smin[lane * d.spl + j];
+                e0 = (uint32_t)(ej >> 32) < (uint32_t)(e0 >> 32) ? ej : e0;
+            }
             const uint32_t k0 = (uint32_t)(e0 >> 32), c0 = (uint32_t)e0;
             const uint32_t m = wave_min_all_u32(k0);
             const int s = __builtin_amdgcn_readlane((int)c0, __builtin_ctzll(__ballot(k0 == m)));  // wave-uniform, in a scalar register (the lane that holds m exists)

@@ -154,6 +154,32 @@ def load_dev() -> ctypes.CDLL:
     return _dev_lib
 
 
+FASTLANE_PATH = os.path.join(_PKG_ROOT, "lib", "_nastar_fastlane.so")
+_fastlane = False  # False: not looked for yet; None: absent / switched off
+
+
+def load_fastlane():
+    """(module, address of nastar_forward_ex, address of nastar_placement_from_levels) of the native host lane (csrc/nastar_fastlane.cpp: output allocation, the launch and the poll of
+    its completion flag in C++), or None when lib/_nastar_fastlane.so has not been built (`make -C csrc fastlane`) or NASTAR_FASTLANE=0 --
+    the Python lane then issues the SAME launch through ctypes (slower on the host, identical on the device)."""
+    global _fastlane
+    if _fastlane is False:
+        _fastlane = None
+        if os.environ.get("NASTAR_FASTLANE", "1") != "0" and os.path.exists(FASTLANE_PATH) and not os.environ.get("NASTAR_LIB"):
+            import importlib.util
+            try:
+                spec = importlib.util.spec_from_file_location("_nastar_fastlane", FASTLANE_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                fn = ctypes.cast(load().nastar_forward_ex, ctypes.c_void_p).value
+                sort_fn = ctypes.cast(load().nastar_placement_from_levels, ctypes.c_void_p).value
+                _fastlane = (mod, int(fn), int(sort_fn))
+            except Exception as e:  # noqa: BLE001 -- an ABI mismatch of the extension must not take the package down
+                import warnings
+                warnings.warn(f"neural_astar: {FASTLANE_PATH} could not be loaded ({type(e).__name__}: {e}); using the Python host lane", RuntimeWarning)
+    return _fastlane
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:

@@ -13,7 +13,7 @@ import torch
 
 from . import _native
 
-__all__ = ["astar_forward", "astar_backward_replay", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for", "search_nograd", "order_from_levels", "OrderHint", "attach_order",
+__all__ = ["astar_forward", "astar_backward_replay", "astar_backward_l1_replay", "l1_loss", "astar_l1_loss", "heuristic", "max_iters_for", "search_nograd", "order_from_levels", "OrderHint", "attach_order", "attach_levels",
            "StatusBoard"]
 
 
@@ -365,15 +365,32 @@ class OrderHint:
     (``DeviceMazeBatches``, ``order_hint_from_distances``): the reference's 4-tuple batches keep their shape, ``PlannerModule`` and
     ``DifferentiableAstar.forward`` pick the hint up from the tensor.  ``trusted`` = a permutation by construction."""
 
-    __slots__ = ("order", "trusted")
+    __slots__ = ("order", "trusted", "levels")
 
-    def __init__(self, order: torch.Tensor, trusted: bool = False):
-        self.order, self.trusted = order, trusted
+    def __init__(self, order: Optional[torch.Tensor], trusted: bool = False, levels: Optional[torch.Tensor] = None):
+        self.order, self.trusted, self.levels = order, trusted, levels
+
+    def resolve(self) -> Optional[torch.Tensor]:
+        """the order, computed from the levels on first use (``attach_levels``)"""
+        if self.order is None and self.levels is not None:
+            self.order, self.trusted = order_from_levels(self.levels), True
+        return self.order
 
 
 def attach_order(start_maps: torch.Tensor, levels: torch.Tensor) -> torch.Tensor:
-    """tag ``start_maps`` with the placement ``order_from_levels(levels)``; returns ``start_maps``"""
+    """tag ``start_maps`` with the placement ``order_from_levels(levels)`` (the sort runs NOW: batch assembly); returns ``start_maps``"""
     start_maps.placement_order = OrderHint(order_from_levels(levels), trusted=True)
+    return start_maps
+
+
+def attach_levels(start_maps: torch.Tensor, levels: torch.Tensor) -> torch.Tensor:
+    """tag ``start_maps`` with the LEVELS its loader has (``levels[b]`` = |opt_dists[start]| of map b, int32 [B] on the device; see
+    ``order_from_levels``) and leave the sort to the ``forward()`` call that searches the batch: its counting-sort launch then goes out right in
+    front of the search launch, from the same native call (csrc/nastar_fastlane.cpp).  Returns ``start_maps``."""
+    lv = levels.reshape(-1)
+    if lv.dtype != torch.int32:
+        lv = lv.abs().to(torch.int32)
+    start_maps.placement_order = OrderHint(None, trusted=True, levels=lv.contiguous())
     return start_maps
 
 

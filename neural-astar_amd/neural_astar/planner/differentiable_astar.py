@@ -13,7 +13,9 @@ from typing import List, NamedTuple, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _native, ops
+
+_ERROR_BITS = sum(1 << c for c in range(1, 14))  # summary cells 1..13 are per-map error codes (ops.SUMMARY_ERRORS); 14 / 15 are notes
 
 
 class AstarOutput(NamedTuple):
@@ -284,9 +286,23 @@ class DifferentiableAstar(nn.Module):
     def _repair_in_place(self, inputs, outputs, max_iters, want_log):
         """for a DEFERRED verdict: the launch it belongs to reported the note after its outputs had been handed out -- run the exact search now
         and overwrite those tensors (histories, paths, iters, status, sel_log) before the caller, who asked for the verdict first, reads them"""
+        import weakref
+        # weak references only: a verdict still pending must not keep the outputs of a pipelined loop (48 MB per 4096-map call, up to 64 calls
+        # deep) or its inputs alive -- outputs nobody holds any more need no repair
+        ins = [weakref.ref(t) for t in inputs]
+        outs = [weakref.ref(t) if t is not None else None for t in outputs]
+
         def repair():
-            new = self.exact_search(*inputs, max_iters, want_log, out_4d=False)
-            for old, fresh in zip(outputs, new):
+            live = [(r() if r is not None else None) for r in outs]
+            if all(t is None for t in live):
+                return
+            src = [r() for r in ins]
+            if any(t is None for t in src):
+                raise RuntimeError("a batch searched with check_solvable='deferred' holds a map that is not at a fixed point of the reference's batch loop "
+                                   "(negative costs), and its inputs were released before the verdict was collected: the outputs still alive are those of "
+                                   "each map searched alone.  Keep the inputs until raise_if_unsolvable(), or use check_solvable=True (DESIGN.md section 2.3)")
+            new = self.exact_search(*src, max_iters, want_log, out_4d=False)
+            for old, fresh in zip(live, new):
                 if old is not None and fresh is not None and old.numel() == fresh.numel():
                     old.data.copy_(fresh.reshape(old.shape))
         return repair
@@ -307,12 +323,76 @@ class DifferentiableAstar(nn.Module):
             prev, order_out = pl.buffers(B, start_maps.device)
         hint = getattr(start_maps, "placement_order", None)
         if hint is not None:
-            o = hint.order if isinstance(hint, ops.OrderHint) else hint
+            o = hint.resolve() if isinstance(hint, ops.OrderHint) else hint
             if torch.is_tensor(o) and o.numel() == B and o.device == start_maps.device and o.dtype == torch.int32:
                 order, check = o.reshape(-1), not getattr(hint, "trusted", False)
         if order is None and prev is not None:
             order = prev[:B]
         return order, order_out, check, pl
+
+    def _forward_fast(self, cost_maps, start_maps, goal_maps, obstacles_maps) -> Optional[AstarOutput]:
+        """The common call -- no gradient, default checking, an LDS-resident size, nothing tracing or capturing -- with its host side in native
+        code (csrc/nastar_fastlane.cpp: output allocation, nastar_forward_ex, the poll of the launch's completion flag).  None = not a call for
+        this lane (the general path below takes it and raises whatever needs raising).  Same launch, same outputs, same verdict policy."""
+        fl = _native.load_fastlane()
+        if fl is None:
+            return None
+        B, _, H, W = cost_maps.shape
+        dev = cost_maps.device
+        if (not cost_maps.is_cuda or not ops.in_lds(H, W) or (B > 1 and ops.coupling_possible(self.g_ratio)) or torch.compiler.is_compiling()
+                or torch.cuda.is_current_stream_capturing() or dev.index != torch.cuda.current_device()):
+            return None
+        same = obstacles_maps is cost_maps
+        flags = ops.FLAG_UNIT_COST if (same and self.unit_cost is True) else 0
+        flags |= ops.FORWARD_FLAGS
+        order = order_out = pl = levels = None
+        ws_bytes = 0
+        hint = getattr(start_maps, "placement_order", None)
+        if (self.placement is None and type(hint) is ops.OrderHint and hint.order is None and hint.levels is not None and hint.levels.numel() == B
+                and hint.levels.device == dev):
+            levels = hint.levels  # the loader's levels: the native call sorts them into a placement right in front of the search launch
+        elif self.placement is not None or hint is not None:
+            order, order_out, check_order, pl = self.resolve_placement(B, start_maps, True)
+            if order is not None and check_order:
+                flags |= ops.FLAG_CHECK_ORDER
+                ws_bytes = 16
+        board = ops.StatusBoard.of(dev)
+        row = board.acquire()
+        try:
+            hist, paths, iters, status, _, rc, verdict = fl[0].search(
+                fl[1], cost_maps, start_maps, goal_maps, None if same else obstacles_maps, float(self.g_ratio),
+                ops.max_iters_for(W, self.Tmax, self.training), False, flags, order, order_out, ws_bytes, board.ptr(row), board.counter_ptr(row),
+                torch._C._cuda_getCurrentRawStream(dev.index), 2000, levels, fl[2])
+        except BaseException:
+            board.release(row)
+            raise
+        if rc:
+            board.release(row)
+            if rc == -1:
+                return None  # (strided / mistyped inputs: the general path copies or complains)
+            _native.check(rc, "nastar_forward_ex")
+        if pl is not None and order_out is not None:
+            pl.commit()
+        self.last_status, self.last_iters = status, iters
+        self._calls += 1
+        if verdict == 0:  # every map ended with status 0 (the row came back zeroed)
+            board.free.append(row)
+            return AstarOutput(hist, paths, [])
+        if verdict < 0:  # the flag did not come up within the spin budget (a very long launch): wait for the stream, read the row
+            summ = self._collect_sync(row, dev, True)
+            verdict = 0 if summ is None else int(sum((1 << c) for c in range(1, ops.SUMMARY_WORDS) if summ[c]))
+        else:
+            board.free.append(row)
+        if verdict & (1 << ops.SUMMARY_BAD_ORDER):
+            _warn_bad_order()
+        if verdict & _ERROR_BITS:
+            _raise_unsolvable(status, self._calls)
+        if verdict & (1 << ops.SUMMARY_COUPLED) and B > 1:
+            # a finished map of this batch is not at a fixed point of the reference's batch loop (negative costs): the batch again, exactly
+            hist, paths, iters, status, _ = self.exact_search(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
+                                                              ops.max_iters_for(W, self.Tmax, self.training))
+            self.last_status, self.last_iters = status, iters
+        return AstarOutput(hist, paths, [])
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
                 obstacles_maps: torch.Tensor, store_intermediate_results: bool = False) -> AstarOutput:
@@ -320,6 +400,11 @@ class DifferentiableAstar(nn.Module):
         assert start_maps.ndim == 4
         assert goal_maps.ndim == 4
         assert obstacles_maps.ndim == 4
+        if (self.check_solvable is True and not store_intermediate_results and not self._pending and type(cost_maps) is torch.Tensor
+                and not (cost_maps.requires_grad and torch.is_grad_enabled())):
+            out = self._forward_fast(cost_maps, start_maps, goal_maps, obstacles_maps)
+            if out is not None:
+                return out
 
         B, _, H, W = cost_maps.shape
         max_iters = ops.max_iters_for(W, self.Tmax, self.training)

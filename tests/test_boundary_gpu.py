@@ -413,6 +413,86 @@ def test_forward_host_overhead_is_bounded():
         assert t_sync < kern + 80e-6, f"sync forward() {t_sync * 1e6:.0f} us vs kernel {kern * 1e6:.0f} us"
 
 
+def test_native_host_lane_equals_the_python_lane():
+    """lib/_nastar_fastlane.so (csrc/nastar_fastlane.cpp: allocation + nastar_forward_ex + the poll of the completion flag in C++) is a faster
+    way to ISSUE the same launch: outputs, verdicts, placements and the fall-through cases must be those of the Python lane."""
+    from neural_astar import _native, ops
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar, UnsolvableMapError
+    fl = _native.load_fastlane()
+    assert fl is not None, "lib/_nastar_fastlane.so missing: __graft_entry__.build() builds it (make -C neural-astar_amd/csrc fastlane)"
+    dev = _dev()
+    pr, (m, s, g) = _problems(1024, 32, seed=77)
+    u = torch.rand_like(m) + 0.05
+
+    calls = {"n": 0}
+    real = fl[0].search
+
+    class _Counting:
+        @staticmethod
+        def search(*a):
+            calls["n"] += 1
+            return real(*a)
+    _native._fastlane = (_Counting, fl[1], fl[2])
+    fl_counting = _native._fastlane
+    try:
+        va = VanillaAstar().to(dev).eval()
+        da = DifferentiableAstar(0.5, 1.0).to(dev).eval()
+        with torch.no_grad():
+            n0 = calls["n"]
+            a = va(m, s, g)
+            assert calls["n"] == n0 + 1  # the lane was taken
+            _native._fastlane = None
+            b = va(m, s, g)
+            _native._fastlane = fl_counting
+            assert torch.equal(a.histories, b.histories) and torch.equal(a.paths, b.paths) and a.histories.shape == (1024, 1, 32, 32)
+            a = da(u, s, g, m)
+            _native._fastlane = None
+            b = da(u, s, g, m)
+            _native._fastlane = fl_counting
+            assert torch.equal(a.histories, b.histories) and torch.equal(a.paths, b.paths)
+            # a placement hint rides along; outputs do not depend on it -- as an order sorted at batch assembly, or as the loader's levels, which
+            # the native call sorts in front of its search launch (and the Python lane on first use)
+            lv = torch.from_numpy(_levels(pr)).to(dev)
+            ops.attach_order(s, lv)
+            c = va(m, s, g)
+            ops.attach_levels(s, lv)
+            assert s.placement_order.order is None
+            c2 = va(m, s, g)
+            assert s.placement_order.order is None  # (sorted inside the native call: nothing cached on the hint)
+            _native._fastlane = None
+            c3 = va(m, s, g)
+            _native._fastlane = fl_counting
+            o = s.placement_order.order  # (the Python lane sorts on first use and keeps the order on the hint; equal levels come in arbitrary order)
+            assert o is not None and torch.equal(torch.sort(o.long())[0], torch.arange(o.numel(), device=dev)) and bool((lv[o.long()][1:] <= lv[o.long()][:-1]).all())
+            del s.placement_order
+            plain = va(m, s, g)
+            assert all(torch.equal(x.histories, plain.histories) and torch.equal(x.paths, plain.paths) for x in (c, c2, c3))
+            # strided inputs, gradients, deferred checking: not this lane's calls -- same answers from the general path
+            n0 = calls["n"]
+            big = torch.cat((m, m), 1)
+            out = va(big[:, 1:2], s, g)
+            assert torch.equal(out.histories, c.histories)
+            va.astar.check_solvable = "deferred"
+            va(m, s, g)
+            va.astar.raise_if_unsolvable()
+            va.astar.check_solvable = True
+        ug = u.clone().requires_grad_(True)
+        da(ug, s, g, m).histories.sum().backward()
+        assert calls["n"] == n0 + 1 and ug.grad is not None  # (only the strided call tried the lane, and was sent back)
+        # an unsolvable map raises in the same call, naming its row
+        mm = m.clone()
+        mm[3, 0] = 0
+        mm[3, 0].view(-1)[s[3, 0].view(-1).argmax()] = 1
+        mm[3, 0].view(-1)[g[3, 0].view(-1).argmax()] = 1
+        with torch.no_grad(), pytest.raises(UnsolvableMapError, match="rows \\[3\\]"):
+            va(mm, s, g)
+        with torch.no_grad():
+            assert torch.equal(va(m, s, g).histories, c.histories)  # the status row went back clean
+    finally:
+        _native._fastlane = fl
+
+
 def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
     """NeuralAstar.encode decides per call between the MI355X encoder kernels and torch.nn.  The decision is recorded
     (planner.last_encoder_route), the BASELINE configurations take the kernels in eval() AND train() -- config 3 (U-Net on 32x32 mazes),

@@ -49,7 +49,9 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nastar_forward(None, one, one, one, 1, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     assert lib.nastar_forward(one, one, one, one, 0, 8, 8, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
     assert lib.nastar_forward(one, one, one, one, 1, 8, 8, 0.5, 0, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_BAD_SHAPE
-    assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward(one, one, one, one, 1, 2048, 2048, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_UNSUPPORTED
+    assert lib.nastar_forward(one, one, one, one, 1, 1024, 1024, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL  # (round 6: a supported size, it wants its workspace)
+    assert lib.nastar_workspace_bytes(1, 1024, 1024, 0) >= 5 * 1024 * 1024 and lib.nastar_workspace_bytes(1, 1024, 1153, 0) == 0
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, one, 16, 0, None) == _native.NASTAR_ERR_WORKSPACE
     assert lib.nastar_forward(one, one, one, one, 1, 200, 150, 0.5, 64, one, one, None, one, one, None, 0, 0, None) == _native.NASTAR_ERR_NULL
     # placement: argument checks of nastar_forward carry over; maps whose state lives in HBM take none

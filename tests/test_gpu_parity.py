@@ -272,6 +272,40 @@ def test_full_size_bench_batches_match_oracle_on_every_row(kind, H, B):
         assert np.array_equal(hist, o.histories) and np.array_equal(paths, o.paths) and np.array_equal(iters, o.iters)
 
 
+@pytest.mark.parametrize("shard", ["contiguous", "interleaved"])
+def test_config4_shard_of_one_rank_matches_the_oracle_on_every_row(shard):
+    """BASELINE config 4 (32768 maps of 64x64 over 8 GPUs): ONE rank's whole shard -- 4096 maps, the rows `parallel.shard_rows` gives rank 3
+    of 8, contiguous and interleaved -- through VanillaAstar.forward(), every row against the oracle, and the bit-packed collation payload of
+    the shard (what the rank contributes to the one all-gather) against the host expression (the test used to cover 1024 rows)."""
+    from neural_astar import parallel
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    world, rank, total = 8, 3, 32768
+    rows = parallel.shard_rows(total, world, rank, shard).numpy()
+    assert rows.size == 4096 and (np.diff(rows) > 0).all()
+    # the global batch is defined chunk-wise (1024 maps per chunk, seeded per chunk) exactly as bench.py --global-batch does it
+    parts = []
+    for c in np.unique(rows // 1024):
+        pc = syn.random_obstacle_maps(1024, 64, 64, 0.20, seed=1234 * 100003 + int(c))
+        sel = rows[(rows // 1024) == c] - c * 1024
+        parts.append(tuple(x[sel] for x in pc))
+    m, s, g = (np.concatenate([p_[k] for p_ in parts]) for k in range(3))
+    va = VanillaAstar().to(_dev()).eval()
+    with torch.no_grad():
+        out = va(_t(m), _t(s), _t(g))
+    o = O.forward(m, s, g, m, 0.5, 64 * 64, mode="sm")
+    assert np.array_equal(out.histories[:, 0].cpu().numpy(), o.histories) and np.array_equal(out.paths[:, 0].cpu().numpy(), o.paths)
+    assert np.array_equal(va.astar.last_iters.cpu().numpy(), o.iters) and int(va.astar.last_status.abs().sum()) == 0
+    packed = parallel.pack_masks(out.histories, out.paths)
+    host = parallel.pack_masks(torch.from_numpy(o.histories[:, None]), torch.from_numpy(o.paths[:, None]))
+    assert packed.shape == (4096, 2 * 512) and torch.equal(packed.cpu(), host)
+    # the collated order restores the global row order whichever way the rows were dealt
+    perm = parallel.collated_order(total, world, shard)
+    dealt = torch.cat([parallel.shard_rows(total, world, r, shard) for r in range(world)])
+    assert torch.equal(dealt[perm], torch.arange(total))
+
+
 def test_neural_astar_unet_runs_on_device():
     """BASELINE config 3's architecture (Unet vgg16_bn encoder, from-scratch definition, torch convolutions) in front of the HIP search."""
     from neural_astar.planner import NeuralAstar
@@ -781,14 +815,15 @@ def test_instruction_streams_agree_with_the_compiled_step_on_whole_batches(kind,
     u = syn.random_costs(B, H, H, seed=5)
     prev = ops.FORWARD_FLAGS
 
-    def _run_flags(cost, start, goal, passable, g_ratio, max_iters, want_log, flags):
+    def _run_flags(cost, start, goal, passable, g_ratio, max_iters, want_log, flags, product=False):
         c, s, g, p = (_t(x[:, 0]) for x in (cost, start, goal, passable))
-        hist, paths, iters, status, log = ops.search_nograd(c, s, g, p, float(g_ratio), int(max_iters), want_log, flags, lib=dev_lib if flags else None)
+        hist, paths, iters, status, log = ops.search_nograd(c, s, g, p, float(g_ratio), int(max_iters), want_log, flags,
+                                                            lib=dev_lib if (flags and not product) else None)
         torch.cuda.synchronize()
         return hist.cpu().numpy(), paths.cpu().numpy(), iters.cpu().numpy(), status.cpu().numpy(), log.cpu().numpy()
 
     with pytest.raises(RuntimeError):  # the product ABI has no A/B switches any more
-        _run_flags(u[:2], pr.start_maps[:2], pr.goal_maps[:2], pr.map_designs[:2], 0.5, H * H, False, 128)
+        _run_flags(u[:2], pr.start_maps[:2], pr.goal_maps[:2], pr.map_designs[:2], 0.5, H * H, False, 128, product=True)
     try:
         for label, cost, mi, gr, log in (("vanilla", pr.map_designs, H * H, 0.5, True), ("ucost", u, H * H, 0.5, True),
                                          ("signed", u - np.float32(0.3), H * H, 0.5, True), ("budget", u, H * H // 4, 0.5, True),
@@ -831,8 +866,8 @@ def test_unit_cost_kernel_equals_the_general_kernel_and_the_oracle(kind, H, B):
     from oracle import oracle as O
     pr = syn.maze_maps(B, H, seed=1234) if kind == "maze" else syn.random_obstacle_maps(B, H, H, 0.25 if H == 32 else 0.2, seed=1234)
     for gr, mi in ((0.5, H * H), (0.2, H * H), (1.0, H * H), (0.5, H * H // 4), (0.5, 20)):
-        ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 8)   # hipcc's own code for the step, general layout
-        for fl in (64, 64 | 32):  # unit-cost layout with and without the dive / the per-map dive switch
+        ref = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, 0)   # the general layout (itself pinned to the goldens, the oracle and, in
+        for fl in (64,):                                                              # the stream-equality test, to hipcc's own code for the step)
             got = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, gr, mi, fl)
             for k, name in enumerate(("histories", "paths", "iters", "status")):
                 assert np.array_equal(ref[k], got[k]), (gr, mi, fl, name)
@@ -889,6 +924,9 @@ def test_unit_cost_kernel_edge_cases_and_the_promise_check():
     def spy(*a, **k):
         seen.append(int(a[7]))
         return orig(*a, **k)
+    from neural_astar import _native
+    lane = _native.load_fastlane()
+    _native._fastlane = None  # the Python host lane (the spy sees its launches); the native lane takes the same decisions: test_native_host_lane_...
     ops.search_nograd = spy
     try:
         with torch.no_grad():
@@ -900,7 +938,12 @@ def test_unit_cost_kernel_edge_cases_and_the_promise_check():
                 va(_t(m2), _t(pr.start_maps), _t(pr.goal_maps))
     finally:
         ops.search_nograd = orig
+        _native._fastlane = lane
     assert seen == [0, 0, 64, 64], seen
+    with torch.no_grad():  # ... and through the native lane: unit_cost=True reaches the unit-cost kernel there too, a broken promise raises
+        assert torch.equal(va(_t(pr.map_designs), _t(pr.start_maps), _t(pr.goal_maps)).histories, out.histories)
+        with pytest.raises(ValueError, match="unit_cost=True"):
+            va(_t(m2), _t(pr.start_maps), _t(pr.goal_maps))
     assert torch.equal(out3.histories, out.histories) and torch.equal(out3.paths, out.paths)
     full = _run_aliased(pr.map_designs, pr.start_maps, pr.goal_maps, 0.5, H * H, 0)
     assert np.array_equal(out.histories[:, 0].cpu().numpy(), full[0]) and np.array_equal(out.paths[:, 0].cpu().numpy(), full[1])

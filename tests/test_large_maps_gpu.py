@@ -1,5 +1,5 @@
 """GPU parity of the large-map search (maps whose state does not fit LDS: 129x129 ... 512x512; csrc/nastar_search_hybrid.hip.h -- open list
-in LDS, cells in HBM), the replacement for the reference's advice to leave the differentiable search for the CPU pq_astar on large maps
+in LDS, cells in HBM; round 6: up to 1,179,648 cells -- 1024x1024 included -- with several super-chunk entries per lane), the replacement for the reference's advice to leave the differentiable search for the CPU pq_astar on large maps
 (astar.py:36-37).  Against the oracle's state-machine restatement, long searches (tens of thousands of steps) included.  Bit-exact histories,
 paths, step counts, logs.  (Rounds 4-5 cross-checked the long searches against the round-4 all-HBM kernel; that kernel left the library in
 round 6 and the oracle, a few seconds per map here, took its place.)"""
@@ -50,7 +50,7 @@ def _run(cost, s, g, passable, max_iters, flags=0, log=True):
 
 
 @pytest.mark.parametrize("H,W,p,Tmax,reach", [(256, 256, 0.2, 1.0, 60), (512, 512, 0.2, 1.0, 80), (512, 512, 0.25, 0.05, 200), (300, 170, 0.15, 1.0, 50),
-                                               (140, 140, 0.2, 1.0, 40)])
+                                               (140, 140, 0.2, 1.0, 40), (1024, 1024, 0.2, 1.0, 400), (700, 1100, 0.15, 1.0, 300)])
 def test_large_maps_match_the_oracle(H, W, p, Tmax, reach):
     from neural_astar import ops
     from neural_astar.utils import synthetic as syn

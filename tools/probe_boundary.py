@@ -12,6 +12,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+import bench_extras  # noqa: E402
 from neural_astar import _native, ops  # noqa: E402
 from neural_astar.parallel import InFlightPlanner  # noqa: E402
 from neural_astar.planner import VanillaAstar  # noqa: E402
@@ -100,7 +101,7 @@ def main():
         for unit in (True, False):
             for k in (3, 4, 6):
                 runs = [bench.Runner(prs[i % 3], dev, flags=64 if unit else 0, placement="natural") for i in range(k)]
-                raw = bench.multi_stream_throughput(prs[0], n, dev, k, runs=runs)
+                raw = bench_extras.multi_stream_throughput(prs[0], n, dev, k, runs=runs)
                 del runs
                 fly = InFlightPlanner(va, streams=k, unit_cost="auto" if unit else False)
                 fly.plan_many(batches[i % 3] for i in range(n))  # warm: the allocator now holds n output sets

@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "neural-astar_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bench  # noqa: E402
+import bench_extras  # noqa: E402
 from neural_astar.utils import synthetic as syn  # noqa: E402
 
 
@@ -56,7 +57,7 @@ def main():
                 r0 = bench.Runner(prs[0], dev)
                 bench.prewarm(r0, dev, 0.2)
                 for s in (int(x) for x in a.streams.split(",")):
-                    out["streams"][str(s)] = round(bench.multi_stream_throughput(prs[0], a.steps, dev, s) / 1e6, 2)
+                    out["streams"][str(s)] = round(bench_extras.multi_stream_throughput(prs[0], a.steps, dev, s) / 1e6, 2)
                 for k in (int(x) for x in a.bigb.split(",")):
                     if k > 0:
                         v, ms = big_batch_throughput(prs[:k], max(10, a.steps // k), dev)

@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
 import bench  # noqa: E402
+import bench_extras  # noqa: E402
 from neural_astar.planner import NeuralAstar  # noqa: E402
 from neural_astar.utils import distributed as D  # noqa: E402
 from neural_astar.utils.training import fused_l1_step  # noqa: E402
@@ -23,9 +24,9 @@ if cfg_name == "unet":
     kw = dict(encoder_input="m+", encoder_arch="Unet", encoder_depth=4, Tmax=0.25)
     data_cfg = "maze"
 else:
-    kw = bench.TRAIN_CONFIGS[cfg_name]["kw"]
+    kw = bench_extras.TRAIN_CONFIGS[cfg_name]["kw"]
     data_cfg = cfg_name
-batches = [bench.train_batch(data_cfg, B, 1234 + 1000 * k, dev) for k in range(4)]
+batches = [bench_extras.train_batch(data_cfg, B, 1234 + 1000 * k, dev) for k in range(4)]
 
 
 def make():

@@ -12,12 +12,13 @@ STEPS, WARM = 8, 4
 def run(cfg_name, B):
     import torch
     sys.path[:0] = [os.path.join(ROOT, "neural-astar_amd"), ROOT]
-    import bench
+    import bench  # noqa: F401
+    import bench_extras
     from neural_astar.planner import NeuralAstar
     from neural_astar.utils import distributed as D
     dev = torch.device("cuda:0")
-    kw = dict(encoder_input="m+", encoder_arch="Unet", encoder_depth=4, Tmax=0.25) if cfg_name == "unet" else bench.TRAIN_CONFIGS[cfg_name]["kw"]
-    batches = [bench.train_batch("maze" if cfg_name == "unet" else cfg_name, B, 1234 + 1000 * k, dev) for k in range(2)]
+    kw = dict(encoder_input="m+", encoder_arch="Unet", encoder_depth=4, Tmax=0.25) if cfg_name == "unet" else bench_extras.TRAIN_CONFIGS[cfg_name]["kw"]
+    batches = [bench_extras.train_batch("maze" if cfg_name == "unet" else cfg_name, B, 1234 + 1000 * k, dev) for k in range(2)]
     torch.manual_seed(1234)
     p = NeuralAstar(**kw).to(dev)
     p.encoder_backend = "hip_f16x3"
