@@ -184,7 +184,7 @@ def two_stream_throughput(pr, steps, dev):
 def training_step_ms(pr, dev, reps=10):
     """Extra: forward + straight-through backward (nastar_backward_replay) of one 4096-map batch with U(0,1) costs in
     training mode, Tmax = 0.25 (the reference's scripts/config/train.yaml), through the torch custom ops."""
-    from neural_astar import ops  # noqa: F401
+    from neural_astar import ops
     from neural_astar.utils import synthetic as syn
     m = torch.from_numpy(pr.map_designs[:, 0]).to(dev)
     s = torch.from_numpy(pr.start_maps[:, 0]).to(dev)
@@ -211,6 +211,44 @@ def training_step_ms(pr, dev, reps=10):
         e1.record()
         torch.cuda.synchronize(dev)
         out[name] = e0.elapsed_time(e1) / reps
+    # the replay backward on its own: one launch at a time and with several batches in flight, against the HBM roofline on
+    # its algorithmic bytes -- reads cost + start + goal + passable + upstream gradient (5 x 4 B per cell) and the executed part of the
+    # selection log (4 B per step), writes dL/dcost (4 B per cell); placed by the forward's completion order as the training paths do
+    from neural_astar import _native
+    lib = _native.load()
+    B = m.shape[0]
+    ord_buf = ops.new_placement_buffer(B, dev)
+    h, _, it, _, log = torch.ops.nastar.astar_forward_ordered(cost, s, g, m, G_RATIO, mi, True, 0, None, ord_buf, False)
+    order = ord_buf[:B].contiguous()
+    torch.cuda.synchronize(dev)
+    alg_bytes = B * H * W * 24 + int(it.sum().item()) * 4
+    ws_bytes = int(lib.nastar_backward_workspace_bytes(B, H, W, mi))
+
+    def make_set():
+        return dict(gc=torch.empty_like(cost), ws=torch.empty((ws_bytes,), dtype=torch.uint8, device=dev))
+
+    def launch(z, stream):
+        rc = lib.nastar_backward_replay_ordered(gh.data_ptr(), None, None, None, cost.data_ptr(), s.data_ptr(), g.data_ptr(), m.data_ptr(), log.data_ptr(), B,
+                                                H, W, G_RATIO, mi, it.data_ptr(), tb.data_ptr(), z["gc"].data_ptr(), z["ws"].data_ptr(), ws_bytes, 0,
+                                                order.data_ptr(), stream.cuda_stream)
+        _native.check(rc, "nastar_backward_replay_ordered")
+    res = {}
+    for k in (1, 2, 3, 4):
+        streams = [torch.cuda.Stream(dev) for _ in range(k)]
+        sets = [make_set() for _ in range(k)]
+        n = 24 * k
+        for i in range(2 * k):
+            launch(sets[i % k], streams[i % k])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            launch(sets[i % k], streams[i % k])
+        torch.cuda.synchronize(dev)
+        dtk = (time.perf_counter() - t0) / n
+        res[str(k)] = {"ms_per_batch": dtk * 1e3, "maps_per_s": B / dtk, "hbm_frac": alg_bytes / dtk / 1e9 / HBM_PEAK_GBS}
+    out["backward_replay_alone"] = {"streams": res, "algorithmic_bytes_per_batch": alg_bytes, "mean_steps_per_map": float(it.float().mean().item()),
+                                    "note": "nastar_backward_replay_ordered (hand-scheduled 32x32 loop, 16 B cell records + 16 B of history per step in LDS: 8 maps per "
+                                            "CU), k batches in flight on k streams; a map's replay is a serial chain exactly as long as its search was"}
     return out
 
 

@@ -22,6 +22,10 @@
 //   * kSplit ("f16x3", fp32-grade): activations are [hi(C) | lo(C)] fp16 pairs per pixel, the weights are packed over 3C virtual
 //     channels [W_hi | W_hi | W_lo] that meet the activation segments [x_hi | x_lo | x_hi] (nastar_encoder.hip.h); the epilogue
 //     emits both halves;
+//   * images wider than 126 pixels (round 6; the reference has no size limit, encoder.py:60-97, and its own test drives 64x128): the same
+//     kernel on 2-D tiles -- 64 columns x 4 rows of ONE image, one tile row per wavefront, staged with a one-pixel frame at pitch 66 (396
+//     slots); frame slots outside the image are staged as zeros, so a tap is again a constant slot offset (dy * 66 + dx) and the matrix
+//     loop is untouched: only the staging plan, the read plan and the epilogue's pixel index know about the mode (`wide`, wave-uniform);
 //   * epilogue: y = acc*scale + shift (folded BatchNorm / bias), optional ReLU, fp16 NHWC stores of 4 channels per lane (the MFMA D
 //     layout); kFinal: channel 0 only, sigmoid(y) * final_mul as fp32 [B,H,W] (encoder.py:32-34).
 // Workgroup ids are remapped so that the NT-channel blocks of one pixel tile run on the same XCD back to back (they re-read the
@@ -38,7 +42,10 @@ constexpr int FC_TP = 256;       // flat pixels per workgroup
 constexpr int FC_KS = 32;        // channels per LDS slice (two MFMA k-steps)
 constexpr int FC_PIXB = 64;      // bytes per pixel slot in LDS
 constexpr int FC_THREADS = 256;
-constexpr int FC_MAXW = 126;     // widest image row the staging registers cover (tile slots = 256 + 2W + 2 <= 8*64)
+constexpr int FC_MAXW = 126;     // widest image row the FLAT tiles' staging registers cover (tile slots = 256 + 2W + 2 <= 8*64); wider images: 2-D tiles
+constexpr int FC_WTW = 64, FC_WTH = 4;              // 2-D tile of the wide mode: 64 columns x 4 rows = the same 256 pixels, one tile row per wavefront
+constexpr int FC_WPITCH = FC_WTW + 2;               // its LDS pitch: a one-pixel frame around the tile ...
+constexpr int FC_WSLOTS = (FC_WTH + 2) * FC_WPITCH; // ... 6 x 66 = 396 slots (<= 512)
 constexpr int FC_NTQ = 8;        // 16-byte pixel chunks staged per thread and slice
 
 struct FlatConvArgs {
@@ -56,7 +63,8 @@ struct FlatConvArgs {
     int ups;               // 1: `in` is [B, H/2, W/2, C1], nearest-upsampled x2 on the fly
     int relu;
     int raw;               // kFinal: store y[channel 0] itself instead of sigmoid(y) * final_mul (training: BatchNorm follows)
-    int ntiles;            // ceil(npix / FC_TP)
+    int ntiles;            // ceil(npix / FC_TP)  (wide: B * ceil(H / 4) * ceil(W / 64))
+    int wide;              // 1: W > FC_MAXW -- 2-D tiles (FC_WTW x FC_WTH pixels of ONE image with a staged one-pixel frame) instead of flat pixel ranges
 };
 
 __device__ __forceinline__ int fc_slot_off(int slot, int c) { return FC_PIXB + slot * FC_PIXB + (((c + (slot >> 2)) & 3) << 4); }
@@ -73,8 +81,9 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     constexpr int NWQ = (NWC + FC_THREADS - 1) / FC_THREADS;  // ... per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: zero slot (64 B) | pixel slots | weights | scale, shift
+    const bool wide = a.wide != 0;
     const int halo = a.W + 1;
-    const int nslot = FC_TP + 2 * halo;
+    const int nslot = wide ? FC_WSLOTS : FC_TP + 2 * halo;
     unsigned char* wl = smem + FC_PIXB + (size_t)nslot * FC_PIXB;
     float* ss = reinterpret_cast<float*>(wl + (size_t)NWC * 16);
 
@@ -87,6 +96,15 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     if (tile >= a.ntiles) return;
     const int p0 = tile * FC_TP, n0 = nblk * NT;
     const int q0 = p0 - halo;  // flat pixel held by slot 0
+    // wide mode: tile -> (image, first row, first column)
+    int wb = 0, wy0 = 0, wx0 = 0;
+    if (wide) {
+        const int tx = (a.W + FC_WTW - 1) / FC_WTW, ty = (a.H + FC_WTH - 1) / FC_WTH;
+        wb = tile / (tx * ty);
+        const int r = tile - wb * (tx * ty);
+        wy0 = (r / tx) * FC_WTH;
+        wx0 = (r - (r / tx) * tx) * FC_WTW;
+    }
 
     const int CIN = a.C1 + a.C2;
     const int NSL = CIN / FC_KS;                 // slices per precision segment
@@ -105,8 +123,14 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     for (int i = 0; i < FC_NTQ; ++i) {
         const int idx = tid + i * FC_THREADS;
         const int c = idx & 3, slot = idx >> 2;
-        const int q = q0 + slot;
-        const bool ok = slot < nslot && q >= 0 && q < a.npix;
+        int q = q0 + slot;
+        bool ok = slot < nslot && q >= 0 && q < a.npix;
+        if (wide) {  // slot -> (row, column) of the framed 2-D tile; frame slots outside the image are zero fill
+            const int sr = slot / FC_WPITCH, sc = slot - sr * FC_WPITCH;
+            const int y = wy0 + sr - 1, x = wx0 + sc - 1;
+            ok = slot < nslot && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            q = (wb * a.H + y) * a.W + x;
+        }
         int o1 = -1, o2 = -1;
         if (ok) {
             if (a.ups) {
@@ -180,6 +204,8 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
             const bool ok = p < a.npix && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
             const int slot = lp + halo + dy * a.W + dx;
             baddr[tap][pb] = ok ? fc_slot_off(slot, kh) : (kh << 4);
+            // wide: wavefront = tile row, (pb, px) = tile column; the frame is staged (zeros outside the image): no select
+            if (wide) baddr[tap][pb] = fc_slot_off((wave + 1 + dy) * FC_WPITCH + pb * 32 + px + 1 + dx, kh);
         }
     }
 
@@ -227,8 +253,14 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
     if constexpr (kFinal) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
-            const int p = p0 + wave * 64 + pb * 32 + px;
-            if (p < a.npix && kh == 0 && nblk == 0) {
+            int p = p0 + wave * 64 + pb * 32 + px;
+            bool pv = p < a.npix;
+            if (wide) {
+                const int y = wy0 + wave, x = wx0 + pb * 32 + px;
+                pv = y < a.H && x < a.W;
+                p = (wb * a.H + y) * a.W + x;
+            }
+            if (pv && kh == 0 && nblk == 0) {
                 const float z = acc[pb][0][0] * ss[0] + ss[NT];
                 a.out_f32[p] = a.raw ? z : a.final_mul / (1.0f + __expf(-z));
             }
@@ -277,8 +309,14 @@ __global__ __launch_bounds__(FC_THREADS, 2) void nastar_conv3x3_flat_kernel(cons
                 for (int j = 0; j < 32 / PPR; ++j) {
                     const int q = j * PPR + lane / CPP, chunk = lane % CPP;
                     const uint4 v = *reinterpret_cast<const uint4*>(ob + q * (NT * 2) + ((chunk ^ ((q >> 1) & (CPP - 1))) << 4));
-                    const int p = p0 + wave * 64 + pb * 32 + q;
-                    if (p < a.npix) *reinterpret_cast<uint4*>(a.out + (size_t)p * ostride + part * a.COUT + n0 + chunk * 8) = v;
+                    int p = p0 + wave * 64 + pb * 32 + q;
+                    bool pv = p < a.npix;
+                    if (wide) {
+                        const int y = wy0 + wave, x = wx0 + pb * 32 + q;
+                        pv = y < a.H && x < a.W;
+                        p = (wb * a.H + y) * a.W + x;
+                    }
+                    if (pv) *reinterpret_cast<uint4*>(a.out + (size_t)p * ostride + part * a.COUT + n0 + chunk * 8) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
             }

@@ -23,7 +23,11 @@
 //   * no atomics: every workgroup stores its partial tile to part[split][tap][ci][co]; nastar_wgrad_reduce_kernel sums the splits in
 //     a fixed order (bitwise reproducible), applies out_scale (undoes the power-of-two gradient scale read from device memory) and
 //     writes torch's [co][ci][3][3] layout cropped to the real channel counts.
-// Shapes: 2 <= W <= 96, H a multiple of the chunk's row count R (nastar_wgrad_chunk_rows); CO, CI multiples of 32 (zero padded).
+//   * images wider than 96 pixels (round 6): a chunk row is a SEGMENT of an image row -- the widest divisor of the image width that is <= 96
+//     pixels (nastar_wgrad_segment) -- framed exactly like a whole row, except that a frame COLUMN now holds the neighbouring segment's pixel
+//     when there is one (in-image test per chunk: x0 + column); everything inside the matrix loop is unchanged.
+// Shapes: W >= 2 with a divisor in [2, 96] (any width <= 96; 128 -> 64, 160 -> 80, ...), H a multiple of the chunk's row count R
+// (nastar_wgrad_chunk_rows); CO, CI multiples of 32 (zero padded).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,7 +40,8 @@ struct WgradArgs {
     const uint16_t* dz;  // [P][CO (x2)] fp16 NHWC
     const uint16_t* a;   // [P][CI (x2)] fp16 NHWC (the layer's input activations)
     float* part;         // [nsplit][9][CI][CO] fp32 partial sums
-    int B, H, W, CO, CI;
+    int B, H, W, CO, CI; // W = width of a CHUNK row: the image width, or a segment of it (Wimg % W == 0) for images wider than 96 pixels
+    int Wimg, nseg;      // image width; segments per image row (1: W == Wimg)
     int R, G, NP, KS;    // chunk: G blocks of R image rows (G > 1: whole tiny images, R == H) = NP pixels = KS k-steps of 16 (KS*16 >= NP)
     int nchunk;          // B*H / R  (G == 1)  or  ceil(B / G)
     int nsplit;          // pixel splits: gridDim.x = nsplit * (CO/(32 COB)) * (CI/(32 CIB))
@@ -47,9 +52,18 @@ constexpr int WG_MAX_SLOTS = 200;       // (R+2)*(W+2) for W <= 64: 198 for W = 
 constexpr int WG_MAX_SLOTS_WIDE = 294;  // 64 < W <= 96: 3 x 98
 constexpr int WG_MAX_PIX = 96, WG_MAX_KS = 6;
 
-// rows per chunk for an H x W map, 0 = unsupported: 64-pixel chunks where W divides 64, otherwise the most rows with R*W <= 96
-inline int nastar_wgrad_chunk_rows(int H, int W)
+// width of a chunk row: the image width up to 96 pixels, otherwise its widest divisor <= 96 (0: none above 1 -- a prime width beyond 96)
+inline int nastar_wgrad_segment(int W)
 {
+    if (W <= WG_MAX_PIX) return W;
+    for (int d = WG_MAX_PIX; d >= 2; --d)
+        if (W % d == 0) return d;
+    return 0;
+}
+// rows per chunk for an H x W map, 0 = unsupported: 64-pixel chunks where the chunk row divides 64, otherwise the most rows with R*W <= 96
+inline int nastar_wgrad_chunk_rows(int H, int Wimg)
+{
+    const int W = nastar_wgrad_segment(Wimg);
     if (W < 2 || W > WG_MAX_PIX || H <= 0) return 0;
     if (64 % W == 0 && H % (64 / W) == 0) return 64 / W;
     for (int r = WG_MAX_PIX / W; r >= 1; --r)
@@ -60,7 +74,7 @@ inline int nastar_wgrad_chunk_rows(int H, int W)
 // frame in LDS, as many as fit 96 pixels and the 200 frame slots; 1 for everything else (then a chunk is R rows of ONE image)
 inline int nastar_wgrad_chunk_images(int H, int W)
 {
-    if (H * W > 48 || nastar_wgrad_chunk_rows(H, W) < H) return 1;
+    if (H * W > 48 || W > WG_MAX_PIX || nastar_wgrad_chunk_rows(H, W) < H) return 1;
     int g = WG_MAX_PIX / (H * W);
     const int by_slots = WG_MAX_SLOTS / ((H + 2) * (W + 2));
     if (g > by_slots) g = by_slots;
@@ -112,14 +126,16 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
     const int sdz = M * g.CO, sa = M * g.CI;      // fp16 elements per pixel in HBM
 
     // ---- staging plan (constants per thread): global element offset relative to the chunk's first pixel, LDS byte offset ----
-    int zsrc[NZ], zdst[NZ], zblk[NZ], asrc[NA], adst[NA], arow[NA], ablk[NA];
+    const int Wi = g.Wimg, BPi = RC * Wi;  // image row pitch / pixels per block in HBM (== W, BP unless the chunk rows are segments)
+    int zsrc[NZ], zdst[NZ], zblk[NZ], asrc[NA], adst[NA], arow[NA], ablk[NA], acol[NA];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const int q = tid + i * NTHR;
         const int pix = q / CPZ, c = q - pix * CPZ;
         const int half = c / (COB * 4), cc = c - half * (COB * 4);
         const bool ok = q < NP * CPZ;
-        zsrc[i] = ok ? pix * sdz + half * g.CO + co0 + cc * 8 : -1;
+        const int zr = (pix % BP) / W, zc = pix - (pix / W) * W;  // row / column inside the block (a block = R chunk rows of W pixels)
+        zsrc[i] = ok ? ((pix / BP) * BPi + zr * Wi + zc) * sdz + half * g.CO + co0 + cc * 8 : -1;
         zdst[i] = pix * RDZ + half * (COB * 64) + cc * 16;
         zblk[i] = pix / BP;  // which image of the chunk (0 when G == 1)
     }
@@ -131,12 +147,12 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         const int gi = slot / BS, sb = slot - gi * BS;
         const int sr = sb / PW, sc = sb - sr * PW;
         const bool ok = q < nslot_a * CPA;
-        const bool inx = sc >= 1 && sc <= W;
-        // relative to the chunk's first pixel (row y0, column 0): block gi, (sr - 1) rows up/down, column sc - 1
-        asrc[i] = (gi * BP + (sr - 1) * W + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
+        // relative to the chunk's first pixel (row y0, column x0): block gi, (sr - 1) rows up/down, column sc - 1
+        asrc[i] = (gi * BPi + (sr - 1) * Wi + (sc - 1)) * sa + half * g.CI + ci0 + cc * 8;
         ablk[i] = gi;
         adst[i] = ok ? ZROWS * RDZ + slot * RA + half * (CIB * 64) + cc * 16 : -1;
-        arow[i] = (ok && inx) ? sr - 1 : -(1 << 28);  // image row offset of the slot; hugely negative = always zero (frame column / unused)
+        arow[i] = ok ? sr - 1 : -(1 << 28);  // image row offset of the slot; hugely negative = always zero (unused)
+        acol[i] = sc - 1;                    // image column offset of the slot: a frame column is zero unless a neighbouring segment holds it
     }
 
     // ---- per-lane fragment addresses (constants): k-step ks, read half tt: pixel = 16 ks + 8 kh + 4 tt + (r16 >> 2) ----
@@ -167,14 +183,16 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    const int rows_per_img = g.H / RC;  // chunks per image
+    const int rows_per_img = g.H / RC;  // chunk rows per image (x nseg chunks each)
     uint4 zq[NZ], aq[NA];
     auto load_chunk = [&](int ch) {
         // G == 1: rows [y0, y0 + R) of image b;  G > 1: whole images [b, b + G), the last chunk possibly fewer (gcount)
-        const int b = g.G > 1 ? ch * g.G : ch / rows_per_img;
-        const int y0 = g.G > 1 ? 0 : (ch - b * rows_per_img) * RC;
+        const int cr = g.G > 1 ? 0 : ch / g.nseg;          // chunk row (over all images), segment of it
+        const int x0 = g.G > 1 ? 0 : (ch - cr * g.nseg) * W;
+        const int b = g.G > 1 ? ch * g.G : cr / rows_per_img;
+        const int y0 = g.G > 1 ? 0 : (cr - b * rows_per_img) * RC;
         const int gcount = g.G > 1 ? (g.B - b < g.G ? g.B - b : g.G) : 1;
-        const size_t p0 = ((size_t)b * g.H + y0) * W;
+        const size_t p0 = ((size_t)b * g.H + y0) * Wi + x0;
         const uint16_t* zb = g.dz + p0 * sdz;
         const uint16_t* ab = g.a + (ptrdiff_t)p0 * sa;
 #pragma unroll
@@ -185,7 +203,8 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             aq[i] = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)(y0 + arow[i]) < (unsigned)g.H && ablk[i] < gcount) aq[i] = *reinterpret_cast<const uint4*>(ab + asrc[i]);
+            if ((unsigned)(y0 + arow[i]) < (unsigned)g.H && (unsigned)(x0 + acol[i]) < (unsigned)Wi && ablk[i] < gcount)
+                aq[i] = *reinterpret_cast<const uint4*>(ab + asrc[i]);
         }
     };
     auto store_chunk = [&]() {

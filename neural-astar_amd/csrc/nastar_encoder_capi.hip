@@ -510,7 +510,7 @@ template <int NT, bool kFinal, bool kSplit>
 static int launch_flat(const FlatConvArgs& fa, hipStream_t s)
 {
     auto kern = &nastar_conv3x3_flat_kernel<NT, kFinal, kSplit>;
-    const size_t lds = (size_t)FC_PIXB + (size_t)(FC_TP + 2 * (fa.W + 1)) * FC_PIXB + (size_t)9 * 4 * NT * 16 + (size_t)NT * 8;
+    const size_t lds = (size_t)FC_PIXB + (size_t)(fa.wide ? FC_WSLOTS : FC_TP + 2 * (fa.W + 1)) * FC_PIXB + (size_t)9 * 4 * NT * 16 + (size_t)NT * 8;
     int rc = ensure_lds(kern, lds);
     if (rc) return rc;
     const unsigned grid = (unsigned)(((fa.ntiles + 7) / 8) * 8 * (fa.COUT / NT));
@@ -532,7 +532,7 @@ int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* 
                split = flags & NASTAR_CONV_SPLIT;
     if (!in || !wpack || !scale || !shift || (fin ? !out_f32 : !out) || (c2 > 0 && !in2)) return NASTAR_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || c1 <= 0 || c2 < 0 || cout <= 0) return NASTAR_ERR_BAD_SHAPE;
-    if (c1 % FC_KS || c2 % FC_KS || cout % 32 || W > FC_MAXW || (fin && cout != 32) || (ups && ((H | W) & 1))) return NASTAR_ERR_UNSUPPORTED;
+    if (c1 % FC_KS || c2 % FC_KS || cout % 32 || (fin && cout != 32) || (ups && ((H | W) & 1))) return NASTAR_ERR_UNSUPPORTED;
     const long long npix = (long long)B * H * W;
     const long long widest = (long long)(split ? 2 : 1) * (c1 > c2 ? (c1 > cout ? c1 : cout) : (c2 > cout ? c2 : cout));
     if (npix >= (1ll << 31) || npix * widest >= (1ll << 34)) return NASTAR_ERR_UNSUPPORTED;  // 32-bit offsets in 16-byte units
@@ -541,6 +541,8 @@ int nastar_conv3x3_f16(const uint16_t* in, const uint16_t* in2, const uint16_t* 
     fa.in = in; fa.in2 = in2; fa.wpack = wpack; fa.scale = scale; fa.shift = shift; fa.out = out; fa.out_f32 = out_f32;
     fa.final_mul = final_mul; fa.B = B; fa.H = H; fa.W = W; fa.C1 = c1; fa.C2 = c2; fa.COUT = cout; fa.npix = (int)npix;
     fa.ups = ups ? 1 : 0; fa.relu = relu ? 1 : 0; fa.raw = (flags & NASTAR_CONV_RAW) ? 1 : 0; fa.ntiles = (int)((npix + FC_TP - 1) / FC_TP);
+    fa.wide = W > FC_MAXW ? 1 : 0;  // images wider than the flat tiles' halo allows: 2-D tiles (64 x 4 pixels of one image, framed)
+    if (fa.wide) fa.ntiles = B * ((H + FC_WTH - 1) / FC_WTH) * ((W + FC_WTW - 1) / FC_WTW);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (fin) return split ? launch_flat<32, true, true>(fa, s) : launch_flat<32, true, false>(fa, s);
     if (cout % 64 == 0) return split ? launch_flat<64, false, true>(fa, s) : launch_flat<64, false, false>(fa, s);

@@ -48,7 +48,8 @@ size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci)
     const int R = nastar_wgrad_chunk_rows(H, W);
     if (R == 0) return 0;
     const int G = nastar_wgrad_chunk_images(H, W);
-    const int nchunk = G > 1 ? (B + G - 1) / G : (int)(((long long)B * H) / R);
+    const int nseg = W / nastar_wgrad_segment(W);
+    const int nchunk = G > 1 ? (B + G - 1) / G : (int)(((long long)B * H) / R) * nseg;
     return (size_t)wgrad_nsplit(nchunk, co, ci) * 9 * ci * co * sizeof(float);
 }
 
@@ -64,10 +65,11 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
     if (workspace_bytes < nastar_conv3x3_wgrad_workspace_bytes(B, H, W, co, ci)) return NASTAR_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     WgradArgs g;
-    g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.W = W; g.CO = co; g.CI = ci;
+    g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.CO = co; g.CI = ci;
+    g.Wimg = W; g.W = nastar_wgrad_segment(W); g.nseg = W / g.W;  // images wider than 96 pixels: chunk rows are segments of an image row
     g.G = nastar_wgrad_chunk_images(H, W);
-    g.R = R; g.NP = g.G * R * W; g.KS = (g.NP + 15) / 16;
-    g.nchunk = g.G > 1 ? (B + g.G - 1) / g.G : (int)(((long long)B * H) / R);
+    g.R = R; g.NP = g.G * R * g.W; g.KS = (g.NP + 15) / 16;
+    g.nchunk = g.G > 1 ? (B + g.G - 1) / g.G : (int)(((long long)B * H) / R) * g.nseg;
     g.nsplit = wgrad_nsplit(g.nchunk, co, ci);
     const bool co2 = co % 64 == 0, ci2 = ci % 64 == 0;
     int rc;

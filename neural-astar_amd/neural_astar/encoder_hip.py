@@ -418,8 +418,8 @@ class HipUnetEncoder:
         lib = _native.load()
         m = map_designs[:, 0].contiguous()
         B, H, W = m.shape
-        if H % self.size_multiple or W % self.size_multiple or W > 126:
-            raise NotImplementedError(f"H, W must be multiples of {self.size_multiple} and W <= 126")
+        if H % self.size_multiple or W % self.size_multiple:
+            raise NotImplementedError(f"H, W must be multiples of {self.size_multiple}")
         dev = m.device
         s = start_maps[:, 0].contiguous() if plus else None
         g = goal_maps[:, 0].contiguous() if plus else None
@@ -466,7 +466,7 @@ class HipUnetEncoder:
 
 
 class HipFlatCnnEncoder(HipUnetEncoder):
-    """Eval-mode ``planner.encoder.CNN`` of ANY depth on maps of ANY size (W <= 126) through the same generic fp16 / f16x3 MFMA
+    """Eval-mode ``planner.encoder.CNN`` of ANY depth on maps of ANY size through the same generic fp16 / f16x3 MFMA
     convolution: what ``NeuralAstar.encode`` uses when the fixed-shape kernels of ``HipCnnEncoder`` (depth 4, H and W multiples of
     32 / 16) do not apply -- e.g. 20x45 or 24x40 maps, ``encoder_depth=3``."""
 

@@ -373,8 +373,20 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() and t.dtype == torch.float32 else t.float().contiguous()
 
 
+def wgrad_segment(W: int) -> int:
+    """width of a weight-gradient chunk row (csrc/nastar_conv_wgrad.hip.h: nastar_wgrad_segment): the image width up to 96 pixels, else its
+    widest divisor <= 96 (0: a width beyond 96 without a divisor above 1 -- a prime)"""
+    if W <= 96:
+        return W
+    for d in range(96, 1, -1):
+        if W % d == 0:
+            return d
+    return 0
+
+
 def chunk_rows(H: int, W: int) -> int:
     """rows per weight-gradient chunk (csrc/nastar_conv_wgrad.hip.h: nastar_wgrad_chunk_rows); 0 = unsupported shape"""
+    W = wgrad_segment(W)
     if W < 2 or W > 96 or H <= 0:
         return 0
     if 64 % W == 0 and H % (64 // W) == 0:
@@ -386,13 +398,14 @@ def chunk_rows(H: int, W: int) -> int:
 
 
 def supported_shape(H: int, W: int, depth: int = 4, pool: bool = False) -> bool:
-    """every resolution the stack visits must suit the weight-gradient kernel (whole image rows per <= 96-pixel chunk) and the
-    generic convolution (W <= 126); pooling stacks halve the resolution after every hidden block"""
+    """every resolution the stack visits must suit the weight-gradient kernel (<= 96-pixel chunks of whole image rows, or of row segments for
+    images wider than 96 pixels: the width then needs a divisor in [2, 96]); pooling stacks halve the resolution after every hidden block.
+    (The generic convolution takes any width since round 6: 2-D tiles beyond 126 pixels.)"""
     for l in range(depth + 1):
         h, w = (H >> l, W >> l) if pool else (H, W)
         if pool and l < depth and ((h | w) & 1):
             return False
-        if chunk_rows(h, w) == 0 or w > 126:
+        if chunk_rows(h, w) == 0:
             return False
     return True
 
@@ -1027,7 +1040,7 @@ def unet_supported(unet: nn.Module, H: int, W: int) -> bool:
     if not isinstance(model, VggUnet):
         return False
     depth = model.depth
-    if H % (1 << depth) or W % (1 << depth) or W > 126:
+    if H % (1 << depth) or W % (1 << depth):
         return False
     # every convolution but the 1-channel head must produce a multiple of 32 channels (the training kernels do not pad outputs; the
     # inference path does): encoder_depth = 5 ends in a 16-channel decoder block and stays on torch.nn -- decided HERE, before any
@@ -1067,7 +1080,7 @@ def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: t
     in TRAINING mode, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
     B, _, H, W = map_designs.shape
     if not unet_supported(unet, H, W):
-        raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (W <= 126)")
+        raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (and whose widths suit the weight-gradient chunks)")
     plan, params = unet_training_plan(unet.model)
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")

@@ -127,7 +127,7 @@ class NeuralAstar(VanillaAstar):
                 and isinstance(self.encoder, encoder.Unet) and isinstance(self.encoder.model, encoder.VggUnet)
                 and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
                 and map_designs.shape[-2] % (1 << self.encoder.model.depth) == 0
-                and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0 and map_designs.shape[-1] <= 126):
+                and map_designs.shape[-1] % (1 << self.encoder.model.depth) == 0):
             # Unet(vgg16_bn): generic fp16 MFMA convolution (csrc/nastar_conv_flat.hip.h); "hip_f16x3" = split operands, fp32-grade
             precision = "f16x3" if backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipUnetEncoder
@@ -172,7 +172,7 @@ class NeuralAstar(VanillaAstar):
             return self._routed(f"hip:CNN-infer-img32/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
         if (backend.startswith("hip") and not self.training and not torch.is_grad_enabled()
                 and type(self.encoder) is encoder.CNN and map_designs.shape[1] == 1 and map_designs.shape[-2:] == start_maps.shape[-2:]
-                and map_designs.shape[-1] <= 126 and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
+                and self.encoder.model[0].in_channels == 1 + int("+" in self.encoder_input)):
             # any other depth / map size: the generic fp16 MFMA convolution ("hip_f16x3" = split operands, otherwise plain fp16)
             precision = "f16x3" if backend == "hip_f16x3" else "f16"
             from ..encoder_hip import HipFlatCnnEncoder

@@ -57,8 +57,22 @@ def test_astar_on_rectangle(setup):
     map_designs = torch.concat((map_designs, map_designs), -1)
     start_maps = torch.concat((start_maps, torch.zeros_like(start_maps)), -1)
     goal_maps = torch.concat((torch.zeros_like(goal_maps), goal_maps), -1)
-    output = NeuralAstar().cuda()(map_designs, start_maps, goal_maps)
+    import warnings
+    planner = NeuralAstar().cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # (a fall-through to torch.nn would warn)
+        output = planner(map_designs, start_maps, goal_maps)
     assert output.histories.shape == (8, 1, 64, 128)
+    # round 6: the reference's own rectangle scenario -- 64 x 128, training mode, gradients on -- runs on the MI355X encoder kernels (2-D conv
+    # tiles beyond 126 pixels per row, weight-gradient chunks of row segments), not on torch.nn / MIOpen
+    assert planner.last_encoder_route.startswith("hip:CNN-train"), planner.last_encoder_route
+    output.histories.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in planner.encoder.parameters() if p.requires_grad)
+    planner.eval()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        planner(map_designs, start_maps, goal_maps)
+    assert planner.last_encoder_route.startswith("hip:CNN-infer"), planner.last_encoder_route
     g = G.load("rect64x128_g050")  # the search-only part of this scenario, reference answer
     out_v = VanillaAstar().cuda()(map_designs, start_maps, goal_maps)
     assert np.array_equal(out_v.histories.cpu().numpy(), np.repeat(g.histories[:1], 8, 0))

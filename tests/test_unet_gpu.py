@@ -73,6 +73,10 @@ CASES = [
     (6, 96, 96, 32, 0, 32, True, False, True),
     (1, 40, 56, 96, 0, 64, True, False, True),
     (40, 2, 2, 512, 512, 256, True, True, False),   # deepest decoder block: 1024 input channels
+    (2, 6, 127, 32, 0, 32, False, False, False),    # round 6: rows wider than the flat tiles' halo -- 2-D tiles (64 x 4 pixels of one image);
+    (3, 64, 128, 32, 0, 64, True, False, True),     # the reference's rectangle scenario (tests/astar_test.py:45-53)
+    (2, 10, 200, 64, 0, 32, True, False, True),     # partial tiles both ways (200 = 3 x 64 + 8, 10 = 2 x 4 + 2)
+    (2, 8, 256, 32, 64, 64, True, True, False),     # upsample + concat at 256 pixels per row
 ]
 
 
@@ -215,7 +219,8 @@ def test_unet_encoder_matches_torch(precision, tol_truth, tol_torch):
 
 
 @pytest.mark.parametrize("depth,H,W,enc_in,precision,tol", [(3, 20, 45, "m+", "f16x3", 1e-5), (2, 24, 40, "m", "f16x3", 1e-5),
-                                                             (4, 20, 45, "m+", "f16", 2e-2), (4, 12, 12, "m+", "bf16", 2e-2)])
+                                                             (4, 20, 45, "m+", "f16", 2e-2), (4, 12, 12, "m+", "bf16", 2e-2),
+                                                             (4, 24, 200, "m+", "f16x3", 1e-5), (3, 150, 130, "m", "f16x3", 1e-5)])
 def test_cnn_of_any_depth_and_size_takes_the_generic_kernel(depth, H, W, enc_in, precision, tol):
     """CNN encoders the fixed-shape kernels do not cover (depth != 4, H / W not multiples of 32 or 16) run on the generic fp16 MFMA
     convolution instead of falling back to torch.nn (reference encoder.py:60-78 at any encoder_depth)."""
