@@ -527,26 +527,28 @@ def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
     g12[:, 0, -1, -1] = 1
     r = routes(NeuralAstar(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3, const=10.0, learn_obstacles=True, Tmax=0.25), img, s12, g12)
     assert r == {"eval": "hip:CNNDownSize-infer/f32", "train": "hip:CNNDownSize-train/f16x3"}, r
-    # a map wider than the generic convolution's row tile (126 px): torch.nn, said out loud once
+    # a map wider than the generic convolution's flat row tile (126 px): round 6 -- 2-D tiles, still the kernels (eval and train)
     wide = torch.ones(2, 1, 8, 160, device=dev)
     sw = torch.zeros_like(wide)
     gw = torch.zeros_like(wide)
     sw[:, 0, 0, 0] = 1
     gw[:, 0, 7, 159] = 1
+    r = routes(NeuralAstar(encoder_arch="CNN", encoder_depth=2, Tmax=0.25), wide, sw, gw)
+    assert r == {"eval": "hip:CNN-infer-flat/f16x3", "train": "hip:CNN-train/f16x3"}, r
+    # what the kernels still do not take -- EVAL mode with gradients on (BatchNorm on running statistics under autograd): torch.nn, said out loud once
     na = NeuralAstar(encoder_arch="CNN", encoder_depth=2).to(dev).eval()
-    with torch.no_grad():
-        with pytest.warns(RuntimeWarning, match="not covered by the MI355X encoder kernels"):
-            na(wide, sw, gw)
-        assert na.last_encoder_route.startswith("torch.nn (fell through from hip_f16x3")
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")
-            na(wide, sw, gw)  # once per reason
-        na.encoder_backend = "hip_strict"
-        with pytest.raises(RuntimeError, match="hip_strict"):
-            na(wide, sw, gw)
-        na.encoder_backend = "torch"
+    with pytest.warns(RuntimeWarning, match="not covered by the MI355X encoder kernels"):
         na(wide, sw, gw)
-        assert na.last_encoder_route == "torch.nn"
+    assert na.last_encoder_route.startswith("torch.nn (fell through from hip_f16x3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        na(wide, sw, gw)  # once per reason
+    na.encoder_backend = "hip_strict"
+    with pytest.raises(RuntimeError, match="hip_strict"):
+        na(wide, sw, gw)
+    na.encoder_backend = "torch"
+    na(wide, sw, gw)
+    assert na.last_encoder_route == "torch.nn"
 
 
 def test_validation_pass_in_flight_equals_the_per_batch_steps(tmp_path):

@@ -3,12 +3,13 @@
 #   1. rocprofv3 kernel trace + stats of the default bench command (N=1; hinted placement, and once more with --placement natural) -> kernel_stats
 #   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slot limit), kernel-trace only
 #   3. SQ counters of the shipped forward kernel and, for comparison, of other streams / layouts (SQ_FLAGS, default "0 128 64":
-#      round-4 stream, round-3 stream, unit-cost layout)
+#      general layout, unit-cost layout; the older instruction streams need NASTAR_LIB=.../libnastar_hip_dev.so since round 6)
 #   4. kernel stats of the fused training step (forward with selection log + replay backward), 4096 maps, Tmax = 0.25
+#   5. (round 6) per-kernel table of the ENCODERS: CNN f16x3 / bf16 inference and one f16x3 training step on 4096 maps of 32x32
 # Usage: tools/profile_round.sh r03   -> writes gpurun_out/profiles_<tag>/ (copy the summaries into profiles/<tag>/)
 set -u
 TAG=${1:-r04}
-SQ_FLAGS=${SQ_FLAGS:-0 128 64}
+SQ_FLAGS=${SQ_FLAGS:-0 64}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -43,14 +44,46 @@ for _ in range(20):
 torch.cuda.synchronize()
 PY
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/train -o train --output-format csv -- python /tmp/train_step.py > $OUT/train.log 2>&1
+cat > /tmp/encoder_step.py <<PY
+import sys
+sys.path[:0] = ["$R/neural-astar_amd", "$R"]
+import torch
+from neural_astar.planner import NeuralAstar
+from neural_astar.utils import synthetic as syn
+dev = torch.device("cuda:0")
+pr = syn.maze_maps(4096, 32, seed=1234)
+m, s, g = (torch.from_numpy(x).to(dev).contiguous() for x in pr)
+torch.manual_seed(0)
+na = NeuralAstar(encoder_arch="CNN", encoder_depth=4).to(dev)
+mode = sys.argv[1]
+if mode == "train":
+    na.train()
+    na.encoder_backend = "hip_f16x3"
+    for _ in range(4):
+        for p in na.parameters():
+            p.grad = None
+        c = na.encode(m, s, g)
+        (c * 1e-6).sum().backward()
+else:
+    na.eval()
+    na.encoder_backend = "hip_" + mode
+    with torch.no_grad():
+        for _ in range(6):
+            na.encode(m, s, g)
+torch.cuda.synchronize()
+PY
+for M in f16x3 bf16 train; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/enc_$M -o enc --output-format csv -- python /tmp/encoder_step.py $M > $OUT/enc_$M.log 2>&1
+done
 python - <<PY
 import csv, glob, json, collections
 out = {}
 for tag, pat in (("bench_kernel_stats", "$OUT/trace/**/*kernel_stats.csv"), ("bench_natural_order_kernel_stats", "$OUT/trace_natural/**/*kernel_stats.csv"),
-                 ("train_step_kernel_stats", "$OUT/train/**/*kernel_stats.csv")):
+                 ("train_step_kernel_stats", "$OUT/train/**/*kernel_stats.csv"), ("encoder_cnn_f16x3_infer_kernel_stats", "$OUT/enc_f16x3/**/*kernel_stats.csv"),
+                 ("encoder_cnn_bf16_infer_kernel_stats", "$OUT/enc_bf16/**/*kernel_stats.csv"), ("encoder_cnn_f16x3_train_kernel_stats", "$OUT/enc_train/**/*kernel_stats.csv")):
     for f in glob.glob(pat, recursive=True):
         rows = list(csv.DictReader(open(f)))
-        out[tag] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in rows[:6]]
+        out[tag] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs", "Percentage")} for r in rows[:14]]
         open("$OUT/%s.csv" % tag, "w").write(open(f).read())
 def counters(pat):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
