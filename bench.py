@@ -806,9 +806,12 @@ def main():
         # the dominant kernel's duration: HIP events around single launches on the launch stream, same placement as the headline
         krun = Runner(sets[:per_pass] if n_fresh else sets, dev, placement=args.placement)
         avg_ms, med_ms, min_ms = kernel_launch_ms(krun, min(args.steps, 100), dev)
-        krun_n = Runner(sets[:per_pass] if n_fresh else sets, dev, placement="natural")
-        nat_ms = kernel_launch_ms(krun_n, min(args.steps, 100), dev)[0]
-        del krun, krun_n
+        nat_ms = None
+        if not args.no_natural:  # (--no-natural: a kernel profile of this run must hold ONE placement)
+            krun_n = Runner(sets[:per_pass] if n_fresh else sets, dev, placement="natural")
+            nat_ms = kernel_launch_ms(krun_n, min(args.steps, 100), dev)[0]
+            del krun_n
+        del krun
         achieved = bytes_moved_per_map * b_rank / (avg_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -871,8 +874,8 @@ def main():
                          "kernel": "nastar_forward_compact_kernel (hand-scheduled step loop: nastar_search_asm4.hip.h)",
                          "launch_ms_avg": avg_ms, "launch_ms_median": med_ms, "launch_ms_min": min_ms,
                          "launch_ms_avg_natural_order": nat_ms,
-                         "frac_natural_order": bytes_moved_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "launch_ms_note": "HIP events around single launches on the launch stream, measured in THIS run on never-searched batches, placement as the headline",
+                         "frac_natural_order": (bytes_moved_per_map * b_rank / (nat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if nat_ms else None,
+                         "launch_ms_note": "HIP events around single bare launches (C ABI, preallocated outputs) on the launch stream, measured in THIS run on the headline pass's batches, placement as the headline",
                          "committed_kernel_profile_us": kprof["avg_us"] if kprof else None,
                          "committed_kernel_profile_source": kprof["source"] if kprof else None,
                          "committed_frac_from_kernel_profile": (bytes_moved_per_map * b_rank / (kprof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if kprof else None},

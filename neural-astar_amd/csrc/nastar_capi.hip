@@ -467,6 +467,11 @@ thread_local char g_last_error[256] = "";
 // maps whose state lives in HBM: three levels (cell -> chunk minimum per 64 cells -> super-chunk minimum per 64 chunks), the two minima arrays in
 // LDS: 8 B per 64 cells must fit one CU -- 1,179,648 cells (1024 x 1152; 1024 x 1024 takes 130 KiB)
 constexpr long long kMaxGlobalCells = 1179648;
+// from 12288 cells (~111 x 111) on the large-map kernel is the faster one although the compact state would still fit LDS up to ~17 k cells: the
+// compiled LDS loop scans HW / 1024 chunk entries per lane and step (1.5-1.9 us per step at 128x128), the hybrid step does not grow with the map
+// (0.9-1.5 us) and keeps 32 instead of 1 maps resident per CU.  Measured (tools/probe_large.py mid, profiles/r06/probe_mid.jsonl): 96x96 LDS
+// 1.2-1.3x faster, 112x112 equal (one map) to 1.1-1.8x slower (batches), 128x128 1.3-2.2x slower.
+constexpr long long kHybridFromCells = 12288;
 constexpr size_t kOrderCheckBytes = 16;                // NASTAR_FLAG_CHECK_ORDER: verdict word at the end of the workspace
 
 // maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
@@ -508,9 +513,23 @@ static int make_cdims(int B, int H, int W, int max_iters, double g_ratio, Compac
 }
 
 // maps whose compact state (9 B/cell, nastar_search_compact.hip.h) does not fit the 160 KiB of one CU keep it in HBM
+// cells from which a map takes the large-map kernel although its compact state would still fit LDS (the compiled LDS loop scans CPL = HW / 1024
+// chunk entries per lane and step; the hybrid kernel's step does not grow with the map).  NASTAR_HYBRID_FROM_CELLS overrides it (probes).
+static long long hybrid_from_cells()
+{
+    static long long v = -1;
+    if (v < 0) {
+        const char* e = getenv("NASTAR_HYBRID_FROM_CELLS");
+        v = (e && *e) ? atoll(e) : kHybridFromCells;
+        if (v < 4097) v = 4097;  // (the hand-scheduled 64x64 stream and everything below it stay LDS-resident)
+    }
+    return v;
+}
+
 static bool needs_global_state(int H, int W)
 {
     const long long HW = (long long)H * W;
+    if (HW >= hybrid_from_cells()) return true;
     if (HW > 65535 - CCSZ) return true;
     const long long nchunks = (HW + CCSZ - 1) / CCSZ;
     return compact_lds_bytes((int)(nchunks * CCSZ), (int)(((nchunks + 63) / 64) * 64)) > kMaxLdsBytes;

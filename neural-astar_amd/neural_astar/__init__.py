@@ -5,4 +5,4 @@ Only the hot path is re-implemented: ``neural_astar.planner.{VanillaAstar, Neura
 encoders (CNN, CNNDownSize, Unet) run inference and training on MFMA kernels (``planner.encoder_backend``: "auto" = "hip_f16x3" on a
 HIP device; "torch" keeps torch.nn).
 """
-__version__ = "0.4.0"
+__version__ = "0.6.0"  # == NASTAR_VERSION 600 of include/nastar.h (tests/test_capi_library.py checks the pair)

@@ -458,13 +458,20 @@ class _CnnTrunk(torch.autograd.Function):
                 z = torch.empty((npix * cout * mult,), dtype=torch.int16, device=dev)
                 L.conv(acts[-1], wpack, scale, shift, B, h, w, cin_p, cout, sflag, out=z)
                 bn = cfg["bns"][l]
-                track = bn is not None and bn.track_running_stats and bn.running_mean is not None
+                track = bn is not None and bn.track_running_stats and bn.running_mean is not None and not cfg.get("eval_bn")
                 mom = 0.0
                 if track:  # nn.BatchNorm2d's training-mode side effect (unbiased variance), done inside the coefficient kernel
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     tracked.append(bn.num_batches_tracked)
                 gam, bet = gammas[l].detach(), betas[l].detach()
-                if not sync:  # partial rows, then finish + coefficients in one kernel
+                if cfg.get("eval_bn"):
+                    # EVAL-mode BatchNorm under autograd (module.eval() with gradients on): the coefficients come from the RUNNING statistics,
+                    # nothing is updated; [C]-sized host-side tensor math (a handful of tiny launches on a rare path)
+                    invstd = torch.rsqrt(bn.running_var.double() + float(cfg["eps"][l]))
+                    mean = bn.running_mean.double().clone()
+                    k2 = (gam.double() * invstd).float()
+                    k3 = (bet.double() - mean * gam.double() * invstd).float()
+                elif not sync:  # partial rows, then finish + coefficients in one kernel
                     mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, gam, bet, cfg["eps"][l], mom, bn.running_mean if track else None,
                                                     bn.running_var if track else None)
                 else:  # data parallel: the sums of the GLOBAL batch go through an all-reduce between the halves
@@ -541,6 +548,7 @@ class _CnnTrunk(torch.autograd.Function):
             # gradients travel multiplied by a power of two S (device scalar `gscale`, re-centred per block): scaled values peak near
             # 2^10, so fp16 neither overflows nor loses the small terms; S is divided out inside the weight-gradient / coefficient kernels
             gscale, amax = L.f32(1), L.f32(1)
+            bias_grads = {}  # eval-mode BatchNorm only: conv-bias gradients of the hidden blocks
             top = D
             # closing convolution as streams: its weight gradient from d itself, its input gradient never stored -- the BatchNorm backward
             # of block D forms it on the fly (not for pooling stacks, whose gradient passes through the max-pool first)
@@ -553,23 +561,27 @@ class _CnnTrunk(torch.autograd.Function):
                     if ctx.fuse_act:
                         return L.wgrad_co1(d, ctx.zs[D - 1], B, h, w, C, split, ctx.coef[D - 1][2], ctx.coef[D - 1][3])
                     return L.wgrad_co1(d, ctx.acts[D], B, h, w, C, split)
-                if not ctx.sync_state[0]:
+                # eval-mode BatchNorm = the batch-statistics closed form in the limit of infinitely many pixels (the mean terms vanish): the
+                # unfused path below with npix -> 1e30 and the running statistics as mean / invstd; dgamma / dbeta need the same sums
+                eval_bn = bool(cfg.get("eval_bn"))
+                unfused = ctx.sync_state[0] or eval_bn
+                if not unfused:
                     grads[4 * D] = closing_wgrad()
                 grads[4 * D + 1] = torch.empty_like(params[4 * D + 1])
                 z = ctx.zs[D - 1]
                 mean, invstd, k2f, k3f = ctx.coef[D - 1]
                 wlc = _f32c(wl)
                 gs_new = L.f32(1)
-                if not ctx.sync_state[0]:
+                if not unfused:
                     dgamma, dbeta, c1, c2, c3 = L.bn_bwd_u1(d, wlc, B, h, w, z, k2f, k3f, C, split, mean, invstd, gammas[D - 1].detach(), gscale, gs_new)
-                else:  # data parallel: the sums of the GLOBAL batch (all-reduced between the statistics and the coefficients)
+                else:  # data parallel: the sums of the GLOBAL batch (all-reduced between the statistics and the coefficients); or eval mode
                     sums = L.stats_u1(d, wlc, gscale, B, h, w, z, k2f, k3f, C, split, amax)
                     work = _sync_sums_begin(sums, gscale, ctx.sync_state)
                     grads[4 * D] = closing_wgrad()  # beside the collective, which it does not need
                     world = _sync_sums_end(work, sums, gscale, ctx.sync_state)
                     dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                     rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                     gammas[D - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), gs_new.data_ptr(),
+                                                     gammas[D - 1].detach().data_ptr(), (1 << 62) if eval_bn else npix * world, gscale.data_ptr(), gs_new.data_ptr(),
                                                      dgamma.data_ptr(), dbeta.data_ptr(), c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
                     _native.check(rc, "nastar_bn_coef_bwd_io")
                     if world > 1:  # the flat gradient all-reduce AVERAGES over the ranks
@@ -577,6 +589,9 @@ class _CnnTrunk(torch.autograd.Function):
                         dbeta /= world
                 grads[4 * (D - 1) + 2] = dgamma
                 grads[4 * (D - 1) + 3] = dbeta
+                if eval_bn:  # the conv bias in front of an EVAL-mode BatchNorm has a gradient: sum_p dz = gamma invstd sum_p dy
+                    nb = params[4 * (D - 1) + 1].numel()
+                    bias_grads[D - 1] = (dbeta[:nb].double() * gammas[D - 1].detach().double()[:nb] * invstd[:nb]).float()
                 dzb = torch.empty((npix * C * mult,), dtype=torch.int16, device=dev)
                 L.affine_u1(d, wlc, gscale, B, h, w, z, c1, c2, c3, k2f, k3f, dzb, C, split)
                 gscale = gs_new
@@ -593,7 +608,9 @@ class _CnnTrunk(torch.autograd.Function):
                 cin_p = _pad32(cin)
                 # data-parallel (sync) steps launch this layer's weight gradient BESIDE the all-reduce of the next BatchNorm backward's
                 # sums (below): it needs neither, and a small collective costs ~80 us of latency even in a 1-rank group
-                late_wgrad = ctx.sync_state[0] and l > 0
+                eval_bn = bool(cfg.get("eval_bn"))
+                unfused = ctx.sync_state[0] or eval_bn
+                late_wgrad = unfused and l > 0
                 wg_h, wg_w = h, w  # (the pooling stacks change h, w before the deferred launch)
                 if not late_wgrad:
                     grads[4 * l] = L.wgrad(dzb, ctx.acts[l], B, h, w, cur_co, cin_p, cout, cin, split, gscale)
@@ -615,7 +632,7 @@ class _CnnTrunk(torch.autograd.Function):
                 # ReLU mask + BatchNorm backward of hidden block l (pre-activation zs[l-1])
                 z = ctx.zs[l - 1]
                 mean, invstd, k2f, k3f = ctx.coef[l - 1]
-                if not ctx.sync_state[0]:  # (sum dy, sum dy z) * S, max|dy| * S: partial rows, then finish + coefficients in one kernel
+                if not unfused:  # (sum dy, sum dy z) * S, max|dy| * S: partial rows, then finish + coefficients in one kernel
                     gs_new = L.f32(1)  # NOT in place: the finishing kernel has many workgroups, all of which read the incoming scale
                     dgamma, dbeta, c1, c2, c3 = L.bn_bwd(da, z, k2f, k3f, npix, C, split, mean, invstd, gammas[l - 1].detach(), gscale, gs_new)
                     gscale = gs_new
@@ -627,7 +644,7 @@ class _CnnTrunk(torch.autograd.Function):
                     world = _sync_sums_end(work, sums, gscale, ctx.sync_state)
                     dgamma, dbeta, c1, c2, c3 = (L.f32(C) for _ in range(5))
                     rc = L.lib.nastar_bn_coef_bwd(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                  gammas[l - 1].detach().data_ptr(), npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                  gammas[l - 1].detach().data_ptr(), (1 << 62) if eval_bn else npix * world, gscale.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                   c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), C, L.stream)
                     _native.check(rc, "nastar_bn_coef_bwd")
                     if world > 1:  # the kernel formed dgamma / dbeta from the GLOBAL sums; the flat gradient all-reduce AVERAGES over ranks
@@ -635,10 +652,17 @@ class _CnnTrunk(torch.autograd.Function):
                         dbeta /= world
                 grads[4 * (l - 1) + 2] = dgamma
                 grads[4 * (l - 1) + 3] = dbeta
+                if eval_bn:
+                    nb = params[4 * (l - 1) + 1].numel()
+                    bias_grads[l - 1] = (dbeta[:nb].double() * gammas[l - 1].detach().double()[:nb] * invstd[:nb]).float()
                 dzb = torch.empty_like(da)
                 L.affine(da, z, c1, c2, c3, k2f, k3f, dzb, npix, C, False, split)
                 cur_co = C
             torch._foreach_zero_([grads[4 * l + 1] for l in range(D + 1)])  # one launch for all of them
+            if cfg.get("eval_bn"):  # ... except in eval mode, where the biases in front of a BatchNorm on running statistics do get gradients
+                for l, bg in bias_grads.items():
+                    grads[4 * l + 1] = bg
+                grads[4 * D + 1] = dzl.float().sum().reshape(1)
         return (None, None) + tuple(grads)
 
 
@@ -671,10 +695,25 @@ class _LastBlock(torch.autograd.Function):
         cost = torch.empty_like(zc)
         stat = torch.empty((2,), dtype=torch.float64, device=dev)
         g, b, c = gamma.detach(), beta.detach(), cmul.detach()
+        eval_bn = momentum is None  # (cnn_train_forward's signal: module.eval() with gradients on -- BatchNorm on its running statistics)
+        ctx.eval_bn = eval_bn
         with torch.cuda.device(dev):
-            _native.check(lib.nastar_bn1_fwd_partial(zc.data_ptr(), n, part.data_ptr(), st), "nastar_bn1_fwd_partial")
             world = 1
             ctx.sync_state = SyncBatchNorm.snapshot()
+            if eval_bn:
+                # one fabricated row of "sums" over n elements whose mean / variance are the running statistics: the kernel's own arithmetic
+                # then normalises with exactly those; nothing is updated (momentum 0, no running pointers)
+                rm, rv = running_mean.double().reshape(1), running_var.double().reshape(1)
+                part = (torch.stack((rm, rv + rm * rm), dim=1) * float(n)).contiguous()
+                _native.check(lib.nastar_bn1_sigmoid_fwd(zc.data_ptr(), n, part.data_ptr(), 1, float(n), g.data_ptr(), b.data_ptr(), float(eps), c.data_ptr(), 0.0,
+                                                         None, None, cost.data_ptr(), stat.data_ptr(), st), "nastar_bn1_sigmoid_fwd")
+                ctx.save_for_backward(zc, g, b, c, stat)
+                ctx.n_total = 1e30  # backward: the batch-mean terms vanish -- eval-mode BatchNorm's dz = gamma invstd dy
+                ctx.world = 1
+                ctx.sync_state = (False, None, 1)
+                ctx.set_materialize_grads(False)
+                return cost
+            _native.check(lib.nastar_bn1_fwd_partial(zc.data_ptr(), n, part.data_ptr(), st), "nastar_bn1_fwd_partial")
             if ctx.sync_state[0]:
                 part = part.sum(0, keepdim=True)
                 world = _sync_sums(part, state=ctx.sync_state)
@@ -776,9 +815,10 @@ def _assemble_input(map_designs, start_maps, goal_maps, plus, split, L) -> torch
 
 def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
                       precision: str = "f16x3") -> torch.Tensor:
-    """``cnn(cat(map, start + goal))`` for a ``planner.encoder.CNN`` / ``CNNDownSize`` in TRAINING mode (batch-statistics BatchNorm,
-    running statistics updated), differentiable w.r.t. every encoder parameter, on the MI355X kernels.  Returns the cost map
-    [B,1,h,w] fp32 (h, w = H, W >> depth for the pooling stack)."""
+    """``cnn(cat(map, start + goal))`` for a ``planner.encoder.CNN`` / ``CNNDownSize`` under autograd, differentiable w.r.t. every encoder
+    parameter, on the MI355X kernels: in TRAINING mode (batch-statistics BatchNorm, running statistics updated) or -- round 6 -- in EVAL mode
+    (``module.eval()`` with gradients on: BatchNorm on its running statistics, nothing updated).  Returns the cost map [B,1,h,w] fp32
+    (h, w = H, W >> depth for the pooling stack)."""
     st = _structure(cnn)
     if st is None:
         raise NotImplementedError("conv3x3 -> BatchNorm -> ReLU [-> max-pool] blocks with 32 * 2^k channels, closed by a 1-channel "
@@ -793,14 +833,23 @@ def cnn_train_forward(cnn: nn.Module, map_designs: torch.Tensor, start_maps: tor
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")
     split = precision == "f16x3"
+    eval_bn = not cnn.training  # module.eval() with gradients on: BatchNorm on its running statistics (no update), still differentiable
+    if eval_bn and any(bn.running_mean is None or bn.weight is None for bn in bns):
+        raise NotImplementedError("eval-mode BatchNorm without running statistics / affine parameters")
     cfg = {"split": split, "depth": D, "pool": pool, "shape": (B, H, W), "eps": [bn.eps for bn in bns[:D]], "bns": bns[:D],
-           "debug": getattr(cnn, "_nastar_debug", None)}
+           "debug": getattr(cnn, "_nastar_debug", None), "eval_bn": eval_bn}
     with torch.cuda.device(map_designs.device):
         x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
     zl = _CnnTrunk.apply(cfg, x0, *params[:4 * D + 2])
     # last block: 1-channel BatchNorm (batch statistics) + sigmoid * const as ONE autograd node on two launches each way (the plain
     # tensor form was ~35 framework launches per step; MIOpen's spatial BatchNorm kernels are slow on a single channel)
     bnl = bns[D]
+    if eval_bn:
+        const = cnn.const if isinstance(cnn.const, torch.Tensor) else _const_tensor(float(cnn.const), zl.device)
+        if const.numel() != 1 or const.dtype != torch.float32:
+            y = (zl - bnl.running_mean) * torch.rsqrt(bnl.running_var + bnl.eps) * bnl.weight + bnl.bias
+            return torch.sigmoid(y) * cnn.const
+        return _LastBlock.apply(zl, bnl.weight, bnl.bias, const.reshape(1), bnl.eps, None, bnl.running_mean, bnl.running_var)  # momentum None = eval
     track = bnl.track_running_stats and bnl.running_mean is not None
     mom = 0.0
     if track:

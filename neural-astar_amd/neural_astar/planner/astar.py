@@ -144,11 +144,12 @@ class NeuralAstar(VanillaAstar):
                 prec = "f16" if backend == "hip_f16" else "f16x3"
                 return self._routed(f"hip:Unet-train/{prec}", unet_train_forward(self.encoder, map_designs, start_maps, goal_maps,
                                                                                  "+" in self.encoder_input, prec))
-        if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
-                and isinstance(self.encoder, encoder.CNN)):
-            # TRAINING: convolutions, batch-statistics BatchNorm, ReLU, max-pool and all their gradients on the MI355X kernels
-            # (neural_astar/encoder_train.py); "hip_f16" = plain fp16 operands, anything else = split operands (fp32-grade).
-            # CNN (any depth) and CNNDownSize (WarCraft); shapes the kernels do not take stay on torch.nn.
+        if (backend.startswith("hip") and torch.is_grad_enabled() and map_designs.is_cuda and isinstance(self.encoder, encoder.CNN)
+                and (self.encoder.training or any(p.requires_grad for p in self.encoder.parameters()))):
+            # UNDER AUTOGRAD: convolutions, BatchNorm (batch statistics in training mode; the running statistics in eval mode -- round 6),
+            # ReLU, max-pool and all their gradients on the MI355X kernels (neural_astar/encoder_train.py); "hip_f16" = plain fp16
+            # operands, anything else = split operands (fp32-grade).  CNN (any depth) and CNNDownSize (WarCraft); shapes the kernels do
+            # not take stay on torch.nn.
             from ..encoder_train import cnn_train_forward, supported
             convs = [m for m in self.encoder.model if isinstance(m, nn.Conv2d)]
             pool = isinstance(self.encoder, encoder.CNNDownSize)
@@ -157,7 +158,8 @@ class NeuralAstar(VanillaAstar):
                     and map_designs.shape[1] + int(plus) == convs[0].in_channels
                     and (pool or map_designs.shape[-2:] == start_maps.shape[-2:])):
                 prec = "f16" if backend == "hip_f16" else "f16x3"
-                return self._routed(f"hip:{'CNNDownSize' if pool else 'CNN'}-train/{prec}",
+                kind = "train" if self.encoder.training else "evalgrad"
+                return self._routed(f"hip:{'CNNDownSize' if pool else 'CNN'}-{kind}/{prec}",
                                     cnn_train_forward(self.encoder, map_designs, start_maps, goal_maps, plus, prec))
         tile = 32 if backend in ("hip_f16", "hip_f16x3") else 16
         if (backend in ("hip_bf16", "hip_f16", "hip_f16x3") and not self.training and not torch.is_grad_enabled()

@@ -535,8 +535,15 @@ def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
     gw[:, 0, 7, 159] = 1
     r = routes(NeuralAstar(encoder_arch="CNN", encoder_depth=2, Tmax=0.25), wide, sw, gw)
     assert r == {"eval": "hip:CNN-infer-flat/f16x3", "train": "hip:CNN-train/f16x3"}, r
-    # what the kernels still do not take -- EVAL mode with gradients on (BatchNorm on running statistics under autograd): torch.nn, said out loud once
+    # EVAL mode with gradients on (BatchNorm on its running statistics under autograd): round 6 -- the CNN stacks take the kernels there too
     na = NeuralAstar(encoder_arch="CNN", encoder_depth=2).to(dev).eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        na(wide, sw, gw).histories.sum().backward()
+    assert na.last_encoder_route == "hip:CNN-evalgrad/f16x3", na.last_encoder_route
+    # what the kernels still do not take -- the U-Net in eval mode with gradients on: torch.nn, said out loud once
+    na = NeuralAstar(encoder_arch="Unet").to(dev).eval()
+    wide, sw, gw = m[:2], s[:2], g[:2]
     with pytest.warns(RuntimeWarning, match="not covered by the MI355X encoder kernels"):
         na(wide, sw, gw)
     assert na.last_encoder_route.startswith("torch.nn (fell through from hip_f16x3")

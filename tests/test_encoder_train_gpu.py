@@ -248,6 +248,48 @@ def test_cnn_encoder_training_step_matches_torch_autograd(precision, tol_grad, t
             assert int(b) == int(c), name
 
 
+@pytest.mark.parametrize("arch,depth,H,W", [("CNN", 4, 32, 32), ("CNN", 2, 24, 40), ("CNNDownSize", 2, 32, 64)])
+def test_eval_mode_with_gradients_runs_on_the_kernels_and_matches_torch_autograd(arch, depth, H, W):
+    """module.eval() with gradients on (saliency maps, fine-tuning with frozen statistics): BatchNorm normalises with its RUNNING statistics and
+    updates nothing, yet every parameter gets its gradient.  Round 6: on the MI355X kernels (the batch-statistics closed form in the limit of
+    infinitely many pixels); against the torch module in float64, eval mode."""
+    from neural_astar.planner import NeuralAstar
+    dev = _dev()
+    torch.manual_seed(depth * 7 + H)
+    B = 5
+    g = torch.Generator().manual_seed(H + W)
+    ref = NeuralAstar(encoder_input="m+", encoder_arch=arch, encoder_depth=depth, const=3.0)
+    with torch.no_grad():
+        for m_ in ref.encoder.modules():
+            if isinstance(m_, nn.BatchNorm2d):
+                m_.weight.uniform_(0.5, 1.5); m_.bias.normal_(0, 0.2)
+                m_.running_mean.normal_(0, 0.3); m_.running_var.uniform_(0.5, 2.0)
+    na = copy.deepcopy(ref).to(dev).eval()
+    ref = ref.double().eval()
+    img = (torch.rand((B, 1, H, W), generator=g) > 0.25).float()
+    s = torch.zeros((B, 1, H, W)); s[:, 0, 1, 1] = 1
+    gl = torch.zeros((B, 1, H, W)); gl[:, 0, H - 2, W - 2] = 1
+    ho, wo = (H >> depth, W >> depth) if arch == "CNNDownSize" else (H, W)
+    R = torch.randn((B, 1, ho, wo), generator=g) / (B * ho * wo)
+    before = {k: v.clone() for k, v in na.encoder.named_buffers()}
+    cost_ref = ref.encode(img.double(), s.double(), gl.double())
+    (cost_ref * R.double()).sum().backward()
+    cost = na.encode(img.to(dev), s.to(dev), gl.to(dev))
+    assert na.last_encoder_route.endswith("-evalgrad/f16x3"), na.last_encoder_route
+    (cost * R.to(dev)).sum().backward()
+    assert float((cost.detach().cpu().double() - cost_ref.detach()).abs().max()) <= 1e-5 * 3.0
+    worst = {}
+    for (name, p), (_, q) in zip(na.encoder.named_parameters(), ref.encoder.named_parameters()):
+        assert p.grad is not None, name
+        if float(q.grad.abs().max()) == 0:
+            continue
+        worst[name] = _rel(p.grad, q.grad)
+    print("EVALGRAD", arch, depth, H, W, " ".join(f"{k}={v:.1e}" for k, v in worst.items()))
+    assert len(worst) >= 3 * depth + 2 and max(worst.values()) <= 1e-4, worst  # (eval mode: the conv biases in front of a BatchNorm DO get gradients)
+    for k, v in na.encoder.named_buffers():  # nothing was updated
+        assert torch.equal(v, before[k]), k
+
+
 def _decision_margins(encoder):
     """Forward hooks on a float64 reference encoder: the smallest relative gap between the two largest values of a max-pool window
     (both positive) and the smallest |ReLU input|.  ReLU masks and pooling arg-maxes are DISCRETE decisions: where the float64

@@ -15,9 +15,10 @@ OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (--no-natural: the default bench line also times the natural-order placement beside the hinted one; a kernel average must not mix the two)
-B="python $R/bench.py --no-cpu-baseline --no-secondary --no-natural"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $B --steps 50 --warmup 5 > $OUT/bench_under_rocprof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_natural -o bench --output-format csv -- $B --placement natural --steps 50 --warmup 5 > $OUT/bench_natural_under_rocprof.log 2>&1
+# (--no-prewarm: the pre-warm launches are bare dataset-placed launches and would dominate the kernel's call count)
+B="python $R/bench.py --no-cpu-baseline --no-secondary --no-natural --no-prewarm"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $B --steps 200 --warmup 20 > $OUT/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_natural -o bench --output-format csv -- $B --placement natural --steps 200 --warmup 20 > $OUT/bench_natural_under_rocprof.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- $B --steps 20 --warmup 2 > $OUT/pmc_$C.log 2>&1
 done
@@ -102,3 +103,8 @@ for V in "$SQ_FLAGS".split():
 json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:5000])
 PY
+# the raw traces are hundreds of MB (gpurun copies back at most 64 MiB): keep the per-run kernel-stats CSVs + summary.json + the logs
+for d in trace trace_natural train enc_f16x3 enc_bf16 enc_train; do rm -rf $OUT/$d; done
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/sq_f* $OUT/sq2_f* 2>/dev/null
+find $OUT -maxdepth 1 -type d -name "sq*" -exec rm -rf {} + 2>/dev/null
+du -sh $OUT
