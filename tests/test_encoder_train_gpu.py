@@ -248,15 +248,16 @@ def test_cnn_encoder_training_step_matches_torch_autograd(precision, tol_grad, t
             assert int(b) == int(c), name
 
 
-@pytest.mark.parametrize("arch,depth,H,W", [("CNN", 4, 32, 32), ("CNN", 2, 24, 40), ("CNNDownSize", 2, 32, 64)])
-def test_eval_mode_with_gradients_runs_on_the_kernels_and_matches_torch_autograd(arch, depth, H, W):
+@pytest.mark.parametrize("arch,depth,H,W,B", [("CNN", 4, 32, 32, 16), ("CNN", 2, 24, 40, 5), ("CNNDownSize", 2, 32, 64, 5), ("CNN", 4, 16, 64, 5)])
+def test_eval_mode_with_gradients_runs_on_the_kernels_and_matches_torch_autograd(arch, depth, H, W, B):
     """module.eval() with gradients on (saliency maps, fine-tuning with frozen statistics): BatchNorm normalises with its RUNNING statistics and
     updates nothing, yet every parameter gets its gradient.  Round 6: on the MI355X kernels (the batch-statistics closed form in the limit of
-    infinitely many pixels); against the torch module in float64, eval mode."""
+    infinitely many pixels); against the torch module in float64, eval mode.  1e-4 per tensor when every ReLU decision of the reference is clear
+    of the arithmetic's resolution; one mask bit decided by less than that moves a whole gradient ELEMENT (dbeta of a 256-channel block is a
+    sum of ~sqrt(N) |dy|: one flipped pixel is ~1 / sqrt(B H W) of it), so 3e-2 is asserted then -- as in the training-mode tests above."""
     from neural_astar.planner import NeuralAstar
     dev = _dev()
     torch.manual_seed(depth * 7 + H)
-    B = 5
     g = torch.Generator().manual_seed(H + W)
     ref = NeuralAstar(encoder_input="m+", encoder_arch=arch, encoder_depth=depth, const=3.0)
     with torch.no_grad():
@@ -272,7 +273,10 @@ def test_eval_mode_with_gradients_runs_on_the_kernels_and_matches_torch_autograd
     ho, wo = (H >> depth, W >> depth) if arch == "CNNDownSize" else (H, W)
     R = torch.randn((B, 1, ho, wo), generator=g) / (B * ho * wo)
     before = {k: v.clone() for k, v in na.encoder.named_buffers()}
+    margins, hooks = _decision_margins(ref.encoder)
     cost_ref = ref.encode(img.double(), s.double(), gl.double())
+    for hk in hooks:
+        hk.remove()
     (cost_ref * R.double()).sum().backward()
     cost = na.encode(img.to(dev), s.to(dev), gl.to(dev))
     assert na.last_encoder_route.endswith("-evalgrad/f16x3"), na.last_encoder_route
@@ -284,8 +288,11 @@ def test_eval_mode_with_gradients_runs_on_the_kernels_and_matches_torch_autograd
         if float(q.grad.abs().max()) == 0:
             continue
         worst[name] = _rel(p.grad, q.grad)
-    print("EVALGRAD", arch, depth, H, W, " ".join(f"{k}={v:.1e}" for k, v in worst.items()))
-    assert len(worst) >= 3 * depth + 2 and max(worst.values()) <= 1e-4, worst  # (eval mode: the conv biases in front of a BatchNorm DO get gradients)
+    clear = margins["relu"] >= 3e-6 and margins["pool"] >= 3e-6  # (eval-mode pre-activations are O(1..10): the resolution of split-fp16 products scales with them)
+    print("EVALGRAD", arch, depth, H, W, margins, " ".join(f"{k}={v:.1e}" for k, v in worst.items()))
+    assert len(worst) >= 3 * depth + 2 and max(worst.values()) <= (1e-4 if clear else 3e-2), (margins, worst)  # (eval mode: the conv biases in front of a BatchNorm DO get gradients)
+    lower = [v for k, v in worst.items() if k.split(".")[1] in ("0", "1")]  # the first block sees the flipped element diluted through every block above it
+    assert max(lower) <= 5e-3, worst
     for k, v in na.encoder.named_buffers():  # nothing was updated
         assert torch.equal(v, before[k]), k
 

@@ -10,6 +10,29 @@ cd "$R"
 # those kernels -- two maps per wavefront among them -- were measured there one last time and then deleted (NOTES.md)
 DEVLIB=$R/neural-astar_amd/lib/libnastar_hip_dev.so
 case "$S" in
+r06_final)
+  # round 6, final tree: the whole GPU suite, the driver's bench command, rocprofv3 kernel stats + PMC traffic + encoder tables, the boundary probe
+  # (native and Python host lanes), the N > 1 branches of bench.py with 8 gloo ranks sharing the GPU and a 1-rank RCCL group
+  O=gpurun_out/r06/final; mkdir -p $O
+  python -m pytest tests -q -m gpu > $O/gpu_tests_final.log 2>&1; echo "suite rc=$?"; tail -6 $O/gpu_tests_final.log
+  python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_command.json 2> $O/bench_n1_driver_command.err; echo "bench rc=$?"
+  python bench.py --steps 200 --warmup 20 --no-secondary --no-cpu-baseline > $O/bench_n1_steps200.json 2>/dev/null
+  bash tools/profile_round.sh r06 > $O/profile_round.log 2>&1; tail -c 400 $O/profile_round.log
+  python tools/probe_boundary.py > $O/probe_boundary.jsonl 2> $O/probe_boundary.err
+  NASTAR_FASTLANE=0 python tools/probe_boundary.py 2>/dev/null | head -1 > $O/probe_boundary_python_lane.jsonl
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 8 --steps 10 --warmup 2 --dist-backend gloo --share-gpu --no-cpu-baseline --no-secondary > $O/world8_maze32_weak.json 2> $O/world8.err; echo "world8 rc=$?"
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python bench.py --force-collate --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_force_collate_rccl1.json 2> $O/rccl1.err; echo "rccl1 rc=$?"
+  python - <<'P'
+import json
+for f in ("bench_n1_driver_command", "bench_n1_steps200", "world8_maze32_weak", "bench_force_collate_rccl1"):
+    try:
+        j = json.load(open(f"gpurun_out/r06/final/{f}.json"))
+        print(f, {k: j.get(k) for k in ("value", "ms_per_step", "value_natural_order", "value_bare_launch", "n_gpus", "extras_note")}, "frac", j["roofline"]["frac"], "launch_ms", j["roofline"]["launch_ms_avg"], j["config"].get("distributed"))
+    except Exception as e:
+        print(f, "ERR", e)
+P
+  ;;
 r04_a)
   # Throughput regime of the search: what binds it, and what two maps per wavefront can and cannot buy.
   #  1. aggregate issue rates of one CU (tools/ubench/rate.hip)
