@@ -26,10 +26,12 @@ def test_random_small_maps_gradients_match_the_oracle_reverse_mode():
 
 
 def test_module_forward_equals_the_literal_batch_loop_also_in_the_coupled_class():
-    """forward() against the oracle's literal restatement of the reference's batch loop on small random batches with g_ratio below, at and above
-    0.5 and costs up to 10: batches in which a finished map is not at a fixed point are re-run in lock-step mode and must come out exact"""
+    """forward() against the oracle's literal restatement of the reference's batch loop on random batches with g_ratio below, at and above 0.5,
+    costs up to 10 and costs below -1: every checking mode, a third of the cases UNDER AUTOGRAD (gradients against the oracle's literal reverse
+    mode, 1e-5), a tenth on maps whose state does not fit LDS (to 150x200), training budgets -- batches in which a finished map is not at a
+    fixed point of the batch loop go through the exact pipeline (marks + lock-step re-run of the marked maps) and must come out exact"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
-    n, reruns, bad = fuzz_parity.run_module(seed=9, N=60, verbose=False)
-    assert n == 60 and not bad, bad[:5]
-    assert reruns >= 2, reruns  # the sweep does visit the class
+    n, reruns, bad = fuzz_parity.run_module(seed=9, N=70, verbose=False)
+    assert n >= 60 and not bad, bad[:5]
+    assert reruns >= 4 and fuzz_parity.run_module.ngrad >= 8, (reruns, fuzz_parity.run_module.ngrad)  # the sweep does visit the class, also under autograd
