@@ -74,6 +74,41 @@ __device__ __forceinline__ uint32_t wave_min_scalar_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// two independent minima side by side: stage k of one sits in the two wait states a VALU write -> DPP read of the other needs
+__device__ __forceinline__ void wave_min_scalar_u32x2(uint32_t a, uint32_t b, uint32_t& ma, uint32_t& mb)
+{
+    a = min(a, dpp_mov_id<DPP_QUAD_XOR1>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_QUAD_XOR1>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_QUAD_XOR2>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_QUAD_XOR2>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_ROW_HALF_MIRROR>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_ROW_HALF_MIRROR>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_ROW_MIRROR>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_ROW_MIRROR>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_rows<0x142, 0xA>(a, 0xFFFFFFFFu));  // row_bcast:15
+    b = min(b, dpp_mov_rows<0x142, 0xA>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_rows<0x143, 0xC>(a, 0xFFFFFFFFu));  // row_bcast:31
+    b = min(b, dpp_mov_rows<0x143, 0xC>(b, 0xFFFFFFFFu));
+    ma = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    mb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+}
+
+// the minimum of all 64 lanes of `a` and, beside it, the minimum of lanes 0..7 of `b` (its first three stages)
+__device__ __forceinline__ void wave_min_scalar_u32_and8(uint32_t a, uint32_t b, uint32_t& ma, uint32_t& mb8)
+{
+    a = min(a, dpp_mov_id<DPP_QUAD_XOR1>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_QUAD_XOR1>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_QUAD_XOR2>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_QUAD_XOR2>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_ROW_HALF_MIRROR>(a, 0xFFFFFFFFu));
+    b = min(b, dpp_mov_id<DPP_ROW_HALF_MIRROR>(b, 0xFFFFFFFFu));
+    a = min(a, dpp_mov_id<DPP_ROW_MIRROR>(a, 0xFFFFFFFFu));
+    mb8 = (uint32_t)__builtin_amdgcn_readlane((int)b, 0);
+    a = min(a, dpp_mov_rows<0x142, 0xA>(a, 0xFFFFFFFFu));  // row_bcast:15
+    a = min(a, dpp_mov_rows<0x143, 0xC>(a, 0xFFFFFFFFu));  // row_bcast:31
+    ma = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+}
+
 // min over each 16-lane DPP row, result in every lane of the row
 __device__ __forceinline__ uint32_t row_min16_u32(uint32_t v)
 {

@@ -13,11 +13,19 @@
 //     cmin[c] per 64-cell chunk: (key << 32 | cell) of its first minimal open cell, ~0 when it holds none   (u64 order = first-index tie-break)
 //     smin[s] per 64 chunks: the minimum of their cmin entries
 //
-// Three launches per call (fill / search / store, see below).  A step of the search (round 4's kernel kept all three levels in HBM and paid SEVEN dependent L2 round trips per step):
-//   select   ONE ds_read_b64 per lane of smin + a wave minimum: the entry itself names s*                               (LDS only)
-//   load     g / cost of s*, of its 8 neighbours and of the 64 cells of its chunk: issued together, ONE round trip       (HBM)
-//   update   g / pdir stores of the relaxed neighbours (drain overlapped with the LDS work below); chunk minimum without s*
-//            recomputed from the loaded cells; ds_min_u64 inserts the neighbours; the super-chunk of s* is re-minimised     (LDS)
+// Three launches per call (fill / search / store, see below).  A step of the search (round 4's kernel kept all three levels in HBM and paid
+// SEVEN dependent L2 round trips per step; round 5's read the open list back from LDS twice per step and ran five wave minima in series):
+//   select   nothing to do: (key, cell) of s* is in two scalar registers, left there by the previous step
+//   load     g / cost of s*, of its 8 neighbours and of the 64 cells of its chunk: issued together, ONE round trip               (HBM)
+//   shadow   while that round trip is in flight: the open list WITHOUT s* 's chunk and super-chunk -- restS = minimum of the other 63 chunk
+//            entries of its super-chunk, restE = minimum of the other super-chunk entries (two wave minima side by side, LDS reads issued
+//            before the loads) -- and both heuristics (the chunk's cells, the neighbours)
+//   update   newC = the chunk's minimum without s*, nbr = minimum of the relaxed neighbours (one 64-lane and one 8-lane minimum side by
+//            side); g / pdir stores; cmin[C] = newC and smin[S] = min(restS, newC) by plain writes, the neighbours enter both levels by
+//            ds_min_u64 -- nothing is read back                                                                                     (LDS)
+//   next     s* of the next step = min(restE, restS, newC, nbr): every open cell is in exactly one of the four sets          (scalar)
+// All four are first-index minima of (key << 32 | cell): entries ascend with the lane in each set, so "the first lane holding the minimal
+// key" (ballot + s_ff1 + v_readlane) replaces a second wave minimum over the cells.
 // Keys are never stored: q = fl(f / fl32(sqrt(W))) is re-derived from (g, cost, coordinates), with the IEEE division (no reciprocal).
 #pragma once
 #include "nastar_search.hip.h"
@@ -242,10 +250,14 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     int goal_c;
     const int goal_r = hybrid_row(gi, d, goal_c);
     __syncthreads();
-    if (lane == 0 && sidx >= 0) {  // open list = {start} (:187), g[start] = 0 (:193); the start is expanded even on an obstacle
+    float h_start = 0.f;  // :191-192 h = h0 + cost at the start cell (wave-uniform)
+    if (sidx >= 0) {
         int sc;
         const int sr = hybrid_row(sidx, d, sc);
-        const uint32_t k0 = hybrid_key<kFastDiv>(d, 0.0f, heuristic0(sr, sc, goal_r, goal_c) + cost[sidx]);  // :191-192 h = h0 + cost
+        h_start = heuristic0(sr, sc, goal_r, goal_c) + cost[sidx];
+    }
+    if (lane == 0 && sidx >= 0) {  // open list = {start} (:187), g[start] = 0 (:193); the start is expanded even on an obstacle
+        const uint32_t k0 = hybrid_key<kFastDiv>(d, 0.0f, h_start);
         const unsigned long long e = ((unsigned long long)k0 << 32) | (uint32_t)sidx;
         g[sidx] = 0.0f;
         pdir[sidx] = (uint8_t)(PARENT_UNSET | P_PASS);
@@ -264,16 +276,12 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
     if (sidx < 0 || gidx < 0) {
         status = NASTAR_ERR_UNSOLVABLE;  // not a one-hot start / goal map
     } else {
+        // (key << 32 | cell) of the next selection, wave-uniform in scalar registers; ~0 = open list empty
+        uint32_t sel_key = hybrid_key<kFastDiv>(d, 0.0f, __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h_start))));
+        uint32_t sel_cell = (uint32_t)sidx;
         while (iters < budget) {  // :203
-            // ---- select: the minimal super-chunk entry IS (key, cell) of s* ------------------------------------------
-            unsigned long long e0 = smin[lane * d.spl];
-            for (int j = 1; j < d.spl; ++j) {  // (maps above 512x512: several super-chunk entries per lane, contiguous -- the first minimal one wins)
-                const unsigned long long ej = smin[lane * d.spl + j];
-                e0 = (uint32_t)(ej >> 32) < (uint32_t)(e0 >> 32) ? ej : e0;
-            }
-            const uint32_t k0 = (uint32_t)(e0 >> 32), c0 = (uint32_t)e0;
-            const uint32_t m = wave_min_all_u32(k0);
-            const int s = __builtin_amdgcn_readlane((int)c0, __builtin_ctzll(__ballot(k0 == m)));  // wave-uniform, in a scalar register (the lane that holds m exists)
+            // ---- select: the entry the previous step left behind names s* (no LDS read, no reduction on this path) -------------
+            const int s = (int)sel_cell;
             if (s < 0) {  // every entry idle (~0ull: key KEY_INF, cell ~0): open list empty (:68 would divide by zero)
                 status = NASTAR_ERR_UNSOLVABLE;
                 break;
@@ -300,6 +308,13 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             }
             goal_hit |= at_goal;
             const int C = s >> 6, S = s >> 12;
+            // ---- the open list WITHOUT the chunk / super-chunk of s*, as the previous step left it (LDS, issued ahead of the HBM loads) ----
+            const unsigned long long ev = cmin[S * 64 + lane];
+            unsigned long long e0 = (lane * d.spl == S) ? ~0ull : smin[lane * d.spl];
+            for (int j = 1; j < d.spl; ++j) {  // (maps above 512x512: several super-chunk entries per lane, contiguous -- the first minimal one wins)
+                const unsigned long long ej = (lane * d.spl + j == S) ? ~0ull : smin[lane * d.spl + j];
+                e0 = (uint32_t)(ej >> 32) < (uint32_t)(e0 >> 32) ? ej : e0;
+            }
             int c;
             const int r = hybrid_row_nb(s, d, c);
             const int nr = r + dr, nc = c + dc;
@@ -307,41 +322,72 @@ __global__ __launch_bounds__(64) void nastar_forward_hybrid_kernel(const FwdHybr
             const int n = inb ? s + dr * d.W + dc : s;
             const int ic = C * 64 + lane;
             const bool icv = ic < d.HW;
-            global_step_fence();  // the previous step's g / pdir stores have reached L2 (their drain overlapped the selection above)
+            global_step_fence();  // the previous step's g / pdir stores have reached L2
             // ---- ONE round trip: everything this step reads from HBM --------------------------------------------------
             const float gs = g[s];
             const float gn = g[n];
             const float gc = g[ic];
             const float cs = cost[s];
             const float cn = cost[n];
-            const float cc = icv ? cost[ic] : 0.f;
+            const float cc = cost[icv ? ic : 0];
+            // ---- in the shadow of that round trip: nothing below needs a loaded value until `g2` -------------------------
+            // rest of the super-chunk of s* (its 64 chunk entries but the one of s*) and rest of the map (every other super-chunk): entries
+            // ascend with the lane, so the first lane that holds the minimal key holds the first minimal entry
+            const uint32_t kS = lane == (C & 63) ? KEY_INF : (uint32_t)(ev >> 32);
+            const uint32_t kE = (uint32_t)(e0 >> 32);
+            uint32_t mS, mE;
+            wave_min_scalar_u32x2(kS, kE, mS, mE);
+            const uint32_t cS = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ev, __builtin_ctzll(__ballot(kS == mS)));
+            const uint32_t cE = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, __builtin_ctzll(__ballot(kE == mE)));
             int icc;
             const int icr = hybrid_row_nb(icv ? ic : 0, d, icc);
+            float hn = heuristic0(nr, nc, goal_r, goal_c);
+            float hc = heuristic0(icr, icc, goal_r, goal_c);
+            // (the compiler otherwise sinks both heuristics below the first use of a loaded value, into regions predicated on `upd` / `open_c`:
+            //  a lone wavefront pays for predicated-off lanes anyway, and there they sit behind the round trip instead of inside it)
+            asm volatile("" : "+v"(hn), "+v"(hc) : : "memory");
+            // ---- the loaded values ------------------------------------------------------------------------------------------
             const float g2 = gs + cs;                                              // :234 step cost of the node being LEFT
             const bool upd = inb & (gn > g2);                                      // :229,:235
-            const uint32_t kn = hybrid_key<kFastDiv>(d, g2, heuristic0(nr, nc, goal_r, goal_c) + cn);
             // chunk minimum without s* (lock-step: a selected goal stays on the open list, :224): open <=> finite g
             const bool open_c = icv & (fabsf(gc) < NASTAR_POS_INF) & ((ic != s) | (kLock && at_goal));
-            const uint32_t kc = open_c ? hybrid_key<kFastDiv>(d, gc, heuristic0(icr, icc, goal_r, goal_c) + cc) : KEY_INF;
-            const unsigned long long newC = first_min_entry(kc, (uint32_t)ic);
+            uint32_t kn_all = hybrid_key<kFastDiv>(d, g2, hn + cn);
+            uint32_t kc_all = hybrid_key<kFastDiv>(d, gc, hc + cc);                // (of +-inf for cells that are not open: discarded)
+            asm volatile("" : "+v"(kn_all), "+v"(kc_all));                         // both keys for all lanes, side by side (no predicated regions)
+            const uint32_t kn = upd ? kn_all : KEY_INF;
+            const uint32_t kc = open_c ? kc_all : KEY_INF;
+            // the chunk of s* without s* (64 lanes, ascending cells) and, beside it, the relaxed neighbours (lanes 0..7 in raster order: ascending cells)
+            uint32_t mC, mN;
+            wave_min_scalar_u32_and8(kc, kn, mC, mN);
+            const uint32_t cC = (uint32_t)(C * 64 + __builtin_ctzll(__ballot(kc == mC)));   // (mC == KEY_INF: every lane matches, masked below)
+            const uint32_t cN = (uint32_t)__builtin_amdgcn_readlane(n, __builtin_ctzll(__ballot(kn == mN)));
             // ---- stores: closed list, relaxed neighbours (:222-225, :238-249) ----------------------------------------
             if (lane == 0 && !(kLock && at_goal)) g[s] = NASTAR_NEG_INF;
             if (upd) {
                 g[n] = g2;
                 pdir[n] = (uint8_t)(P_PASS | (uint32_t)lane);
             }
-            // ---- open list (LDS executes a wavefront's operations in order) --------------------------------------------
+            // ---- open list (LDS executes a wavefront's operations in order; nothing is read back in this step) ------------
+            // chunk of s*: its cells without s* ...; super-chunk of s*: its other chunks and that; the neighbours enter both levels by ds_min
+            const uint32_t kCS = min(mC, mS);
+            const uint32_t cCS = min(mC == kCS ? cC : 0xFFFFFFFFu, mS == kCS ? cS : 0xFFFFFFFFu);
             const unsigned long long en = ((unsigned long long)kn << 32) | (uint32_t)n;
-            if (lane == 0) cmin[C] = newC;
+            if (lane == 0) {
+                cmin[C] = mC == KEY_INF ? ~0ull : (((unsigned long long)mC << 32) | cC);
+                smin[S] = kCS == KEY_INF ? ~0ull : (((unsigned long long)kCS << 32) | cCS);
+            }
             wave_order();
-            if (upd) atomicMin(&cmin[n >> 6], en);                                 // :242 (re)opened neighbours enter their chunk's minimum
+            if (upd) {
+                atomicMin(&cmin[n >> 6], en);                                      // :242 (re)opened neighbours enter their chunk's minimum
+                atomicMin(&smin[n >> 12], en);                                     // ... and their super-chunk's (a neighbour may sit in another one)
+            }
             wave_order();
-            const unsigned long long ev = cmin[S * 64 + lane];
-            const unsigned long long newS = first_min_entry((uint32_t)(ev >> 32), (uint32_t)ev);  // the super-chunk of s*, exactly
-            if (lane == 0) smin[S] = newS;
-            wave_order();
-            if (upd) atomicMin(&smin[n >> 12], en);                                // ... and their super-chunk's (a neighbour may sit in another one)
-            wave_order();
+            // ---- the next selection: first-index minimum of {rest of the map, super-chunk of s* without s*, relaxed neighbours} ----
+            const uint32_t kX = min(mE, mN);
+            const uint32_t cX = min(mE == kX ? cE : 0xFFFFFFFFu, mN == kX ? cN : 0xFFFFFFFFu);
+            sel_key = min(kCS, kX);
+            sel_cell = min(kCS == sel_key ? cCS : 0xFFFFFFFFu, kX == sel_key ? cX : 0xFFFFFFFFu);
+            if (sel_key == KEY_INF) sel_cell = 0xFFFFFFFFu;
         }
     }
     global_step_fence();

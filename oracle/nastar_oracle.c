@@ -93,7 +93,7 @@ static int dense_alloc(dense_map_t* m, int HW)
 static float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 
 /* One loop iteration (differentiable_astar.py:203-252) for one map.  Returns is_unsolved (0/1)
- * or -1 when the open list is empty (sum == 0 -> NaN in the reference).  If y_out != NULL the
+ * or -1 when the open list is empty or the exponentials overflow (sum == 0 or inf -> NaN in the reference).  If y_out != NULL the
  * softmax y_t (needed by the backward) is copied there; *pass_goal gets the clamp-backward mask. */
 static int dense_step(dense_map_t* m, const float* cost, const float* goal, const float* passable,
                       int H, int W, float gr, float omg, float sqrtW, int* sel_idx,
@@ -115,7 +115,8 @@ static int dense_step(dense_map_t* m, const float* cost, const float* goal, cons
         m->fe[i] = e * m->open[i];
         s += m->fe[i]; /* :67-68 val_.sum(dim=-1) (summation order differs from ATen's; only ordering of y matters) */
     }
-    if (!(s > 0.0f)) return -1;
+    if (!(s > 0.0f) || isinf(s)) return -1; /* empty open list (0 / 0), or exp overflowed (f / sqrt(W) < -88.7: costs below zero summed over a long
+                                             * route): inf / inf -- the reference's softmax is NaN either way and its arg-max meaningless */
     /* :68-69  y = val / sum ; _, ind = y.max(dim=-1)  (first maximal index) */
     int ind = 0;
     float best = -1.0f;
