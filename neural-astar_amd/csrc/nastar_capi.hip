@@ -467,11 +467,12 @@ thread_local char g_last_error[256] = "";
 // maps whose state lives in HBM: three levels (cell -> chunk minimum per 64 cells -> super-chunk minimum per 64 chunks), the two minima arrays in
 // LDS: 8 B per 64 cells must fit one CU -- 1,179,648 cells (1024 x 1152; 1024 x 1024 takes 130 KiB)
 constexpr long long kMaxGlobalCells = 1179648;
-// from 12288 cells (~111 x 111) on the large-map kernel is the faster one although the compact state would still fit LDS up to ~17 k cells: the
-// compiled LDS loop scans HW / 1024 chunk entries per lane and step (1.5-1.9 us per step at 128x128), the hybrid step does not grow with the map
-// (0.9-1.5 us) and keeps 32 instead of 1 maps resident per CU.  Measured (tools/probe_large.py mid, profiles/r06/probe_mid.jsonl): 96x96 LDS
-// 1.2-1.3x faster, 112x112 equal (one map) to 1.1-1.8x slower (batches), 128x128 1.3-2.2x slower.
-constexpr long long kHybridFromCells = 12288;
+// from 6400 cells (80 x 80) on the large-map kernel is the faster one although the compact state would still fit LDS up to ~17 k cells: the
+// compiled LDS loop scans HW / 1024 chunk entries per lane and step and keeps 1-2 maps resident per CU; the hybrid step (0.66-0.68 us since its
+// next selection travels in scalar registers, nastar_search_hybrid.hip.h) does not grow with the map and keeps 32 maps resident per CU.
+// Measured (tools/probe_large.py mid, profiles/r06/probe_mid.jsonl; hybrid / LDS launch time, one map .. 1024 maps): 72x72 0.9-1.33,
+// 80x80 0.76-1.01, 96x96 0.76-1.05, 112x112 0.50-0.82, 128x128 0.41-0.58.
+constexpr long long kHybridFromCells = 6400;
 constexpr size_t kOrderCheckBytes = 16;                // NASTAR_FLAG_CHECK_ORDER: verdict word at the end of the workspace
 
 // maps one launch keeps resident at once: LDS bytes per map against 160 KiB per CU (and 32 wavefront slots), times the CUs of the device
