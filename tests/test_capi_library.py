@@ -32,8 +32,9 @@ def test_library_builds_loads_and_exports_everything():
     major, minor, patch = (int(x) for x in neural_astar.__version__.split("."))
     assert major * 1000 + minor * 100 + patch == lib.nastar_version()  # ... and the package names the same version
     assert lib.nastar_workspace_bytes(4096, 32, 32, 0) == 0
-    assert lib.nastar_workspace_bytes(2, 110, 110, 0) == 0  # 9 B/cell compact state in LDS up to 12287 cells ...
-    assert lib.nastar_workspace_bytes(2, 128, 128, 0) >= 2 * 128 * 128 * 5  # ... beyond, the large-map kernel (faster from ~111x111 on: profiles/r06/probe_mid.jsonl)
+    assert lib.nastar_workspace_bytes(2, 79, 79, 0) == 0  # 9 B/cell compact state in LDS up to 6399 cells ...
+    assert lib.nastar_workspace_bytes(2, 80, 80, 0) >= 2 * 80 * 80 * 5  # ... beyond, the large-map kernel (faster from 80x80 on: profiles/r06/probe_mid.jsonl)
+    assert lib.nastar_workspace_bytes(2, 128, 128, 0) >= 2 * 128 * 128 * 5
     assert 2 * 200 * 150 * 5 <= lib.nastar_workspace_bytes(2, 200, 150, 0) < 2 * 200 * 150 * 6  # larger maps: 5 B/cell in the workspace (open list in LDS)
     # round 6: the marks of NASTAR_FLAG_MARK_COUPLED (B int32, 16-byte aligned, + the t_end cell) behind the slabs; the probe bitmaps of the finish call behind those
     assert lib.nastar_workspace_bytes(6, 32, 32, 32768) == 32 + 16 and lib.nastar_workspace_bytes(6, 32, 32, 32768 | 256) == 32 + 16 + 16

@@ -212,6 +212,8 @@ def run_module(seed=31, N=60, verbose=True, grad_frac=0.35, large_frac=0.1, larg
             bad.append(d)
             if verbose:
                 print(json.dumps(d), flush=True)
+        if verbose and case % 20 == 19:
+            print(json.dumps({"module_cases_so_far": n, "of": case + 1, "coupled": reruns, "with_grad": ngrad, "failures": len(bad)}), flush=True)
     run_module.ngrad = ngrad
     return n, reruns, bad
 
