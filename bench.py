@@ -10,8 +10,8 @@ maze files carries it, utils/data.py:127-134) and attaches the placement hint a 
 runs INSIDE the timed step.  ``value`` is therefore what a caller of the reference's signature gets; the bare C-ABI launch
 on preallocated outputs -- rounds 1-5's headline -- is reported beside it (``bare_launch``), and so is the same call without a hint
 (``natural_order``).  With N > 1 (launched by ``python -m torch.distributed.run --nproc-per-node N``) every rank owns its own 4096 maps
-(weak scaling) and each step also collates the bit-packed ``AstarOutput`` of all ranks with ONE RCCL all-gather, overlapped with the next
-step's search.  Rank 0 prints ONE JSON line.
+(weak scaling) and the bit-packed ``AstarOutput`` of all ranks is collated with ONE RCCL all-gather per 16 steps (``--collate-bucket``; emitted by
+the search launch itself, the tail bucket flushed inside the timed region), overlapped with the following steps' searches.  Rank 0 prints ONE JSON line.
 
 The line's core (headline, roofline, cpu_baseline) is computed first; every secondary experiment (other workloads, batches in flight, encoders,
 training steps, the reference run on this GPU) lives in ``bench_extras.py`` and runs in a CHILD process with a time limit: whatever happens
@@ -585,6 +585,7 @@ class ApiRunner:
         self.placement = placement
         self.out = None
         self.packed = None
+        self.collator = None
         self._i = 0
 
     def step(self):
@@ -592,6 +593,8 @@ class ApiRunner:
         self._i += 1
         if self.placement == "dataset":
             self.ops.attach_levels(z["s"], z["levels"])  # what the loader knows; forward() sorts it into a placement right in front of its search launch
+        if self.collator is not None:  # N > 1: the search launch writes its bit-packed masks straight into the collation bucket's next slot
+            self.va.astar.packed_sink = self.collator.next_slot(self.B, self.H, self.W, self.dev)
         self.out = self.va(z["m"], z["s"], z["g"])
 
     @property
@@ -665,6 +668,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip bench_extras.py (the secondary experiments)")
     ap.add_argument("--extras-timeout", type=float, default=420.0, help="time limit of the bench_extras.py child process, seconds")
     ap.add_argument("--no-collate", action="store_true", help="N>1: skip the all-gather of AstarOutput")
+    ap.add_argument("--collate-bucket", type=int, default=16, help="N>1: steps per all-gather (parallel.BucketedCollator)")
     ap.add_argument("--force-collate", action="store_true", help="dev: run the N>1 collation path (pack kernel + all-gather) in a 1-rank RCCL group")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = the headline (BASELINE config 2 / 4); train = one full NeuralAstar training step per bench step "
@@ -752,18 +756,24 @@ def main():
     if (world > 1 or args.force_collate) and not args.no_collate:
         from neural_astar import parallel
 
+        # every step's outputs are bit-packed (2 bits per cell) into a slot of a staging buffer on a side stream, and the ranks exchange ONE
+        # all-gather per `--collate-bucket` steps (parallel.BucketedCollator: fewer, larger collectives -- a collective per 0.14 ms step costs
+        # more host and launch time than the search itself); the partly filled last bucket is flushed INSIDE the timed region
+        collator = parallel.BucketedCollator(bucket=max(1, args.collate_bucket), keep="last")
+
+        if isinstance(run, ApiRunner):
+            run.collator = collator
+
         def collate(pending):
-            # pack kernel + all-gather of step i (2 bits per cell, kept packed) overlap the search of step i+1: wait for the previous one only now
-            _, fin = parallel.all_gather_output(run.out, async_op=True, unpack=False, check_sizes=False)
-            if pending is not None:
-                pending()
-            return fin
+            collator.add(run.out, packed=run.va.astar.last_packed if isinstance(run, ApiRunner) else None)
+            return collator.flush  # timed_loop calls the last one after the K steps: the tail bucket + the wait for everything in flight
         try:
             run.step()
             collate(None)()
             torch.cuda.synchronize(dev)
-            collate_note = (f"AstarOutput of every rank as 2 bits per cell (nastar_pack_outputs), 1 all-gather per step over "
-                            f"{'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} (kept packed), overlapped with the next step's search")
+            collate_note = (f"AstarOutput of every rank as 2 bits per cell (emitted by the search launch itself into the bucket's slot), ONE all-gather per "
+                            f"{collator.bucket} steps over {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} (kept packed; the tail "
+                            f"bucket is flushed inside the timed region), overlapped with the following steps' searches")
         except Exception as e:  # reported, not hidden: the line then says the collective was not part of the step
             collate = None
             collate_note = f"FAILED ({type(e).__name__}: {e}); steps timed without the all-gather"

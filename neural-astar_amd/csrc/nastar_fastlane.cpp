@@ -6,10 +6,11 @@
 // data_ptr(), one 23-argument ctypes call, the status-board bookkeeping).  This file is that host work in C++, behind the SAME C ABI:
 //
 //   search(fn, cost, start, goal, passable | None, g_ratio, max_iters, want_log, flags, order | None, order_out | None, ws_bytes,
-//          summary_host, counter_dev, stream, spin_us, levels | None, sort_fn)
+//          summary_host, counter_dev, stream, spin_us, levels | None, sort_fn, packed | None)
 //     0. (a batch that carries its loader's levels instead of an order: launches nastar_placement_from_levels in front of the search)
 //     1. allocates the AstarOutput tensors in their final layout ([B,1,H,W] fp32 / int64, iters + status as one [2,B] int32 block) through ATen
 //        (the caching allocator; no torch types cross the C ABI below),
+//        (`packed`: the caller's uint8 slot for the bit-packed masks, 2 bits per cell, which the search launch then emits itself),
 //     2. calls nastar_forward_ex -- `fn` is its address, taken from the ctypes handle of libnastar_hip.so: this extension links against neither
 //        HIP nor the kernel library,
 //     3. with the GIL released, polls the launch's completion flag in pinned host memory (include/nastar.h: completion_counter /
@@ -36,7 +37,7 @@ inline bool plain_f32(const at::Tensor& t) { return t.is_cuda() && t.scalar_type
 py::tuple search(uintptr_t fn, const at::Tensor& cost, const at::Tensor& start, const at::Tensor& goal, const c10::optional<at::Tensor>& passable,
                  double g_ratio, int64_t max_iters, bool want_log, int64_t flags, const c10::optional<at::Tensor>& order,
                  const c10::optional<at::Tensor>& order_out, int64_t ws_bytes, uintptr_t summary_host, uintptr_t counter_dev, uintptr_t stream,
-                 int64_t spin_us, const c10::optional<at::Tensor>& levels, uintptr_t sort_fn)
+                 int64_t spin_us, const c10::optional<at::Tensor>& levels, uintptr_t sort_fn, const c10::optional<at::Tensor>& packed)
 {
     const at::Tensor& pas = passable.has_value() ? *passable : cost;
     // anything the fast lane does not take goes back to the Python path, which raises the proper errors: rc = -1
@@ -74,12 +75,19 @@ py::tuple search(uintptr_t fn, const at::Tensor& cost, const at::Tensor& start, 
             return py::make_tuple(py::none(), py::none(), py::none(), py::none(), py::none(), -1, -1);
         oo = order_out->data_ptr<int32_t>();
     }
+    uint8_t* pk = nullptr;
+    if (packed.has_value()) {
+        // the caller's slot for the bit-packed masks (2 bits per cell: a collation bucket of parallel.BucketedCollator): the search launch emits them
+        if (packed->scalar_type() != at::kByte || packed->numel() != B * 2 * ((H * W + 7) / 8) || !packed->is_contiguous() || packed->device() != cost.device())
+            return py::make_tuple(py::none(), py::none(), py::none(), py::none(), py::none(), -1, -1);
+        pk = packed->data_ptr<uint8_t>();
+    }
     int32_t* iters = meta.data_ptr<int32_t>();
     int32_t* status = iters + B;
     volatile int32_t* summ = reinterpret_cast<volatile int32_t*>(summary_host);
     const int rc = reinterpret_cast<fwd_ex_t>(fn)(cost.data_ptr<float>(), start.data_ptr<float>(), goal.data_ptr<float>(), pas.data_ptr<float>(), (int)B, (int)H,
                                                   (int)W, g_ratio, (int)max_iters, hist.data_ptr<float>(), paths.data_ptr<int64_t>(),
-                                                  want_log ? log.data_ptr<int32_t>() : nullptr, iters, status, nullptr,
+                                                  want_log ? log.data_ptr<int32_t>() : nullptr, iters, status, pk,
                                                   ws_bytes > 0 ? ws.data_ptr() : nullptr, (size_t)ws_bytes, (int)flags, op, oo,
                                                   reinterpret_cast<int32_t*>(summary_host), summary_host ? reinterpret_cast<int32_t*>(counter_dev) : nullptr,
                                                   reinterpret_cast<void*>(stream));
@@ -118,5 +126,6 @@ PYBIND11_MODULE(_nastar_fastlane, m)
     m.doc() = "host side of one checked nastar_forward_ex call in native code (csrc/nastar_fastlane.cpp)";
     m.def("search", &search, py::arg("fn"), py::arg("cost"), py::arg("start"), py::arg("goal"), py::arg("passable"), py::arg("g_ratio"),
           py::arg("max_iters"), py::arg("want_log"), py::arg("flags"), py::arg("order"), py::arg("order_out"), py::arg("ws_bytes"),
-          py::arg("summary_host"), py::arg("counter_dev"), py::arg("stream"), py::arg("spin_us"), py::arg("levels") = py::none(), py::arg("sort_fn") = 0);
+          py::arg("summary_host"), py::arg("counter_dev"), py::arg("stream"), py::arg("spin_us"), py::arg("levels") = py::none(), py::arg("sort_fn") = 0,
+          py::arg("packed") = py::none());
 }

@@ -172,6 +172,11 @@ class DifferentiableAstar(nn.Module):
         self.Tmax = Tmax
         self.check_solvable = check_solvable
         self.unit_cost = unit_cost
+        # collation of sharded steps (parallel.BucketedCollator): a contiguous uint8 tensor [B, 2 * ceil(HW / 8)] the NEXT call's search launch
+        # writes its bit-packed masks into (2 bits per cell; fused into the launch for 32x32 / 64x64 maps).  `last_packed` is that tensor when
+        # the call did fill it (the checked no-grad call through the native host lane), None otherwise (the collator then packs the outputs itself)
+        self.packed_sink = None
+        self.last_packed = None
         self.last_status: Optional[torch.Tensor] = None
         self.last_iters: Optional[torch.Tensor] = None
         self._pending: List[_PendingStatus] = []
@@ -356,13 +361,14 @@ class DifferentiableAstar(nn.Module):
             if order is not None and check_order:
                 flags |= ops.FLAG_CHECK_ORDER
                 ws_bytes = 16
+        sink = self.packed_sink  # (a collation slot: the search launch emits the 2-bit-per-cell masks itself, include/nastar.h: packed_out)
         board = ops.StatusBoard.of(dev)
         row = board.acquire()
         try:
             hist, paths, iters, status, _, rc, verdict = fl[0].search(
                 fl[1], cost_maps, start_maps, goal_maps, None if same else obstacles_maps, float(self.g_ratio),
                 ops.max_iters_for(W, self.Tmax, self.training), False, flags, order, order_out, ws_bytes, board.ptr(row), board.counter_ptr(row),
-                torch._C._cuda_getCurrentRawStream(dev.index), 2000, levels, fl[2])
+                torch._C._cuda_getCurrentRawStream(dev.index), 2000, levels, fl[2], sink)
         except BaseException:
             board.release(row)
             raise
@@ -375,6 +381,7 @@ class DifferentiableAstar(nn.Module):
             pl.commit()
         self.last_status, self.last_iters = status, iters
         self._calls += 1
+        self.last_packed = sink
         if verdict == 0:  # every map ended with status 0 (the row came back zeroed)
             board.free.append(row)
             return AstarOutput(hist, paths, [])
@@ -392,6 +399,7 @@ class DifferentiableAstar(nn.Module):
             hist, paths, iters, status, _ = self.exact_search(cost_maps, start_maps, goal_maps, cost_maps if same else obstacles_maps,
                                                               ops.max_iters_for(W, self.Tmax, self.training))
             self.last_status, self.last_iters = status, iters
+            self.last_packed = None  # (the slot holds the masks of the first launch)
         return AstarOutput(hist, paths, [])
 
     def forward(self, cost_maps: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor,
@@ -400,6 +408,7 @@ class DifferentiableAstar(nn.Module):
         assert start_maps.ndim == 4
         assert goal_maps.ndim == 4
         assert obstacles_maps.ndim == 4
+        self.last_packed = None
         if (self.check_solvable is True and not store_intermediate_results and not self._pending and type(cost_maps) is torch.Tensor
                 and not (cost_maps.requires_grad and torch.is_grad_enabled())):
             out = self._forward_fast(cost_maps, start_maps, goal_maps, obstacles_maps)

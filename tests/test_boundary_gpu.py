@@ -413,6 +413,42 @@ def test_forward_host_overhead_is_bounded():
         assert t_sync < kern + 80e-6, f"sync forward() {t_sync * 1e6:.0f} us vs kernel {kern * 1e6:.0f} us"
 
 
+def test_packed_sink_is_filled_by_the_search_launch_itself():
+    """planner.astar.packed_sink (the collation slot of parallel.BucketedCollator): the checked no-grad call hands it to nastar_forward_ex as
+    packed_out -- the launch emits the 2-bit-per-cell masks itself (32x32: fused; 20x45: the C ABI adds its pack launch) -- and reports it as
+    last_packed; a call that cannot (autograd) reports None.  The packed bytes equal pack_masks() of the outputs."""
+    from neural_astar import parallel
+    from neural_astar.planner import VanillaAstar
+    from neural_astar.utils import synthetic as syn
+    dev = torch.device("cuda:0")
+    for (H, W, B) in ((32, 32, 512), (20, 45, 16)):
+        pr = syn.random_obstacle_maps(B, H, W, 0.2, seed=11)
+        m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+        va = VanillaAstar().to(dev).eval()
+        col = parallel.BucketedCollator(bucket=4)
+        slot = col.next_slot(B, H, W, dev)
+        slot.fill_(0xAA)
+        va.astar.packed_sink = slot
+        with torch.no_grad():
+            out = va(m, s, g)
+        assert va.astar.last_packed is slot
+        torch.cuda.synchronize()
+        assert torch.equal(slot, parallel.pack_masks(out.histories, out.paths))
+        h2, p2 = parallel.unpack_masks(slot, H, W)
+        assert torch.equal(h2, out.histories) and torch.equal(p2, out.paths)
+        va.astar.packed_sink = None
+        with torch.no_grad():
+            va(m, s, g)
+        assert va.astar.last_packed is None
+    da_in = torch.from_numpy(syn.random_costs(4, 32, 32, seed=1)).to(dev).requires_grad_(True)
+    pr = syn.random_obstacle_maps(4, 32, 32, 0.2, seed=12)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    va = VanillaAstar().to(dev).eval()
+    va.astar.packed_sink = torch.empty((4, 256), dtype=torch.uint8, device=dev)
+    va.astar(da_in, s, g, m)
+    assert va.astar.last_packed is None  # (under autograd the custom op runs: the collator packs the outputs itself)
+
+
 def test_native_host_lane_equals_the_python_lane():
     """lib/_nastar_fastlane.so (csrc/nastar_fastlane.cpp: allocation + nastar_forward_ex + the poll of the completion flag in C++) is a faster
     way to ISSUE the same launch: outputs, verdicts, placements and the fall-through cases must be those of the Python lane."""

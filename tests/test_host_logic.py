@@ -134,6 +134,27 @@ def _gloo_worker(rank, world, port, tmp):
     idx = list(range(lo, hi)) + ([slow] if not (lo <= slow < hi) else [])
     part = O.backward(up[idx], cost[idx], pr.start_maps[idx], pr.goal_maps[idx], pr.map_designs[idx], 0.5, 1024)[:hi - lo]
     ok = ok and float(np.abs(part - whole[lo:hi]).max()) <= 1e-6 * max(1.0, float(np.abs(whole).max()))
+    # a SEQUENCE of sharded steps: one all-gather per bucket of steps (BucketedCollator; bench.py --gpus N collates like this), incl. a
+    # partly filled last bucket: slot [r, i] of the collated buckets holds rank r's step i
+    steps = []
+    for i in range(5):
+        q = syn.random_obstacle_maps(B, 32, 32, 0.2, seed=300 + i)
+        steps.append(O.forward(q.map_designs, q.start_maps, q.goal_maps, q.map_designs, 0.5, 1024, mode="sm"))
+    seen = []
+    col = parallel.BucketedCollator(bucket=2, on_bucket=lambda t, n: seen.append(n))
+    for f in steps:
+        col.add(AstarOutput(torch.from_numpy(f.histories[lo:hi]).unsqueeze(1), torch.from_numpy(f.paths[lo:hi]).unsqueeze(1), None))
+    buckets = col.flush()
+    ok = ok and [b.shape[1] for b in buckets] == [2, 2, 1] and seen == [2, 2, 1] and col.collectives == 3 and all(b.shape[0] == world for b in buckets)
+    k = 0
+    for b in buckets:
+        for i in range(b.shape[1]):
+            for r in range(world):
+                rlo, rhi = parallel.shard_bounds(B, world, r)
+                h, pth = parallel.unpack_masks(b[r, i], 32, 32)
+                ok = ok and np.array_equal(h[:, 0].numpy(), steps[k].histories[rlo:rhi]) and np.array_equal(pth[:, 0].numpy(), steps[k].paths[rlo:rhi])
+            k += 1
+    ok = ok and k == 5 and col.flush() == []
     # ragged shards are refused with a clear error instead of hanging in the collective
     try:
         n_bad = (hi - lo) - (1 if rank == 0 else 0)
