@@ -279,7 +279,10 @@ def run_encoder(seed=21, N=30, verbose=True):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "module":
     # python tools/fuzz_parity.py module <seed> <N>: only the module sweep (every mode, autograd, large maps) against the literal batch loop
-    nm, rr, bad_m = run_module(seed=int(sys.argv[2]) if len(sys.argv) > 2 else 31, N=int(sys.argv[3]) if len(sys.argv) > 3 else 300)
+    # (a 4th argument "small": large maps only to 125x130 -- the oracle's dense restatement needs tens of seconds for one 150x200 batch)
+    small = len(sys.argv) > 4 and sys.argv[4] == "small"
+    nm, rr, bad_m = run_module(seed=int(sys.argv[2]) if len(sys.argv) > 2 else 31, N=int(sys.argv[3]) if len(sys.argv) > 3 else 300,
+                               **({"large_frac": 0.06, "large_hw": ((112, 126), (112, 131))} if small else {}))
     print(json.dumps({"module_vs_literal_batch_loop_cases": nm, "batches_in_the_coupled_class": rr, "gradient_cases": run_module.ngrad, "module_failures": len(bad_m)}))
     sys.exit(1 if bad_m else 0)
 
