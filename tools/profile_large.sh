@@ -1,0 +1,42 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel stats of the LARGE-MAP kernel (csrc/nastar_search_hybrid.hip.h) on the probe's inputs --
+# the per-launch durations behind DESIGN.md section 4.4's "ns per step of the longest search" (tools/probe_large.py times with HIP events).
+# Usage: tools/profile_large.sh r06 -> gpurun_out/profiles_<tag>/large_map_kernel_stats.csv (copy into profiles/<tag>/)
+set -u
+TAG=${1:-r06}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cat > /tmp/large_probe.py <<PY
+import sys
+sys.path[:0] = ["$R/neural-astar_amd", "$R"]
+import torch
+from neural_astar import ops
+from neural_astar.utils import synthetic as syn
+dev = torch.device("cuda:0")
+for H, B in ((256, 256), (512, 256)):
+    pr = syn.random_obstacle_maps(B, H, H, 0.2, seed=7)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    for _ in range(6):
+        out = ops.search_nograd(m, s, g, m, 0.5, H * H)
+    torch.cuda.synchronize()
+    print(H, B, "longest search", int(out[2].max()), "steps")
+PY
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_large -o large --output-format csv -- python /tmp/large_probe.py > $OUT/large_under_rocprof.log 2>&1
+python - <<PY
+import csv, glob
+rows = []
+for f in glob.glob("$OUT/trace_large/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "hybrid" in r["Kernel_Name"]:
+            rows.append((r["Kernel_Name"].split("(")[0][-60:], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size", "")))
+with open("$OUT/large_map_kernel_launches.csv", "w") as o:
+    o.write("kernel,duration_ns,grid_size\n")
+    for k, d, g in rows:
+        o.write(f"{k},{d},{g}\n")
+print(len(rows), "hybrid launches")
+PY
+for f in $(find $OUT/trace_large -name "*kernel_stats.csv"); do cp $f $OUT/large_map_kernel_stats.csv; done
+rm -rf $OUT/trace_large
+tail -3 $OUT/large_under_rocprof.log
