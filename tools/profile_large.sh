@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel stats of the LARGE-MAP kernel (csrc/nastar_search_hybrid.hip.h) on the probe's inputs --
 # the per-launch durations behind DESIGN.md section 4.4's "ns per step of the longest search" (tools/probe_large.py times with HIP events).
-# Usage: tools/profile_large.sh r06 -> gpurun_out/profiles_<tag>/large_map_kernel_stats.csv (copy into profiles/<tag>/)
+# Usage: tools/profile_large.sh r06 -> gpurun_out/profiles_<tag>/large_map_kernel_stats.csv (copy into profiles/<tag>/): MinNs = the 256x256
+# launches, MaxNs = the 512x512 ones
 set -u
 TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -24,19 +25,6 @@ for H, B in ((256, 256), (512, 256)):
     print(H, B, "longest search", int(out[2].max()), "steps")
 PY
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_large -o large --output-format csv -- python /tmp/large_probe.py > $OUT/large_under_rocprof.log 2>&1
-python - <<PY
-import csv, glob
-rows = []
-for f in glob.glob("$OUT/trace_large/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "hybrid" in r["Kernel_Name"]:
-            rows.append((r["Kernel_Name"].split("(")[0][-60:], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size", "")))
-with open("$OUT/large_map_kernel_launches.csv", "w") as o:
-    o.write("kernel,duration_ns,grid_size\n")
-    for k, d, g in rows:
-        o.write(f"{k},{d},{g}\n")
-print(len(rows), "hybrid launches")
-PY
 for f in $(find $OUT/trace_large -name "*kernel_stats.csv"); do cp $f $OUT/large_map_kernel_stats.csv; done
 rm -rf $OUT/trace_large
 tail -3 $OUT/large_under_rocprof.log
