@@ -271,10 +271,12 @@ class BucketedCollator:
         gathered = torch.empty((world,) + tuple(stage.shape), dtype=torch.uint8, device=stage.device)
         side = self._side(stage.device)
         if side is not None:
-            if self._sync_main:  # slots written by the steps' own launches (next_slot): behind the caller's stream, once per bucket
-                self._event.record(torch.cuda.current_stream(stage.device))
-                side.wait_event(self._event)
-                self._sync_main = False
+            # once per bucket the side stream is ordered behind the caller's stream: slots written by the steps' own launches (next_slot)
+            # are complete there, and `gathered` -- allocated just now for the CALLER's stream -- may be a block that kernels still
+            # pending on that stream use
+            self._event.record(torch.cuda.current_stream(stage.device))
+            side.wait_event(self._event)
+            self._sync_main = False
             with torch.cuda.stream(side):  # the collective is ordered behind the packs of this bucket, which ran on the side stream
                 work = dist.all_gather_into_tensor(gathered.view(world * n * stage.shape[1], stage.shape[2]),
                                                    stage.reshape(n * stage.shape[1], stage.shape[2]), group=self.group, async_op=True)
