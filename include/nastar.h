@@ -399,7 +399,7 @@ int nastar_encoder_prep_f16(const float* map, const float* start, const float* g
  *   padding) on the fp16 MFMA with gfx950's LDS transpose reads (csrc/nastar_conv_wgrad.hip.h).  dz [B,H,W,co], a [B,H,W,ci] with co, ci the
  *   PADDED channel counts (multiples of 32); dw fp32 [co_real][ci_real][3][3] = torch's weight layout, cropped.  grad_scale_dev: device
  *   float holding the power-of-two gradient scale to divide out, or NULL.  Deterministic (per-workgroup partial sums in `workspace`,
- *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  W >= 2; a chunk is R whole image rows -- for W > 96 R row SEGMENTS of the widest divisor of W that is <= 96 (a prime W > 96 is NASTAR_ERR_UNSUPPORTED) -- (R*W <= 96 pixels, 64 for
+ *   nastar_conv3x3_wgrad_workspace_bytes, summed in a fixed order).  W >= 2; a chunk is R whole image rows -- for W > 96 R row SEGMENTS: the widest divisor of W in [64, 96], else equal ragged segments of ceil(W / ceil(W / 96)) pixels, the last one of a row staged with zeros beyond the image -- (R*W <= 96 pixels, 64 for
  *   the power-of-two widths) and H must be a multiple of R (workspace_bytes == 0 flags an unsupported shape); images of <= 48 pixels
  *   (the 4x4 / 2x2 levels of a U-Net) are taken several per chunk, each with its own zero frame.
  * nastar_chan_stats_f16: per-channel sums over all pixels in double: sums[c] = (sum v, sum v^2), or with u != NULL

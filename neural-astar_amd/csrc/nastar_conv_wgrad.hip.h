@@ -40,7 +40,7 @@ struct WgradArgs {
     const uint16_t* dz;  // [P][CO (x2)] fp16 NHWC
     const uint16_t* a;   // [P][CI (x2)] fp16 NHWC (the layer's input activations)
     float* part;         // [nsplit][9][CI][CO] fp32 partial sums
-    int B, H, W, CO, CI; // W = width of a CHUNK row: the image width, or a segment of it (Wimg % W == 0) for images wider than 96 pixels
+    int B, H, W, CO, CI; // W = width of a CHUNK row: the image width, or a segment of it for images wider than 96 pixels (the last segment of a row may reach beyond the image)
     int Wimg, nseg;      // image width; segments per image row (1: W == Wimg)
     int R, G, NP, KS;    // chunk: G blocks of R image rows (G > 1: whole tiny images, R == H) = NP pixels = KS k-steps of 16 (KS*16 >= NP)
     int nchunk;          // B*H / R  (G == 1)  or  ceil(B / G)
@@ -52,13 +52,21 @@ constexpr int WG_MAX_SLOTS = 200;       // (R+2)*(W+2) for W <= 64: 198 for W = 
 constexpr int WG_MAX_SLOTS_WIDE = 294;  // 64 < W <= 96: 3 x 98
 constexpr int WG_MAX_PIX = 96, WG_MAX_KS = 6;
 
-// width of a chunk row: the image width up to 96 pixels, otherwise its widest divisor <= 96 (0: none above 1 -- a prime width beyond 96)
+// width of a chunk row: the image width up to 96 pixels; otherwise its widest divisor <= 96 when that is at least 64 pixels wide, else
+// equal RAGGED segments -- ceil(W / ceil(W / 96)) pixels, the last one of an image row shorter (a prime width, or one whose divisors are all
+// small: 194 = 2 x 97): the columns of a segment that lie beyond the image are staged as zeros on both sides of the product
 inline int nastar_wgrad_segment(int W)
 {
     if (W <= WG_MAX_PIX) return W;
-    for (int d = WG_MAX_PIX; d >= 2; --d)
+    for (int d = WG_MAX_PIX; d >= 64; --d)
         if (W % d == 0) return d;
-    return 0;
+    const int nseg = (W + WG_MAX_PIX - 1) / WG_MAX_PIX;
+    return (W + nseg - 1) / nseg;
+}
+inline int nastar_wgrad_segments(int W)
+{
+    const int seg = nastar_wgrad_segment(W);
+    return seg > 0 ? (W + seg - 1) / seg : 0;
 }
 // rows per chunk for an H x W map, 0 = unsupported: 64-pixel chunks where the chunk row divides 64, otherwise the most rows with R*W <= 96
 inline int nastar_wgrad_chunk_rows(int H, int Wimg)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
 
     // ---- staging plan (constants per thread): global element offset relative to the chunk's first pixel, LDS byte offset ----
     const int Wi = g.Wimg, BPi = RC * Wi;  // image row pitch / pixels per block in HBM (== W, BP unless the chunk rows are segments)
-    int zsrc[NZ], zdst[NZ], zblk[NZ], asrc[NA], adst[NA], arow[NA], ablk[NA], acol[NA];
+    int zsrc[NZ], zdst[NZ], zblk[NZ], zcol[NZ], asrc[NA], adst[NA], arow[NA], ablk[NA], acol[NA];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
         const int q = tid + i * NTHR;
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
         zsrc[i] = ok ? ((pix / BP) * BPi + zr * Wi + zc) * sdz + half * g.CO + co0 + cc * 8 : -1;
         zdst[i] = pix * RDZ + half * (COB * 64) + cc * 16;
         zblk[i] = pix / BP;  // which image of the chunk (0 when G == 1)
+        zcol[i] = zc;        // column inside the chunk row: beyond the image in the ragged last segment of a row
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(192 * COB * CIB) void nastar_conv3x3_wgrad_kernel(c
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             zq[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (zsrc[i] >= 0 && zblk[i] < gcount) zq[i] = *reinterpret_cast<const uint4*>(zb + zsrc[i]);
+            if (zsrc[i] >= 0 && zblk[i] < gcount && x0 + zcol[i] < Wi) zq[i] = *reinterpret_cast<const uint4*>(zb + zsrc[i]);
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {

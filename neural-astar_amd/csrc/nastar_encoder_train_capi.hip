@@ -48,7 +48,7 @@ size_t nastar_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int co, int ci)
     const int R = nastar_wgrad_chunk_rows(H, W);
     if (R == 0) return 0;
     const int G = nastar_wgrad_chunk_images(H, W);
-    const int nseg = W / nastar_wgrad_segment(W);
+    const int nseg = nastar_wgrad_segments(W);
     const int nchunk = G > 1 ? (B + G - 1) / G : (int)(((long long)B * H) / R) * nseg;
     return (size_t)wgrad_nsplit(nchunk, co, ci) * 9 * ci * co * sizeof(float);
 }
@@ -66,7 +66,7 @@ int nastar_conv3x3_wgrad_f16(const uint16_t* dz, const uint16_t* a, float* dw, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     WgradArgs g;
     g.dz = dz; g.a = a; g.part = static_cast<float*>(workspace); g.B = B; g.H = H; g.CO = co; g.CI = ci;
-    g.Wimg = W; g.W = nastar_wgrad_segment(W); g.nseg = W / g.W;  // images wider than 96 pixels: chunk rows are segments of an image row
+    g.Wimg = W; g.W = nastar_wgrad_segment(W); g.nseg = nastar_wgrad_segments(W);  // images wider than 96 pixels: chunk rows are segments of an image row
     g.G = nastar_wgrad_chunk_images(H, W);
     g.R = R; g.NP = g.G * R * g.W; g.KS = (g.NP + 15) / 16;
     g.nchunk = g.G > 1 ? (B + g.G - 1) / g.G : (int)(((long long)B * H) / R) * g.nseg;

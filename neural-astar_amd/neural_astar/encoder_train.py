@@ -375,13 +375,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 def wgrad_segment(W: int) -> int:
     """width of a weight-gradient chunk row (csrc/nastar_conv_wgrad.hip.h: nastar_wgrad_segment): the image width up to 96 pixels, else its
-    widest divisor <= 96 (0: a width beyond 96 without a divisor above 1 -- a prime)"""
+    widest divisor <= 96 when that is at least 64 pixels, else equal RAGGED segments of ceil(W / ceil(W / 96)) pixels (prime widths, 2 x 97, ...:
+    the last segment of a row is shorter, its columns beyond the image are staged as zeros)"""
     if W <= 96:
         return W
-    for d in range(96, 1, -1):
+    for d in range(96, 63, -1):
         if W % d == 0:
             return d
-    return 0
+    nseg = (W + 95) // 96
+    return (W + nseg - 1) // nseg
 
 
 def chunk_rows(H: int, W: int) -> int:

@@ -55,6 +55,8 @@ WG_CASES = [
     (3, 8, 128, 64, 32, True),     # round 6: images wider than 96 pixels -- chunk rows are SEGMENTS of an image row (128 = 2 x 64)
     (2, 6, 200, 32, 64, False),    # ... 200 = 4 x 50: one 50-pixel segment per chunk, frame columns hold the neighbouring segments' pixels
     (2, 4, 160, 96, 32, True),     # ... 160 = 2 x 80 (the wide staging variant)
+    (2, 5, 127, 64, 32, True),     # ... a prime width: two ragged segments (64 + 63 pixels; the last column of the second lies beyond the image)
+    (1, 3, 197, 32, 64, False),    # ... 197 (prime) = 66 + 66 + 65
 ]
 
 
@@ -332,7 +334,8 @@ def _decision_margins(encoder):
     ("CNN", "m+", 3, 1, 20, 45, None, 2.0, 0),
     ("CNN", "m", 2, 1, 24, 24, None, None, 0),
     ("CNN", "m+", 4, 1, 64, 128, None, None, 0),             # round 6: the reference's own rectangle scenario (tests/astar_test.py:45-53), wider than
-    ("CNN", "m+", 2, 1, 12, 200, None, 5.0, 1)])             # the flat tiles (2-D tiles in the convolutions, row segments in the weight gradients)
+    ("CNN", "m+", 2, 1, 12, 200, None, 5.0, 1),
+    ("CNN", "m+", 2, 1, 10, 127, None, 5.0, 1)])             # the flat tiles (2-D tiles in the convolutions, row segments in the weight gradients)
 def test_other_encoder_stacks_train_on_the_hip_kernels(arch, enc_in, depth, C, H, W, hw, const, seed):
     """CNNDownSize (max-pool after every hidden block; the WarCraft configuration 96x96 RGB -> 12x12) and CNNs of other depths / map
     sizes: forward + every parameter gradient against the torch module in float64.  f16x3: 1e-4 relative per tensor whenever every

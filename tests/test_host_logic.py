@@ -328,15 +328,15 @@ def test_encoder_training_support_checks_are_host_logic():
     # chunk = R whole rows, R*W <= 96 pixels; 64-pixel chunks where W divides 64
     assert [ET.chunk_rows(h, w) for (h, w) in ((32, 32), (64, 64), (16, 16), (8, 8), (96, 96), (48, 48), (24, 24), (12, 12), (20, 45), (7, 5))] \
         == [2, 1, 4, 8, 1, 2, 4, 6, 2, 7]
-    assert ET.chunk_rows(10, 97) == 0 and ET.chunk_rows(5, 1) == 0  # (97: a prime beyond 96 -- no segment divides it)
-    # round 6: images wider than 96 pixels -- chunk rows are SEGMENTS, the widest divisor of W that is <= 96
-    assert [ET.wgrad_segment(w) for w in (32, 96, 128, 130, 160, 200, 256, 97, 202)] == [32, 96, 64, 65, 80, 50, 64, 0, 2]
+    assert ET.chunk_rows(10, 97) == 1 and ET.chunk_rows(5, 1) == 0  # (97: a prime beyond 96 -- two ragged segments of 49 / 48 pixels)
+    # round 6: images wider than 96 pixels -- chunk rows are SEGMENTS: the widest divisor of W in [64, 96], else equal ragged segments
+    assert [ET.wgrad_segment(w) for w in (32, 96, 128, 130, 160, 200, 256, 97, 202, 127)] == [32, 96, 64, 65, 80, 67, 64, 49, 68, 64]
     assert [ET.chunk_rows(h, w) for (h, w) in ((64, 128), (8, 130), (10, 200), (6, 256))] == [1, 1, 1, 1]
     assert ET.supported(CNN(2, 4, None), 32, 32) and ET.supported(CNN(1, 2, None), 20, 45)
     assert ET.supported(CNNDownSize(4, 3, 10.0), 96, 96)            # WarCraft: 96 -> 48 -> 24 -> 12
     assert not ET.supported(CNNDownSize(4, 3, 10.0), 100, 100)      # 25 x 25 cannot be pooled again
-    assert ET.supported(CNN(2, 4, None), 8, 130) and ET.supported(CNN(2, 4, None), 64, 128)   # any width with a divisor in [2, 96] (round 6)
-    assert not ET.supported(CNN(2, 4, None), 8, 127)                # a prime width beyond 96: no weight-gradient segment
+    assert ET.supported(CNN(2, 4, None), 8, 130) and ET.supported(CNN(2, 4, None), 64, 128)   # any width (round 6) ...
+    assert ET.supported(CNN(2, 4, None), 8, 127)                    # ... a prime one too: ragged weight-gradient segments
     odd = CNN(2, 2, None)
     odd.model[0] = nn.Conv2d(2, 48, 3, padding=1)                   # 48 channels: not 32 * 2^k
     assert not ET.supported(odd, 32, 32)
