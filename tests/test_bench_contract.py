@@ -95,3 +95,22 @@ def test_train_bench_prints_one_json_line(config):
     assert abs(j["value"] - 100 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     import math
     assert math.isfinite(j["final_loss"])
+
+
+@pytest.mark.gpu
+def test_sharded_step_collates_per_bucket_over_rccl_in_a_one_rank_group():
+    """The N > 1 step of bench.py (`--force-collate`: a 1-rank RCCL group on this GPU): the API call writes its bit-packed masks into the
+    collation bucket's slot (planner.astar.packed_sink -> packed_out of nastar_forward_ex), one all-gather per `--collate-bucket` steps on a side
+    stream, the tail bucket flushed inside the timed region (parallel.BucketedCollator; the world-2 content check runs over gloo on the CPU:
+    tests/test_host_logic.py).  5 steps with buckets of 2 = three collectives incl. a partly filled one."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-collate", "--collate-bucket", "2", "--steps", "5", "--warmup", "2",
+                        "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    note = j["config"]["collate"]
+    assert "FAILED" not in note and "ONE all-gather per 2 steps" in note and "emitted by the search launch itself" in note, note
+    assert j["config"]["distributed"]["backend"] == "nccl" and j["config"]["distributed"]["world_size"] == 1
+    assert j["value"] > 0 and j["config"]["host_lane"].startswith("native")
