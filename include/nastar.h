@@ -251,8 +251,8 @@ int nastar_backward_replay_ordered(const float* grad_histories, const float* his
  *   grad_cost_out  [B,H,W] fp32, fully written
  * By REPLAY of the selection log: no selection is repeated and the softmax is accounted per open-list event, O(9) work per
  * step instead of O(open list) (csrc/nastar_backward_replay.hip.h).  (Rounds 1-3 also exported nastar_backward /
- * nastar_backward_l1, which repeated the selection instead of reading a log; superseded, removed in 0.4.0.)  Any map of up to 65519 cells: the per-map state lives in LDS up to ~11.6 k cells and in
- * the workspace beyond.  workspace: nastar_backward_workspace_bytes(B,H,W,max_iters) bytes (per-step history of the running
+ * nastar_backward_l1, which repeated the selection instead of reading a log; superseded, removed in 0.4.0.)  Any map size the forward takes (1,179,648 cells): the per-map state lives in LDS up to ~11.6 k cells and in
+ * the workspace beyond (maps above 65,519 cells, or a history of more than 65535 entries: 32-bit history stamps, 16 instead of 14 B per cell).  workspace: nastar_backward_workspace_bytes(B,H,W,max_iters) bytes (per-step history of the running
  * sums, 16 B per executed step, + the state slabs of maps too large for LDS).  grad_cost_out is fully written.
  * nastar_backward_l1_replay: the fused-L1 form (see nastar_l1_loss below).
  */

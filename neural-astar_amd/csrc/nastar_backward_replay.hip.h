@@ -18,6 +18,8 @@
 // w_tau = 1 except for the reference's batch-coupled fixed-point steps (`extra`, see nastar_backward in include/nastar.h).
 // Prototype with the same arithmetic, checked against the reference's autograd: tools/proto_backward_events.py.
 #pragma once
+#include <type_traits>
+
 #include "nastar_search_compact.hip.h"
 
 namespace nastar {
@@ -48,7 +50,8 @@ struct BwdRArgs {
     CompactDims d;
 };
 
-__host__ __device__ inline size_t bwdr_state_bytes(int HWp) { return (size_t)HWp * 14 + 64; }  // gc 8 + G 4 + t0 2 per cell, + (S, D)
+// gc 8 + G 4 + t0 2 per cell (wide: t0 4 -- history stamps beyond 65535: the HBM state of maps above 65,519 cells), + (S, D)
+__host__ __device__ inline size_t bwdr_state_bytes(int HWp, bool wide = false) { return (size_t)HWp * (wide ? 16 : 14) + 64; }
 
 __device__ __forceinline__ float bwdr_upstream(const BwdRArgs& a, size_t i)
 {
@@ -103,9 +106,14 @@ __device__ __forceinline__ float bwdr_v(const CompactDims& d, float G, float hh,
 
 // kHistLds: the (A, B) history lives in LDS behind the state (16 B per executed step): no global round trip inside the loop
 // (an HBM history costs a write-through store + a vmcnt(0) drain per step, ~1 us).  kFastDiv: see compact_key.
-template <bool kGlobal, bool kHistLds, bool kFastDiv>
+// kWide (with kGlobal): maps above 65,519 cells / histories beyond 65535 entries -- 32-bit history stamps, and the heuristic with the
+// correctly rounded square root (coordinates differences reach past 140: nastar_device.hip.h, sqrt_rn_int)
+template <bool kGlobal, bool kHistLds, bool kFastDiv, bool kWide = false>
 __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRArgs a, const float rcp_sqrtW)
 {
+    static_assert(!kWide || kGlobal, "wide stamps exist for the HBM state only");
+    using stamp_t = typename std::conditional<kWide, uint32_t, unsigned short>::type;
+    auto h0 = [](int r, int c, int gr, int gc) { return kWide ? heuristic0(r, c, gr, gc) : heuristic0_fast(r, c, gr, gc); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = (a.order == nullptr || (a.order_bad != nullptr && *a.order_bad != 0)) ? (int)blockIdx.x : a.order[blockIdx.x];
     if ((unsigned)b >= (unsigned)a.B_total) return;  // not a permutation: never touch memory outside the batch
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     float* g = reinterpret_cast<float*>(base);                 // [HWp] g-value / node state (sign of infinity, as the forward)
     float* cst = g + d.HWp;                                     // [HWp] cost
     float* G = cst + d.HWp;                                     // [HWp] upstream gradient
-    unsigned short* t0 = reinterpret_cast<unsigned short*>(G + d.HWp);  // [HWp] history index at which the cell was (re)opened
+    stamp_t* t0 = reinterpret_cast<stamp_t*>(G + d.HWp);  // [HWp] history index at which the cell was (re)opened
     double* sd = reinterpret_cast<double*>(smem + (kGlobal ? 0 : (size_t)d.HWp * 14));  // S, D: always in LDS
     const size_t off = (size_t)b * (size_t)d.HW;
     static_assert(!(kGlobal && kHistLds), "a map too large for LDS keeps its history in the workspace as well");
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         st_st<kGlobal>(&g[i], a.passable[off + i] != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF);
         st_st<kGlobal>(&cst[i], a.cost[off + i]);
         st_st<kGlobal>(&G[i], bwdr_upstream(a, off + i));
-        st_st<kGlobal>(&t0[i], (unsigned short)0);
+        st_st<kGlobal>(&t0[i], (stamp_t)0);
         gout[i] = 0.f;
     }
     sidx = wave_max_i32(sidx);
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         if (goal_zeroed) st_st<kGlobal>(&G[gidx], 0.f);
         // open list = {start} (:187), g[start] = 0 (:193): the start is open from history index 0
         const int r = sidx / d.W, c = sidx - r * d.W;
-        const float hh = d.omg * (heuristic0_fast(r, c, goal_r, goal_c) + st_ld<kGlobal>(&cst[sidx]));
+        const float hh = d.omg * (h0(r, c, goal_r, goal_c) + st_ld<kGlobal>(&cst[sidx]));
         const float v = bwdr_v<kFastDiv>(d, 0.0f, hh, rcp_sqrtW);
         st_st<kGlobal>(&g[sidx], 0.0f);
         sd[0] = (double)v;
@@ -221,9 +229,9 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         const float gs = st_ld<kGlobal>(&g[s]), cs = st_ld<kGlobal>(&cst[s]);
         const float gl = st_ld<kGlobal>(&g[il]), cl = st_ld<kGlobal>(&cst[il]);
         const float Gl = st_ld<kGlobal>(&G[il]);
-        const int tl = st_ld<kGlobal>(&t0[il]);
+        const int tl = (int)st_ld<kGlobal>(&t0[il]);
         const int rl = il / d.W, cc = il - rl * d.W;
-        const float hh = d.omg * (heuristic0_fast(rl, cc, goal_r, goal_c) + cl);
+        const float hh = d.omg * (h0(rl, cc, goal_r, goal_c) + cl);
         const float g2 = gs + cs;
         const bool upd = inb & (gl > g2);
         const bool was_open = fabsf(gl) < NASTAR_POS_INF;
@@ -243,12 +251,12 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         }
         if (upd) {
             st_st<kGlobal>(&g[il], g2);
-            st_st<kGlobal>(&t0[il], (unsigned short)(t + 1));
+            st_st<kGlobal>(&t0[il], (stamp_t)(t + 1));
         }
         if ((lane == 8) & !goal_step) st_st<kGlobal>(&g[s], NASTAR_NEG_INF);
         if (restore) {
             st_st<kGlobal>(&G[s], goal_up);
-            st_st<kGlobal>(&t0[s], (unsigned short)(t + 1));
+            st_st<kGlobal>(&t0[s], (stamp_t)(t + 1));
         }
         if (lane == 0) {  // history entry t+1 = (A, B) after step t
             hist_st<kHistLds>(&hist[2 * (t + 1)], A);
@@ -287,11 +295,11 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     for (int i = lane; i < d.HW; i += 64) {
         const float gi = st_ld<kGlobal>(&g[i]);
         if (fabsf(gi) < NASTAR_POS_INF) {
-            const int ti = st_ld<kGlobal>(&t0[i]);
+            const int ti = (int)st_ld<kGlobal>(&t0[i]);
             const double A0 = hist_ld<kHistLds>(&hist[2 * ti]);
             const double B0 = hist_ld<kHistLds>(&hist[2 * ti + 1]);
             const int ri = i / d.W, ci = i - ri * d.W;
-            const float hh = d.omg * (heuristic0_fast(ri, ci, goal_r, goal_c) + st_ld<kGlobal>(&cst[i]));
+            const float hh = d.omg * (h0(ri, ci, goal_r, goal_c) + st_ld<kGlobal>(&cst[i]));
             const float v = bwdr_v<kFastDiv>(d, gi, hh, rcp_sqrtW);
             const float dA = (float)(A - A0), dB = (float)(B - B0);
             unsafeAtomicAdd(&gout[i], (a.kfac * v) * (st_ld<kGlobal>(&G[i]) * dA - dB));

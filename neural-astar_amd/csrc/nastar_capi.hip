@@ -925,12 +925,17 @@ int nastar_forward_packed(const float* cost, const float* start, const float* go
 static int bwdr_hist_len(int HW, int max_iters) { return (max_iters < 2 * HW + 2 ? max_iters : 2 * HW + 2) + 2; }
 static bool bwdr_fits_lds(int HW) { return bwdr_state_bytes(((HW + 63) / 64) * 64) <= kMaxLdsBytes; }
 
+// 32-bit history stamps (2 B more per cell of the HBM state): maps above 65,519 cells, or a history that can outrun 16 bits
+static bool bwdr_wide(int HW, int max_iters) { return HW > 65535 - CCSZ || bwdr_hist_len(HW, max_iters) > 65535; }
+
 size_t nastar_backward_workspace_bytes(int B, int H, int W, int max_iters)
 {
-    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0 || (long long)H * W > 65535 - CCSZ) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0 || (long long)H * W > kMaxGlobalCells) return 0;
     const int HW = H * W, HWp = ((HW + 63) / 64) * 64;
     size_t n = (size_t)B * (size_t)bwdr_hist_len(HW, max_iters) * 16;
-    if (!bwdr_fits_lds(HW)) n += (size_t)B * ((bwdr_state_bytes(HWp) + 255) & ~(size_t)255);
+    // (a wide history on an LDS-sized map -- a lock-step log beyond 65535 entries -- takes the HBM state too)
+    const bool wide = bwdr_wide(HW, max_iters);
+    if (wide || !bwdr_fits_lds(HW)) n += (size_t)B * ((bwdr_state_bytes(HWp, wide) + 255) & ~(size_t)255);
     return n + kOrderCheckBytes;  // + the verdict word of NASTAR_FLAG_CHECK_ORDER (nastar_backward_replay_ordered)
 }
 
@@ -940,8 +945,19 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
                                 int flags = 0)
 {
     if (!cost || !start || !goal || !passable || !sel_log || !iters || !grad_cost_out || !workspace) return NASTAR_ERR_NULL;
-    int rc = make_cdims(B, H, W, max_iters, g_ratio, a.d);
-    if (rc) return rc;
+    if (B <= 0 || H <= 0 || W <= 0 || max_iters <= 0) return NASTAR_ERR_BAD_SHAPE;
+    if ((long long)H * W > kMaxGlobalCells) return NASTAR_ERR_UNSUPPORTED;
+    if ((long long)H * W > 65535 - CCSZ) {
+        // above the compact layouts' 16-bit cell indices: the replay needs the geometry and the priority's constants only
+        a.d = CompactDims{};
+        a.d.H = H; a.d.W = W; a.d.HW = H * W;
+        a.d.gr = (float)g_ratio;
+        a.d.omg = (float)(1.0 - g_ratio);
+        a.d.sqrtW = (float)sqrt((double)W);
+    } else {
+        int rc = make_cdims(B, H, W, max_iters, g_ratio, a.d);
+        if (rc) return rc;
+    }
     if (workspace_bytes < nastar_backward_workspace_bytes(B, H, W, max_iters)) return NASTAR_ERR_WORKSPACE;
     a.d.HWp = ((a.d.HW + 63) / 64) * 64;
     a.cost = cost; a.start = start; a.goal = goal; a.passable = passable; a.sel_log = sel_log; a.iters = iters;
@@ -960,8 +976,7 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
     const bool fast = fastdiv_verified(W);
     const int max_steps = hlen - 2;
     if ((flags & ~(kKnownFlags)) != 0) return NASTAR_ERR_UNSUPPORTED;
-    // history stamps are 16-bit: a lock-step log of a map with more than ~32 k cells could outrun them
-    if ((flags & NASTAR_FLAG_LOCKSTEP) && hlen > 65535) return NASTAR_ERR_UNSUPPORTED;
+    const bool wide = bwdr_wide(a.d.HW, max_iters);  // (history stamps are 16-bit otherwise)
     // (the hand-scheduled loop closes every selected cell: a lock-step log, whose goal selections leave the goal open, takes the general loop)
     if ((flags & (NASTAR_FLAG_NO_ASM | NASTAR_FLAG_LOCKSTEP)) == 0 && fast && H == W && (W == 32 || W == 16) && aligned16(cost) && aligned16(start) &&
         aligned16(goal) && aligned16(passable) && aligned16(grad_cost_out) && bwdr_asm_lds_bytes(a.d.HW, max_steps) <= kMaxLdsBytes) {
@@ -970,7 +985,7 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
         return W == 32 ? launch(nastar_backward_replay_asm_kernel<5>, B, lds, s, a, rcp)
                        : launch(nastar_backward_replay_asm_kernel<4>, B, lds, s, a, rcp);
     }
-    if (bwdr_fits_lds(a.d.HW)) {
+    if (!wide && bwdr_fits_lds(a.d.HW)) {
         // history in LDS as long as at least 2 maps (or what the state alone allows) stay resident per CU
         const size_t st = bwdr_state_bytes(a.d.HWp), with_hist = st + (size_t)hlen * 16;
         const bool hist_lds = with_hist <= kMaxLdsBytes && (kMaxLdsBytes / with_hist >= 2 || kMaxLdsBytes / st < 2);
@@ -979,8 +994,10 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
         return fast ? launch(nastar_backward_replay_kernel<false, false, true>, B, st, s, a, rcp)
                     : launch(nastar_backward_replay_kernel<false, false, false>, B, st, s, a, rcp);
     }
-    a.state_stride = (bwdr_state_bytes(a.d.HWp) + 255) & ~(size_t)255;
+    a.state_stride = (bwdr_state_bytes(a.d.HWp, wide) + 255) & ~(size_t)255;
     a.state = static_cast<unsigned char*>(workspace) + (size_t)B * (size_t)hlen * 16;
+    if (wide) return fast ? launch(nastar_backward_replay_kernel<true, false, true, true>, B, 64, s, a, rcp)
+                          : launch(nastar_backward_replay_kernel<true, false, false, true>, B, 64, s, a, rcp);
     return fast ? launch(nastar_backward_replay_kernel<true, false, true>, B, 64, s, a, rcp)
                 : launch(nastar_backward_replay_kernel<true, false, false>, B, 64, s, a, rcp);
 }

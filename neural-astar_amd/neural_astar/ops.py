@@ -440,7 +440,7 @@ def astar_backward_replay(grad_hist: torch.Tensor, cost: torch.Tensor, start: to
                           passable: torch.Tensor, sel_log: torch.Tensor, g_ratio: float, max_iters: int, iters: torch.Tensor,
                           t_batch: Optional[torch.Tensor], order: Optional[torch.Tensor] = None, flags: int = 0) -> torch.Tensor:
     """dL/dcost by replaying the forward's selection log (csrc/nastar_backward_replay.hip.h): any map size the forward takes
-    up to 65519 cells, O(9) accounting work per step.  ``order`` (int32 permutation of 0..B-1): workgroup i replays map order[i] --
+    (1,179,648 cells; 32-bit history stamps above 65519), O(9) accounting work per step.  ``order`` (int32 permutation of 0..B-1): workgroup i replays map order[i] --
     the forward's own completion order (``astar_forward_ordered``'s ``order_out``) puts the longest replays first.  ``flags``:
     ``FLAG_LOCKSTEP`` for the log of an ``exact`` forward (goal selections before the last entry: the general replay loop)."""
     _require_device(grad_hist, cost, start, goal, passable)

@@ -108,3 +108,32 @@ def test_long_searches_match_the_oracle_and_unsolvable_maps_are_flagged():
     out = va(_t(m[1:]), _t(s[1:]), _t(g[1:]))
     va.astar.raise_if_unsolvable()
     assert int(out.paths.sum()) == 186  # the diagonal 5,5 -> 190,190
+
+
+@pytest.mark.parametrize("H,W,reach,train", [(260, 270, 30, False), (512, 512, 25, False), (300, 260, 40, True), (1024, 1024, 25, False)])
+def test_gradients_on_maps_above_65519_cells_match_the_oracle(H, W, reach, train):
+    """The replay backward on maps whose history stamps need 32 bits (round 6: every size the forward takes; rounds 2-5 stopped at 65,519
+    cells): DifferentiableAstar under autograd -- hybrid forward with a selection log, HBM-state replay with wide stamps -- against the
+    oracle's literal reverse mode of the reference's graph (differentiable_astar.py:203-252), 1e-5 of the gradient's scale.  Short searches
+    (start and goal `reach` cells apart; the training case stops at a budget of 40 steps, before either map reaches its goal): the oracle scans every cell per step."""
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    from neural_astar.utils import synthetic as syn
+    from oracle import oracle as O
+    B = 2
+    m, s, g = _near_pairs(B, H, W, 0.15, seed=H + W, reach=reach)
+    cost = syn.random_costs(B, H, W, seed=5, hi=2.0)
+    Tmax = 40.5 / (W * W) if train else 1.0
+    T = int(Tmax * W * W) if train else W * W
+    fw = O.forward(cost, s, g, m, 0.5, T, mode="sm")
+    assert fw.status == 0 if np.isscalar(fw.status) else not np.any(fw.status)
+    Tref = int(fw.iters.max())  # the dense reverse mode needs the batch's steps only
+    up = np.random.Generator(np.random.PCG64(3)).standard_normal((B, 1, H, W)).astype(np.float32)
+    ref = O.backward(up, cost, s, g, m, 0.5, T if train else Tref)
+    da = DifferentiableAstar(0.5, Tmax).to(_dev()).train(train)
+    c = _t(cost).requires_grad_(True)
+    out = da(c, _t(s), _t(g), _t(m))
+    (out.histories * _t(up)).sum().backward()
+    assert np.array_equal(out.histories[:, 0].detach().cpu().numpy(), fw.histories) and np.array_equal(da.last_iters.cpu().numpy(), fw.iters)
+    err = float(np.abs(c.grad[:, 0].cpu().numpy() - ref).max())
+    assert err <= 1e-5 * max(1.0, float(np.abs(ref).max())), (err, float(np.abs(ref).max()))
+    assert float(np.abs(ref).max()) > 0
