@@ -61,31 +61,30 @@ __device__ __forceinline__ float bwdr_upstream(const BwdRArgs& a, size_t i)
     return sg * (a.l1_scale * (a.l1_up != nullptr ? *a.l1_up : 1.f));
 }
 
-// state accessors: LDS (plain) or the HBM workspace (agent-scope relaxed atomics = sc1, served by L2)
+// state accessors: LDS, or the HBM workspace through the CU's vector L1.  The slab and the history of a map are touched by ONE wavefront
+// between the fill and the sweep launch, and the lanes of a wavefront are coherent through their L1 without further action (write-through,
+// accesses processed in order; global_step_fence per step) -- the neighbourhood of s* is mostly that of the previous step, i.e. L1 hits.
+// (Rounds 2-5 used agent-scope relaxed atomics = sc1, served by L2: the forward's large-map kernel made the same move in round 5, 1275 -> 986 ns.)
 template <bool kGlobal, typename T>
 __device__ __forceinline__ T st_ld(const T* p)
 {
-    if constexpr (kGlobal) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
+    return *p;
 }
 template <bool kGlobal, typename T>
 __device__ __forceinline__ void st_st(T* p, T v)
 {
-    if constexpr (kGlobal) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
+    *p = v;
 }
 
 template <bool kLds>
 __device__ __forceinline__ double hist_ld(const double* p)
 {
-    if constexpr (kLds) return *p;
-    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
 }
 template <bool kLds>
 __device__ __forceinline__ void hist_st(double* p, double v)
 {
-    if constexpr (kLds) *p = v;
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *p = v;
 }
 
 // q = fl(f / fl32(sqrt(W))) of a cell with g-value G and hh = (1-g_ratio)(h0 + cost)   (:206-207); exp(-q) by v_exp_f32
@@ -102,6 +101,75 @@ __device__ __forceinline__ float bwdr_v(const CompactDims& d, float G, float hh,
         q = f / d.sqrtW;
     }
     return __builtin_amdgcn_exp2f(q * -1.4426950408889634f);
+}
+
+// ---- maps whose state lives in the HBM workspace (kGlobal): the per-cell passes are launches of their own --------------------------------
+// One wavefront initialising and, at the end, sweeping 262144 cells took ~10 ms per 512x512 map (its loop body is five agent-scope stores);
+// as in the forward (nastar_search_hybrid.hip.h: fill / search / store) the two O(cells) passes run on ALL CUs and the one-wavefront-per-map
+// launch between them does the O(steps) replay only.  Slab of a map: g | cost | G | t0 (bwdr_state_bytes) and, in its last 64 bytes, a header
+// {int start, int goal, double A, double B}: start / goal cells found by the fill launch (atomicMax on -1), the final running sums left by
+// the replay for the sweep.
+__host__ __device__ inline size_t bwdr_header_offset(int HWp, bool wide) { return bwdr_state_bytes(HWp, wide) - 64; }
+
+template <bool kWide>
+__global__ __launch_bounds__(256) void nastar_bwdr_fill_kernel(const BwdRArgs a)
+{
+    using stamp_t = typename std::conditional<kWide, uint32_t, unsigned short>::type;
+    const int b = blockIdx.y;
+    const CompactDims& d = a.d;
+    unsigned char* base = a.state + (size_t)b * a.state_stride;
+    float* g = reinterpret_cast<float*>(base);
+    float* cst = g + d.HWp;
+    float* G = cst + d.HWp;
+    stamp_t* t0 = reinterpret_cast<stamp_t*>(G + d.HWp);
+    int* hdr = reinterpret_cast<int*>(base + bwdr_header_offset(d.HWp, kWide));  // {-1, -1, ..} on entry (nastar_hybrid_header_kernel)
+    const size_t off = (size_t)b * (size_t)d.HW;
+    float* gout = a.grad_cost + off;
+    int sidx = -1, gidx = -1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.HW; i += gridDim.x * 256) {
+        if (a.start[off + i] != 0.f) sidx = i;
+        if (a.goal[off + i] != 0.f) gidx = i;
+        g[i] = a.passable[off + i] != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF;
+        cst[i] = a.cost[off + i];
+        G[i] = bwdr_upstream(a, off + i);
+        t0[i] = (stamp_t)0;
+        gout[i] = 0.f;
+    }
+    if (sidx >= 0) atomicMax(&hdr[0], sidx);
+    if (gidx >= 0) atomicMax(&hdr[1], gidx);
+}
+
+// cells still on the open list when the replay ended: their intervals close at the final (A, B) the replay left in the header
+template <bool kWide, bool kFastDiv>
+__global__ __launch_bounds__(256) void nastar_bwdr_sweep_kernel(const BwdRArgs a, const float rcp_sqrtW)
+{
+    using stamp_t = typename std::conditional<kWide, uint32_t, unsigned short>::type;
+    const int b = blockIdx.y;
+    const CompactDims& d = a.d;
+    const unsigned char* base = a.state + (size_t)b * a.state_stride;
+    const float* g = reinterpret_cast<const float*>(base);
+    const float* cst = g + d.HWp;
+    const float* G = cst + d.HWp;
+    const stamp_t* t0 = reinterpret_cast<const stamp_t*>(G + d.HWp);
+    const int* hdr = reinterpret_cast<const int*>(base + bwdr_header_offset(d.HWp, kWide));
+    const int sidx = hdr[0], gidx = hdr[1];
+    if (sidx < 0 || gidx < 0) return;  // not a one-hot start / goal map: no replay ran, the gradient stays zero
+    const double A = *reinterpret_cast<const double*>(hdr + 2), B = *reinterpret_cast<const double*>(hdr + 4);
+    const double* hist = a.hist + (size_t)b * (size_t)a.hist_len * 2;
+    float* gout = a.grad_cost + (size_t)b * (size_t)d.HW;
+    const int goal_r = gidx / d.W, goal_c = gidx - goal_r * d.W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.HW; i += gridDim.x * 256) {
+        const float gi = g[i];
+        if (fabsf(gi) < NASTAR_POS_INF) {
+            const int ti = (int)t0[i];
+            const double A0 = hist[2 * ti], B0 = hist[2 * ti + 1];
+            const int ri = i / d.W, ci = i - ri * d.W;
+            const float h0v = kWide ? heuristic0(ri, ci, goal_r, goal_c) : heuristic0_fast(ri, ci, goal_r, goal_c);
+            const float v = bwdr_v<kFastDiv>(d, gi, d.omg * (h0v + cst[i]), rcp_sqrtW);
+            const float dA = (float)(A - A0), dB = (float)(B - B0);
+            gout[i] += (a.kfac * v) * (G[i] * dA - dB);  // (the replay's atomics are over: one thread per cell)
+        }
+    }
 }
 
 // kHistLds: the (A, B) history lives in LDS behind the state (16 B per executed step): no global round trip inside the loop
@@ -131,17 +199,23 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
     float* gout = a.grad_cost + off;
 
     int sidx = -1, gidx = -1;
-    for (int i = lane; i < d.HW; i += 64) {
-        if (a.start[off + i] != 0.f) sidx = i;
-        if (a.goal[off + i] != 0.f) gidx = i;
-        st_st<kGlobal>(&g[i], a.passable[off + i] != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF);
-        st_st<kGlobal>(&cst[i], a.cost[off + i]);
-        st_st<kGlobal>(&G[i], bwdr_upstream(a, off + i));
-        st_st<kGlobal>(&t0[i], (stamp_t)0);
-        gout[i] = 0.f;
+    int* const hdr = kGlobal ? reinterpret_cast<int*>(base + bwdr_header_offset(d.HWp, kWide)) : nullptr;
+    if constexpr (kGlobal) {  // the fill launch initialised the slab and found the start / goal cells
+        sidx = __builtin_amdgcn_readfirstlane(hdr[0]);
+        gidx = __builtin_amdgcn_readfirstlane(hdr[1]);
+    } else {
+        for (int i = lane; i < d.HW; i += 64) {
+            if (a.start[off + i] != 0.f) sidx = i;
+            if (a.goal[off + i] != 0.f) gidx = i;
+            st_st<kGlobal>(&g[i], a.passable[off + i] != 0.f ? NASTAR_POS_INF : NASTAR_NEG_INF);
+            st_st<kGlobal>(&cst[i], a.cost[off + i]);
+            st_st<kGlobal>(&G[i], bwdr_upstream(a, off + i));
+            st_st<kGlobal>(&t0[i], (stamp_t)0);
+            gout[i] = 0.f;
+        }
+        sidx = wave_max_i32(sidx);
+        gidx = wave_max_i32(gidx);
     }
-    sidx = wave_max_i32(sidx);
-    gidx = wave_max_i32(gidx);
     if (lane == 0) {
         sd[0] = 0.0;
         sd[1] = 0.0;
@@ -290,6 +364,13 @@ __global__ __launch_bounds__(64) void nastar_backward_replay_kernel(const BwdRAr
         const float rS = __builtin_amdgcn_rcpf((float)S);
         A += (double)extra * (double)rS;
         B += (double)extra * (double)((float)D * rS * rS);
+    }
+    if constexpr (kGlobal) {  // the sweep launch closes the intervals of the cells still on the open list
+        if (lane == 0) {
+            *reinterpret_cast<double*>(hdr + 2) = A;
+            *reinterpret_cast<double*>(hdr + 4) = B;
+        }
+        return;
     }
     // cells still on the open list: close their intervals at the final (A, B)
     for (int i = lane; i < d.HW; i += 64) {

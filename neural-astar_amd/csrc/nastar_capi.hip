@@ -994,12 +994,34 @@ static int backward_replay_impl(BwdRArgs& a, const float* cost, const float* sta
         return fast ? launch(nastar_backward_replay_kernel<false, false, true>, B, st, s, a, rcp)
                     : launch(nastar_backward_replay_kernel<false, false, false>, B, st, s, a, rcp);
     }
+    // state in the HBM workspace: FILL (all CUs: slab, zeroed gradient, start / goal cells into the slab's header), REPLAY (one wavefront per map:
+    // O(steps)), SWEEP (all CUs: the cells still open at the end) -- nastar_backward_replay.hip.h
     a.state_stride = (bwdr_state_bytes(a.d.HWp, wide) + 255) & ~(size_t)255;
     a.state = static_cast<unsigned char*>(workspace) + (size_t)B * (size_t)hlen * 16;
-    if (wide) return fast ? launch(nastar_backward_replay_kernel<true, false, true, true>, B, 64, s, a, rcp)
-                          : launch(nastar_backward_replay_kernel<true, false, false, true>, B, 64, s, a, rcp);
-    return fast ? launch(nastar_backward_replay_kernel<true, false, true>, B, 64, s, a, rcp)
-                : launch(nastar_backward_replay_kernel<true, false, false>, B, 64, s, a, rcp);
+    // headers (start / goal cell per map) to -1: the fill launch raises them with atomicMax (the forward's header kernel: same layout of two ints)
+    hipLaunchKernelGGL(nastar_hybrid_header_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, a.state, a.state_stride,
+                       bwdr_header_offset(a.d.HWp, wide), B);
+    hipError_t he;
+    const unsigned per_map = (unsigned)((a.d.HW + 255) / 256);
+    const dim3 grid2(per_map < 64u ? per_map : 64u, (unsigned)B);
+    if (wide) hipLaunchKernelGGL(nastar_bwdr_fill_kernel<true>, grid2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(nastar_bwdr_fill_kernel<false>, grid2, dim3(256), 0, s, a);
+    int rc2;
+    if (wide) rc2 = fast ? launch(nastar_backward_replay_kernel<true, false, true, true>, B, 64, s, a, rcp)
+                         : launch(nastar_backward_replay_kernel<true, false, false, true>, B, 64, s, a, rcp);
+    else rc2 = fast ? launch(nastar_backward_replay_kernel<true, false, true>, B, 64, s, a, rcp)
+                    : launch(nastar_backward_replay_kernel<true, false, false>, B, 64, s, a, rcp);
+    if (rc2 != NASTAR_OK) return rc2;
+    if (wide) {
+        if (fast) hipLaunchKernelGGL((nastar_bwdr_sweep_kernel<true, true>), grid2, dim3(256), 0, s, a, rcp);
+        else hipLaunchKernelGGL((nastar_bwdr_sweep_kernel<true, false>), grid2, dim3(256), 0, s, a, rcp);
+    } else {
+        if (fast) hipLaunchKernelGGL((nastar_bwdr_sweep_kernel<false, true>), grid2, dim3(256), 0, s, a, rcp);
+        else hipLaunchKernelGGL((nastar_bwdr_sweep_kernel<false, false>), grid2, dim3(256), 0, s, a, rcp);
+    }
+    he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "kernel launch");
+    return NASTAR_OK;
 }
 
 int nastar_backward_replay(const float* grad_histories, const float* cost, const float* start, const float* goal,

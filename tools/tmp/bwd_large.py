@@ -6,10 +6,10 @@ from neural_astar import ops
 from neural_astar.planner.differentiable_astar import DifferentiableAstar
 from neural_astar.utils import synthetic as syn
 dev = torch.device("cuda:0")
-for (H, B, Tmax) in ((64, 1024, 1.0), (96, 256, 1.0), (128, 256, 1.0), (256, 64, 0.25), (256, 64, 1.0)):
+for (H, B, Tmax) in ((128, 256, 1.0), (256, 64, 1.0), (512, 64, 1.0), (1024, 16, 1.0)):
     pr = syn.random_obstacle_maps(B, H, H, 0.2, seed=7)
     m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
-    cost = torch.from_numpy(syn.random_costs(B, H, H, seed=3)).to(dev).requires_grad_(True)
+    cost = (torch.from_numpy(syn.random_costs(B, H, H, seed=3)).to(dev) * 0.2 + m * 0.8).requires_grad_(True)  # mostly the map: long searches
     da = DifferentiableAstar(0.5, Tmax).to(dev).train(Tmax < 1.0)
     def fwd():
         return da(cost, s, g, m)
