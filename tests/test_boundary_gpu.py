@@ -375,42 +375,59 @@ def test_forward_host_overhead_is_bounded():
     """The module boundary must not dominate a 4096-map call (+70 %).  Deferred checking never waits for the device: 48 calls
     (fewer than the 64 verdicts the module lets queue up before it waits for the oldest) are ISSUED in far less time than they take to
     run -- the host runs ahead -- and a checked (sync) call costs at most ~60 us more than the launch it waits for."""
+    import gc
     import time
+    from neural_astar import ops
     from neural_astar.planner import VanillaAstar
     pr, (m, s, g) = _problems(4096, 32, seed=1234)
     dev = _dev()
     va = VanillaAstar().to(dev).eval()
-    with torch.no_grad():
-        va.astar.check_solvable = "deferred"
-        for _ in range(10):
-            va(m, s, g)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(48):
-            va(m, s, g)
-        t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-        va.astar.raise_if_unsolvable()
-        assert t_issue / 48 < 60e-6, f"issuing a deferred forward() takes {t_issue / 48 * 1e6:.0f} us of host time"
-        assert t_issue < 0.6 * t_all
-        va.astar.check_solvable = True
-        for _ in range(10):
-            va(m, s, g)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(100):
-            va(m, s, g)
-        t_sync = (time.perf_counter() - t0) / 100
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        from neural_astar import ops
-        e0.record()
-        for _ in range(20):
-            ops.search_nograd(m, s, g, m, 0.5, 1024, flags=ops.FLAG_UNIT_COST)
-        e1.record()
-        torch.cuda.synchronize()
-        kern = e0.elapsed_time(e1) / 20 * 1e-3
-        assert t_sync < kern + 80e-6, f"sync forward() {t_sync * 1e6:.0f} us vs kernel {kern * 1e6:.0f} us"
+    # best of three rounds, cyclic garbage collector off: one round in twenty or so contained ONE host-side stall of 50-160 ms (seen in the
+    # bench's child process and here, never in a small dedicated probe) -- what a generation-2 collection costs in a process whose heap holds
+    # a whole test session; bench.py's timed loop switches the collector off for the same reason.  The bounds are on what a call costs
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.no_grad():
+            va.astar.check_solvable = "deferred"
+            for _ in range(10):
+                va(m, s, g)
+            torch.cuda.synchronize()
+            t_issue = t_all = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(48):
+                    va(m, s, g)
+                ti = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                ta = time.perf_counter() - t0
+                va.astar.raise_if_unsolvable()
+                if ti < t_issue:
+                    t_issue, t_all = ti, ta
+            va.astar.check_solvable = True
+            for _ in range(10):
+                va(m, s, g)
+            torch.cuda.synchronize()
+            t_sync = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    va(m, s, g)
+                t_sync = min(t_sync, (time.perf_counter() - t0) / 40)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.search_nograd(m, s, g, m, 0.5, 1024, flags=ops.FLAG_UNIT_COST)
+            e1.record()
+            torch.cuda.synchronize()
+            kern = e0.elapsed_time(e1) / 20 * 1e-3
+    finally:
+        if gc_was:
+            gc.enable()
+    assert t_issue / 48 < 60e-6, f"issuing a deferred forward() takes {t_issue / 48 * 1e6:.0f} us of host time"
+    assert t_issue < 0.6 * t_all
+    assert t_sync < kern + 80e-6, f"sync forward() {t_sync * 1e6:.0f} us vs kernel {kern * 1e6:.0f} us"
 
 
 def test_packed_sink_is_filled_by_the_search_launch_itself():
