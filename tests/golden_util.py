@@ -8,7 +8,7 @@ from typing import NamedTuple, Optional
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NON_SEARCH_PREFIXES = ("ckpt_", "data_", "trainstep_", "trainloop_", "enc_", "tieclass_", "coupled_", "gradnoise_")  # weight / dataset / training-step / encoder fixtures; tieclass_* / coupled_* / gradnoise_*: tests/test_tie_class.py, tests/test_coupled_forward.py, tests/test_oracle_golden.py
+NON_SEARCH_PREFIXES = ("ckpt_", "data_", "trainstep_", "trainloop_", "enc_", "tieclass_", "coupled_", "gradnoise_", "wide_")  # weight / dataset / training-step / encoder fixtures; tieclass_* / coupled_* / gradnoise_*: tests/test_tie_class.py, tests/test_coupled_forward.py, tests/test_oracle_golden.py; wide_*: tests/test_large_maps_gpu.py + tests/test_oracle_golden.py
 
 
 class Golden(NamedTuple):

@@ -137,3 +137,19 @@ def test_gradients_on_maps_above_65519_cells_match_the_oracle(H, W, reach, train
     err = float(np.abs(c.grad[:, 0].cpu().numpy() - ref).max())
     assert err <= 1e-5 * max(1.0, float(np.abs(ref).max())), (err, float(np.abs(ref).max()))
     assert float(np.abs(ref).max()) > 0
+
+
+def test_gradient_above_65519_cells_equals_the_reference_golden():
+    """wide_grad_260x270: the reference's own histories, paths and autograd gradient on 260x270 maps (oracle/gen_golden_large_grad.py) -- the
+    hybrid forward with a selection log and the HBM-state replay with 32-bit history stamps, through DifferentiableAstar under autograd"""
+    from neural_astar.planner.differentiable_astar import DifferentiableAstar
+    from test_oracle_golden import wide_golden
+    g, cost, up, grad_ref = wide_golden()
+    da = DifferentiableAstar(g.g_ratio, 1.0).to(_dev()).eval()
+    c = _t(cost).requires_grad_(True)
+    out = da(c, _t(g.start_maps), _t(g.goal_maps), _t(g.passable))
+    (out.histories * _t(up)).sum().backward()
+    assert np.array_equal(out.histories.detach().cpu().numpy(), g.histories) and np.array_equal(out.paths.cpu().numpy(), g.paths)
+    ref = grad_ref.reshape(c.grad.shape)
+    err = float(np.abs(c.grad.cpu().numpy() - ref).max())
+    assert err <= 1e-5 * max(1.0, float(np.abs(ref).max())), err

@@ -107,3 +107,27 @@ def test_unsolvable_is_reported():
     g[0, 0, 7, 7] = 1
     assert O.forward(m, s, g, m, mode="dense").status == O.ERR_UNSOLVABLE
     assert O.forward(m, s, g, m, mode="sm").status == O.ERR_UNSOLVABLE
+
+
+def wide_golden():
+    """wide_grad_260x270 (oracle/gen_golden_large_grad.py: outputs of the reference itself on maps above 65,519 cells): costs and the upstream
+    gradient regenerated from the stored seeds -> (golden, cost, upstream, the reference's dL/dcost)"""
+    from neural_astar.utils import synthetic as syn
+    g = G.load("wide_grad_260x270")
+    z = np.load(G.GOLDEN_DIR + "/wide_grad_260x270.npz")
+    cost = syn.random_costs(g.B, g.H, g.W, seed=int(z["cost_seed"]), hi=float(z["cost_hi"]))
+    up = np.random.Generator(np.random.PCG64(int(z["up_seed"]))).standard_normal((g.B, 1, g.H, g.W)).astype(np.float32)
+    return g, cost, up, z["grad_cost_ref"]
+
+
+def test_oracle_reproduces_the_reference_above_65519_cells():
+    """the checker pinned where the replay backward needs 32-bit history stamps (round 6): forward outputs exact (both restatements), dL/dcost
+    within 1e-5 of the reference's autograd"""
+    g, cost, up, grad_ref = wide_golden()
+    assert g.H * g.W > 65519
+    for mode in ("sm", "dense"):
+        o = O.forward(cost, g.start_maps, g.goal_maps, g.passable, g.g_ratio, g.max_iters, mode=mode)
+        assert not o.status and np.array_equal(o.histories, g.histories[:, 0]) and np.array_equal(o.paths, g.paths[:, 0]), mode
+    gr = O.backward(up, cost, g.start_maps, g.goal_maps, g.passable, g.g_ratio, int(o.iters.max()))
+    ref = grad_ref.reshape(gr.shape)
+    assert float(np.abs(gr - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
