@@ -134,7 +134,9 @@ class NeuralAstar(VanillaAstar):
             if type(self._hip_encoder) is not HipUnetEncoder or self._hip_encoder.precision != precision:
                 self._hip_encoder = HipUnetEncoder(self.encoder, precision)
             return self._routed(f"hip:Unet-infer/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
-        if (backend.startswith("hip") and self.encoder.training and torch.is_grad_enabled() and map_designs.is_cuda
+        # (training mode under no_grad -- a validation pass somebody forgot to switch to eval() -- is the same forward: batch statistics, running
+        #  statistics updated; the autograd functions then simply record nothing)
+        if (backend.startswith("hip") and self.encoder.training and map_designs.is_cuda
                 and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
                 and map_designs.shape[-2:] == start_maps.shape[-2:]):
             from ..encoder_train import unet_supported, unet_train_forward
@@ -144,8 +146,8 @@ class NeuralAstar(VanillaAstar):
                 prec = "f16" if backend == "hip_f16" else "f16x3"
                 return self._routed(f"hip:Unet-train/{prec}", unet_train_forward(self.encoder, map_designs, start_maps, goal_maps,
                                                                                  "+" in self.encoder_input, prec))
-        if (backend.startswith("hip") and torch.is_grad_enabled() and map_designs.is_cuda and isinstance(self.encoder, encoder.CNN)
-                and (self.encoder.training or any(p.requires_grad for p in self.encoder.parameters()))):
+        if (backend.startswith("hip") and map_designs.is_cuda and isinstance(self.encoder, encoder.CNN)
+                and (self.encoder.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder.parameters())))):
             # UNDER AUTOGRAD: convolutions, BatchNorm (batch statistics in training mode; the running statistics in eval mode -- round 6),
             # ReLU, max-pool and all their gradients on the MI355X kernels (neural_astar/encoder_train.py); "hip_f16" = plain fp16
             # operands, anything else = split operands (fp32-grade).  CNN (any depth) and CNNDownSize (WarCraft); shapes the kernels do

@@ -844,3 +844,34 @@ def test_closing_convolution_as_streams_equals_the_padded_matrix_form(precision)
     assert max(v[0] for v in worst.values()) <= tol_g, worst
     if precision == "f16x3":  # (gradients against float64 are judged on the clear-margin batch of the test above: this batch has ReLU decisions inside fp32 noise)
         assert float((out[True][0].cpu().double() - cost_ref.detach()).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("arch,depth,H,W", [("CNN", 4, 32, 32), ("CNN", 2, 20, 45), ("CNNDownSize", 2, 64, 64), ("Unet", 3, 32, 32)])
+def test_training_mode_without_autograd_runs_on_the_kernels(arch, depth, H, W):
+    """module.train() under torch.no_grad() -- a validation pass nobody switched to eval() (the reference's Lightning loop does switch): batch
+    statistics, running statistics and num_batches_tracked updated, nothing recorded.  Round 6: the training kernels' forward (it used to fall
+    back to torch.nn with a warning); cost map within 1e-5 of the same module on torch.nn, buffers within 1e-6."""
+    import copy
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    dev = torch.device("cuda:0")
+    pr = syn.random_obstacle_maps(16, H, W, 0.2, seed=3)
+    m, s, g = (torch.from_numpy(x).to(dev) for x in pr)
+    if arch == "CNNDownSize":
+        s = torch.zeros(16, 1, H // 4, W // 4, device=dev)
+        g = torch.zeros_like(s)
+        s[:, 0, 1, 1] = 1
+        g[:, 0, -2, -2] = 1
+    torch.manual_seed(0)
+    a = NeuralAstar(encoder_arch=arch, encoder_depth=depth, learn_obstacles=(arch == "CNNDownSize")).to(dev).train()
+    b = copy.deepcopy(a)
+    b.encoder_backend = "torch"
+    with torch.no_grad():
+        ca, cb = a.encode(m, s, g), b.encode(m, s, g)
+    assert a.last_encoder_route.startswith(f"hip:{arch}-train/"), a.last_encoder_route
+    assert float((ca - cb).abs().max()) <= 1e-5
+    for (n, x), (_, y) in zip(a.encoder.named_buffers(), b.encoder.named_buffers()):
+        if "num_batches" in n:
+            assert int(x) == int(y), n  # (1 for every layer the stack visits; a depth-3 U-Net leaves the deeper VGG layers at 0)
+        elif "running" in n:
+            assert float((x - y).abs().max()) <= 1e-6, n
