@@ -936,12 +936,21 @@ class _UnetTrunk(torch.autograd.Function):
                 z = L.i16(npix * cout * mult)
                 L.conv(src, wpack, scale, shift, B, h, w, c1, cout, sflag | ups, out=z, src2=src2, c2=c2)
                 bn = st["bn"]
-                track = bn.track_running_stats and bn.running_mean is not None
+                eval_bn = bool(cfg.get("eval_bn"))
+                track = bn.track_running_stats and bn.running_mean is not None and not eval_bn
                 mom = 0.0
                 if track:
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     tracked.append(bn.num_batches_tracked)
-                if not sync:  # partial rows, then finish + coefficients in one kernel
+                if eval_bn:
+                    # EVAL-mode BatchNorm under autograd (module.eval() with gradients on): coefficients from the RUNNING statistics, nothing is
+                    # updated; [C]-sized host-side tensor math (as in _CnnTrunk)
+                    gam, bet = params[st["g"]].detach().double(), params[st["be"]].detach().double()
+                    invstd = torch.rsqrt(bn.running_var.double() + float(bn.eps))
+                    mean = bn.running_mean.double().clone()
+                    k2 = (gam * invstd).float()
+                    k3 = (bet - mean * gam * invstd).float()
+                elif not sync:  # partial rows, then finish + coefficients in one kernel
                     mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, params[st["g"]].detach(), params[st["be"]].detach(), bn.eps, mom,
                                                     bn.running_mean if track else None, bn.running_var if track else None)
                 else:  # data parallel: statistics of the GLOBAL batch (all-reduce between the halves)
@@ -1030,7 +1039,8 @@ class _UnetTrunk(torch.autograd.Function):
                     z = sv["z"]
                     mean, invstd, k2f, k3f = sv["coef"]
                     sums = None
-                    if not ctx.sync_state[0]:  # partial rows, then finish + coefficients in one kernel
+                    eval_bn = bool(cfg.get("eval_bn"))
+                    if not ctx.sync_state[0] and not eval_bn:  # partial rows, then finish + coefficients in one kernel
                         if cfg.get("debug") is not None:
                             sums = torch.empty((cout, 2), dtype=torch.float64, device=dev)
                         dgamma, dbeta, c1v, c2v, c3v = L.bn_bwd(g, z, k2f, k3f, npix, cout, split, mean, invstd, params[st["g"]].detach(), S_in, S,
@@ -1039,8 +1049,9 @@ class _UnetTrunk(torch.autograd.Function):
                         sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
                         world = _sync_sums(sums, S_in, ctx.sync_state)
                         dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
+                        # (eval mode: BatchNorm on its running statistics = the batch-statistics closed form with infinitely many pixels)
                         rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                         params[st["g"]].detach().data_ptr(), npix * world, S_in.data_ptr(), S.data_ptr(),
+                                                         params[st["g"]].detach().data_ptr(), (1 << 62) if eval_bn else npix * world, S_in.data_ptr(), S.data_ptr(),
                                                          dgamma.data_ptr(), dbeta.data_ptr(), c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout,
                                                          L.stream)
                         _native.check(rc, "nastar_bn_coef_bwd_io")
@@ -1053,7 +1064,11 @@ class _UnetTrunk(torch.autograd.Function):
                     dzb = L.i16(npix * cout * mult)
                     L.affine(g, z, c1v, c2v, c3v, k2f, k3f, dzb, npix, cout, False, split)
                     cur_co = cout
-                    if st["b"] is not None:
+                    if st["b"] is not None and eval_bn:
+                        # ... whose conv bias DOES have a gradient then: sum_p dz = gamma invstd sum_p dy
+                        nb = params[st["b"]].numel()
+                        grads_p[st["b"]] = (dbeta[:nb].double() * params[st["g"]].detach().double()[:nb] * invstd[:nb]).float()
+                    elif st["b"] is not None:
                         grads_p[st["b"]] = torch.empty_like(params[st["b"]])  # conv bias in front of a BatchNorm: exactly 0 (zeroed below)
                         zero_bias.append(grads_p[st["b"]])
                 # the convolution's input as ONE tensor (the decoder's upsample + concat is materialised for the weight gradient)
@@ -1128,7 +1143,8 @@ def unet_training_plan(model: nn.Module):
 def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: torch.Tensor, goal_maps: torch.Tensor, plus: bool,
                        precision: str = "f16x3") -> torch.Tensor:
     """``unet(cat(map, start + goal))`` for this package's ``VggUnet`` definition of the reference's Unet(vgg16_bn) (encoder.py:37-57)
-    in TRAINING mode, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map [B,1,H,W] fp32."""
+    in TRAINING mode -- or in eval mode under autograd --, differentiable w.r.t. every parameter, on the MI355X kernels.  Returns the cost map
+    [B,1,H,W] fp32."""
     B, _, H, W = map_designs.shape
     if not unet_supported(unet, H, W):
         raise NotImplementedError("VggUnet on maps whose size is a multiple of 2^depth (and whose widths suit the weight-gradient chunks)")
@@ -1136,7 +1152,8 @@ def unet_train_forward(unet: nn.Module, map_designs: torch.Tensor, start_maps: t
     if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
         raise NotImplementedError("fp32 contiguous parameters expected")
     split = precision == "f16x3"
-    cfg = {"split": split, "shape": (B, H, W), "plan": plan, "debug": getattr(unet, "_nastar_debug", None)}
+    # module.eval() with gradients on: BatchNorm on its running statistics (no update), still differentiable (round 6, as cnn_train_forward)
+    cfg = {"split": split, "shape": (B, H, W), "plan": plan, "debug": getattr(unet, "_nastar_debug", None), "eval_bn": not unet.training}
     with torch.cuda.device(map_designs.device):
         x0 = _assemble_input(map_designs, start_maps, goal_maps, plus, split, _Lib(map_designs.device))
     z = _UnetTrunk.apply(cfg, x0, *params)

@@ -136,7 +136,8 @@ class NeuralAstar(VanillaAstar):
             return self._routed(f"hip:Unet-infer/{precision}", self._hip_encoder(map_designs, start_maps, goal_maps, "+" in self.encoder_input))
         # (training mode under no_grad -- a validation pass somebody forgot to switch to eval() -- is the same forward: batch statistics, running
         #  statistics updated; the autograd functions then simply record nothing)
-        if (backend.startswith("hip") and self.encoder.training and map_designs.is_cuda
+        if (backend.startswith("hip") and map_designs.is_cuda
+                and (self.encoder.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder.parameters())))
                 and isinstance(self.encoder, encoder.Unet) and map_designs.shape[1] == 1
                 and map_designs.shape[-2:] == start_maps.shape[-2:]):
             from ..encoder_train import unet_supported, unet_train_forward
@@ -144,7 +145,7 @@ class NeuralAstar(VanillaAstar):
             if (unet_supported(self.encoder, map_designs.shape[-2], map_designs.shape[-1])
                     and first.in_channels == 1 + int("+" in self.encoder_input)):
                 prec = "f16" if backend == "hip_f16" else "f16x3"
-                return self._routed(f"hip:Unet-train/{prec}", unet_train_forward(self.encoder, map_designs, start_maps, goal_maps,
+                return self._routed(f"hip:Unet-{'train' if self.encoder.training else 'evalgrad'}/{prec}", unet_train_forward(self.encoder, map_designs, start_maps, goal_maps,
                                                                                  "+" in self.encoder_input, prec))
         if (backend.startswith("hip") and map_designs.is_cuda and isinstance(self.encoder, encoder.CNN)
                 and (self.encoder.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.encoder.parameters())))):

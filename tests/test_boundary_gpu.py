@@ -594,8 +594,15 @@ def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
         warnings.simplefilter("error")
         na(wide, sw, gw).histories.sum().backward()
     assert na.last_encoder_route == "hip:CNN-evalgrad/f16x3", na.last_encoder_route
-    # what the kernels still do not take -- the U-Net in eval mode with gradients on: torch.nn, said out loud once
+    # ... and, later in round 6, the U-Net
     na = NeuralAstar(encoder_arch="Unet").to(dev).eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        na(m[:2], s[:2], g[:2]).histories.sum().backward()
+    assert na.last_encoder_route == "hip:Unet-evalgrad/f16x3", na.last_encoder_route
+    # what the kernels still do not take -- a U-Net of encoder_depth 5 in training mode (its last decoder block has 16 channels): torch.nn,
+    # said out loud once
+    na = NeuralAstar(encoder_arch="Unet", encoder_depth=5).to(dev).train()
     wide, sw, gw = m[:2], s[:2], g[:2]
     with pytest.warns(RuntimeWarning, match="not covered by the MI355X encoder kernels"):
         na(wide, sw, gw)

@@ -875,3 +875,55 @@ def test_training_mode_without_autograd_runs_on_the_kernels(arch, depth, H, W):
             assert int(x) == int(y), n  # (1 for every layer the stack visits; a depth-3 U-Net leaves the deeper VGG layers at 0)
         elif "running" in n:
             assert float((x.double() - y).abs().max()) <= 1e-6, n
+
+
+@pytest.mark.parametrize("seed,depth", [(4, 4), (11, 3)])
+def test_unet_eval_mode_with_gradients_runs_on_the_kernels(seed, depth):
+    """Unet(vgg16_bn) in eval mode with gradients on (a planner somebody calls without torch.no_grad(), saliency maps, fine-tuning with frozen
+    statistics): round 6 -- the training kernels with BatchNorm on its RUNNING statistics (coefficients formed on the host side, the backward
+    through the unfused path with `npix -> 2^62`, conv biases in front of a BatchNorm get gamma invstd sum dy); it used to fall back to torch.nn
+    with a warning.  Against the same module in float64: cost map within 2e-5, every parameter gradient within 3e-2 (a 26-layer network's handful of
+    ReLU / pooling decisions that fp32-grade arithmetic takes the other way each move one gradient element: test_unet_trains_on_the_hip_kernels
+    arbitrates those for the training mode), most tensors within 2e-4, buffers untouched."""
+    from neural_astar.planner import NeuralAstar
+    from neural_astar.utils import synthetic as syn
+    import test_unet_gpu as TU
+    dev = _dev()
+    B = 3
+    pr = syn.random_obstacle_maps(B, 32, 32, 0.25, seed=seed)
+    m, s, g = (torch.from_numpy(x) for x in pr)
+    base = NeuralAstar(encoder_arch="Unet", encoder_depth=depth)
+    base.encoder = TU._calibrated_unet(depth=depth, seed=3)
+    with torch.no_grad():
+        for mod in base.encoder.modules():
+            if isinstance(mod, nn.ReLU):
+                mod.inplace = False
+            if isinstance(mod, nn.BatchNorm2d):  # running statistics that are not the batch's
+                mod.running_mean.mul_(0.9).add_(0.05)
+                mod.running_var.mul_(1.2)
+    na = copy.deepcopy(base).to(dev).eval()
+    ref = copy.deepcopy(base).double().eval()
+    R = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(9 + seed)) / (B * 1024)
+    before = {k: v.clone() for k, v in na.encoder.named_buffers()}
+    na.encoder_backend = "hip_f16x3"
+    cost = na.encode(m.to(dev), s.to(dev), g.to(dev))
+    assert na.last_encoder_route == "hip:Unet-evalgrad/f16x3", na.last_encoder_route
+    (cost * R.to(dev)).sum().backward()
+    cost_ref = ref.encode(m.double(), s.double(), g.double())
+    (cost_ref * R.double()).sum().backward()
+    assert float((cost.detach().cpu().double() - cost_ref.detach()).abs().max()) <= 2e-5
+    worst = {}
+    for (name, p), (_, q) in zip(na.encoder.named_parameters(), ref.encoder.named_parameters()):
+        if q.grad is None:
+            continue  # (VGG layers a shallower U-Net does not visit)
+        assert p.grad is not None, name
+        if float(q.grad.abs().max()) == 0:
+            continue
+        worst[name] = _rel(p.grad, q.grad)
+    tight = sum(v <= 2e-4 for v in worst.values())
+    print("UNET EVALGRAD seed", seed, "depth", depth, "tensors", len(worst), "within 2e-4:", tight, "max", max(worst.values()))
+    assert len(worst) >= (40 if depth == 4 else 30) and max(worst.values()) <= 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    assert tight >= len(worst) // 2
+    assert any(k.endswith("bias") and "features" in k for k in worst)  # eval mode: the conv biases in front of a BatchNorm have gradients
+    for k, v in na.encoder.named_buffers():
+        assert torch.equal(v, before[k]), k
