@@ -22,9 +22,26 @@ for H, B in ((256, 256), (512, 256)):
     for _ in range(6):
         out = ops.search_nograd(m, s, g, m, 0.5, H * H)
     torch.cuda.synchronize()
-    print(H, B, "longest search", int(out[2].max()), "steps")
+    print(H, B, "longest search", int(out[2].max()), "steps; all maps", int(out[2].sum()), "steps")
 PY
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_large -o large --output-format csv -- python /tmp/large_probe.py > $OUT/large_under_rocprof.log 2>&1
 for f in $(find $OUT/trace_large -name "*kernel_stats.csv"); do cp $f $OUT/large_map_kernel_stats.csv; done
 rm -rf $OUT/trace_large
 tail -3 $OUT/large_under_rocprof.log
+# instruction counts of the search launch (PMC, own pass; kernel trace only): per launch, to be divided by the launch's total steps
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-trace -d $OUT/pmc_large -o large --output-format csv -- python /tmp/large_probe.py > $OUT/large_pmc.log 2>&1
+python - <<PY
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_large/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "forward_hybrid" in r["Kernel_Name"]:
+            acc[(int(r["Grid_Size"]), r["Counter_Name"])]["v"].append(float(r["Counter_Value"]))
+out = {}
+for (grid, name), d in sorted(acc.items()):
+    out.setdefault(str(grid), {})[name] = sum(d["v"]) / len(d["v"])
+json.dump(out, open("$OUT/large_map_kernel_counters.json", "w"), indent=1)
+print(json.dumps(out)[:600])
+PY
+rm -rf $OUT/pmc_large
+grep "longest search" $OUT/large_pmc.log
