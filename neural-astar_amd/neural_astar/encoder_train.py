@@ -932,7 +932,9 @@ class _UnetTrunk(torch.autograd.Function):
                     L.conv(src, wpack, scale, shift, B, h, w, c1, 32, sflag | CONV_FINAL | CONV_RAW, out_f32=out)
                     saved.append({"scal": scal})
                     continue
-                cout = wt.shape[0]
+                cout_r = wt.shape[0]
+                cout = _pad32(cout_r)  # (encoder_depth = 5 ends in a 16-channel decoder block: the packed weights, z and the BatchNorm vectors carry
+                #                         16 zero channels more -- gamma = beta = 0 there, so they stay exactly zero through the ReLU)
                 z = L.i16(npix * cout * mult)
                 L.conv(src, wpack, scale, shift, B, h, w, c1, cout, sflag | ups, out=z, src2=src2, c2=c2)
                 bn = st["bn"]
@@ -942,32 +944,41 @@ class _UnetTrunk(torch.autograd.Function):
                 if track:
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                     tracked.append(bn.num_batches_tracked)
+                padc = cout - cout_r
+                gam_v, bet_v = params[st["g"]].detach(), params[st["be"]].detach()
+                rm_v, rv_v = (bn.running_mean, bn.running_var) if (track or eval_bn) else (None, None)
+                if padc:  # padded copies of the per-channel vectors (the running statistics are copied back below)
+                    gam_v, bet_v = torch.nn.functional.pad(gam_v, (0, padc)), torch.nn.functional.pad(bet_v, (0, padc))
+                    if rm_v is not None:
+                        rm_v, rv_v = torch.nn.functional.pad(rm_v, (0, padc)), torch.nn.functional.pad(rv_v, (0, padc), value=1.0)
                 if eval_bn:
                     # EVAL-mode BatchNorm under autograd (module.eval() with gradients on): coefficients from the RUNNING statistics, nothing is
                     # updated; [C]-sized host-side tensor math (as in _CnnTrunk)
-                    gam, bet = params[st["g"]].detach().double(), params[st["be"]].detach().double()
-                    invstd = torch.rsqrt(bn.running_var.double() + float(bn.eps))
-                    mean = bn.running_mean.double().clone()
+                    gam, bet = gam_v.double(), bet_v.double()
+                    invstd = torch.rsqrt(rv_v.double() + float(bn.eps))
+                    mean = rm_v.double().clone()
                     k2 = (gam * invstd).float()
                     k3 = (bet - mean * gam * invstd).float()
                 elif not sync:  # partial rows, then finish + coefficients in one kernel
-                    mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, params[st["g"]].detach(), params[st["be"]].detach(), bn.eps, mom,
-                                                    bn.running_mean if track else None, bn.running_var if track else None)
+                    mean, invstd, k2, k3 = L.bn_fwd(z, npix, cout, split, gam_v, bet_v, bn.eps, mom, rm_v if track else None, rv_v if track else None)
                 else:  # data parallel: statistics of the GLOBAL batch (all-reduce between the halves)
                     sums = L.stats(None, z, None, None, npix, cout, split)
                     npix_bn = npix * _sync_sums(sums, state=ctx.sync_state)
                     k2, k3 = L.f32(cout), L.f32(cout)
                     mean = torch.empty((cout,), dtype=torch.float64, device=dev)
                     invstd = torch.empty((cout,), dtype=torch.float64, device=dev)
-                    rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), params[st["g"]].detach().data_ptr(), params[st["be"]].detach().data_ptr(),
-                                                  float(bn.eps), npix_bn, float(mom), bn.running_mean.data_ptr() if track else None,
-                                                  bn.running_var.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
+                    rc = L.lib.nastar_bn_coef_fwd(sums.data_ptr(), gam_v.data_ptr(), bet_v.data_ptr(),
+                                                  float(bn.eps), npix_bn, float(mom), rm_v.data_ptr() if track else None,
+                                                  rv_v.data_ptr() if track else None, k2.data_ptr(), k3.data_ptr(),
                                                   mean.data_ptr(), invstd.data_ptr(), cout, L.stream)
                     _native.check(rc, "nastar_bn_coef_fwd")
+                if padc and track:  # the kernels updated the padded copies
+                    bn.running_mean.copy_(rm_v[:cout_r])
+                    bn.running_var.copy_(rv_v[:cout_r])
                 a = L.i16(npix * cout * mult)
                 L.affine(None, z, None, k2, k3, None, None, a, npix, cout, True, split)
                 acts[st["dst"]] = (a, cout)
-                saved.append({"z": z, "coef": (mean, invstd, k2, k3), "scal": scal})
+                saved.append({"z": z, "coef": (mean, invstd, k2, k3), "scal": scal, "gam": gam_v})
                 if cfg.get("debug") is not None:  # ... and the ReLU mask of this block: [k2 z + k3 > 0]
                     cfg["debug"]["fwd:" + st["dst"]] = (z, k2, k3, (B, h, w, cout))
             if tracked:
@@ -1018,7 +1029,8 @@ class _UnetTrunk(torch.autograd.Function):
                     accumulate(st["src"], dr, S, B * hi * wi, C)
                     continue
                 wt = params[st["w"]]
-                cout, cin = wt.shape[:2]
+                cout_r, cin = wt.shape[:2]
+                cout = cout_r if st["final"] else _pad32(cout_r)  # buffers of a hidden block carry whole 32-channel groups (16 -> 32: zeros)
                 src, c1 = acts[st["src"]]
                 src2, c2 = acts[st["skip"]] if st["skip"] is not None else (None, 0)
                 if st["final"]:
@@ -1043,15 +1055,14 @@ class _UnetTrunk(torch.autograd.Function):
                     if not ctx.sync_state[0] and not eval_bn:  # partial rows, then finish + coefficients in one kernel
                         if cfg.get("debug") is not None:
                             sums = torch.empty((cout, 2), dtype=torch.float64, device=dev)
-                        dgamma, dbeta, c1v, c2v, c3v = L.bn_bwd(g, z, k2f, k3f, npix, cout, split, mean, invstd, params[st["g"]].detach(), S_in, S,
-                                                                sums_out=sums)
+                        dgamma, dbeta, c1v, c2v, c3v = L.bn_bwd(g, z, k2f, k3f, npix, cout, split, mean, invstd, sv["gam"], S_in, S, sums_out=sums)
                     else:
                         sums = L.stats(g, z, k2f, k3f, npix, cout, split, amax=amax)
                         world = _sync_sums(sums, S_in, ctx.sync_state)
                         dgamma, dbeta, c1v, c2v, c3v = (L.f32(cout) for _ in range(5))
                         # (eval mode: BatchNorm on its running statistics = the batch-statistics closed form with infinitely many pixels)
                         rc = L.lib.nastar_bn_coef_bwd_io(sums.data_ptr(), amax.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                                         params[st["g"]].detach().data_ptr(), (1 << 62) if eval_bn else npix * world, S_in.data_ptr(), S.data_ptr(),
+                                                         sv["gam"].data_ptr(), (1 << 62) if eval_bn else npix * world, S_in.data_ptr(), S.data_ptr(),
                                                          dgamma.data_ptr(), dbeta.data_ptr(), c1v.data_ptr(), c2v.data_ptr(), c3v.data_ptr(), cout,
                                                          L.stream)
                         _native.check(rc, "nastar_bn_coef_bwd_io")
@@ -1060,14 +1071,14 @@ class _UnetTrunk(torch.autograd.Function):
                             dbeta /= world
                     if cfg.get("debug") is not None:
                         cfg["debug"][st["dst"] + ":bn"] = (z, k2f, k3f, dbeta.clone(), dgamma.clone(), sums.clone(), S_in.clone())
-                    grads_p[st["g"]], grads_p[st["be"]] = dgamma, dbeta
+                    grads_p[st["g"]], grads_p[st["be"]] = (dgamma, dbeta) if cout == cout_r else (dgamma[:cout_r].contiguous(), dbeta[:cout_r].contiguous())
                     dzb = L.i16(npix * cout * mult)
                     L.affine(g, z, c1v, c2v, c3v, k2f, k3f, dzb, npix, cout, False, split)
                     cur_co = cout
                     if st["b"] is not None and eval_bn:
                         # ... whose conv bias DOES have a gradient then: sum_p dz = gamma invstd sum_p dy
                         nb = params[st["b"]].numel()
-                        grads_p[st["b"]] = (dbeta[:nb].double() * params[st["g"]].detach().double()[:nb] * invstd[:nb]).float()
+                        grads_p[st["b"]] = (dbeta[:nb].double() * sv["gam"].double()[:nb] * invstd[:nb]).float()
                     elif st["b"] is not None:
                         grads_p[st["b"]] = torch.empty_like(params[st["b"]])  # conv bias in front of a BatchNorm: exactly 0 (zeroed below)
                         zero_bias.append(grads_p[st["b"]])
@@ -1079,7 +1090,7 @@ class _UnetTrunk(torch.autograd.Function):
                                                          c1, c2, int(split), L.stream), "nastar_upcat_f16")
                 else:
                     a_in = src
-                grads_p[st["w"]] = L.wgrad(dzb, a_in, B, h, w, cur_co, cin_p, cout, cin, split, S)
+                grads_p[st["w"]] = L.wgrad(dzb, a_in, B, h, w, cur_co, cin_p, cout_r, cin, split, S)
                 if st["src"] == "x0":
                     continue
                 wpack, scale, shift, _ = ctx.tpack[id(st)] if ctx.tpack is not None else L.pack(wt, True, split, scal=sv["scal"])
@@ -1108,11 +1119,10 @@ def unet_supported(unet: nn.Module, H: int, W: int) -> bool:
     depth = model.depth
     if H % (1 << depth) or W % (1 << depth):
         return False
-    # every convolution but the 1-channel head must produce a multiple of 32 channels (the training kernels do not pad outputs; the
-    # inference path does): encoder_depth = 5 ends in a 16-channel decoder block and stays on torch.nn -- decided HERE, before any
-    # BatchNorm running statistic has been touched
+    # every convolution but the 1-channel head produces a multiple of 32 channels -- or 16 (encoder_depth = 5 ends in a 16-channel decoder
+    # block: _UnetTrunk pads it to 32 with zero channels) -- decided HERE, before any BatchNorm running statistic has been touched
     convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
-    if not convs or any(c.out_channels % 32 for c in convs if c.out_channels != 1) or convs[0].in_channels > 32:
+    if not convs or any(c.out_channels % 32 and c.out_channels != 16 for c in convs if c.out_channels != 1) or convs[0].in_channels > 32:
         return False
     return all(chunk_rows(H >> l, W >> l) > 0 and (W >> l) >= 2 for l in range(depth + 1))
 

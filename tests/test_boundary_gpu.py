@@ -600,8 +600,8 @@ def test_encoder_routes_are_recorded_and_a_fall_back_to_torch_nn_speaks_up():
         warnings.simplefilter("error")
         na(m[:2], s[:2], g[:2]).histories.sum().backward()
     assert na.last_encoder_route == "hip:Unet-evalgrad/f16x3", na.last_encoder_route
-    # what the kernels still do not take -- a U-Net of encoder_depth 5 in training mode (its last decoder block has 16 channels): torch.nn,
-    # said out loud once
+    # what the kernels still do not take -- a U-Net of encoder_depth 5 on 32x32 maps in training mode (its deepest level would be 1x1: one pixel
+    # per image is below the weight-gradient kernel's chunks; from 64x64 on depth 5 trains on the kernels too): torch.nn, said out loud once
     na = NeuralAstar(encoder_arch="Unet", encoder_depth=5).to(dev).train()
     wide, sw, gw = m[:2], s[:2], g[:2]
     with pytest.warns(RuntimeWarning, match="not covered by the MI355X encoder kernels"):
