@@ -26,6 +26,53 @@ class AstarOutput(NamedTuple):
     intermediate_results: Optional[List[dict]] = None
 
 
+# ---- the reference module's public helpers, kept importable under their names (differentiable_astar.py:26-52, :77-93, :96-125) -------------
+# The search kernel fuses all three (a-2, a-4, a-7 of SURVEY.md 8a): nothing in this package calls them.  They exist for code that imports them
+# from the reference's module -- same arguments, same results -- and work on device tensors (no CPU path in this package).
+
+def get_heuristic(goal_maps: torch.Tensor, tb_factor: float = 0.001) -> torch.Tensor:
+    """Chebyshev distance + ``tb_factor`` x Euclidean distance to the one-hot goal of every map (reference :26-52), same shape as ``goal_maps``.
+    The default ``tb_factor`` runs the ``nastar_heuristic`` kernel (bit-exact with the reference's fp32 arithmetic, tests/test_gpu_parity.py);
+    any other factor is the same sequence of fp32 operations as device tensor ops."""
+    ops._require_device(goal_maps)
+    if float(tb_factor) == 0.001 and goal_maps.dtype == torch.float32:
+        return ops.heuristic(goal_maps)
+    B, H, W = goal_maps.shape[0], goal_maps.shape[-2], goal_maps.shape[-1]
+    flat = goal_maps.reshape(B, H * W)
+    rows = torch.arange(H, device=goal_maps.device).repeat_interleave(W).to(goal_maps.dtype)
+    cols = torch.arange(W, device=goal_maps.device).repeat(H).to(goal_maps.dtype)
+    gr, gc = flat @ rows, flat @ cols                                # (one-hot goal maps: the goal's row / column)
+    dr, dc = rows[None, :] - gr[:, None], cols[None, :] - gc[:, None]
+    ar, ac = dr.abs(), dc.abs()
+    cheb = (ar + ac) - torch.minimum(ar, ac)
+    return (cheb + tb_factor * torch.sqrt(dr * dr + dc * dc)).reshape(goal_maps.shape)
+
+
+def expand(x: torch.Tensor, neighbor_filter: torch.Tensor) -> torch.Tensor:
+    """The 8-neighbourhood of the selected nodes ``x`` [B,H,W]: one grouped 3x3 convolution with zero padding (reference :77-93;
+    ``neighbor_filter`` [B,1,3,3], ``DifferentiableAstar.neighbor_filter`` repeated per map)."""
+    ops._require_device(x)
+    y = torch.nn.functional.conv2d(x[None], neighbor_filter, padding=1, groups=x.shape[0])
+    return y.squeeze().squeeze(0)  # (the reference's squeezes: a batch of one comes back as [H,W])
+
+
+def backtrack(start_maps: torch.Tensor, goal_maps: torch.Tensor, parents: torch.Tensor, current_t: int) -> torch.Tensor:
+    """Path maps (int64, shape of ``goal_maps``) from a parent table [B,HW]: the goal, then ``current_t`` hops along ``parents`` starting at the
+    goal's parent, every visited cell marked (reference :96-125; like it, the walk does not stop at the start -- the initial table points every cell
+    at the goal, so it re-walks cells it has marked)."""
+    ops._require_device(parents)
+    B = parents.shape[0]
+    par = parents.to(torch.long).reshape(B, -1)
+    path = goal_maps.to(torch.long).clone()
+    flat = path.view(B, -1)
+    loc = (par * flat).sum(-1, keepdim=True)                          # the goal's parent
+    one = torch.ones_like(loc)
+    for _ in range(int(current_t)):
+        flat.scatter_(1, loc, one)
+        loc = par.gather(1, loc)
+    return path
+
+
 class UnsolvableMapError(RuntimeError):
     """Raised (when ``check_solvable``) for maps whose goal is unreachable.
 
