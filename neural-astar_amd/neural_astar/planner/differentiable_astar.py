@@ -214,6 +214,9 @@ class DifferentiableAstar(nn.Module):
         nf[0, 0, 1, 1] = 0
         # never read by the kernel (the Moore-8 stencil is hard-wired) but part of every reference checkpoint
         self.neighbor_filter = nn.Parameter(nf, requires_grad=False)
+        # the reference keeps its heuristic as an INSTANCE attribute (:143), i.e. as something a user may replace; the kernels hard-wire that
+        # function (Chebyshev + 0.001 Euclidean): forward() refuses, loudly, to run with anything else in this attribute
+        self.get_heuristic = get_heuristic
         self.g_ratio = g_ratio
         assert (Tmax > 0) & (Tmax <= 1), "Tmax must be within (0, 1]"
         self.Tmax = Tmax
@@ -455,6 +458,9 @@ class DifferentiableAstar(nn.Module):
         assert start_maps.ndim == 4
         assert goal_maps.ndim == 4
         assert obstacles_maps.ndim == 4
+        if self.get_heuristic is not get_heuristic:
+            raise NotImplementedError("DifferentiableAstar.get_heuristic was replaced: the MI355X search kernels hard-wire the reference's heuristic "
+                                      "(Chebyshev + 0.001 x Euclidean, differentiable_astar.py:26-52) and would silently ignore another one")
         self.last_packed = None
         if (self.check_solvable is True and not store_intermediate_results and not self._pending and type(cost_maps) is torch.Tensor
                 and not (cost_maps.requires_grad and torch.is_grad_enabled())):

@@ -26,6 +26,15 @@ def test_module_surface_matches_reference():
     assert "encoder.model.0.weight" in keys and "encoder.model.13.running_var" in keys
     with pytest.raises(AssertionError):
         DifferentiableAstar(Tmax=0.0)
+    # the reference module's public helpers exist under their names (the kernel fuses them), and the instance attribute the reference keeps its
+    # heuristic in (:143) is there -- replaced by a user, forward() refuses loudly instead of ignoring it (the kernels hard-wire the function)
+    from neural_astar.planner import differentiable_astar as M
+    assert all(callable(getattr(M, n)) for n in ("get_heuristic", "expand", "backtrack"))
+    assert va.astar.get_heuristic is M.get_heuristic
+    va.astar.get_heuristic = lambda goal_maps: goal_maps * 0
+    z = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(NotImplementedError, match="get_heuristic was replaced"):
+        va(z, z, z)
     x = torch.rand(2, 1, 16, 16)
     assert na.encode(x, x, x).shape == (2, 1, 16, 16)
     wc = NeuralAstar(encoder_input="rgb+", encoder_arch="CNNDownSize", encoder_depth=3)
