@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Authoring container only (imports the reference by path): every PUBLIC name of the reference's hot-path modules -- planner.astar,
 planner.differentiable_astar, planner.encoder, utils.data, utils.training -- must exist in this package's module of the same name, classes with
-the same constructor parameters (names, order, defaults; this package may append more) and every public method likewise.  Dependencies the
+the same constructor parameters (names, order, defaults; this package may append more) and every public method likewise; constructed planners /
+encoders carry every public instance attribute of the reference's objects and the same state_dict keys.  Dependencies the
 container lacks (segmentation_models_pytorch, torchvision, pytorch_lightning, PIL, moviepy, pqdict) are stubbed: only signatures are read.
 Prints one line per difference and a summary; exit code 1 on any difference that is not on the EXPECTED list (pq_astar: out of scope)."""
 import importlib
@@ -67,6 +68,27 @@ def main():
                         diffs.append(f"{modname}.{n}.{meth}: missing")
                     elif params(g)[:len(params(f))] != params(f):
                         diffs.append(f"{modname}.{n}.{meth}: parameters {params(f)} vs {params(g)}")
+    # constructed objects: every public instance attribute / submodule / parameter / buffer of the reference's object exists here, state_dict
+    # keys equal (a reference checkpoint loads strict=True)
+    ra, ma = importlib.import_module("ref_neural_astar.planner.astar"), importlib.import_module("neural_astar.planner.astar")
+    re_, me = importlib.import_module("ref_neural_astar.planner.encoder"), importlib.import_module("neural_astar.planner.encoder")
+
+    def attrs(o):
+        return {k for k in vars(o) if not k.startswith("_")} | set(o._modules) | set(o._parameters) | set(o._buffers)
+    cases = [("VanillaAstar()", ra.VanillaAstar, ma.VanillaAstar, {}),
+             ("NeuralAstar(CNN)", ra.NeuralAstar, ma.NeuralAstar, dict(encoder_arch="CNN")),
+             ("NeuralAstar(CNNDownSize, rgb+, 3, const 10, learn_obstacles)", ra.NeuralAstar, ma.NeuralAstar,
+              dict(encoder_arch="CNNDownSize", encoder_input="rgb+", encoder_depth=3, const=10.0, learn_obstacles=True)),
+             ("DifferentiableAstar()", lambda: ra.VanillaAstar().astar, lambda: ma.VanillaAstar().astar, {}),
+             ("encoder.CNN(2, 4, None)", lambda: re_.CNN(2, 4, None), lambda: me.CNN(2, 4, None), {}),
+             ("encoder.CNNDownSize(4, 3, 10.0)", lambda: re_.CNNDownSize(4, 3, 10.0), lambda: me.CNNDownSize(4, 3, 10.0), {})]
+    for label, rc, mc, kw in cases:
+        checked += 1
+        r, m = rc(**kw), mc(**kw)
+        if attrs(r) - attrs(m):
+            diffs.append(f"{label}: instance attributes missing {sorted(attrs(r) - attrs(m))}")
+        if list(r.state_dict()) != list(m.state_dict()):
+            diffs.append(f"{label}: state_dict keys differ")
     unexpected = [d for d in diffs if d.split(":")[0] not in EXPECTED]
     for d in diffs:
         print(("expected   " if d.split(":")[0] in EXPECTED else "DIFFERENCE ") + d)
