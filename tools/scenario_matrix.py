@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A sweep of USER scenarios through the planner API (run on the GPU box): VanillaAstar / NeuralAstar (CNN; at 64x64 also Unet with g_ratio 0.2 --
+"""A sweep of USER scenarios through the planner API (run on the GPU box): VanillaAstar / NeuralAstar (CNN; at 64x64 also Unet of depth 4 and 5 with g_ratio 0.2 --
 the exact batch pipeline -- and CNNDownSize) x map sizes from 32x32 to 1024x1024 incl. rectangles, a prime width and sizes either side of every
 kernel boundary x {eval forward, store_intermediate_results, one training step with torch.nn.L1Loss + RMSprop}.  One JSON line per scenario:
 wall-clock ms per call, the encoder route the call took (hip:* = the MFMA kernels; "torch.nn" would be a fall-back) and any warning --
@@ -58,9 +58,11 @@ for (H, W, B) in ((32, 32, 256), (64, 64, 128), (64, 128, 64), (79, 79, 64), (80
             with torch.no_grad():
                 va(m, s, g, store_intermediate_results=True)
         run(f"VanillaAstar store_intermediate_results {H}x{W} B={B}", f_inter, n=1)
-    for arch in (("CNN", "Unet", "CNNDownSize") if (H, W) == (64, 64) else ("CNN",)):
+    for arch in (("CNN", "Unet", "Unet5", "CNNDownSize") if (H, W) == (64, 64) else ("CNN",)):
         torch.manual_seed(0)
-        na = NeuralAstar(encoder_arch=arch, encoder_depth=2 if arch == "CNNDownSize" else 4, Tmax=0.25, g_ratio=0.2 if arch == "Unet" else 0.5).to(dev)
+        depth = {"CNNDownSize": 2, "Unet5": 5}.get(arch, 4)  # (Unet5: encoder_depth 5, a 16-channel last decoder block)
+        arch = "Unet" if arch == "Unet5" else arch
+        na = NeuralAstar(encoder_arch=arch, encoder_depth=depth, Tmax=0.25, g_ratio=0.2 if arch == "Unet" else 0.5).to(dev)
         ss, gg = s, g
         if arch == "CNNDownSize":  # the WarCraft arrangement: the search runs on the pooled grid, obstacles are learnt
             ss = torch.zeros(B, 1, H // 4, W // 4, device=dev)
@@ -73,7 +75,7 @@ for (H, W, B) in ((32, 32, 256), (64, 64, 128), (64, 128, 64), (79, 79, 64), (80
         def f_na():
             with torch.no_grad():
                 na(m, ss, gg)
-        run(f"NeuralAstar({arch}) eval {H}x{W} B={B}", f_na, route=lambda: na.last_encoder_route)
+        run(f"NeuralAstar({arch}, depth {depth}) eval {H}x{W} B={B}", f_na, route=lambda: na.last_encoder_route)
         na.train()
         opt = torch.optim.RMSprop(na.parameters(), lr=1e-3)
         traj = (torch.rand_like(ss) < 0.1).float()
@@ -83,6 +85,6 @@ for (H, W, B) in ((32, 32, 256), (64, 64, 128), (64, 128, 64), (79, 79, 64), (80
             out = na(m, ss, gg)
             torch.nn.L1Loss()(out.histories, traj).backward()
             opt.step()
-        run(f"NeuralAstar({arch}) training step {H}x{W} B={B}", f_tr, route=lambda: na.last_encoder_route)
+        run(f"NeuralAstar({arch}, depth {depth}) training step {H}x{W} B={B}", f_tr, route=lambda: na.last_encoder_route)
 print(json.dumps({"scenarios_with_an_error_or_a_fall_back_to_torch_nn": bad}))
 sys.exit(1 if bad else 0)
