@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import encoder
 from .differentiable_astar import AstarOutput, DifferentiableAstar
+from .pq_astar import pq_astar  # noqa: F401  (the reference's astar.py imports it here: a stub that fails loudly when called)
 
 
 def _is_depth4_cnn(enc: nn.Module) -> bool:

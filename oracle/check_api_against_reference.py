@@ -4,7 +4,7 @@ planner.differentiable_astar, planner.encoder, utils.data, utils.training -- mus
 the same constructor parameters (names, order, defaults; this package may append more) and every public method likewise; constructed planners /
 encoders carry every public instance attribute of the reference's objects and the same state_dict keys.  Dependencies the
 container lacks (segmentation_models_pytorch, torchvision, pytorch_lightning, PIL, moviepy, pqdict) are stubbed: only signatures are read.
-Prints one line per difference and a summary; exit code 1 on any difference that is not on the EXPECTED list (pq_astar: out of scope)."""
+Prints one line per difference and a summary; exit code 1 on any difference that is not on the EXPECTED list (empty: pq_astar, out of scope, is a stub that raises)."""
 import importlib
 import importlib.util
 import inspect
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.join(ROOT, "oracle")]
 sys.path.insert(0, os.path.join(ROOT, "neural-astar_amd"))
 REF = "/root/reference/src/neural_astar"
-EXPECTED = {"planner.astar.pq_astar"}
+EXPECTED: set = set()  # (pq_astar exists as a stub that raises: out of scope)
 
 
 class _Stub(types.ModuleType):
